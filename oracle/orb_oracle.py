@@ -1,0 +1,261 @@
+"""ctypes loader for the CPU oracle (oracle/liborb_oracle.so).  TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module; the product package (pilotguru_amd) never does.  See
+oracle/orb_oracle.h for the "PARITY UNPINNED" statement.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liborb_oracle.so")
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                           ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+CAND_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("response", "<i4")])
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB) or any(
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB)
+            for f in ("orb_oracle.c", "orb_oracle.h", "orb_pattern31.inc")):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liborb_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        L = C.CDLL(_LIB)
+        u8p, i32p, u16p, fp = (C.POINTER(C.c_uint8), C.POINTER(C.c_int32),
+                               C.POINTER(C.c_uint16), C.POINTER(C.c_float))
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_destroy.argtypes = [C.c_void_p]
+        for name in ("orc_scale_factors", "orc_inv_scale_factors", "orc_level_sigma2",
+                     "orc_inv_level_sigma2"):
+            getattr(L, name).restype = fp
+            getattr(L, name).argtypes = [C.c_void_p]
+        for name in ("orc_features_per_level", "orc_umax"):
+            getattr(L, name).restype = i32p
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.orc_extract.restype = C.c_int
+        L.orc_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                  C.c_void_p, C.c_void_p, C.c_int, i32p]
+        L.orc_level_size.argtypes = [C.c_void_p, C.c_int, i32p, i32p]
+        L.orc_level_image.restype = C.c_void_p
+        L.orc_level_image.argtypes = [C.c_void_p, C.c_int]
+        L.orc_level_blurred.restype = C.c_void_p
+        L.orc_level_blurred.argtypes = [C.c_void_p, C.c_int]
+        L.orc_level_candidates.restype = C.c_int
+        L.orc_level_candidates.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.orc_level_keypoints.restype = C.c_int
+        L.orc_level_keypoints.argtypes = [C.c_void_p, C.c_int]
+        L.orc_resize_linear_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                           C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.orc_fast9_nms.restype = C.c_int
+        L.orc_fast9_nms.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_distribute_octtree.restype = C.c_int
+        L.orc_distribute_octtree.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_fast_atan2.restype = C.c_float
+        L.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.orc_ic_angle.restype = C.c_float
+        L.orc_ic_angle.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, i32p]
+        L.orc_gaussian_blur7.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        L.orc_sincos_f.argtypes = [C.c_float, fp, fp]
+        L.orc_orb_descriptor.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
+        L.orc_rgb_to_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_descriptor_distance.restype = C.c_int
+        L.orc_descriptor_distance.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_hamming_matrix.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_hamming_best2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OrbOracle:
+    """Mirror of ORB_SLAM2::ORBextractor (ref: include/ORBextractor.h:44-110)."""
+
+    def __init__(self, nfeatures=2000, scale_factor=1.2, nlevels=8, ini_th_fast=20,
+                 min_th_fast=7, blur_tie_mode=0):
+        self.L = lib()
+        self.nlevels = nlevels
+        self.nfeatures = nfeatures
+        self.h = self.L.orc_create(nfeatures, scale_factor, nlevels, ini_th_fast,
+                                   min_th_fast, blur_tie_mode)
+        if not self.h:
+            raise ValueError("orc_create failed")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_destroy(self.h)
+            self.h = None
+
+    def _tab(self, fn, n, dt):
+        return np.ctypeslib.as_array(fn(self.h), shape=(n,)).astype(dt).copy()
+
+    @property
+    def scale_factors(self):
+        return self._tab(self.L.orc_scale_factors, self.nlevels + 1, np.float32)
+
+    @property
+    def inv_scale_factors(self):
+        return self._tab(self.L.orc_inv_scale_factors, self.nlevels + 1, np.float32)
+
+    @property
+    def level_sigma2(self):
+        return self._tab(self.L.orc_level_sigma2, self.nlevels + 1, np.float32)
+
+    @property
+    def inv_level_sigma2(self):
+        return self._tab(self.L.orc_inv_level_sigma2, self.nlevels + 1, np.float32)
+
+    @property
+    def features_per_level(self):
+        return self._tab(self.L.orc_features_per_level, self.nlevels + 1, np.int32)
+
+    @property
+    def umax(self):
+        return self._tab(self.L.orc_umax, 16, np.int32)
+
+    def extract(self, gray, cap=None):
+        gray = np.ascontiguousarray(gray, dtype=np.uint8)
+        h, w = gray.shape
+        cap = cap or (self.nfeatures + 3 * self.nlevels + 64)
+        kps = np.zeros(cap, KEYPOINT_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int32(0)
+        rc = self.L.orc_extract(self.h, _p(gray), w, h, w, _p(kps), _p(desc), cap, C.byref(n))
+        if rc != 0:
+            raise RuntimeError("orc_extract rc=%d" % rc)
+        return kps[: n.value].copy(), desc[: n.value].copy()
+
+    def level_size(self, level):
+        w, h = C.c_int32(), C.c_int32()
+        self.L.orc_level_size(self.h, level, C.byref(w), C.byref(h))
+        return w.value, h.value
+
+    def _img(self, ptr, level):
+        w, h = self.level_size(level)
+        if not ptr:
+            return None
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(h, w)).copy()
+
+    def level_image(self, level):
+        return self._img(self.L.orc_level_image(self.h, level), level)
+
+    def level_blurred(self, level):
+        return self._img(self.L.orc_level_blurred(self.h, level), level)
+
+    def level_candidates(self, level):
+        p = C.c_void_p()
+        n = self.L.orc_level_candidates(self.h, level, C.byref(p))
+        if n <= 0:
+            return np.zeros(0, CAND_DTYPE)
+        buf = (C.c_char * (n * CAND_DTYPE.itemsize)).from_address(p.value)
+        return np.frombuffer(buf, dtype=CAND_DTYPE, count=n).copy()
+
+    def level_keypoints(self, level):
+        return self.L.orc_level_keypoints(self.h, level)
+
+
+def resize_linear(src, dw, dh):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().orc_resize_linear_u8(_p(src), src.shape[1], src.shape[0], src.shape[1], _p(dst), dw, dh, dw)
+    return dst
+
+
+def fast9_nms(img, threshold):
+    img = np.ascontiguousarray(img, np.uint8)
+    cap = img.size
+    out = np.zeros(cap, CAND_DTYPE)
+    n = lib().orc_fast9_nms(_p(img), img.shape[1], img.shape[0], img.shape[1], threshold, _p(out), cap)
+    return out[:n].copy()
+
+
+def distribute_octtree(cand, minX, maxX, minY, maxY, N):
+    cand = np.ascontiguousarray(cand, CAND_DTYPE)
+    out = np.zeros(len(cand) + 4, np.int32)
+    n = lib().orc_distribute_octtree(_p(cand), len(cand), minX, maxX, minY, maxY, N, _p(out), len(out))
+    if n < 0:
+        raise RuntimeError("orc_distribute_octtree rc=%d" % n)
+    return out[:n].copy()
+
+
+def gaussian_blur7(img, tie_mode=0):
+    img = np.ascontiguousarray(img, np.uint8)
+    dst = np.zeros_like(img)
+    lib().orc_gaussian_blur7(_p(img), img.shape[1], img.shape[0], img.shape[1], _p(dst), img.shape[1], tie_mode)
+    return dst
+
+
+def fast_atan2(y, x):
+    return lib().orc_fast_atan2(float(y), float(x))
+
+
+def ic_angle(img, x, y, umax):
+    img = np.ascontiguousarray(img, np.uint8)
+    um = np.ascontiguousarray(umax, np.int32)
+    return lib().orc_ic_angle(C.c_void_p(img.ctypes.data), img.shape[1], x, y,
+                              um.ctypes.data_as(C.POINTER(C.c_int32)))
+
+
+def sincos_f(angle):
+    s, c = C.c_float(), C.c_float()
+    lib().orc_sincos_f(float(angle), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def orb_descriptor(blurred, x, y, angle_deg):
+    blurred = np.ascontiguousarray(blurred, np.uint8)
+    d = np.zeros(32, np.uint8)
+    lib().orc_orb_descriptor(_p(blurred), blurred.shape[1], x, y, float(angle_deg), _p(d))
+    return d
+
+
+def rgb_to_gray(rgb):
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    h, w, _ = rgb.shape
+    g = np.zeros((h, w), np.uint8)
+    lib().orc_rgb_to_gray(_p(rgb), w, h, 3 * w, _p(g), w)
+    return g
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return lib().orc_descriptor_distance(_p(a), _p(b))
+
+
+def hamming_matrix(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    out = np.zeros((len(a), len(b)), np.uint16)
+    lib().orc_hamming_matrix(_p(a), len(a), _p(b), len(b), _p(out))
+    return out
+
+
+def hamming_best2(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    bi = np.zeros(len(a), np.int32)
+    b1 = np.zeros(len(a), np.uint16)
+    b2 = np.zeros(len(a), np.uint16)
+    lib().orc_hamming_best2(_p(a), len(a), _p(b), len(b), _p(bi), _p(b1), _p(b2))
+    return bi, b1, b2
