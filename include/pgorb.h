@@ -1,0 +1,145 @@
+/* include/pgorb.h -- C ABI of libpgorb.so, the MI355X (gfx950) ORB front end.
+ *
+ * Drop-in boundary for pilotguru's per-frame visual-odometry front end.  The
+ * reference has no FFI layer; its seam is a C++ functor plus two helpers
+ * (SURVEY.md section 8b).  Each entry point below names the reference
+ * interface it replaces (paths relative to the reference tree):
+ *
+ *   pgorb_create / pgorb_destroy     ORBextractor::ORBextractor(nfeatures, scaleFactor,
+ *                                    nlevels, iniThFAST, minThFAST)
+ *                                    thirdparty/orb-slam2/include/ORBextractor.h:51-54,
+ *                                    constructed at src/Tracking.cc:137-143
+ *   pgorb_extract*                   ORBextractor::operator()(image, mask, keypoints,
+ *                                    descriptors)  include/ORBextractor.h:59-61,
+ *                                    called from Frame::ExtractORB src/Frame.cc:251-257
+ *   pgorb_scale_tables, _levels      GetScaleFactors()/GetInverseScaleFactors()/
+ *                                    GetScaleSigmaSquares()/GetInverseScaleSigmaSquares()/
+ *                                    GetLevels()  include/ORBextractor.h:63-83
+ *   pgorb_descriptor_distance        static ORBmatcher::DescriptorDistance(a, b)
+ *                                    include/ORBmatcher.h:44, src/ORBmatcher.cc:1651-1667
+ *   pgorb_hamming_*                  the candidate-scan inner loops of the matchers
+ *                                    (src/ORBmatcher.cc:438-459 etc.) as an all-pairs
+ *                                    superset
+ *
+ * Conventions: plain pointers and sizes, caller owns every buffer, integer
+ * status codes (0 = ok, <0 = error, text via pgorb_last_error) instead of the
+ * reference's assert()/silent return (src/ORBextractor.cc:1045-1049).  One
+ * context per host thread and device, like the reference's non-re-entrant
+ * extractor.  There is NO CPU fallback: without a HIP device pgorb_create
+ * fails with PGORB_E_NODEVICE.
+ *
+ * "_device" entry points take device pointers and a hipStream_t (passed as
+ * void*) and are asynchronous on that stream; the others take host pointers
+ * and are synchronous.
+ */
+#ifndef PGORB_H
+#define PGORB_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGORB_MAX_LEVELS 16
+
+enum {
+    PGORB_OK = 0,
+    PGORB_E_ARG = -1,        /* bad argument                                            */
+    PGORB_E_TOOSMALL = -2,   /* a pyramid level has no 30-px cell (the reference divides
+                                by zero there) or aspect < 0.5 (DistributeOctTree nIni=0) */
+    PGORB_E_CAP = -3,        /* output capacity too small; nothing truncated silently   */
+    PGORB_E_NODEVICE = -4,   /* no HIP device / wrong architecture                      */
+    PGORB_E_HIP = -5,        /* HIP runtime error (see pgorb_last_error)                */
+    PGORB_E_LIMIT = -6,      /* exceeds max_width/max_height/max_batch of the context   */
+    PGORB_E_OVERFLOW = -7    /* internal candidate capacity exceeded                    */
+};
+
+typedef struct pgorb_ctx pgorb_ctx;
+
+typedef struct pgorb_params {
+    int32_t nfeatures;       /* ORBextractor_nFeatures  (src/Tracking.cc:131)            */
+    float   scale_factor;    /* ORBextractor_scaleFactor                                 */
+    int32_t nlevels;         /* ORBextractor_nLevels, 1..PGORB_MAX_LEVELS                */
+    int32_t ini_th_fast;     /* ORBextractor_iniThFAST                                   */
+    int32_t min_th_fast;     /* ORBextractor_minThFAST                                   */
+    int32_t max_width;       /* largest frame the context must hold (<= 4095)            */
+    int32_t max_height;
+    int32_t max_batch;       /* frames per pgorb_extract_batch* call                     */
+    int32_t device;          /* HIP device ordinal                                       */
+    int32_t blur_tie_mode;   /* 0: OpenCV x86-64 binary rounding of the blur column pass
+                                (ties to even for x < (w & ~3)); 1: half-up everywhere   */
+} pgorb_params;
+
+/* == cv::KeyPoint of OpenCV 2.4 (pt.x, pt.y, size, angle, response, octave, class_id) */
+typedef struct pgorb_keypoint {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} pgorb_keypoint;
+
+int  pgorb_create(const pgorb_params* params, pgorb_ctx** out);
+void pgorb_destroy(pgorb_ctx* ctx);
+/* Last error text of `ctx` (or of the failed pgorb_create when ctx == NULL). */
+const char* pgorb_last_error(const pgorb_ctx* ctx);
+
+int  pgorb_levels(const pgorb_ctx* ctx);
+/* nlevels+1 entries each (the reference sizes its tables nlevels+1, ORBextractor.cc:415-433);
+ * any pointer may be NULL. */
+int  pgorb_scale_tables(const pgorb_ctx* ctx, float* scale, float* inv_scale,
+                        float* sigma2, float* inv_sigma2);
+/* nlevels+1 entries (last = the fork's unused remainder slot, ORBextractor.cc:446) */
+int  pgorb_features_per_level(const pgorb_ctx* ctx, int32_t* out);
+/* Keypoint capacity that a w x h frame can never exceed: sum over levels of
+ * max(quota + 2, 4 * nIni) (DistributeOctTree may overshoot its quota by up to 2 when the
+ * last split adds 3 nodes, ORBextractor.cc:730; nIni = initial nodes, :543).
+ * <0 when the frame is unusable (PGORB_E_TOOSMALL / PGORB_E_LIMIT). */
+int  pgorb_max_keypoints(const pgorb_ctx* ctx, int w, int h);
+
+/* One frame, host buffers.  gray: h rows of `stride` bytes.  kps[cap], desc[cap*32]. */
+int  pgorb_extract(pgorb_ctx* ctx, const uint8_t* gray, int w, int h, int stride,
+                   pgorb_keypoint* kps, uint8_t* desc, int cap, int* n);
+/* nframes frames of equal size, host buffers; frame f writes kps[f*cap_per_frame ...],
+ * desc[(f*cap_per_frame)*32 ...], n[f]. */
+int  pgorb_extract_batch(pgorb_ctx* ctx, const uint8_t* const* gray, int nframes,
+                         int w, int h, int stride,
+                         pgorb_keypoint* kps, uint8_t* desc, int cap_per_frame, int* n);
+/* Same, everything resident in HBM: d_gray = nframes planes `frame_stride` bytes apart.
+ * Asynchronous on `hip_stream`.  d_n[f] receives the true count even when it exceeds
+ * cap_per_frame (then only the first cap_per_frame entries were written). */
+int  pgorb_extract_batch_device(pgorb_ctx* ctx, const uint8_t* d_gray, int nframes,
+                                int w, int h, int stride, int64_t frame_stride,
+                                pgorb_keypoint* d_kps, uint8_t* d_desc, int cap_per_frame,
+                                int32_t* d_n, void* hip_stream);
+/* Device status word of the last *_device call: 0 or PGORB_E_OVERFLOW.  Synchronises. */
+int  pgorb_check_async(pgorb_ctx* ctx, void* hip_stream);
+
+/* ORBmatcher::DescriptorDistance on two 32-byte descriptors (host, no device work). */
+int  pgorb_descriptor_distance(const uint8_t* a, const uint8_t* b);
+/* All-pairs Hamming: out[i*nb + j] = distance(a[i], b[j]).  Host buffers. */
+int  pgorb_hamming_matrix(pgorb_ctx* ctx, const uint8_t* a, int na, const uint8_t* b, int nb,
+                          uint16_t* out);
+/* Best and second-best train descriptor per query (first minimum wins, strict <, like
+ * the bestDist/bestDist2 scans in src/ORBmatcher.cc:438-459).  best_idx = -1 and
+ * best = second = 65535 when nb == 0; second = 65535 when nb == 1. */
+int  pgorb_hamming_best2(pgorb_ctx* ctx, const uint8_t* a, int na, const uint8_t* b, int nb,
+                         int32_t* best_idx, uint16_t* best, uint16_t* second);
+/* Batched, resident: pair p matches descriptors of frame qa[p] (queries) against frame
+ * qb[p] (train) inside one extract batch layout (desc base + f*cap_per_frame*32, counts
+ * d_n[f] clamped to cap_per_frame).  Outputs are [npairs][cap_per_frame]. */
+int  pgorb_match_batch_device(pgorb_ctx* ctx, const uint8_t* d_desc, const int32_t* d_n,
+                              int cap_per_frame, const int32_t* d_pair_query,
+                              const int32_t* d_pair_train, int npairs,
+                              int32_t* d_best_idx, uint16_t* d_best, uint16_t* d_second,
+                              void* hip_stream);
+
+/* Stage taps for parity tests (host buffers, synchronous; operate on the LAST batch). */
+int  pgorb_debug_level_size(const pgorb_ctx* ctx, int level, int* w, int* h);
+int  pgorb_debug_level_image(pgorb_ctx* ctx, int frame, int level, uint8_t* out /* w*h */);
+/* candidates of (frame, level) in device order (unordered set); x,y region-relative like
+ * the reference's vToDistributeKeys (ORBextractor.cc:818-826).  Returns the count. */
+int  pgorb_debug_level_candidates(pgorb_ctx* ctx, int frame, int level,
+                                  int32_t* x, int32_t* y, int32_t* response, int cap);
+int  pgorb_debug_level_keypoints(pgorb_ctx* ctx, int frame, int level);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

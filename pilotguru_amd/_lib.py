@@ -1,0 +1,80 @@
+"""ctypes binding of libpgorb.so (the C ABI declared in include/pgorb.h).
+
+The HIP library is the product: importing this module without a built
+pilotguru_amd/libpgorb.so raises immediately -- there is no Python or CPU fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpgorb.so")
+
+PGORB_MAX_LEVELS = 16
+PGORB_OK, PGORB_E_ARG, PGORB_E_TOOSMALL, PGORB_E_CAP = 0, -1, -2, -3
+PGORB_E_NODEVICE, PGORB_E_HIP, PGORB_E_LIMIT, PGORB_E_OVERFLOW = -4, -5, -6, -7
+
+# every symbol include/pgorb.h declares (tests check the .so exports all of them)
+SYMBOLS = (
+    "pgorb_create", "pgorb_destroy", "pgorb_last_error", "pgorb_levels", "pgorb_scale_tables",
+    "pgorb_features_per_level", "pgorb_max_keypoints", "pgorb_extract", "pgorb_extract_batch",
+    "pgorb_extract_batch_device", "pgorb_check_async", "pgorb_descriptor_distance",
+    "pgorb_hamming_matrix", "pgorb_hamming_best2", "pgorb_match_batch_device",
+    "pgorb_debug_level_size", "pgorb_debug_level_image", "pgorb_debug_level_candidates",
+    "pgorb_debug_level_keypoints",
+)
+
+
+class PgorbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("max_width", C.c_int32),
+                ("max_height", C.c_int32), ("max_batch", C.c_int32), ("device", C.c_int32),
+                ("blur_tie_mode", C.c_int32)]
+
+
+class PgorbError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("pgorb error %d: %s" % (code, text))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: build it with `make -C pilotguru_amd/csrc` "
+                          "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32p, fp = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float)
+    L.pgorb_create.restype = C.c_int
+    L.pgorb_create.argtypes = [C.POINTER(PgorbParams), C.POINTER(vp)]
+    L.pgorb_destroy.restype = None
+    L.pgorb_destroy.argtypes = [vp]
+    L.pgorb_last_error.restype = C.c_char_p
+    L.pgorb_last_error.argtypes = [vp]
+    L.pgorb_levels.argtypes = [vp]
+    L.pgorb_scale_tables.argtypes = [vp, fp, fp, fp, fp]
+    L.pgorb_features_per_level.argtypes = [vp, i32p]
+    L.pgorb_max_keypoints.argtypes = [vp, C.c_int, C.c_int]
+    L.pgorb_extract.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, i32p]
+    L.pgorb_extract_batch.argtypes = [vp, C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int,
+                                      vp, vp, C.c_int, i32p]
+    L.pgorb_extract_batch_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64,
+                                             vp, vp, C.c_int, vp, vp]
+    L.pgorb_check_async.argtypes = [vp, vp]
+    L.pgorb_descriptor_distance.argtypes = [vp, vp]
+    L.pgorb_hamming_matrix.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp]
+    L.pgorb_hamming_best2.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp]
+    L.pgorb_match_batch_device.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp]
+    L.pgorb_debug_level_size.argtypes = [vp, C.c_int, i32p, i32p]
+    L.pgorb_debug_level_image.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.pgorb_debug_level_candidates.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int]
+    L.pgorb_debug_level_keypoints.argtypes = [vp, C.c_int, C.c_int]
+    for name in SYMBOLS:
+        if name not in ("pgorb_destroy", "pgorb_last_error"):
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L

@@ -1,0 +1,567 @@
+// api.hip -- host side of libpgorb.so: context, per-frame-size plan, launches, C ABI.
+//
+// Mirrors the host logic of ORB_SLAM2::ORBextractor that is not per-pixel work:
+//   constructor tables      thirdparty/orb-slam2/src/ORBextractor.cc:410-470
+//   level sizes             ORBextractor.cc:1110-1111
+//   cell grid               ORBextractor.cc:773-787
+//   quadtree roots          ORBextractor.cc:543-545
+//   operator() sequencing   ORBextractor.cc:1042-1104
+// Everything per-pixel / per-keypoint runs in the HIP kernels; there is no CPU fallback.
+#include "pgorb_internal.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Arena {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct pgorb_ctx {
+    pgorb_params prm;
+    double scaleFactor;                       // the reference keeps a double member
+    float mvScaleFactor[PG_MAXL + 1], mvInvScaleFactor[PG_MAXL + 1];
+    float mvLevelSigma2[PG_MAXL + 1], mvInvLevelSigma2[PG_MAXL + 1];
+    int mnFeaturesPerLevel[PG_MAXL + 1];
+    std::string err;
+    // plan for the current frame size
+    PgPlan plan;
+    int planW = 0, planH = 0, planBatch = 0;
+    bool planValid = false;
+    // device memory
+    Arena pyr, cand, kpos, sel, nodes, counters, tables;
+    Arena stageKps, stageDesc, stageN, stageA, stageB, stageOut;
+    int lastFrames = 0;
+    bool lastAliased = false;
+};
+
+namespace {
+
+int fail(pgorb_ctx* c, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define PG_HIP(c, call)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail((c), PGORB_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_));   \
+    } while (0)
+
+int ensure(pgorb_ctx* c, Arena& a, size_t bytes)
+{
+    if (a.bytes >= bytes && a.p) return 0;
+    if (a.p) { (void)hipFree(a.p); a.p = nullptr; a.bytes = 0; }
+    bytes = (bytes + 4095) & ~(size_t)4095;
+    PG_HIP(c, hipMalloc(&a.p, bytes));
+    a.bytes = bytes;
+    return 0;
+}
+
+inline int cvRound(double v) { return (int)lrint(v); }
+inline int cvFloor(double v) { int i = (int)v; return i - (v < i); }
+
+// level sizes, ORBextractor.cc:1110-1111
+void level_size(const pgorb_ctx* c, int level, int w, int h, int* lw, int* lh)
+{
+    const float scale = c->mvInvScaleFactor[level];
+    *lw = cvRound((double)((float)w * scale));
+    *lh = cvRound((double)((float)h * scale));
+}
+
+struct LevelGeom { int w, h, nCols, nRows, wCell, hCell, nIni; float hX; };
+
+int level_geometry(const pgorb_ctx* c, int w, int h, LevelGeom* g)
+{
+    for (int l = 0; l < c->prm.nlevels; l++) {
+        level_size(c, l, w, h, &g[l].w, &g[l].h);
+        const float width = (float)(g[l].w - 2 * PG_EDGE), height = (float)(g[l].h - 2 * PG_EDGE);
+        const int nCols = (int)(width / 30.f), nRows = (int)(height / 30.f);     // :784-785
+        if (nCols < 1 || nRows < 1) return PGORB_E_TOOSMALL;
+        g[l].nCols = nCols; g[l].nRows = nRows;
+        g[l].wCell = (int)ceilf(width / nCols);                                   // :786-787
+        g[l].hCell = (int)ceilf(height / nRows);
+        const int rw = g[l].w - 2 * PG_EDGE, rh = g[l].h - 2 * PG_EDGE;
+        g[l].nIni = (int)roundf((float)rw / rh);                                  // :543
+        if (g[l].nIni < 1) return PGORB_E_TOOSMALL;
+        g[l].hX = (float)rw / g[l].nIni;                                          // :545
+    }
+    return 0;
+}
+
+// cv::resize INTER_LINEAR coefficient set-up for 8U (OpenCV 2.4 imgwarp.cpp; Appendix A1)
+void build_resize_tables(int sw, int sh, int dw, int dh, std::vector<int32_t>& xofs,
+                         std::vector<int32_t>& xofs1, std::vector<int16_t>& xalpha,
+                         std::vector<int32_t>& yofs, std::vector<int16_t>& ybeta)
+{
+    const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+    xofs.resize(dw); xofs1.resize(dw); xalpha.resize(2 * dw); yofs.resize(2 * dh); ybeta.resize(2 * dh);
+    auto sat16 = [](int v) { return (int16_t)(v < -32768 ? -32768 : v > 32767 ? 32767 : v); };
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = cvFloor(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }          // single-tap columns (dx >= xmax)
+        xofs[dx] = sx;
+        xofs1[dx] = sx + 1 < sw ? sx + 1 : sw - 1;
+        xalpha[2 * dx] = sat16(cvRound((double)((1.f - fx) * 2048)));
+        xalpha[2 * dx + 1] = sat16(cvRound((double)(fx * 2048)));
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = cvFloor(fy);
+        fy -= sy;
+        int r0 = sy, r1 = sy + 1;
+        r0 = r0 < 0 ? 0 : (r0 >= sh ? sh - 1 : r0);
+        r1 = r1 < 0 ? 0 : (r1 >= sh ? sh - 1 : r1);
+        yofs[2 * dy] = r0; yofs[2 * dy + 1] = r1;
+        ybeta[2 * dy] = sat16(cvRound((double)((1.f - fy) * 2048)));
+        ybeta[2 * dy + 1] = sat16(cvRound((double)(fy * 2048)));
+    }
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Build (or reuse) the plan for w x h frames and a batch of `nframes`.
+int make_plan(pgorb_ctx* c, int w, int h, int nframes)
+{
+    if (w > c->prm.max_width || h > c->prm.max_height)
+        return fail(c, PGORB_E_LIMIT, "frame %dx%d exceeds context maximum %dx%d", w, h,
+                    c->prm.max_width, c->prm.max_height);
+    if (nframes > c->prm.max_batch)
+        return fail(c, PGORB_E_LIMIT, "batch %d exceeds max_batch %d", nframes, c->prm.max_batch);
+    if (c->planValid && c->planW == w && c->planH == h) return 0;
+
+    const int L = c->prm.nlevels, B = c->prm.max_batch;
+    LevelGeom g[PG_MAXL];
+    int rc = level_geometry(c, w, h, g);
+    if (rc) return fail(c, rc, "frame %dx%d too small: every pyramid level needs >= 62 px per side "
+                               "and aspect >= 0.5", w, h);
+    PgPlan& P = c->plan;
+    memset(&P, 0, sizeof(P));
+    P.nlevels = L; P.iniTh = c->prm.ini_th_fast; P.minTh = c->prm.min_th_fast;
+    P.tieMode = c->prm.blur_tie_mode;
+
+    // --- resize tables ---
+    std::vector<uint8_t> tab;
+    struct TabOff { size_t xofs, xofs1, xalpha, yofs, ybeta; } toff[PG_MAXL];
+    for (int l = 1; l < L; l++) {
+        std::vector<int32_t> xo, xo1, yo; std::vector<int16_t> xa, yb;
+        build_resize_tables(g[l - 1].w, g[l - 1].h, g[l].w, g[l].h, xo, xo1, xa, yo, yb);
+        auto put = [&](const void* p, size_t n) {
+            size_t off = align_up(tab.size(), 16);
+            tab.resize(off + n);
+            memcpy(tab.data() + off, p, n);
+            return off;
+        };
+        toff[l].xofs = put(xo.data(), xo.size() * 4);
+        toff[l].xofs1 = put(xo1.data(), xo1.size() * 4);
+        toff[l].xalpha = put(xa.data(), xa.size() * 2);
+        toff[l].yofs = put(yo.data(), yo.size() * 4);
+        toff[l].ybeta = put(yb.data(), yb.size() * 2);
+    }
+    if ((rc = ensure(c, c->tables, tab.size() + 16))) return rc;
+    if (!tab.empty()) PG_HIP(c, hipMemcpy(c->tables.p, tab.data(), tab.size(), hipMemcpyHostToDevice));
+
+    // --- arenas ---
+    size_t pyrFrame = 0, candFrame = 0, selFrame = 0, nodeFrame = 0;
+    int cells = 0, selTotal = 0;
+    size_t pyrOff[PG_MAXL];
+    for (int l = 0; l < L; l++) {
+        PgLevel& V = P.lvl[l];
+        V.w = g[l].w; V.h = g[l].h;
+        V.pitch = (int)align_up(V.w, 64);
+        pyrOff[l] = pyrFrame;
+        pyrFrame += align_up((size_t)V.pitch * V.h + 64, 256);
+        V.nCols = g[l].nCols; V.nRows = g[l].nRows; V.wCell = g[l].wCell; V.hCell = g[l].hCell;
+        V.cellBase = cells; cells += V.nCols * V.nRows;
+        V.quota = c->mnFeaturesPerLevel[l];
+        V.nIni = g[l].nIni; V.hX = g[l].hX;
+        V.selCap = std::max(V.quota + 2, 4 * V.nIni);
+        V.nodeCap = (int)align_up(V.selCap + 8, 4);
+        // NMS survivors are never 8-adjacent: at most ceil(IW/2)*ceil(IH/2) per cell
+        V.candCap = ((V.w - 2 * PG_EDGE) / 2 + V.nCols + 1) * ((V.h - 2 * PG_EDGE) / 2 + V.nRows + 1);
+        V.candOff = (int64_t)candFrame; candFrame += align_up(V.candCap, 64);
+        V.selOff = (int64_t)selFrame; selFrame += align_up(V.selCap, 16);
+        V.nodeOff = (int64_t)nodeFrame; nodeFrame += (size_t)V.nodeCap * 20;
+        V.scale = c->mvScaleFactor[l];
+        V.patchSize = (float)(int)(31 * c->mvScaleFactor[l]);                     // :836
+        selTotal += V.selCap;
+        if ((size_t)V.nodeCap * 6 * sizeof(int) > 60 * 1024)
+            return fail(c, PGORB_E_LIMIT, "nfeatures too large for the quadtree kernel's LDS budget");
+        if (V.w > 4095 + 2 * PG_EDGE || V.h > 4095 + 2 * PG_EDGE)
+            return fail(c, PGORB_E_LIMIT, "level larger than 4095 px is not supported");
+    }
+    P.totalCells = cells; P.selTotal = selTotal;
+    P.candFrame = (int64_t)candFrame; P.selFrame = (int64_t)selFrame; P.nodeFrame = (int64_t)nodeFrame;
+    if ((rc = ensure(c, c->pyr, pyrFrame * B))) return rc;
+    if ((rc = ensure(c, c->cand, candFrame * 4 * B))) return rc;
+    if ((rc = ensure(c, c->kpos, candFrame * 4 * B))) return rc;
+    if ((rc = ensure(c, c->sel, selFrame * 4 * B))) return rc;
+    if ((rc = ensure(c, c->nodes, nodeFrame * 4 * B + 64))) return rc;
+    if ((rc = ensure(c, c->counters, (size_t)B * PG_MAXL * 4 * 2 + 64))) return rc;
+    for (int l = 0; l < L; l++) {
+        PgLevel& V = P.lvl[l];
+        V.img = (uint8_t*)c->pyr.p + pyrOff[l] * B;        // level-major: frames of a level adjacent
+        V.fstride = (int64_t)align_up((size_t)V.pitch * V.h + 64, 256);
+        if (l >= 1) {
+            const uint8_t* t = (const uint8_t*)c->tables.p;
+            V.xofs = (const int32_t*)(t + toff[l].xofs);
+            V.xofs1 = (const int32_t*)(t + toff[l].xofs1);
+            V.xalpha = (const int16_t*)(t + toff[l].xalpha);
+            V.yofs = (const int32_t*)(t + toff[l].yofs);
+            V.ybeta = (const int16_t*)(t + toff[l].ybeta);
+        }
+    }
+    P.cand = (uint32_t*)c->cand.p; P.kpos = (uint32_t*)c->kpos.p; P.sel = (uint32_t*)c->sel.p;
+    P.nodeScratch = (int32_t*)c->nodes.p;
+    P.candCount = (int32_t*)c->counters.p;
+    P.kpCount = P.candCount + (size_t)B * PG_MAXL;
+    P.status = P.kpCount + (size_t)B * PG_MAXL;
+    c->planW = w; c->planH = h; c->planBatch = B; c->planValid = true;
+    return 0;
+}
+
+int run_batch(pgorb_ctx* c, const uint8_t* d_gray, bool resident_in_level0, int nframes, int w, int h,
+              int stride, int64_t frame_stride, pgorb_keypoint* d_kps, uint8_t* d_desc,
+              int cap_per_frame, int32_t* d_n, hipStream_t s)
+{
+    PgPlan P = c->plan;                                   // by-value copy handed to the kernels
+    c->lastAliased = false;
+    if (!resident_in_level0) {
+        const bool aligned = ((uintptr_t)d_gray % 4 == 0) && (stride % 4 == 0) && (frame_stride % 4 == 0);
+        if (aligned) {                                    // zero-copy: level 0 is the caller's buffer
+            P.lvl[0].img = const_cast<uint8_t*>(d_gray);
+            P.lvl[0].pitch = stride;
+            P.lvl[0].fstride = frame_stride;
+            c->lastAliased = true;
+        } else {
+            pg_launch_copy_level0(P, d_gray, stride, frame_stride, nframes, s);
+        }
+    }
+    PG_HIP(c, hipMemsetAsync(P.candCount, 0, (size_t)c->planBatch * PG_MAXL * 4 * 2 + 4, s));
+    for (int l = 1; l < P.nlevels; l++) pg_launch_pyramid_level(P, l, nframes, s);
+    pg_launch_fast(P, nframes, s);
+    pg_launch_quadtree(P, nframes, s);
+    pg_launch_describe(P, nframes, d_kps, d_desc, cap_per_frame, d_n, s);
+    PG_HIP(c, hipGetLastError());
+    c->lastFrames = nframes;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pgorb_create(const pgorb_params* p, pgorb_ctx** out)
+{
+    if (!p || !out) return fail(nullptr, PGORB_E_ARG, "null argument");
+    *out = nullptr;
+    if (p->nlevels < 1 || p->nlevels > PG_MAXL || p->nfeatures < 1 || !(p->scale_factor > 1.0f) ||
+        p->max_batch < 1 || p->max_width < 62 || p->max_height < 62 || p->min_th_fast < 1 ||
+        p->ini_th_fast < p->min_th_fast || p->ini_th_fast > 254)
+        return fail(nullptr, PGORB_E_ARG, "invalid parameters");
+    if (p->max_width > 4095 || p->max_height > 4095)
+        return fail(nullptr, PGORB_E_LIMIT, "max_width/max_height above 4095 not supported");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || p->device < 0 || p->device >= ndev)
+        return fail(nullptr, PGORB_E_NODEVICE, "no HIP device %d (found %d); libpgorb has no CPU path",
+                    p->device, ndev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, p->device) != hipSuccess)
+        return fail(nullptr, PGORB_E_NODEVICE, "hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, PGORB_E_NODEVICE, "device %d is %s; libpgorb is built for gfx950 only",
+                    p->device, prop.gcnArchName);
+    if (hipSetDevice(p->device) != hipSuccess)
+        return fail(nullptr, PGORB_E_HIP, "hipSetDevice failed");
+
+    pgorb_ctx* c = new pgorb_ctx();
+    c->prm = *p;
+    // ORBextractor.cc:415-446
+    const int L = p->nlevels;
+    c->scaleFactor = p->scale_factor;
+    c->mvScaleFactor[0] = 1.0f; c->mvLevelSigma2[0] = 1.0f;
+    for (int i = 1; i <= L; i++) {
+        c->mvScaleFactor[i] = (float)(c->mvScaleFactor[i - 1] * c->scaleFactor);
+        c->mvLevelSigma2[i] = c->mvScaleFactor[i] * c->mvScaleFactor[i];
+    }
+    for (int i = 0; i <= L; i++) {
+        c->mvInvScaleFactor[i] = 1.0f / c->mvScaleFactor[i];
+        c->mvInvLevelSigma2[i] = 1.0f / c->mvLevelSigma2[i];
+    }
+    const float factor = (float)(1.0f / c->scaleFactor);
+    float nDesired = p->nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)L));
+    int sum = 0;
+    for (int l = 0; l < L; l++) {
+        c->mnFeaturesPerLevel[l] = cvRound(nDesired);
+        sum += c->mnFeaturesPerLevel[l];
+        nDesired *= factor;
+    }
+    c->mnFeaturesPerLevel[L] = std::max(p->nfeatures - sum, 0);
+    *out = c;
+    return 0;
+}
+
+void pgorb_destroy(pgorb_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->prm.device);
+    Arena* all[] = {&c->pyr, &c->cand, &c->kpos, &c->sel, &c->nodes, &c->counters, &c->tables,
+                    &c->stageKps, &c->stageDesc, &c->stageN, &c->stageA, &c->stageB, &c->stageOut};
+    for (Arena* a : all) if (a->p) (void)hipFree(a->p);
+    delete c;
+}
+
+const char* pgorb_last_error(const pgorb_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int pgorb_levels(const pgorb_ctx* c) { return c ? c->prm.nlevels : PGORB_E_ARG; }
+
+int pgorb_scale_tables(const pgorb_ctx* c, float* scale, float* inv, float* s2, float* is2)
+{
+    if (!c) return PGORB_E_ARG;
+    const size_t n = (size_t)(c->prm.nlevels + 1) * sizeof(float);
+    if (scale) memcpy(scale, c->mvScaleFactor, n);
+    if (inv) memcpy(inv, c->mvInvScaleFactor, n);
+    if (s2) memcpy(s2, c->mvLevelSigma2, n);
+    if (is2) memcpy(is2, c->mvInvLevelSigma2, n);
+    return 0;
+}
+
+int pgorb_features_per_level(const pgorb_ctx* c, int32_t* out)
+{
+    if (!c || !out) return PGORB_E_ARG;
+    for (int i = 0; i <= c->prm.nlevels; i++) out[i] = c->mnFeaturesPerLevel[i];
+    return 0;
+}
+
+int pgorb_max_keypoints(const pgorb_ctx* c, int w, int h)
+{
+    if (!c) return PGORB_E_ARG;
+    if (w > c->prm.max_width || h > c->prm.max_height) return PGORB_E_LIMIT;
+    LevelGeom g[PG_MAXL];
+    int rc = level_geometry(c, w, h, g);
+    if (rc) return rc;
+    int total = 0;
+    for (int l = 0; l < c->prm.nlevels; l++) total += std::max(c->mnFeaturesPerLevel[l] + 2, 4 * g[l].nIni);
+    return total;
+}
+
+int pgorb_extract_batch_device(pgorb_ctx* c, const uint8_t* d_gray, int nframes, int w, int h,
+                               int stride, int64_t frame_stride, pgorb_keypoint* d_kps,
+                               uint8_t* d_desc, int cap_per_frame, int32_t* d_n, void* stream)
+{
+    if (!c) return PGORB_E_ARG;
+    if (!d_gray || !d_kps || !d_desc || !d_n || nframes < 1 || w < 1 || h < 1 || stride < w ||
+        cap_per_frame < 1)
+        return fail(c, PGORB_E_ARG, "bad argument to pgorb_extract_batch_device");
+    PG_HIP(c, hipSetDevice(c->prm.device));
+    int rc = make_plan(c, w, h, nframes);
+    if (rc) return rc;
+    return run_batch(c, d_gray, false, nframes, w, h, stride, frame_stride, d_kps, d_desc,
+                     cap_per_frame, d_n, (hipStream_t)stream);
+}
+
+int pgorb_check_async(pgorb_ctx* c, void* stream)
+{
+    if (!c) return PGORB_E_ARG;
+    if (!c->planValid) return 0;
+    PG_HIP(c, hipSetDevice(c->prm.device));
+    PG_HIP(c, hipStreamSynchronize((hipStream_t)stream));
+    int32_t st = 0;
+    PG_HIP(c, hipMemcpy(&st, c->plan.status, 4, hipMemcpyDeviceToHost));
+    if (st) return fail(c, st, "device status %d (internal candidate capacity exceeded)", st);
+    return 0;
+}
+
+int pgorb_extract_batch(pgorb_ctx* c, const uint8_t* const* gray, int nframes, int w, int h,
+                        int stride, pgorb_keypoint* kps, uint8_t* desc, int cap, int* n)
+{
+    if (!c) return PGORB_E_ARG;
+    if (!n) return fail(c, PGORB_E_ARG, "null count pointer");
+    for (int f = 0; f < nframes; f++) n[f] = 0;
+    if (nframes < 1 || !gray) return fail(c, PGORB_E_ARG, "bad argument to pgorb_extract_batch");
+    if (w <= 0 || h <= 0) return 0;          // empty image: the reference returns silently (:1045)
+    if (!kps || !desc || cap < 1 || stride < w) return fail(c, PGORB_E_ARG, "bad argument to pgorb_extract_batch");
+    PG_HIP(c, hipSetDevice(c->prm.device));
+    int rc = make_plan(c, w, h, nframes);
+    if (rc) return rc;
+    const PgLevel& L0 = c->plan.lvl[0];
+    for (int f = 0; f < nframes; f++) {
+        if (!gray[f]) return fail(c, PGORB_E_ARG, "null frame %d", f);
+        PG_HIP(c, hipMemcpy2DAsync(L0.img + (int64_t)f * L0.fstride, L0.pitch, gray[f], stride, w, h,
+                                   hipMemcpyHostToDevice, 0));
+    }
+    const int need = c->plan.selTotal;       // device staging always holds the full bound
+    if ((rc = ensure(c, c->stageKps, (size_t)c->prm.max_batch * need * sizeof(pgorb_keypoint)))) return rc;
+    if ((rc = ensure(c, c->stageDesc, (size_t)c->prm.max_batch * need * 32))) return rc;
+    if ((rc = ensure(c, c->stageN, (size_t)c->prm.max_batch * 4))) return rc;
+    rc = run_batch(c, nullptr, true, nframes, w, h, stride, 0, (pgorb_keypoint*)c->stageKps.p,
+                   (uint8_t*)c->stageDesc.p, need, (int32_t*)c->stageN.p, 0);
+    if (rc) return rc;
+    if ((rc = pgorb_check_async(c, 0))) return rc;
+    std::vector<int32_t> cnt(nframes);
+    PG_HIP(c, hipMemcpy(cnt.data(), c->stageN.p, (size_t)nframes * 4, hipMemcpyDeviceToHost));
+    for (int f = 0; f < nframes; f++)
+        if (cnt[f] > cap)
+            return fail(c, PGORB_E_CAP, "frame %d has %d keypoints, capacity %d", f, cnt[f], cap);
+    for (int f = 0; f < nframes; f++) {
+        n[f] = cnt[f];
+        if (!cnt[f]) continue;
+        PG_HIP(c, hipMemcpy(kps + (size_t)f * cap, (pgorb_keypoint*)c->stageKps.p + (size_t)f * need,
+                            (size_t)cnt[f] * sizeof(pgorb_keypoint), hipMemcpyDeviceToHost));
+        PG_HIP(c, hipMemcpy(desc + (size_t)f * cap * 32, (uint8_t*)c->stageDesc.p + (size_t)f * need * 32,
+                            (size_t)cnt[f] * 32, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+int pgorb_extract(pgorb_ctx* c, const uint8_t* gray, int w, int h, int stride, pgorb_keypoint* kps,
+                  uint8_t* desc, int cap, int* n)
+{
+    const uint8_t* frames[1] = {gray};
+    if (c && n && (!gray || w <= 0 || h <= 0)) { *n = 0; return 0; }       // :1045
+    return pgorb_extract_batch(c, frames, 1, w, h, stride, kps, desc, cap, n);
+}
+
+int pgorb_descriptor_distance(const uint8_t* a, const uint8_t* b)
+{
+    if (!a || !b) return PGORB_E_ARG;
+    int dist = 0;
+    for (int i = 0; i < 32; i += 8) {
+        uint64_t x, y;
+        memcpy(&x, a + i, 8); memcpy(&y, b + i, 8);
+        dist += __builtin_popcountll(x ^ y);
+    }
+    return dist;
+}
+
+int pgorb_hamming_matrix(pgorb_ctx* c, const uint8_t* a, int na, const uint8_t* b, int nb, uint16_t* out)
+{
+    if (!c) return PGORB_E_ARG;
+    if (na < 0 || nb < 0 || (na && !a) || (nb && !b) || (na && nb && !out))
+        return fail(c, PGORB_E_ARG, "bad argument to pgorb_hamming_matrix");
+    if (!na || !nb) return 0;
+    PG_HIP(c, hipSetDevice(c->prm.device));
+    int rc;
+    if ((rc = ensure(c, c->stageA, (size_t)na * 32))) return rc;
+    if ((rc = ensure(c, c->stageB, (size_t)nb * 32))) return rc;
+    if ((rc = ensure(c, c->stageOut, (size_t)na * nb * 2))) return rc;
+    PG_HIP(c, hipMemcpy(c->stageA.p, a, (size_t)na * 32, hipMemcpyHostToDevice));
+    PG_HIP(c, hipMemcpy(c->stageB.p, b, (size_t)nb * 32, hipMemcpyHostToDevice));
+    pg_launch_hamming_matrix((uint8_t*)c->stageA.p, na, (uint8_t*)c->stageB.p, nb, (uint16_t*)c->stageOut.p, 0);
+    PG_HIP(c, hipGetLastError());
+    PG_HIP(c, hipMemcpy(out, c->stageOut.p, (size_t)na * nb * 2, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int pgorb_hamming_best2(pgorb_ctx* c, const uint8_t* a, int na, const uint8_t* b, int nb,
+                        int32_t* best_idx, uint16_t* best, uint16_t* second)
+{
+    if (!c) return PGORB_E_ARG;
+    if (na < 0 || nb < 0 || (na && (!a || !best_idx || !best || !second)) || (nb && !b))
+        return fail(c, PGORB_E_ARG, "bad argument to pgorb_hamming_best2");
+    if (!na) return 0;
+    PG_HIP(c, hipSetDevice(c->prm.device));
+    int rc;
+    if ((rc = ensure(c, c->stageA, (size_t)na * 32))) return rc;
+    if ((rc = ensure(c, c->stageB, (size_t)nb * 32 + 32))) return rc;
+    if ((rc = ensure(c, c->stageOut, (size_t)na * 8 + 64))) return rc;
+    PG_HIP(c, hipMemcpy(c->stageA.p, a, (size_t)na * 32, hipMemcpyHostToDevice));
+    if (nb) PG_HIP(c, hipMemcpy(c->stageB.p, b, (size_t)nb * 32, hipMemcpyHostToDevice));
+    int32_t* d_idx = (int32_t*)c->stageOut.p;
+    uint16_t* d_b1 = (uint16_t*)(d_idx + na);
+    uint16_t* d_b2 = d_b1 + na;
+    pg_launch_best2((uint8_t*)c->stageA.p, na, (uint8_t*)c->stageB.p, nb, d_idx, d_b1, d_b2, 0);
+    PG_HIP(c, hipGetLastError());
+    PG_HIP(c, hipMemcpy(best_idx, d_idx, (size_t)na * 4, hipMemcpyDeviceToHost));
+    PG_HIP(c, hipMemcpy(best, d_b1, (size_t)na * 2, hipMemcpyDeviceToHost));
+    PG_HIP(c, hipMemcpy(second, d_b2, (size_t)na * 2, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int pgorb_match_batch_device(pgorb_ctx* c, const uint8_t* d_desc, const int32_t* d_n, int cap,
+                             const int32_t* d_pq, const int32_t* d_pt, int npairs,
+                             int32_t* d_best_idx, uint16_t* d_best, uint16_t* d_second, void* stream)
+{
+    if (!c) return PGORB_E_ARG;
+    if (!d_desc || !d_n || cap < 1 || npairs < 0 || (npairs && (!d_pq || !d_pt || !d_best_idx || !d_best || !d_second)))
+        return fail(c, PGORB_E_ARG, "bad argument to pgorb_match_batch_device");
+    PG_HIP(c, hipSetDevice(c->prm.device));
+    pg_launch_match_batch(d_desc, d_n, cap, d_pq, d_pt, npairs, d_best_idx, d_best, d_second, (hipStream_t)stream);
+    PG_HIP(c, hipGetLastError());
+    return 0;
+}
+
+// ---- stage taps -----------------------------------------------------------------------------
+int pgorb_debug_level_size(const pgorb_ctx* c, int level, int* w, int* h)
+{
+    if (!c || !c->planValid || level < 0 || level >= c->prm.nlevels) return PGORB_E_ARG;
+    *w = c->plan.lvl[level].w; *h = c->plan.lvl[level].h;
+    return 0;
+}
+
+int pgorb_debug_level_image(pgorb_ctx* c, int frame, int level, uint8_t* out)
+{
+    if (!c || !c->planValid || level < 0 || level >= c->prm.nlevels || frame < 0 || frame >= c->lastFrames)
+        return PGORB_E_ARG;
+    if (level == 0 && c->lastAliased) return fail(c, PGORB_E_ARG, "level 0 aliased the caller's buffer");
+    const PgLevel& V = c->plan.lvl[level];
+    PG_HIP(c, hipSetDevice(c->prm.device));
+    PG_HIP(c, hipDeviceSynchronize());
+    PG_HIP(c, hipMemcpy2D(out, V.w, V.img + (int64_t)frame * V.fstride, V.pitch, V.w, V.h, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int pgorb_debug_level_candidates(pgorb_ctx* c, int frame, int level, int32_t* x, int32_t* y,
+                                 int32_t* response, int cap)
+{
+    if (!c || !c->planValid || level < 0 || level >= c->prm.nlevels || frame < 0 || frame >= c->lastFrames)
+        return PGORB_E_ARG;
+    const PgPlan& P = c->plan;
+    PG_HIP(c, hipSetDevice(c->prm.device));
+    PG_HIP(c, hipDeviceSynchronize());
+    int32_t cnt = 0;
+    PG_HIP(c, hipMemcpy(&cnt, P.candCount + frame * PG_MAXL + level, 4, hipMemcpyDeviceToHost));
+    if (cnt > P.lvl[level].candCap) cnt = P.lvl[level].candCap;
+    std::vector<uint32_t> buf(cnt > 0 ? cnt : 1);
+    if (cnt > 0)
+        PG_HIP(c, hipMemcpy(buf.data(), P.cand + (int64_t)frame * P.candFrame + P.lvl[level].candOff,
+                            (size_t)cnt * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < cnt && i < cap; i++) {
+        x[i] = buf[i] & 0xFFF; y[i] = (buf[i] >> 12) & 0xFFF; response[i] = buf[i] >> 24;
+    }
+    return cnt;
+}
+
+int pgorb_debug_level_keypoints(pgorb_ctx* c, int frame, int level)
+{
+    if (!c || !c->planValid || level < 0 || level >= c->prm.nlevels || frame < 0 || frame >= c->lastFrames)
+        return PGORB_E_ARG;
+    PG_HIP(c, hipSetDevice(c->prm.device));
+    PG_HIP(c, hipDeviceSynchronize());
+    int32_t cnt = 0;
+    PG_HIP(c, hipMemcpy(&cnt, c->plan.kpCount + frame * PG_MAXL + level, 4, hipMemcpyDeviceToHost));
+    return cnt;
+}
+
+}  // extern "C"

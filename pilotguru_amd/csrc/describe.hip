@@ -1,0 +1,257 @@
+// describe.hip -- K4+K5+K6 fused: orientation, 7x7 Gaussian blur and rBRIEF-256, one
+// 64-lane wave per keypoint (gfx950).
+//
+// Restates, for every keypoint the quadtree kept:
+//   IC_Angle / computeOrientation   thirdparty/orb-slam2/src/ORBextractor.cc:77-104, 472-479
+//   GaussianBlur(7x7, sigma 2, REFLECT_101) of the level, ORBextractor.cc:1084-1085
+//   computeOrbDescriptor            ORBextractor.cc:107-147 with bit_pattern_31_ :150-408
+//   output assembly (pt *= scale, octave, size)   ORBextractor.cc:836-846, 1094-1102
+//
+// The reference blurs every full pyramid level; only a 37x37 neighbourhood of each keypoint
+// is ever sampled (rotated taps reach +-18 px), so the wave stages the 43x43 RAW window in
+// LDS once (aligned 32-bit loads; reflect-101 addressing only for windows that touch the
+// image edge), takes the integer moments from it, runs the separable fixed-point blur
+// LDS->LDS and samples the 512 taps from the blurred tile.  The 256 comparisons are packed
+// with four 64-bit wave ballots: ballot bit j of round r is descriptor bit 64r+j, which is
+// exactly the reference's LSB-first byte packing (:127-141).
+//
+// Float steps that decide an integer (tap coordinates) use explicit round-to-nearest
+// intrinsics, never contracted to FMA, and the sin/cos pair is evaluated in double by a fixed
+// sequence and rounded once (parity contract, see oracle/orb_oracle.c orc_sincos_f).
+// Algorithmic bytes per keypoint: 43*43 window read + 60 B written.
+#include "pgorb_internal.h"
+
+__device__ static const int8_t pg_pattern31[256 * 4] = {
+#include "orb_pattern31.inc"
+};
+
+// circular patch row half-widths, ORBextractor.cc:452-469 evaluated
+__device__ static const int8_t pg_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+
+#define DW_R 21               // window radius: 18 (taps) + 3 (blur)
+#define DW_N 43               // window side
+#define DW_PITCH 48
+#define DH_N 37               // blurred side
+#define DH_PITCH 38           // u16 row pitch of the horizontal pass
+#define DB_PITCH 40
+
+__device__ __forceinline__ int pg_reflect101(int p, int n)
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = (p < 0) ? -p : 2 * (n - 1) - p;
+    return p;
+}
+
+// cv::fastAtan2 (OpenCV 2.4 core/mathfuncs.cpp), unfused single precision.
+__device__ __forceinline__ float pg_fast_atan2(float y, float x)
+{
+    const float scale = (float)(180 / 3.1415926535897932384626433832795);
+    const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale;
+    const float p5 = 0.1555786518463281f * scale, p7 = -0.04432655554792128f * scale;
+    const float eps = (float)2.2204460492503131e-16;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, __fadd_rn(ax, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    } else {
+        c = __fdiv_rn(ax, __fadd_rn(ay, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+// sin/cos in IEEE double by a fixed operation sequence, rounded once to float.
+__device__ __forceinline__ void pg_sincos_f(float angle, float* s_out, float* c_out)
+{
+    const double INV_PIO2 = 0.63661977236758138243;
+    const double PIO2_HI = 1.57079632673412561417e+00;
+    const double PIO2_LO = 6.07710050650619224932e-11;
+    const double x = (double)angle;
+    const double kd = floor(__dadd_rn(__dmul_rn(x, INV_PIO2), 0.5));
+    const double r = __dsub_rn(__dsub_rn(x, __dmul_rn(kd, PIO2_HI)), __dmul_rn(kd, PIO2_LO));
+    const double r2 = __dmul_rn(r, r);
+    double ps = -1.0 / 355687428096000.0;
+    ps = __dadd_rn(__dmul_rn(ps, r2), 1.0 / 1307674368000.0);
+    ps = __dsub_rn(__dmul_rn(ps, r2), 1.0 / 6227020800.0);
+    ps = __dadd_rn(__dmul_rn(ps, r2), 1.0 / 39916800.0);
+    ps = __dsub_rn(__dmul_rn(ps, r2), 1.0 / 362880.0);
+    ps = __dadd_rn(__dmul_rn(ps, r2), 1.0 / 5040.0);
+    ps = __dsub_rn(__dmul_rn(ps, r2), 1.0 / 120.0);
+    ps = __dadd_rn(__dmul_rn(ps, r2), 1.0 / 6.0);
+    const double sn = __dsub_rn(r, __dmul_rn(__dmul_rn(r, r2), ps));
+    double pc = -1.0 / 6402373705728000.0;
+    pc = __dadd_rn(__dmul_rn(pc, r2), 1.0 / 20922789888000.0);
+    pc = __dsub_rn(__dmul_rn(pc, r2), 1.0 / 87178291200.0);
+    pc = __dadd_rn(__dmul_rn(pc, r2), 1.0 / 479001600.0);
+    pc = __dsub_rn(__dmul_rn(pc, r2), 1.0 / 3628800.0);
+    pc = __dadd_rn(__dmul_rn(pc, r2), 1.0 / 40320.0);
+    pc = __dsub_rn(__dmul_rn(pc, r2), 1.0 / 720.0);
+    pc = __dadd_rn(__dmul_rn(pc, r2), 1.0 / 24.0);
+    pc = __dsub_rn(__dmul_rn(pc, r2), 0.5);
+    const double cs = __dadd_rn(1.0, __dmul_rn(r2, pc));
+    const int k = (int)((long long)kd & 3);
+    const double s = (k == 0) ? sn : (k == 1) ? cs : (k == 2) ? -sn : -cs;
+    const double c = (k == 0) ? cs : (k == 1) ? -sn : (k == 2) ? -cs : sn;
+    *s_out = (float)s;
+    *c_out = (float)c;
+}
+
+struct PgGauss7 { int k0, k1, k2, k3; };     // K[0]=K[6]=k0 ... K[3]=k3 (8-bit fixed point)
+
+__global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 G,
+                                                  pgorb_keypoint* __restrict__ kps,
+                                                  uint8_t* __restrict__ desc, int cap_per_frame,
+                                                  int32_t* __restrict__ n_out)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t raw[DW_N * DW_PITCH];
+    __shared__ __attribute__((aligned(16))) uint16_t hbuf[DW_N * DH_PITCH];
+    __shared__ __attribute__((aligned(16))) uint8_t blur[DH_N * DB_PITCH];
+
+    const int lane = threadIdx.x;
+    const int frame = blockIdx.y;
+    int idx = blockIdx.x;
+    // locate (level, index in level) from the per-level keypoint counts
+    const int32_t* kpc = P.kpCount + frame * PG_MAXL;
+    int l = 0, total = 0, before = 0, found = -1, j = 0;
+    for (int q = 0; q < P.nlevels; q++) {
+        const int c = kpc[q];
+        if (found < 0 && idx < total + c) { found = q; before = total; }
+        total += c;
+    }
+    if (blockIdx.x == 0 && lane == 0) n_out[frame] = total;
+    if (found < 0) return;
+    l = found; j = idx - before;
+    const PgLevel& L = P.lvl[l];
+    const uint32_t cv = P.sel[(int64_t)frame * P.selFrame + L.selOff + j];
+    const int x = (int)(cv & 0xFFF) + PG_EDGE, y = (int)((cv >> 12) & 0xFFF) + PG_EDGE;   // :842-843
+    const int resp = (int)(cv >> 24);
+    const uint8_t* img = L.img + (int64_t)frame * L.fstride;
+    const int w = L.w, h = L.h;
+
+    // ---- stage the raw 43x43 window -----------------------------------------------------
+    const int x0 = x - DW_R, y0 = y - DW_R;
+    int shift;
+    if (x0 >= 0 && y0 >= 0 && x + DW_R < w && y + DW_R < h) {
+        const int xa = x0 & ~3;
+        shift = x0 - xa;
+        const int ndw = (shift + DW_N + 3) >> 2;
+        for (int i = lane; i < ndw * DW_N; i += 64) {
+            const int r = i / ndw, q = i - r * ndw;
+            *reinterpret_cast<uint32_t*>(raw + r * DW_PITCH + 4 * q) =
+                *reinterpret_cast<const uint32_t*>(img + (int64_t)(y0 + r) * L.pitch + xa + 4 * q);
+        }
+    } else {                                   // BORDER_REFLECT_101 (:1085)
+        shift = 0;
+        for (int i = lane; i < DW_N * DW_N; i += 64) {
+            const int r = i / DW_N, c = i - r * DW_N;
+            raw[r * DW_PITCH + c] =
+                img[(int64_t)pg_reflect101(y0 + r, h) * L.pitch + pg_reflect101(x0 + c, w)];
+        }
+    }
+    __syncthreads();
+    const uint8_t* rw = raw + shift;           // rw[r*DW_PITCH + c], (r,c) in 0..42, centre (21,21)
+
+    // ---- IC_Angle: integer moments over the radius-15 disc (:77-104) -------------------
+    int m10 = 0, m01 = 0;
+    for (int i = lane; i < 31 * 31; i += 64) {
+        const int vy = i / 31 - 15, ux = i - (i / 31) * 31 - 15;
+        if (abs(ux) <= pg_umax[abs(vy)]) {
+            const int val = rw[(DW_R + vy) * DW_PITCH + DW_R + ux];
+            m10 += ux * val;
+            m01 += vy * val;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        m10 += __shfl_xor(m10, d);
+        m01 += __shfl_xor(m01, d);
+    }
+    const float angle = pg_fast_atan2((float)m01, (float)m10);
+
+    // ---- 7x7 Gaussian, fixed point, separable (OpenCV 2.4 8U path, Appendix A4) ---------
+    for (int i = lane; i < DW_N * DH_N; i += 64) {
+        const int r = i / DH_N, c = i - r * DH_N;
+        const uint8_t* s = rw + r * DW_PITCH + c;
+        const int acc = G.k0 * (s[0] + s[6]) + G.k1 * (s[1] + s[5]) + G.k2 * (s[2] + s[4]) + G.k3 * s[3];
+        hbuf[r * DH_PITCH + c] = (uint16_t)acc;                 // <= 257*255 = 65535
+    }
+    __syncthreads();
+    const int wvec = w & ~3;
+    for (int i = lane; i < DH_N * DH_N; i += 64) {
+        const int r = i / DH_N, c = i - r * DH_N;
+        const uint16_t* s = hbuf + r * DH_PITCH + c;
+        const int C = G.k0 * (s[0] + s[6 * DH_PITCH]) + G.k1 * (s[DH_PITCH] + s[5 * DH_PITCH]) +
+                      G.k2 * (s[2 * DH_PITCH] + s[4 * DH_PITCH]) + G.k3 * s[3 * DH_PITCH];
+        int v = (C + 32768) >> 16;                               // FixedPtCastEx: half up
+        if (P.tieMode == 0 && (C & 0xFFFF) == 0x8000 && (x - 18 + c) < wvec) v &= ~1;   // SSE2: tie -> even
+        blur[r * DB_PITCH + c] = (uint8_t)min(v, 255);
+    }
+    __syncthreads();
+
+    // ---- rBRIEF-256 (:107-147) ------------------------------------------------------------
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    float a, b;
+    pg_sincos_f(__fmul_rn(angle, factorPI), &b, &a);
+    unsigned long long bits[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int8_t* pt = pg_pattern31 + 4 * (64 * r + lane);
+        const float px0 = (float)pt[0], py0 = (float)pt[1], px1 = (float)pt[2], py1 = (float)pt[3];
+        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(px0, b), __fmul_rn(py0, a)));
+        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(px0, a), __fmul_rn(py0, b)));
+        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1, b), __fmul_rn(py1, a)));
+        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(px1, a), __fmul_rn(py1, b)));
+        const int t0 = blur[(18 + r0) * DB_PITCH + 18 + c0];
+        const int t1 = blur[(18 + r1) * DB_PITCH + 18 + c1];
+        bits[r] = __ballot(t0 < t1);
+    }
+
+    // ---- outputs (:836-846, :1094-1102) -----------------------------------------------------
+    if (idx < cap_per_frame && lane == 0) {
+        const int64_t o = (int64_t)frame * cap_per_frame + idx;
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(desc + o * 32);
+        d[0] = bits[0]; d[1] = bits[1]; d[2] = bits[2]; d[3] = bits[3];
+        pgorb_keypoint k;
+        k.x = (l != 0) ? __fmul_rn((float)x, L.scale) : (float)x;
+        k.y = (l != 0) ? __fmul_rn((float)y, L.scale) : (float)y;
+        k.size = L.patchSize;
+        k.angle = angle;
+        k.response = (float)resp;
+        k.octave = l;
+        k.class_id = -1;
+        kps[o] = k;
+    }
+}
+
+static PgGauss7 pg_gauss7()
+{
+    // cv::getGaussianKernel(7, 2, CV_32F) then Mat::convertTo(CV_32S, 256) (Appendix A4)
+    float cf[7];
+    double sum = 0;
+    for (int i = 0; i < 7; i++) {
+        const double xx = i - 3.0;
+        cf[i] = (float)exp(-0.5 / (2.0 * 2.0) * xx * xx);
+        sum += cf[i];
+    }
+    sum = 1. / sum;
+    int K[7];
+    for (int i = 0; i < 7; i++) {
+        cf[i] = (float)(cf[i] * sum);
+        K[i] = (int)lrint((double)(cf[i] * 256.f));
+    }
+    PgGauss7 g = {K[0], K[1], K[2], K[3]};
+    return g;
+}
+
+void pg_launch_describe(const PgPlan& P, int nframes, pgorb_keypoint* d_kps, uint8_t* d_desc,
+                        int cap_per_frame, int32_t* d_n, hipStream_t s)
+{
+    static const PgGauss7 G = pg_gauss7();
+    dim3 grid(P.selTotal, nframes), block(64);
+    hipLaunchKernelGGL(k_describe, grid, block, 0, s, P, G, d_kps, d_desc, cap_per_frame, d_n);
+}

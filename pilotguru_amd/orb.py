@@ -1,0 +1,210 @@
+"""Host-side mirror of the reference's ORB interface over the C ABI.
+
+Names, argument meaning and error behaviour follow
+  ORB_SLAM2::ORBextractor   thirdparty/orb-slam2/include/ORBextractor.h:44-110
+  ORB_SLAM2::ORBmatcher     thirdparty/orb-slam2/include/ORBmatcher.h:44 (DescriptorDistance)
+so the parity tests read like tests of the reference classes.  All compute happens in
+libpgorb.so (HIP, gfx950); numpy / torch only carry buffers.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                           ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+assert KEYPOINT_DTYPE.itemsize == 28
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+class ORBextractor:
+    """ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST) (ORBextractor.h:51-52).
+
+    Extra keyword arguments size the device context (largest frame, frames per batch, GPU).
+    """
+
+    def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, *,
+                 max_width=1920, max_height=1080, max_batch=1, device=0, blur_tie_mode=0):
+        self._L = _lib.lib()
+        self.nfeatures, self.nlevels = int(nfeatures), int(nlevels)
+        self.scaleFactor = float(scaleFactor)
+        self.max_batch = int(max_batch)
+        prm = _lib.PgorbParams(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST,
+                               max_width, max_height, max_batch, device, blur_tie_mode)
+        h = C.c_void_p()
+        rc = self._L.pgorb_create(C.byref(prm), C.byref(h))
+        if rc != 0:
+            raise _lib.PgorbError(rc, self._L.pgorb_last_error(None).decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pgorb_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc < 0:
+            raise _lib.PgorbError(rc, self._L.pgorb_last_error(self._h).decode())
+        return rc
+
+    # ---- getters, ORBextractor.h:63-83 -------------------------------------------------
+    def GetLevels(self):
+        return self._L.pgorb_levels(self._h)
+
+    def GetScaleFactor(self):
+        return self.scaleFactor
+
+    def _tables(self):
+        n = self.nlevels + 1
+        t = [np.zeros(n, np.float32) for _ in range(4)]
+        fp = C.POINTER(C.c_float)
+        self._check(self._L.pgorb_scale_tables(self._h, *[a.ctypes.data_as(fp) for a in t]))
+        return t
+
+    def GetScaleFactors(self):
+        return self._tables()[0]
+
+    def GetInverseScaleFactors(self):
+        return self._tables()[1]
+
+    def GetScaleSigmaSquares(self):
+        return self._tables()[2]
+
+    def GetInverseScaleSigmaSquares(self):
+        return self._tables()[3]
+
+    def features_per_level(self):
+        out = np.zeros(self.nlevels + 1, np.int32)
+        self._check(self._L.pgorb_features_per_level(self._h, out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out
+
+    def max_keypoints(self, w, h):
+        return self._check(self._L.pgorb_max_keypoints(self._h, w, h))
+
+    # ---- operator(), ORBextractor.h:59-61 -----------------------------------------------
+    def __call__(self, image, mask=None):
+        """(keypoints, descriptors) of one CV_8UC1 image.  `mask` is ignored, as in the
+        reference (ORBextractor.h:58).  An empty image returns empty outputs (:1045)."""
+        image = np.asarray(image)
+        if image.size == 0:
+            return np.zeros(0, KEYPOINT_DTYPE), np.zeros((0, 32), np.uint8)
+        if image.dtype != np.uint8 or image.ndim != 2:
+            raise TypeError("image must be CV_8UC1 (2-D uint8)")      # assert(type==CV_8UC1) :1049
+        out = self.extract_batch([image])
+        return out[0]
+
+    def extract_batch(self, frames):
+        frames = [np.ascontiguousarray(f, np.uint8) for f in frames]
+        h, w = frames[0].shape
+        cap = self.max_keypoints(w, h)
+        nfr = len(frames)
+        kps = np.zeros((nfr, cap), KEYPOINT_DTYPE)
+        desc = np.zeros((nfr, cap, 32), np.uint8)
+        n = np.zeros(nfr, np.int32)
+        ptrs = (C.c_void_p * nfr)(*[f.ctypes.data for f in frames])
+        self._check(self._L.pgorb_extract_batch(self._h, ptrs, nfr, w, h, w, _p(kps), _p(desc), cap,
+                                                n.ctypes.data_as(C.POINTER(C.c_int32))))
+        return [(kps[f, :n[f]].copy(), desc[f, :n[f]].copy()) for f in range(nfr)]
+
+    def extract_batch_device(self, frames_u8, kps_out=None, desc_out=None, n_out=None, stream=None):
+        """Resident path: `frames_u8` is a CUDA(HIP) torch uint8 tensor [B, H, W].  Returns torch
+        tensors (kps [B,cap,7] float32 view of pgorb_keypoint, desc [B,cap,32] u8, n [B] i32);
+        asynchronous on `stream` (default: torch's current stream)."""
+        import torch
+        B, H, W = frames_u8.shape
+        cap = self.max_keypoints(W, H)
+        dev = frames_u8.device
+        if kps_out is None:
+            kps_out = torch.empty((B, cap, 7), dtype=torch.float32, device=dev)
+            desc_out = torch.empty((B, cap, 32), dtype=torch.uint8, device=dev)
+            n_out = torch.empty((B,), dtype=torch.int32, device=dev)
+        s = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+        self._check(self._L.pgorb_extract_batch_device(
+            self._h, C.c_void_p(frames_u8.data_ptr()), B, W, H, frames_u8.stride(1),
+            frames_u8.stride(0), C.c_void_p(kps_out.data_ptr()), C.c_void_p(desc_out.data_ptr()),
+            cap, C.c_void_p(n_out.data_ptr()), C.c_void_p(s)))
+        return kps_out, desc_out, n_out
+
+    def check_async(self, stream=None):
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        self._check(self._L.pgorb_check_async(self._h, C.c_void_p(s)))
+
+    def match_batch_device(self, desc, n, pair_query, pair_train, out=None, stream=None):
+        """best/second-best Hamming match of frame pair_query[p] against pair_train[p]."""
+        import torch
+        B, cap, _ = desc.shape
+        npairs = pair_query.numel()
+        dev = desc.device
+        if out is None:
+            out = (torch.empty((npairs, cap), dtype=torch.int32, device=dev),
+                   torch.empty((npairs, cap), dtype=torch.int16, device=dev),
+                   torch.empty((npairs, cap), dtype=torch.int16, device=dev))
+        s = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+        self._check(self._L.pgorb_match_batch_device(
+            self._h, C.c_void_p(desc.data_ptr()), C.c_void_p(n.data_ptr()), cap,
+            C.c_void_p(pair_query.data_ptr()), C.c_void_p(pair_train.data_ptr()), npairs,
+            C.c_void_p(out[0].data_ptr()), C.c_void_p(out[1].data_ptr()),
+            C.c_void_p(out[2].data_ptr()), C.c_void_p(s)))
+        return out
+
+    # ---- stage taps (parity tests) --------------------------------------------------------
+    def debug_level_size(self, level):
+        w, h = C.c_int32(), C.c_int32()
+        self._check(self._L.pgorb_debug_level_size(self._h, level, C.byref(w), C.byref(h)))
+        return w.value, h.value
+
+    def debug_level_image(self, frame, level):
+        w, h = self.debug_level_size(level)
+        out = np.zeros((h, w), np.uint8)
+        self._check(self._L.pgorb_debug_level_image(self._h, frame, level, _p(out)))
+        return out
+
+    def debug_level_candidates(self, frame, level):
+        w, h = self.debug_level_size(level)
+        cap = w * h // 2 + 64
+        x, y, r = (np.zeros(cap, np.int32) for _ in range(3))
+        n = self._check(self._L.pgorb_debug_level_candidates(self._h, frame, level, _p(x), _p(y), _p(r), cap))
+        return x[:n].copy(), y[:n].copy(), r[:n].copy()
+
+    def debug_level_keypoints(self, frame, level):
+        return self._check(self._L.pgorb_debug_level_keypoints(self._h, frame, level))
+
+    # ---- Hamming (device) -------------------------------------------------------------------
+    def hamming_matrix(self, a, b):
+        a = np.ascontiguousarray(a, np.uint8).reshape(-1, 32)
+        b = np.ascontiguousarray(b, np.uint8).reshape(-1, 32)
+        out = np.zeros((len(a), len(b)), np.uint16)
+        self._check(self._L.pgorb_hamming_matrix(self._h, _p(a), len(a), _p(b), len(b), _p(out)))
+        return out
+
+    def hamming_best2(self, a, b):
+        a = np.ascontiguousarray(a, np.uint8).reshape(-1, 32)
+        b = np.ascontiguousarray(b, np.uint8).reshape(-1, 32)
+        bi = np.zeros(len(a), np.int32)
+        b1 = np.zeros(len(a), np.uint16)
+        b2 = np.zeros(len(a), np.uint16)
+        self._check(self._L.pgorb_hamming_best2(self._h, _p(a), len(a), _p(b), len(b), _p(bi), _p(b1), _p(b2)))
+        return bi, b1, b2
+
+
+class ORBmatcher:
+    """Static helper mirroring ORBmatcher::DescriptorDistance (ORBmatcher.h:44)."""
+
+    @staticmethod
+    def DescriptorDistance(a, b):
+        a = np.frombuffer(bytes(a), np.uint8) if isinstance(a, (bytes, bytearray)) else a
+        b = np.frombuffer(bytes(b), np.uint8) if isinstance(b, (bytes, bytearray)) else b
+        a = np.ascontiguousarray(a, np.uint8).reshape(32)
+        b = np.ascontiguousarray(b, np.uint8).reshape(32)
+        return _lib.lib().pgorb_descriptor_distance(_p(a), _p(b))

@@ -1,0 +1,141 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Bit-exact is the bar: keypoint position / octave / angle / response bytes and
+256-bit descriptors identical, Hamming scores integer-equal."""
+import numpy as np
+import pytest
+
+from pilotguru_amd.synth import synth_ride, synth_scene
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # (w, h, nfeatures, seed)
+    (320, 240, 500, 1),
+    (640, 480, 1000, 0),
+    (641, 479, 1000, 3),       # odd sizes: unaligned pitches, w & 3 != 0 blur tail
+    (1280, 720, 1500, 2),
+]
+
+
+def _make(nfeatures, w, h, batch=1, **kw):
+    import pilotguru_amd as pg
+    return pg.ORBextractor(nfeatures, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=batch, **kw)
+
+
+@pytest.mark.parametrize("w,h,nf,seed", CASES)
+def test_stages_and_output_bit_exact(oracle, w, h, nf, seed):
+    img = synth_scene(seed, w, h)
+    ora = oracle.OrbOracle(nf, 1.2, 8, 20, 7)
+    okp, odesc = ora.extract(img)
+    ext = _make(nf, w, h)
+    kp, desc = ext(img)
+    # constructor tables
+    assert np.array_equal(ext.GetScaleFactors().view(np.uint32), ora.scale_factors.view(np.uint32))
+    assert np.array_equal(ext.GetInverseScaleFactors().view(np.uint32), ora.inv_scale_factors.view(np.uint32))
+    assert np.array_equal(ext.GetScaleSigmaSquares().view(np.uint32), ora.level_sigma2.view(np.uint32))
+    assert np.array_equal(ext.GetInverseScaleSigmaSquares().view(np.uint32), ora.inv_level_sigma2.view(np.uint32))
+    assert np.array_equal(ext.features_per_level(), ora.features_per_level)
+    for l in range(8):
+        # K1 pyramid
+        assert ext.debug_level_size(l) == ora.level_size(l)
+        assert np.array_equal(ext.debug_level_image(0, l), ora.level_image(l)), "pyramid level %d" % l
+        # K2 candidates: same set (device order is arbitrary)
+        x, y, r = ext.debug_level_candidates(0, l)
+        oc = ora.level_candidates(l)
+        got = sorted(zip(y.tolist(), x.tolist(), r.tolist()))
+        exp = sorted(zip(oc["y"].tolist(), oc["x"].tolist(), oc["response"].tolist()))
+        assert got == exp, "FAST candidates level %d" % l
+        # K3 count
+        assert ext.debug_level_keypoints(0, l) == ora.level_keypoints(l), "quadtree count level %d" % l
+    # K3 order + K4 angle + output assembly
+    assert len(kp) == len(okp)
+    assert kp.tobytes() == okp.tobytes()
+    # K5/K6 descriptors
+    assert np.array_equal(desc, odesc)
+
+
+def test_batch_device_resident_matches_oracle(oracle):
+    import torch
+    w, h, nf, B = 640, 480, 1000, 4
+    ride = synth_ride(5, w, h, B)
+    ext = _make(nf, w, h, batch=B)
+    frames = torch.from_numpy(ride).cuda()
+    kps, desc, n = ext.extract_batch_device(frames)
+    ext.check_async()
+    torch.cuda.synchronize()
+    n = n.cpu().numpy()
+    ora = oracle.OrbOracle(nf, 1.2, 8, 20, 7)
+    kps_h = kps.cpu().numpy()
+    desc_h = desc.cpu().numpy()
+    descs = []
+    for f in range(B):
+        okp, odesc = ora.extract(ride[f])
+        assert n[f] == len(okp)
+        assert kps_h[f, :n[f]].tobytes() == okp.tobytes()
+        assert np.array_equal(desc_h[f, :n[f]], odesc)
+        descs.append(odesc)
+    # K7: consecutive-frame best-2 match, integer-equal
+    pq = torch.arange(1, B, dtype=torch.int32, device="cuda")
+    pt = torch.arange(0, B - 1, dtype=torch.int32, device="cuda")
+    bi, b1, b2 = ext.match_batch_device(desc, torch.from_numpy(n).cuda(), pq, pt)
+    torch.cuda.synchronize()
+    for p in range(B - 1):
+        obi, ob1, ob2 = oracle.hamming_best2(descs[p + 1], descs[p])
+        m = len(descs[p + 1])
+        assert np.array_equal(bi[p, :m].cpu().numpy(), obi)
+        assert np.array_equal(b1[p, :m].cpu().numpy().view(np.uint16), ob1)
+        assert np.array_equal(b2[p, :m].cpu().numpy().view(np.uint16), ob2)
+
+
+def test_unaligned_device_input_copy_path(oracle):
+    import torch
+    w, h, nf = 322, 242, 300
+    img = synth_scene(11, w, h)
+    buf = torch.zeros(1 + w * h, dtype=torch.uint8, device="cuda")
+    view = buf[1:].view(1, h, w)                      # base pointer % 4 == 1 -> copy path
+    view.copy_(torch.from_numpy(img).cuda())
+    ext = _make(nf, w, h)
+    kps, desc, n = ext.extract_batch_device(view)
+    ext.check_async()
+    okp, odesc = oracle.OrbOracle(nf, 1.2, 8, 20, 7).extract(img)
+    n0 = int(n[0])
+    assert n0 == len(okp)
+    assert kps[0, :n0].cpu().numpy().tobytes() == okp.tobytes()
+    assert np.array_equal(desc[0, :n0].cpu().numpy(), odesc)
+
+
+def test_hamming_matrix_and_best2(oracle):
+    rng = np.random.RandomState(7)
+    a = rng.randint(0, 256, (777, 32)).astype(np.uint8)
+    b = rng.randint(0, 256, (1033, 32)).astype(np.uint8)
+    b[5] = a[3]
+    b[700] = a[3]                                    # duplicate minimum: first index must win
+    ext = _make(100, 320, 240)
+    assert np.array_equal(ext.hamming_matrix(a, b), oracle.hamming_matrix(a, b))
+    bi, b1, b2 = ext.hamming_best2(a, b)
+    obi, ob1, ob2 = oracle.hamming_best2(a, b)
+    assert np.array_equal(bi, obi) and np.array_equal(b1, ob1) and np.array_equal(b2, ob2)
+    assert bi[3] == 5 and b1[3] == 0 and b2[3] == 0
+    # edge cases: single train descriptor, empty train set
+    bi, b1, b2 = ext.hamming_best2(a[:10], b[:1])
+    assert np.all(bi == 0) and np.all(b2 == 65535)
+    bi, b1, b2 = ext.hamming_best2(a[:10], b[:0])
+    assert np.all(bi == -1) and np.all(b1 == 65535)
+
+
+def test_errors_and_edge_cases():
+    import pilotguru_amd as pg
+    from pilotguru_amd._lib import PGORB_E_LIMIT, PGORB_E_TOOSMALL, PgorbError
+    ext = _make(500, 320, 240)
+    k, d = ext(np.zeros((0, 0), np.uint8))           # empty image: silent empty result (:1045)
+    assert len(k) == 0 and d.shape == (0, 32)
+    k, d = ext(np.full((240, 320), 128, np.uint8))   # flat image: no corners anywhere
+    assert len(k) == 0
+    with pytest.raises(PgorbError) as e:
+        ext(np.zeros((100, 100), np.uint8))          # level 7 would have no 30-px cell
+    assert e.value.code == PGORB_E_TOOSMALL
+    with pytest.raises(PgorbError) as e:
+        ext(np.zeros((480, 640), np.uint8))
+    assert e.value.code == PGORB_E_LIMIT
+    with pytest.raises(TypeError):
+        ext(np.zeros((240, 320), np.float32))
