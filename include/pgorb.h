@@ -130,6 +130,16 @@ int  pgorb_match_batch_device(pgorb_ctx* ctx, const uint8_t* d_desc, const int32
                               int32_t* d_best_idx, uint16_t* d_best, uint16_t* d_second,
                               void* hip_stream);
 
+/* Per-stage device timing with HIP events recorded on the launch stream around the kernel
+ * groups of every *_device call: stage 0 = pyramid chain (K1, nlevels-1 launches), 1 = FAST
+ * cells (K2), 2 = quadtree (K3), 3 = orientation+blur+rBRIEF (K4-6), 4 = Hamming match (K7).
+ * pgorb_profile_begin arms up to max_calls calls (0 disarms); pgorb_profile_read synchronises,
+ * writes the mean milliseconds per call of each stage into ms[5] and returns the number of
+ * calls averaged. */
+#define PGORB_NSTAGES 5
+int  pgorb_profile_begin(pgorb_ctx* ctx, int max_calls);
+int  pgorb_profile_read(pgorb_ctx* ctx, double* ms);
+
 /* Stage taps for parity tests (host buffers, synchronous; operate on the LAST batch). */
 int  pgorb_debug_level_size(const pgorb_ctx* ctx, int level, int* w, int* h);
 int  pgorb_debug_level_image(pgorb_ctx* ctx, int frame, int level, uint8_t* out /* w*h */);

@@ -20,7 +20,7 @@ SYMBOLS = (
     "pgorb_extract_batch_device", "pgorb_check_async", "pgorb_descriptor_distance",
     "pgorb_hamming_matrix", "pgorb_hamming_best2", "pgorb_match_batch_device",
     "pgorb_debug_level_size", "pgorb_debug_level_image", "pgorb_debug_level_candidates",
-    "pgorb_debug_level_keypoints",
+    "pgorb_debug_level_keypoints", "pgorb_profile_begin", "pgorb_profile_read",
 )
 
 
@@ -47,6 +47,14 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s is missing: build it with `make -C pilotguru_amd/csrc` "
                           "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 (+ HSA).  If
+    # libpgorb.so pulled in /opt/rocm's copy first, torch would later load a SECOND runtime and
+    # see no GPUs.  Importing torch first makes the loader satisfy our DT_NEEDED
+    # libamdhip64.so.7 with the already-loaded copy (same SONAME).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32p, fp = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float)
     L.pgorb_create.restype = C.c_int
@@ -73,6 +81,8 @@ def lib():
     L.pgorb_debug_level_image.argtypes = [vp, C.c_int, C.c_int, vp]
     L.pgorb_debug_level_candidates.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int]
     L.pgorb_debug_level_keypoints.argtypes = [vp, C.c_int, C.c_int]
+    L.pgorb_profile_begin.argtypes = [vp, C.c_int]
+    L.pgorb_profile_read.argtypes = [vp, C.POINTER(C.c_double)]
     for name in SYMBOLS:
         if name not in ("pgorb_destroy", "pgorb_last_error"):
             getattr(L, name).restype = C.c_int

@@ -44,6 +44,10 @@ struct pgorb_ctx {
     Arena stageKps, stageDesc, stageN, stageA, stageB, stageOut;
     int lastFrames = 0;
     bool lastAliased = false;
+    // stage profiling (HIP events on the launch stream)
+    std::vector<hipEvent_t> evExtract;        // 5 per armed extract call
+    std::vector<hipEvent_t> evMatch;          // 2 per armed match call
+    int profMax = 0, profExtract = 0, profMatch = 0;
 };
 
 namespace {
@@ -259,10 +263,16 @@ int run_batch(pgorb_ctx* c, const uint8_t* d_gray, bool resident_in_level0, int 
         }
     }
     PG_HIP(c, hipMemsetAsync(P.candCount, 0, (size_t)c->planBatch * PG_MAXL * 4 * 2 + 4, s));
+    hipEvent_t* ev = (c->profExtract < c->profMax) ? &c->evExtract[5 * (size_t)c->profExtract] : nullptr;
+    if (ev) PG_HIP(c, hipEventRecord(ev[0], s));
     for (int l = 1; l < P.nlevels; l++) pg_launch_pyramid_level(P, l, nframes, s);
+    if (ev) PG_HIP(c, hipEventRecord(ev[1], s));
     pg_launch_fast(P, nframes, s);
+    if (ev) PG_HIP(c, hipEventRecord(ev[2], s));
     pg_launch_quadtree(P, nframes, s);
+    if (ev) PG_HIP(c, hipEventRecord(ev[3], s));
     pg_launch_describe(P, nframes, d_kps, d_desc, cap_per_frame, d_n, s);
+    if (ev) { PG_HIP(c, hipEventRecord(ev[4], s)); c->profExtract++; }
     PG_HIP(c, hipGetLastError());
     c->lastFrames = nframes;
     return 0;
@@ -329,6 +339,8 @@ void pgorb_destroy(pgorb_ctx* c)
     Arena* all[] = {&c->pyr, &c->cand, &c->kpos, &c->sel, &c->nodes, &c->counters, &c->tables,
                     &c->stageKps, &c->stageDesc, &c->stageN, &c->stageA, &c->stageB, &c->stageOut};
     for (Arena* a : all) if (a->p) (void)hipFree(a->p);
+    for (hipEvent_t e : c->evExtract) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->evMatch) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -507,9 +519,50 @@ int pgorb_match_batch_device(pgorb_ctx* c, const uint8_t* d_desc, const int32_t*
     if (!d_desc || !d_n || cap < 1 || npairs < 0 || (npairs && (!d_pq || !d_pt || !d_best_idx || !d_best || !d_second)))
         return fail(c, PGORB_E_ARG, "bad argument to pgorb_match_batch_device");
     PG_HIP(c, hipSetDevice(c->prm.device));
+    hipEvent_t* ev = (c->profMatch < c->profMax) ? &c->evMatch[2 * (size_t)c->profMatch] : nullptr;
+    if (ev) PG_HIP(c, hipEventRecord(ev[0], (hipStream_t)stream));
     pg_launch_match_batch(d_desc, d_n, cap, d_pq, d_pt, npairs, d_best_idx, d_best, d_second, (hipStream_t)stream);
+    if (ev) { PG_HIP(c, hipEventRecord(ev[1], (hipStream_t)stream)); c->profMatch++; }
     PG_HIP(c, hipGetLastError());
     return 0;
+}
+
+int pgorb_profile_begin(pgorb_ctx* c, int max_calls)
+{
+    if (!c || max_calls < 0) return PGORB_E_ARG;
+    PG_HIP(c, hipSetDevice(c->prm.device));
+    while ((int)c->evExtract.size() < 5 * max_calls) {
+        hipEvent_t e; PG_HIP(c, hipEventCreate(&e)); c->evExtract.push_back(e);
+    }
+    while ((int)c->evMatch.size() < 2 * max_calls) {
+        hipEvent_t e; PG_HIP(c, hipEventCreate(&e)); c->evMatch.push_back(e);
+    }
+    c->profMax = max_calls; c->profExtract = 0; c->profMatch = 0;
+    return 0;
+}
+
+int pgorb_profile_read(pgorb_ctx* c, double* ms)
+{
+    if (!c || !ms) return PGORB_E_ARG;
+    PG_HIP(c, hipSetDevice(c->prm.device));
+    PG_HIP(c, hipDeviceSynchronize());
+    for (int i = 0; i < PGORB_NSTAGES; i++) ms[i] = 0;
+    for (int k = 0; k < c->profExtract; k++)
+        for (int st = 0; st < 4; st++) {
+            float t = 0;
+            PG_HIP(c, hipEventElapsedTime(&t, c->evExtract[5 * (size_t)k + st], c->evExtract[5 * (size_t)k + st + 1]));
+            ms[st] += t;
+        }
+    for (int k = 0; k < c->profMatch; k++) {
+        float t = 0;
+        PG_HIP(c, hipEventElapsedTime(&t, c->evMatch[2 * (size_t)k], c->evMatch[2 * (size_t)k + 1]));
+        ms[4] += t;
+    }
+    for (int st = 0; st < 4; st++) if (c->profExtract) ms[st] /= c->profExtract;
+    if (c->profMatch) ms[4] /= c->profMatch;
+    const int n = c->profExtract;
+    c->profMax = 0;
+    return n;
 }
 
 // ---- stage taps -----------------------------------------------------------------------------

@@ -158,6 +158,17 @@ class ORBextractor:
             C.c_void_p(out[2].data_ptr()), C.c_void_p(s)))
         return out
 
+    STAGES = ("pyramid", "fast", "quadtree", "describe", "match")
+
+    def profile_begin(self, max_calls):
+        self._check(self._L.pgorb_profile_begin(self._h, max_calls))
+
+    def profile_read(self):
+        """{stage: mean ms per call} measured with HIP events on the launch stream."""
+        ms = (C.c_double * 5)()
+        n = self._check(self._L.pgorb_profile_read(self._h, ms))
+        return n, dict(zip(self.STAGES, list(ms)))
+
     # ---- stage taps (parity tests) --------------------------------------------------------
     def debug_level_size(self, level):
         w, h = C.c_int32(), C.c_int32()
