@@ -103,7 +103,8 @@ def main():
     ext = pg.ORBextractor(NF, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B, device=local_rank)
 
     # one ride per rank (ride id = rank): B consecutive frames, resident in HBM
-    ride = synth_ride(rank, W, H, B)
+    from pilotguru_amd import dist as pgd0
+    ride = synth_ride(pgd0.ride_for_rank(rank, world)[0], W, H, B)
     frames = torch.from_numpy(ride).to(dev)
     cap = ext.max_keypoints(W, H)
     kps = torch.empty((B, cap, 7), dtype=torch.float32, device=dev)
@@ -118,13 +119,11 @@ def main():
     # the one collective of this path: broadcast the (synthetic) ORB vocabulary root -> peers
     vocab_bytes = 0
     if world > 1:
+        from pilotguru_amd import dist as pgd
         from pilotguru_amd.vocab import synth_vocabulary_blob
         blob = synth_vocabulary_blob(k=10, L=5, seed=7) if rank == 0 else None
-        nbytes = torch.tensor([0 if blob is None else blob.numel()], dtype=torch.int64, device=dev)
-        dist.broadcast(nbytes, 0)
-        vt = blob.to(dev) if rank == 0 else torch.empty(int(nbytes.item()), dtype=torch.uint8, device=dev)
-        dist.broadcast(vt, 0)
-        vocab_bytes = int(nbytes.item())
+        vocab = pgd.broadcast_vocabulary(blob, 0, dev)
+        vocab_bytes = int(vocab.numel())
 
     def step():
         ext.extract_batch_device(frames, kps, desc, n)
@@ -149,9 +148,8 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        from pilotguru_amd import dist as pgd
+        elapsed = pgd.max_over_ranks(elapsed, dev)
     ncalls, stage_ms = ext.profile_read()
     ext.check_async()
 

@@ -1,0 +1,365 @@
+"""CPU tests of the oracle: known answers, committed regression vectors, and independent
+numpy restatements of the OpenCV-2.4 stages (so a typo in the C oracle cannot hide).
+
+The reference's own tests hold no vector for this path and the reference
+cannot be built here, so the oracle is PARITY-UNPINNED against a real OpenCV 2.4.9 binary."""
+import glob
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+# ---------------------------------------------------------------- known answers
+def test_pattern_table_hash():
+    """sha256 of bit_pattern_31_ (ORBextractor.cc:150-408) as int8[1024]."""
+    want = "2164181aea6ff9ac426ca512d5130d15e1f6e3cd47b1cbdd568bbe1e55d49023"
+    for path in ("oracle/orb_pattern31.inc", "pilotguru_amd/csrc/orb_pattern31.inc"):
+        txt = open(os.path.join(HERE, "..", path)).read()
+        body = txt[txt.index("*/") + 2:]
+        vals = [int(v) for v in body.replace("\n", " ").split(",") if v.strip()]
+        assert len(vals) == 1024
+        assert vals[:4] == [8, -3, 9, 5] and vals[-4:] == [-1, -6, 0, -11]
+        assert max(abs(v) for v in vals) == 13
+        assert hashlib.sha256(bytes(v & 0xFF for v in vals)).hexdigest() == want
+
+
+def test_constructor_tables(oracle):
+    """Quotas / umax evaluated from ORBextractor.cc:415-469."""
+    o = oracle.OrbOracle(2000, 1.2, 8, 20, 7)
+    assert o.features_per_level.tolist() == [434, 362, 302, 251, 209, 175, 145, 121, 1]
+    assert oracle.OrbOracle(4000).features_per_level.tolist()[:8] == [869, 724, 603, 503, 419, 349, 291, 242]
+    assert oracle.OrbOracle(1000).features_per_level.tolist()[:8] == [217, 181, 151, 126, 105, 87, 73, 61]
+    assert o.umax.tolist() == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    sf = o.scale_factors
+    assert sf[0] == 1.0 and sf[1] == np.float32(1.2)
+    acc = np.float32(1.0)
+    for i in range(1, 9):                       # float * double -> float  (:421)
+        acc = np.float32(np.float64(acc) * np.float64(np.float32(1.2)))
+        assert sf[i] == acc
+    assert np.array_equal(o.inv_scale_factors, (np.float32(1.0) / sf).astype(np.float32))
+
+
+def test_level_sizes_1080p_and_480p(oracle):
+    """Level sizes quoted in SURVEY.md section 8 (cvRound((float)cols*invScale), :1110-1111)."""
+    inv = oracle.OrbOracle(2000).inv_scale_factors
+    got = [(int(np.rint(np.float32(1920) * inv[l])), int(np.rint(np.float32(1080) * inv[l]))) for l in range(8)]
+    assert got == [(1920, 1080), (1600, 900), (1333, 750), (1111, 625), (926, 521), (772, 434), (643, 362), (536, 301)]
+    assert sum(a * b for a, b in got) == 6419321
+    got = [(int(np.rint(np.float32(640) * inv[l])), int(np.rint(np.float32(480) * inv[l]))) for l in range(8)]
+    assert sum(a * b for a, b in got) == 950532
+
+
+def test_descriptor_distance_kats(oracle):
+    z, o = np.zeros(32, np.uint8), np.full(32, 255, np.uint8)
+    assert oracle.descriptor_distance(z, z) == 0
+    assert oracle.descriptor_distance(z, o) == 256
+    for bit in (0, 7, 8, 100, 255):
+        a = z.copy()
+        a[bit // 8] = 1 << (bit % 8)
+        assert oracle.descriptor_distance(a, z) == 1
+        assert oracle.descriptor_distance(a, o) == 255
+    rng = np.random.RandomState(1)
+    a = rng.randint(0, 256, (50, 32)).astype(np.uint8)
+    b = rng.randint(0, 256, (60, 32)).astype(np.uint8)
+    want = np.unpackbits(a[:, None, :] ^ b[None, :, :], axis=2).sum(2)
+    assert np.array_equal(oracle.hamming_matrix(a, b), want)
+    bi, b1, b2 = oracle.hamming_best2(a, b)
+    assert np.array_equal(bi, want.argmin(1))            # argmin = first minimum
+    assert np.array_equal(b1, want.min(1))
+    assert np.array_equal(b2, np.sort(want, 1)[:, 1])
+
+
+def test_fast_atan2_known_points(oracle):
+    f = oracle.fast_atan2
+    assert f(0, 0) == 0.0
+    assert abs(f(0, 1) - 0) < 1e-3 and abs(f(1, 0) - 90) < 1e-3
+    assert abs(f(0, -1) - 180) < 1e-3 and abs(f(-1, 0) - 270) < 1e-3
+    for y, x in ((1, 1), (3, -2), (-5, -7), (-2, 9), (1000, 1), (-1, 1000)):
+        true = np.degrees(np.arctan2(y, x)) % 360
+        assert abs(f(y, x) - true) < 0.02            # polynomial accuracy of cv::fastAtan2
+
+
+def test_sincos_contract_close_to_libm(oracle):
+    """The parity-contract sin/cos is within 1 float ulp of libm everywhere on [0, 2pi]."""
+    for a in np.linspace(0, 2 * np.pi, 4001).astype(np.float32):
+        s, c = oracle.sincos_f(a)
+        assert abs(np.float32(s) - np.float32(np.sin(np.float64(a)))) <= np.spacing(np.float32(1.0))
+        assert abs(np.float32(c) - np.float32(np.cos(np.float64(a)))) <= np.spacing(np.float32(1.0))
+
+
+def test_rgb_to_gray(oracle):
+    rng = np.random.RandomState(0)
+    rgb = rng.randint(0, 256, (9, 13, 3)).astype(np.uint8)
+    want = ((rgb[..., 0].astype(np.int64) * 4899 + rgb[..., 1].astype(np.int64) * 9617 +
+             rgb[..., 2].astype(np.int64) * 1868 + 8192) >> 14).astype(np.uint8)
+    assert np.array_equal(oracle.rgb_to_gray(rgb), want)
+
+
+# ---------------------------------------------------------------- independent restatements
+def _np_resize(src, dw, dh):
+    """cv::resize INTER_LINEAR 8U, vectorised numpy."""
+    sh, sw = src.shape
+
+    def coef(d, s):
+        scale = 1.0 / (np.float64(d) / s)
+        f = ((np.arange(d) + 0.5) * scale - 0.5).astype(np.float32)
+        i = np.floor(f).astype(np.int64)
+        f = (f - i.astype(np.float32)).astype(np.float32)
+        return i, f
+    sx, fx = coef(dw, sw)
+    fx = np.where((sx < 0) | (sx >= sw - 1), np.float32(0), fx)
+    sx = np.clip(sx, 0, sw - 1)
+    sx1 = np.minimum(sx + 1, sw - 1)
+    a0 = np.rint(((np.float32(1) - fx) * np.float32(2048)).astype(np.float64)).astype(np.int64)
+    a1 = np.rint((fx * np.float32(2048)).astype(np.float64)).astype(np.int64)
+    sy, fy = coef(dh, sh)
+    b0 = np.rint(((np.float32(1) - fy) * np.float32(2048)).astype(np.float64)).astype(np.int64)
+    b1 = np.rint((fy * np.float32(2048)).astype(np.float64)).astype(np.int64)
+    r0, r1 = np.clip(sy, 0, sh - 1), np.clip(sy + 1, 0, sh - 1)
+    S = src.astype(np.int64)
+    H0 = S[r0][:, sx] * a0 + S[r0][:, sx1] * a1
+    H1 = S[r1][:, sx] * a0 + S[r1][:, sx1] * a1
+    out = (((b0[:, None] * (H0 >> 4)) >> 16) + ((b1[:, None] * (H1 >> 4)) >> 16) + 2) >> 2
+    return out.astype(np.uint8)
+
+
+@pytest.mark.parametrize("sw,sh,dw,dh", [(640, 480, 533, 400), (97, 61, 81, 51), (33, 20, 40, 31), (10, 10, 5, 3)])
+def test_resize_vs_numpy(oracle, sw, sh, dw, dh):
+    rng = np.random.RandomState(sw + dh)
+    src = rng.randint(0, 256, (sh, sw)).astype(np.uint8)
+    assert np.array_equal(oracle.resize_linear(src, dw, dh), _np_resize(src, dw, dh))
+
+
+def _np_blur(img, tie_mode):
+    t = np.exp(-0.125 * (np.arange(7) - 3.0) ** 2).astype(np.float32)
+    k = (t.astype(np.float64) / t.astype(np.float64).sum()).astype(np.float32)
+    K = np.rint((k * np.float32(256)).astype(np.float64)).astype(np.int64)
+    assert K.tolist() == [18, 34, 49, 55, 49, 34, 18]
+    p = np.pad(img.astype(np.int64), 3, mode="reflect")          # numpy 'reflect' == REFLECT_101
+    h, w = img.shape
+    R = sum(K[i] * p[:, i:i + w] for i in range(7))
+    C = sum(K[i] * R[i:i + h, :] for i in range(7))
+    v = (C + 32768) >> 16
+    if tie_mode == 0:
+        tie = ((C & 0xFFFF) == 0x8000) & (np.arange(w)[None, :] < (w & ~3))
+        v = np.where(tie, v & ~1, v)
+    return np.minimum(v, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("tie", [0, 1])
+def test_blur_vs_numpy(oracle, tie):
+    rng = np.random.RandomState(3)
+    for (h, w) in ((40, 61), (7, 9), (64, 64)):
+        img = rng.randint(0, 256, (h, w)).astype(np.uint8)
+        assert np.array_equal(oracle.gaussian_blur7(img, tie), _np_blur(img, tie))
+    # an exact tie: constant 128 everywhere -> C = 257*257*128 = 8454272 -> 129.0019, no tie;
+    # craft one: R=32768/... use brute search for a tie value on a synthetic image
+    img = np.zeros((16, 16), np.uint8)
+    img[:] = 255
+    assert np.all(oracle.gaussian_blur7(img, tie) == 255)          # saturate_cast
+
+
+_RING = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2),
+         (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+
+
+def _py_fast(img, t):
+    """FAST-9/16 + score + NMS straight from the definition (slow, tiny windows only)."""
+    h, w = img.shape
+    score = np.zeros((h, w), np.int64)
+    I = img.astype(np.int64)
+    for y in range(3, h - 3):
+        for x in range(3, w - 3):
+            v = I[y, x]
+            ring = [I[y + dy, x + dx] for dx, dy in _RING]
+            best = -1
+            for sgn in (1, -1):
+                d = [sgn * (v - r) for r in ring]
+                for k in range(16):
+                    m = min(d[(k + j) % 16] for j in range(9))
+                    if m > t:
+                        best = max(best, m - 1)
+            if best >= 0:
+                score[y, x] = best
+    out = []
+    for y in range(3, h - 3):
+        for x in range(3, w - 3):
+            s = score[y, x]
+            if s and all(s > score[y + dy, x + dx] for dy in (-1, 0, 1) for dx in (-1, 0, 1) if dx or dy):
+                out.append((x, y, s))
+    return out
+
+
+def test_fast_vs_definition(oracle):
+    from pilotguru_amd.synth import synth_scene
+    img = synth_scene(4, 160, 120)
+    for (x0, y0, ww, hh, t) in ((10, 10, 37, 37, 20), (60, 40, 36, 31, 7), (100, 70, 41, 20, 7), (0, 0, 7, 7, 7)):
+        win = img[y0:y0 + hh, x0:x0 + ww]
+        got = oracle.fast9_nms(win, t)
+        want = _py_fast(win, t)
+        assert [(int(c["x"]), int(c["y"]), int(c["response"])) for c in got] == want
+    assert len(oracle.fast9_nms(img[:6, :40], 7)) == 0         # windows under 7 px find nothing
+
+
+def _py_octtree(cand, minX, maxX, minY, maxY, N):
+    """DistributeOctTree (ORBextractor.cc:539-763) with Python lists; tie rule of the parity
+    contract: equal sizes -> later created node first."""
+    nIni = int(np.floor(np.float32(maxX - minX) / np.float32(maxY - minY) + np.float32(0.5)))
+    hX = np.float32(maxX - minX) / np.float32(nIni)
+    seq = [0]
+
+    def node(ULx, ULy, URx, BRy, keys):
+        seq[0] += 1
+        return {"b": (ULx, ULy, URx, BRy), "k": keys, "s": seq[0], "nomore": len(keys) == 1}
+    roots = [node(int(hX * np.float32(i)), 0, int(hX * np.float32(i + 1)), maxY - minY, []) for i in range(nIni)]
+    for i, (x, y, r) in enumerate(cand):
+        roots[int(np.float32(x) / hX)]["k"].append(i)
+    L = [n for n in roots if n["k"]]
+    for n in L:
+        n["nomore"] = len(n["k"]) == 1
+
+    def divide(n):
+        ULx, ULy, URx, BRy = n["b"]
+        hx = int(np.ceil(np.float32(URx - ULx) / 2))
+        hy = int(np.ceil(np.float32(BRy - ULy) / 2))
+        mx, my = ULx + hx, ULy + hy
+        ks = [[], [], [], []]
+        for i in n["k"]:
+            x, y, _ = cand[i]
+            ks[(0 if y < my else 2) if x < mx else (1 if y < my else 3)].append(i)
+        bs = [(ULx, ULy, mx, my), (mx, ULy, URx, my), (ULx, my, mx, BRy), (mx, my, URx, BRy)]
+        return [node(*bs[q], ks[q]) for q in range(4)]
+    finish = False
+    while not finish:
+        prev = len(L)
+        vec, nexp, newL, i = [], 0, [], 0
+        front = []
+        for n in list(L):
+            if n["nomore"]:
+                continue
+            for ch in divide(n):
+                if ch["k"]:
+                    front.insert(0, ch)
+                    if len(ch["k"]) > 1:
+                        nexp += 1
+                        vec.append(ch)
+            L.remove(n)
+        L = front + L
+        if len(L) >= N or len(L) == prev:
+            finish = True
+        elif len(L) + 3 * nexp > N:
+            while not finish:
+                prev = len(L)
+                pv = sorted(vec, key=lambda n: (len(n["k"]), n["s"]))
+                vec = []
+                for n in reversed(pv):
+                    for ch in divide(n):
+                        if ch["k"]:
+                            L.insert(0, ch)
+                            if len(ch["k"]) > 1:
+                                vec.append(ch)
+                    L.remove(n)
+                    if len(L) >= N:
+                        break
+                if len(L) >= N or len(L) == prev:
+                    finish = True
+    out = []
+    for n in L:
+        best = n["k"][0]
+        for i in n["k"][1:]:
+            if cand[i][2] > cand[best][2]:
+                best = i
+        out.append(best)
+    return out
+
+
+def test_octtree_vs_python_lists(oracle):
+    rng = np.random.RandomState(5)
+    for (W, H, n, N) in ((288, 208, 900, 100), (600, 200, 3000, 217), (100, 100, 40, 60), (300, 120, 5, 30),
+                         (288, 208, 2500, 61), (500, 90, 700, 120)):
+        pts = set()
+        while len(pts) < n:
+            pts.add((int(rng.randint(3, W - 3)), int(rng.randint(3, H - 3))))
+        pts = sorted(pts, key=lambda p: (p[1], p[0]))
+        cand = np.zeros(n, oracle.CAND_DTYPE)
+        cand["x"] = [p[0] for p in pts]
+        cand["y"] = [p[1] for p in pts]
+        cand["response"] = rng.randint(7, 40, n)              # many response ties
+        got = oracle.distribute_octtree(cand, 16, 16 + W, 16, 16 + H, N)
+        want = _py_octtree([(int(c["x"]), int(c["y"]), int(c["response"])) for c in cand], 16, 16 + W, 16, 16 + H, N)
+        assert got.tolist() == want
+
+
+def test_descriptor_vs_numpy(oracle):
+    from pilotguru_amd.synth import synth_scene
+    img = synth_scene(2, 96, 96)
+    txt = open(os.path.join(HERE, "..", "oracle", "orb_pattern31.inc")).read()
+    pat = np.array([int(v) for v in txt[txt.index("*/") + 2:].replace("\n", " ").split(",") if v.strip()]).reshape(256, 4)
+    for angle in (0.0, 33.3, 90.0, 181.25, 359.9):
+        s, c = oracle.sincos_f(np.float32(angle) * np.float32(np.pi / 180.0))
+        a, b = np.float32(c), np.float32(s)
+        bits = []
+        for x0, y0, x1, y1 in pat:
+            def tap(px, py):
+                r = int(np.rint(np.float64(np.float32(np.float32(px) * b) + np.float32(np.float32(py) * a))))
+                cc = int(np.rint(np.float64(np.float32(np.float32(px) * a) - np.float32(np.float32(py) * b))))
+                return int(img[48 + r, 48 + cc])
+            bits.append(1 if tap(x0, y0) < tap(x1, y1) else 0)
+        want = np.packbits(np.array(bits, np.uint8), bitorder="little")
+        assert np.array_equal(oracle.orb_descriptor(img, 48, 48, angle), want)
+
+
+def test_ic_angle_vs_numpy(oracle):
+    from pilotguru_amd.synth import synth_scene
+    img = synth_scene(6, 80, 80)
+    umax = oracle.OrbOracle(500).umax
+    m10 = m01 = 0
+    for v in range(-15, 16):
+        for u in range(-int(umax[abs(v)]), int(umax[abs(v)]) + 1):
+            m10 += u * int(img[40 + v, 40 + u])
+            m01 += v * int(img[40 + v, 40 + u])
+    assert oracle.ic_angle(img, 40, 40, umax) == oracle.fast_atan2(np.float32(m01), np.float32(m10))
+
+
+# ---------------------------------------------------------------- committed regression vectors
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(HERE, "golden", "extract_*.npz"))))
+def test_oracle_matches_committed_vectors(oracle, path):
+    from pilotguru_amd.synth import synth_scene
+    g = np.load(path)
+    img = synth_scene(int(g["seed"]), int(g["w"]), int(g["h"]))
+    ora = oracle.OrbOracle(int(g["nfeatures"]), 1.2, 8, 20, 7)
+    kp, desc = ora.extract(img)
+    assert kp.view(np.uint8).reshape(len(kp), 28).tobytes() == g["kp"].tobytes()
+    assert np.array_equal(desc, g["desc"])
+    assert np.array_equal(ora.level_image(7), g["level7"])
+    for l in range(8):
+        c = ora.level_candidates(l)
+        assert np.array_equal(np.stack([c["x"], c["y"], c["response"]], 1).astype(np.int16), g["cand%d" % l])
+        im = ora.level_image(l)
+        assert [int(im.astype(np.uint64).sum()), im.shape[1], im.shape[0]] == g["sum%d" % l].tolist()
+        assert ora.level_keypoints(l) == int(g["nkp%d" % l][0])
+
+
+def test_quota_overshoot_and_order_properties(oracle):
+    """A level never returns more than max(quota + 2, 4*nIni) keypoints; octaves are emitted in
+    level order; every keypoint is >= 19 px from the level border (16-px region + FAST margin)."""
+    from pilotguru_amd.synth import synth_scene
+    img = synth_scene(9, 480, 360)
+    ora = oracle.OrbOracle(800, 1.2, 8, 20, 7)
+    kp, desc = ora.extract(img)
+    q = ora.features_per_level
+    assert np.all(np.diff(kp["octave"]) >= 0)
+    sf = ora.scale_factors
+    for l in range(8):
+        n = ora.level_keypoints(l)
+        assert n <= max(q[l] + 2, 8)
+        w, h = ora.level_size(l)
+        k = kp[kp["octave"] == l]
+        x = np.rint(k["x"] / sf[l])
+        y = np.rint(k["y"] / sf[l])
+        assert np.all(x >= 19) and np.all(x < w - 19) and np.all(y >= 19) and np.all(y < h - 19)
+    assert np.all(kp["class_id"] == -1)
