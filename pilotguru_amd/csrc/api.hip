@@ -40,7 +40,7 @@ struct pgorb_ctx {
     int planW = 0, planH = 0, planBatch = 0;
     bool planValid = false;
     // device memory
-    Arena pyr, cand, kpos, sel, nodes, counters, tables;
+    Arena pyr, cand, kpos, sel, nodes, counters, tables, cellCand, cellCount;
     Arena stageKps, stageDesc, stageN, stageA, stageB, stageOut;
     int lastFrames = 0;
     bool lastAliased = false;
@@ -167,7 +167,7 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
 
     // --- resize tables ---
     std::vector<uint8_t> tab;
-    struct TabOff { size_t xofs, xofs1, xalpha, yofs, ybeta; } toff[PG_MAXL];
+    struct TabOff { size_t xofs, xofs1, xalpha, yofs, ybeta, qtab; bool hasQ; } toff[PG_MAXL];
     for (int l = 1; l < L; l++) {
         std::vector<int32_t> xo, xo1, yo; std::vector<int16_t> xa, yb;
         build_resize_tables(g[l - 1].w, g[l - 1].h, g[l].w, g[l].h, xo, xo1, xa, yo, yb);
@@ -182,12 +182,33 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
         toff[l].xalpha = put(xa.data(), xa.size() * 2);
         toff[l].yofs = put(yo.data(), yo.size() * 4);
         toff[l].ybeta = put(yb.data(), yb.size() * 2);
+        // quad table for the fast path
+        const int nq = (g[l].w + 3) / 4;
+        std::vector<PgQuadTab> qt(nq);
+        bool ok = true;
+        for (int q = 0; q < nq; q++) {
+            PgQuadTab& T = qt[q];
+            memset(&T, 0, sizeof(T));
+            T.base_dw = xo[4 * q] >> 2;
+            for (int k = 0; k < 4; k++) {
+                const int dx = 4 * q + k;
+                if (dx >= g[l].w) break;
+                const int o = xo[dx] - 4 * T.base_dw;
+                if (o < 0 || o > 8) ok = false;
+                // tap 1 is read at o+1; where cv::resize clamps it (xofs1 == xofs) its weight is 0
+                if (xo1[dx] != xo[dx] + 1 && xa[2 * dx + 1] != 0) ok = false;
+                T.offs |= (uint32_t)(o & 15) << (4 * k);
+                T.a0[k] = xa[2 * dx]; T.a1[k] = xa[2 * dx + 1];
+            }
+        }
+        toff[l].hasQ = ok;
+        toff[l].qtab = put(qt.data(), qt.size() * sizeof(PgQuadTab));
     }
     if ((rc = ensure(c, c->tables, tab.size() + 16))) return rc;
     if (!tab.empty()) PG_HIP(c, hipMemcpy(c->tables.p, tab.data(), tab.size(), hipMemcpyHostToDevice));
 
     // --- arenas ---
-    size_t pyrFrame = 0, candFrame = 0, selFrame = 0, nodeFrame = 0;
+    size_t pyrFrame = 0, candFrame = 0, selFrame = 0, nodeFrame = 0, cellCandFrame = 0;
     int cells = 0, selTotal = 0;
     size_t pyrOff[PG_MAXL];
     for (int l = 0; l < L; l++) {
@@ -205,6 +226,9 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
         // NMS survivors are never 8-adjacent: at most ceil(IW/2)*ceil(IH/2) per cell
         V.candCap = ((V.w - 2 * PG_EDGE) / 2 + V.nCols + 1) * ((V.h - 2 * PG_EDGE) / 2 + V.nRows + 1);
         V.candOff = (int64_t)candFrame; candFrame += align_up(V.candCap, 64);
+        V.cellCap = ((V.wCell + 1) / 2) * ((V.hCell + 1) / 2);
+        V.cellCandOff = (int64_t)cellCandFrame;
+        cellCandFrame += align_up((size_t)V.cellCap * V.nCols * V.nRows, 64);
         V.selOff = (int64_t)selFrame; selFrame += align_up(V.selCap, 16);
         V.nodeOff = (int64_t)nodeFrame; nodeFrame += (size_t)V.nodeCap * 20;
         V.scale = c->mvScaleFactor[l];
@@ -216,10 +240,13 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
             return fail(c, PGORB_E_LIMIT, "level larger than 4095 px is not supported");
     }
     P.totalCells = cells; P.selTotal = selTotal;
+    P.cellCandFrame = (int64_t)cellCandFrame;
     P.candFrame = (int64_t)candFrame; P.selFrame = (int64_t)selFrame; P.nodeFrame = (int64_t)nodeFrame;
     if ((rc = ensure(c, c->pyr, pyrFrame * B))) return rc;
     if ((rc = ensure(c, c->cand, candFrame * 4 * B))) return rc;
     if ((rc = ensure(c, c->kpos, candFrame * 4 * B))) return rc;
+    if ((rc = ensure(c, c->cellCand, cellCandFrame * 4 * B))) return rc;
+    if ((rc = ensure(c, c->cellCount, (size_t)cells * 4 * B + 64))) return rc;
     if ((rc = ensure(c, c->sel, selFrame * 4 * B))) return rc;
     if ((rc = ensure(c, c->nodes, nodeFrame * 4 * B + 64))) return rc;
     if ((rc = ensure(c, c->counters, (size_t)B * PG_MAXL * 4 * 2 + 64))) return rc;
@@ -234,8 +261,10 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
             V.xalpha = (const int16_t*)(t + toff[l].xalpha);
             V.yofs = (const int32_t*)(t + toff[l].yofs);
             V.ybeta = (const int16_t*)(t + toff[l].ybeta);
+            V.qtab = toff[l].hasQ ? (const PgQuadTab*)(t + toff[l].qtab) : nullptr;
         }
     }
+    P.cellCand = (uint32_t*)c->cellCand.p; P.cellCount = (int32_t*)c->cellCount.p;
     P.cand = (uint32_t*)c->cand.p; P.kpos = (uint32_t*)c->kpos.p; P.sel = (uint32_t*)c->sel.p;
     P.nodeScratch = (int32_t*)c->nodes.p;
     P.candCount = (int32_t*)c->counters.p;
@@ -336,7 +365,7 @@ void pgorb_destroy(pgorb_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->prm.device);
-    Arena* all[] = {&c->pyr, &c->cand, &c->kpos, &c->sel, &c->nodes, &c->counters, &c->tables,
+    Arena* all[] = {&c->cellCand, &c->cellCount, &c->pyr, &c->cand, &c->kpos, &c->sel, &c->nodes, &c->counters, &c->tables,
                     &c->stageKps, &c->stageDesc, &c->stageN, &c->stageA, &c->stageB, &c->stageOut};
     for (Arena* a : all) if (a->p) (void)hipFree(a->p);
     for (hipEvent_t e : c->evExtract) (void)hipEventDestroy(e);

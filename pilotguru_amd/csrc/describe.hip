@@ -32,7 +32,7 @@ __device__ static const int8_t pg_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13
 #define DW_N 43               // window side
 #define DW_PITCH 48
 #define DH_N 37               // blurred side
-#define DH_PITCH 38           // u16 row pitch of the horizontal pass
+#define DH_PITCH 40           // u16 row pitch of the horizontal pass (even: read as dwords)
 #define DB_PITCH 40
 
 __device__ __forceinline__ int pg_reflect101(int p, int n)
@@ -133,28 +133,28 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
     const uint8_t* img = L.img + (int64_t)frame * L.fstride;
     const int w = L.w, h = L.h;
 
-    // ---- stage the raw 43x43 window -----------------------------------------------------
+    // ---- stage the raw 43x43 window: window column 0 lands on an LDS dword boundary --------
     const int x0 = x - DW_R, y0 = y - DW_R;
-    int shift;
-    if (x0 >= 0 && y0 >= 0 && x + DW_R < w && y + DW_R < h) {
-        const int xa = x0 & ~3;
-        shift = x0 - xa;
-        const int ndw = (shift + DW_N + 3) >> 2;
-        for (int i = lane; i < ndw * DW_N; i += 64) {
-            const int r = i / ndw, q = i - r * ndw;
-            *reinterpret_cast<uint32_t*>(raw + r * DW_PITCH + 4 * q) =
-                *reinterpret_cast<const uint32_t*>(img + (int64_t)(y0 + r) * L.pitch + xa + 4 * q);
+    if (x0 >= 0 && y0 >= 0 && x0 + 52 <= w && y + DW_R < h) {   // 12 dwords + 1 stay inside the row
+        const int xa = x0 & ~3, sh = x0 & 3;
+        for (int i = lane; i < 12 * DW_N; i += 64) {
+            const int r = i / 12, q = i - r * 12;
+            const uint32_t* g = reinterpret_cast<const uint32_t*>(img + (int64_t)(y0 + r) * L.pitch + xa) + q;
+            const uint32_t lo = g[0], hi = g[1];
+            const uint32_t v = sh == 0 ? lo : sh == 1 ? __builtin_amdgcn_alignbyte(hi, lo, 1)
+                             : sh == 2 ? __builtin_amdgcn_alignbyte(hi, lo, 2)
+                                       : __builtin_amdgcn_alignbyte(hi, lo, 3);
+            *reinterpret_cast<uint32_t*>(raw + r * DW_PITCH + 4 * q) = v;
         }
     } else {                                   // BORDER_REFLECT_101 (:1085)
-        shift = 0;
-        for (int i = lane; i < DW_N * DW_N; i += 64) {
-            const int r = i / DW_N, c = i - r * DW_N;
+        for (int i = lane; i < DW_N * DW_PITCH; i += 64) {
+            const int r = i / DW_PITCH, c = i - r * DW_PITCH;
             raw[r * DW_PITCH + c] =
                 img[(int64_t)pg_reflect101(y0 + r, h) * L.pitch + pg_reflect101(x0 + c, w)];
         }
     }
     __syncthreads();
-    const uint8_t* rw = raw + shift;           // rw[r*DW_PITCH + c], (r,c) in 0..42, centre (21,21)
+    const uint8_t* rw = raw;                   // rw[r*DW_PITCH + c], (r,c) in 0..42, centre (21,21)
 
     // ---- IC_Angle: integer moments over the radius-15 disc (:77-104) -------------------
     int m10 = 0, m01 = 0;
@@ -174,22 +174,55 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
     const float angle = pg_fast_atan2((float)m01, (float)m10);
 
     // ---- 7x7 Gaussian, fixed point, separable (OpenCV 2.4 8U path, Appendix A4) ---------
-    for (int i = lane; i < DW_N * DH_N; i += 64) {
-        const int r = i / DH_N, c = i - r * DH_N;
-        const uint8_t* s = rw + r * DW_PITCH + c;
-        const int acc = G.k0 * (s[0] + s[6]) + G.k1 * (s[1] + s[5]) + G.k2 * (s[2] + s[4]) + G.k3 * s[3];
-        hbuf[r * DH_PITCH + c] = (uint16_t)acc;                 // <= 257*255 = 65535
+    // row pass: a lane produces 4 adjacent sums from 3 aligned LDS dwords (10 source bytes)
+    for (int i = lane; i < DW_N * 10; i += 64) {
+        const int r = i / 10, q = i - r * 10;
+        const uint32_t* s = reinterpret_cast<const uint32_t*>(raw + r * DW_PITCH) + q;
+        const uint32_t w0 = s[0], w1 = s[1], w2 = s[2];
+        int b[10];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { b[k] = (w0 >> (8 * k)) & 0xFF; b[4 + k] = (w1 >> (8 * k)) & 0xFF; }
+        b[8] = w2 & 0xFF; b[9] = (w2 >> 8) & 0xFF;
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            o[k] = (uint32_t)(G.k0 * (b[k] + b[k + 6]) + G.k1 * (b[k + 1] + b[k + 5]) +
+                              G.k2 * (b[k + 2] + b[k + 4]) + G.k3 * b[k + 3]);     // <= 257*255
+        uint32_t* d = reinterpret_cast<uint32_t*>(hbuf + r * DH_PITCH + 4 * q);
+        d[0] = o[0] | (o[1] << 16);
+        d[1] = o[2] | (o[3] << 16);
     }
     __syncthreads();
+    // column pass: a lane owns 2 adjacent columns and slides down 13 output rows
     const int wvec = w & ~3;
-    for (int i = lane; i < DH_N * DH_N; i += 64) {
-        const int r = i / DH_N, c = i - r * DH_N;
-        const uint16_t* s = hbuf + r * DH_PITCH + c;
-        const int C = G.k0 * (s[0] + s[6 * DH_PITCH]) + G.k1 * (s[DH_PITCH] + s[5 * DH_PITCH]) +
-                      G.k2 * (s[2 * DH_PITCH] + s[4 * DH_PITCH]) + G.k3 * s[3 * DH_PITCH];
-        int v = (C + 32768) >> 16;                               // FixedPtCastEx: half up
-        if (P.tieMode == 0 && (C & 0xFFFF) == 0x8000 && (x - 18 + c) < wvec) v &= ~1;   // SSE2: tie -> even
-        blur[r * DB_PITCH + c] = (uint8_t)min(v, 255);
+    {
+        const int cp = lane % 19, sg = lane / 19;                 // 19 column pairs x 3 segments
+        if (sg < 3) {
+            const int rbeg = 13 * sg, rend = min(rbeg + 13, DH_N);
+            const uint32_t* s = reinterpret_cast<const uint32_t*>(hbuf + rbeg * DH_PITCH) + cp;
+            uint32_t win[7];
+#pragma unroll
+            for (int k = 0; k < 6; k++) win[k + 1] = s[k * (DH_PITCH / 2)];
+            for (int r = rbeg; r < rend; r++) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) win[k] = win[k + 1];
+                win[6] = s[(r - rbeg + 6) * (DH_PITCH / 2)];
+                uint32_t outp = 0;
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++) {
+                    const int sft = 16 * hf;
+                    const int C = G.k0 * (int)(((win[0] >> sft) & 0xFFFF) + ((win[6] >> sft) & 0xFFFF)) +
+                                  G.k1 * (int)(((win[1] >> sft) & 0xFFFF) + ((win[5] >> sft) & 0xFFFF)) +
+                                  G.k2 * (int)(((win[2] >> sft) & 0xFFFF) + ((win[4] >> sft) & 0xFFFF)) +
+                                  G.k3 * (int)((win[3] >> sft) & 0xFFFF);
+                    int v = (C + 32768) >> 16;                   // FixedPtCastEx: half up
+                    if (P.tieMode == 0 && (C & 0xFFFF) == 0x8000 && (x - 18 + 2 * cp + hf) < wvec)
+                        v &= ~1;                                 // SSE2 column pass: tie -> even
+                    outp |= (uint32_t)min(v, 255) << (8 * hf);
+                }
+                *reinterpret_cast<uint16_t*>(blur + r * DB_PITCH + 2 * cp) = (uint16_t)outp;
+            }
+        }
     }
     __syncthreads();
 

@@ -4,24 +4,35 @@
 // (thirdparty/orb-slam2/src/ORBextractor.cc:765-829), i.e. thousands of small
 // cv::FAST(window, iniThFAST, true) calls with a cv::FAST(window, minThFAST, true) retry for
 // empty cells (:808-816), as ONE launch: one 64-lane wave per 30-px cell, all cells of all
-// pyramid levels of all frames of the batch in one grid.
+// pyramid levels of all frames of the batch in one grid.  Like the reference the wave runs
+// the detector at iniThFAST first and only re-runs the (much denser) minThFAST pass when the
+// cell came back empty -- on textured frames almost every cell is settled by the cheap pass.
 //
-// Equivalence used: for a pixel that is a FAST corner at threshold
-// t its OpenCV score S-1 (S = best 9-arc minimum |difference|) does not depend on t, and
-// "corner at t" <=> score >= t.  So the wave computes the score map of the cell interior once
-// (at minThFAST), runs the 3x3 strict NMS on it with everything outside the cell interior
-// counted as 0 -- exactly what the reference's per-window FAST sees -- and then emits the
-// survivors with score >= iniThFAST if there are any, else those with score >= minThFAST.
+// One detector pass at threshold t == cv::FAST(window, t, nonmax=true):
+//   score(p) = (best 9-arc minimum |centre - ring|) - 1 for FAST corners (independent of t),
+//   0 otherwise; keep p iff score(p) > score of all 8 neighbours, where everything outside the
+//   window interior counts as 0 (the reference's window-local score buffers).
 //
-// Structure per wave: (1) the (wCell+6)x(hCell+6) window is staged into LDS with aligned
-// 32-bit global loads (coalesced rows, ~1.4x halo re-read served by L2); (2) a cheap
-// necessary test (two opposite ring pairs) compacts the few percent of plausible pixels into
-// an LDS list with ballot/mbcnt; (3) full 16-ring scores are computed for the compacted list
-// with all lanes busy; (4) NMS + per-cell threshold + one atomicAdd per cell to reserve
-// slots in the (frame, level) candidate array.  Candidate order in that array is arbitrary;
-// everything downstream orders by the reference's (cell row, cell col, y, x) rank.
+// Structure per wave:
+//  (1) the (wCell+6)x(hCell+6) window is staged into LDS with aligned 32-bit global loads,
+//      re-aligned with v_alignbyte so that interior column 0 sits on an LDS dword boundary;
+//  (2) each lane tests a QUAD of 4 horizontally adjacent pixels per step from 5 aligned LDS
+//      dwords (centre, left, right, 3 rows up, 3 rows down): a pixel can only be a corner if
+//      both opposite ring pairs (0,8) and (4,12) contain a darker (or a brighter) pixel; the
+//      few percent that pass are compacted into an LDS list with ballot/mbcnt;
+//  (3) exact 16-ring scores (min3/max3 sliding arcs) for the compacted list, all lanes busy;
+//  (4) NMS on an LDS score map; survivors go to the cell's own fixed slot range of the
+//      (frame, level) candidate slab plus a per-cell count -- no atomics (a single device-scope
+//      counter per level serialised ~2000 cells at ~180 ns each).  A cell can hold at most
+//      ceil(IW/2)*ceil(IH/2) survivors (no two are 8-adjacent), which is the slot count, so
+//      nothing can overflow.  K3 compacts the slots; order inside a cell is arbitrary and
+//      everything downstream orders by the reference's (cell row, cell col, y, x) rank.
 //
-// Roofline: HBM/L2-read bound in principle (one pass over all pyramid pixels, 1 B/px);
+// blockIdx -> cell mapping is XCD-aware: the dispatcher places consecutive workgroups on
+// consecutive XCDs (private L2s), so cell c = (b % 8) * (G/8) + b / 8 gives every XCD a
+// contiguous run of cells -- neighbouring cells share 128-B lines and 6 halo rows.
+//
+// Roofline: HBM-read bound in principle (one pass over all pyramid pixels, 1 B/px);
 // algorithmic bytes per frame = sum_l w_l*h_l.
 #include "pgorb_internal.h"
 
@@ -61,144 +72,185 @@ __device__ __forceinline__ int fast_score16(const int d[16])
     return max(best_dark, -best_bright) - 1;
 }
 
-__global__ __launch_bounds__(64) void k_fast_cells(const PgPlan P, int tilePitch, int tileRows,
-                                                    int mapPitch, int mapRows)
+__device__ __forceinline__ int wave_prefix(unsigned long long m)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+}
+
+// tile layout: row r at tile + r*TP; window column c at byte 1 + c, so interior column 0
+// (window column 3) is at byte 4.
+template <int QW>      // quads per row handled by consecutive lanes: 8 (IW <= 32) or 16 (IW <= 64)
+__device__ __forceinline__ int quick_pass(const uint8_t* tile, int TP, int IW, int IH, int t,
+                                          uint16_t* list, int lane)
+{
+    const int lq = lane & (QW - 1), lr = lane / QW;
+    const int NQ = (IW + 3) >> 2;
+    int nlist = 0;
+    for (int row0 = 0; row0 < IH; row0 += 64 / QW) {
+        const int iy = row0 + lr;
+        unsigned pass = 0;
+        if (iy < IH && lq < NQ) {
+            const uint32_t* rc = reinterpret_cast<const uint32_t*>(tile + (iy + 3) * TP) + 1 + lq;
+            const uint32_t* ru = reinterpret_cast<const uint32_t*>(tile + iy * TP) + 1 + lq;
+            const uint32_t* rd = reinterpret_cast<const uint32_t*>(tile + (iy + 6) * TP) + 1 + lq;
+            const uint32_t C = rc[0], Lw = rc[-1], Rw = rc[1], U = ru[0], D = rd[0];
+            const uint32_t L3 = __builtin_amdgcn_alignbyte(C, Lw, 1);     // pixels x-3 .. x
+            const uint32_t R3 = __builtin_amdgcn_alignbyte(Rw, C, 3);     // pixels x+3 .. x+6
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int v = (C >> (8 * i)) & 0xFF;
+                const int r0 = (D >> (8 * i)) & 0xFF, r8 = (U >> (8 * i)) & 0xFF;
+                const int r4 = (R3 >> (8 * i)) & 0xFF, r12 = (L3 >> (8 * i)) & 0xFF;
+                const int lo = v - t, hi = v + t;
+                const bool dark = (r0 < lo || r8 < lo) && (r4 < lo || r12 < lo);
+                const bool bright = (r0 > hi || r8 > hi) && (r4 > hi || r12 > hi);
+                if ((dark || bright) && 4 * lq + i < IW) pass |= 1u << i;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const bool p = (pass >> i) & 1;
+            const unsigned long long m = __ballot(p);
+            if (p) list[nlist + wave_prefix(m)] = (uint16_t)(iy * IW + 4 * lq + i);
+            nlist += __popcll(m);
+        }
+    }
+    return nlist;
+}
+
+__global__ __launch_bounds__(64) void k_fast_cells(const PgPlan P, int TP, int tileRows,
+                                                    int mapPitch, int mapRows, int cellsPerXcd)
 {
     const int lane = threadIdx.x;
     const int frame = blockIdx.y;
+    const int cell = (blockIdx.x & 7) * cellsPerXcd + (blockIdx.x >> 3);      // XCD-contiguous
+    if (cell >= P.totalCells) return;
     int l = 0;
-    while (l + 1 < P.nlevels && (int)blockIdx.x >= P.lvl[l + 1].cellBase) l++;
+    while (l + 1 < P.nlevels && cell >= P.lvl[l + 1].cellBase) l++;
     const PgLevel& L = P.lvl[l];
-    const int c = blockIdx.x - L.cellBase;
+    const int c = cell - L.cellBase;
     const int ci = c / L.nCols, cj = c - ci * L.nCols;
     const int maxBorderX = L.w - PG_EDGE, maxBorderY = L.h - PG_EDGE;
     const int iniY = PG_EDGE + ci * L.hCell;
     const int iniX = PG_EDGE + cj * L.wCell;
-    if (iniY >= maxBorderY - 3 || iniX >= maxBorderX - 6) return;      // :794, :803
+    int32_t* cellCnt = P.cellCount + (int64_t)frame * P.totalCells + cell;
+    if (iniY >= maxBorderY - 3 || iniX >= maxBorderX - 6) {             // :794, :803
+        if (lane == 0) *cellCnt = 0;
+        return;
+    }
     const int maxX = min(iniX + L.wCell + 6, maxBorderX);
     const int maxY = min(iniY + L.hCell + 6, maxBorderY);
     const int W = maxX - iniX, H = maxY - iniY;
-    if (W < 7 || H < 7) return;                                         // cv::FAST finds nothing
+    if (W < 7 || H < 7) {                                               // cv::FAST finds nothing
+        if (lane == 0) *cellCnt = 0;
+        return;
+    }
     const int IW = W - 6, IH = H - 6;
 
-    uint8_t* tile = pg_fast_smem;                                  // [tileRows][tilePitch]
-    uint8_t* smap = tile + tileRows * tilePitch;                   // [mapRows][mapPitch], 1-px zero rim
+    uint8_t* tile = pg_fast_smem;                                  // [tileRows][TP]
+    uint8_t* smap = tile + tileRows * TP;                          // [mapRows][mapPitch], 1-px zero rim
     uint16_t* list = reinterpret_cast<uint16_t*>(smap + mapRows * mapPitch);   // pixel ids
-    uint8_t* lscore = reinterpret_cast<uint8_t*>(list + (mapRows - 2) * (mapPitch - 2 > 0 ? mapPitch : 1));
+    uint8_t* lscore = reinterpret_cast<uint8_t*>(list + (mapRows - 2) * mapPitch);
 
-    // (1) stage the window: aligned dwords covering [iniX, maxX) of rows [iniY, maxY)
+    // (1) stage the window.  LDS dword j of a row holds window columns 4j-1 .. 4j+2.
     const uint8_t* img = L.img + (int64_t)frame * L.fstride;
-    const int xa = iniX & ~3, shift = iniX - xa;
-    const int ndw = (shift + W + 3) >> 2;
+    const int gx0 = iniX - 1;                       // global x of LDS byte 0
+    const int ga = gx0 & ~3, sh = gx0 & 3;
+    const int ndw = (W + 1 + 3) >> 2;               // dwords covering bytes 0 .. W
     for (int i = lane; i < ndw * H; i += 64) {
         const int r = i / ndw, q = i - r * ndw;
-        const uint32_t v = *reinterpret_cast<const uint32_t*>(img + (int64_t)(iniY + r) * L.pitch + xa + 4 * q);
-        *reinterpret_cast<uint32_t*>(tile + r * tilePitch + 4 * q) = v;
+        const uint32_t* g = reinterpret_cast<const uint32_t*>(img + (int64_t)(iniY + r) * L.pitch + ga) + q;
+        const uint32_t lo = g[0], hi = g[1];
+        const uint32_t v = sh == 0 ? lo : sh == 1 ? __builtin_amdgcn_alignbyte(hi, lo, 1)
+                         : sh == 2 ? __builtin_amdgcn_alignbyte(hi, lo, 2)
+                                   : __builtin_amdgcn_alignbyte(hi, lo, 3);
+        *reinterpret_cast<uint32_t*>(tile + r * TP + 4 * q) = v;
     }
     for (int i = lane; i < (mapRows * mapPitch) >> 2; i += 64)
         reinterpret_cast<uint32_t*>(smap)[i] = 0;
     __syncthreads();
 
-    // (2) necessary test + compaction.  Any 9-arc of the 16-ring contains at least one pixel
-    // of every opposite pair {k, k+8}; test pairs (0,8) and (4,12).
-    const int t = P.minTh;
-    int nlist = 0;
-    const int npix = IW * IH;
-    for (int base = 0; base < npix; base += 64) {
-        const int p = base + lane;
-        bool pass = false;
-        if (p < npix) {
-            const int iy = p / IW, ix = p - iy * IW;
-            const uint8_t* cp = tile + (iy + 3) * tilePitch + shift + ix + 3;
-            const int v = cp[0];
-            const int r0 = cp[3 * tilePitch], r8 = cp[-3 * tilePitch], r4 = cp[3], r12 = cp[-3];
-            const int lo = v - t, hi = v + t;
-            const bool dark = (r0 < lo || r8 < lo) && (r4 < lo || r12 < lo);
-            const bool bright = (r0 > hi || r8 > hi) && (r4 > hi || r12 > hi);
-            pass = dark || bright;
-        }
-        const unsigned long long m = __ballot(pass);
-        if (pass) {
-            const int pos = nlist + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
-                                       __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-            list[pos] = (uint16_t)p;
-        }
-        nlist += __popcll(m);
-    }
-    __syncthreads();
-
-    // (3) exact scores for the compacted pixels
-    for (int base = 0; base < nlist; base += 64) {
-        const int i = base + lane;
-        if (i < nlist) {
-            const int p = list[i];
-            const int iy = p / IW, ix = p - iy * IW;
-            const uint8_t* cp = tile + (iy + 3) * tilePitch + shift + ix + 3;
-            int d[16];
-            ring_load(cp, tilePitch, cp[0], d);
-            int s = fast_score16(d);
-            s = (s >= t) ? s : 0;                    // not a corner at minThFAST
-            lscore[i] = (uint8_t)s;
-            if (s) smap[(iy + 1) * mapPitch + ix + 1] = (uint8_t)s;
-        }
-    }
-    __syncthreads();
-
-    // (4) NMS (strictly greater than all 8 neighbours; outside the interior = 0), per-cell
-    // threshold choice, slot reservation, emit.
-    bool anyIni = false;
-    int nsurv = 0;
-    for (int base = 0; base < nlist; base += 64) {
-        const int i = base + lane;
-        bool keep = false;
-        int s = 0;
-        if (i < nlist) {
-            s = lscore[i];
-            if (s) {
+    for (int pass = 0; pass < 2; pass++) {
+        const int t = pass == 0 ? P.iniTh : P.minTh;
+        // (2) necessary test + compaction
+        const int nlist = (IW <= 32) ? quick_pass<8>(tile, TP, IW, IH, t, list, lane)
+                                     : quick_pass<16>(tile, TP, IW, IH, t, list, lane);
+        __syncthreads();
+        // (3) exact scores for the compacted pixels
+        for (int base = 0; base < nlist; base += 64) {
+            const int i = base + lane;
+            if (i < nlist) {
                 const int p = list[i];
                 const int iy = p / IW, ix = p - iy * IW;
-                const uint8_t* m = smap + (iy + 1) * mapPitch + ix + 1;
-                keep = s > m[-1] && s > m[1] && s > m[-mapPitch - 1] && s > m[-mapPitch] &&
-                       s > m[-mapPitch + 1] && s > m[mapPitch - 1] && s > m[mapPitch] &&
-                       s > m[mapPitch + 1];
+                const uint8_t* cp = tile + (iy + 3) * TP + 4 + ix;
+                int d[16];
+                ring_load(cp, TP, cp[0], d);
+                int s = fast_score16(d);
+                s = (s >= t) ? s : 0;                    // not a corner at this threshold
+                lscore[i] = (uint8_t)s;
+                if (s) smap[(iy + 1) * mapPitch + ix + 1] = (uint8_t)s;
             }
-            lscore[i] = keep ? (uint8_t)s : 0;       // reuse as "survivor score"
         }
-        anyIni |= (__ballot(keep && s >= P.iniTh) != 0ull);
-        nsurv += __popcll(__ballot(keep));
-    }
-    if (nsurv == 0) return;
-    __syncthreads();
-    const int thr = anyIni ? P.iniTh : t;
-
-    int total = 0;
-    for (int base = 0; base < nlist; base += 64) {
-        const int i = base + lane;
-        const bool emit = (i < nlist) && lscore[i] >= thr && lscore[i] != 0;
-        total += __popcll(__ballot(emit));
-    }
-    int slot0 = 0;
-    if (lane == 0) slot0 = atomicAdd(&P.candCount[frame * PG_MAXL + l], total);
-    slot0 = __shfl(slot0, 0);
-    uint32_t* out = P.cand + (int64_t)frame * P.candFrame + L.candOff;
-    int done = 0;
-    for (int base = 0; base < nlist; base += 64) {
-        const int i = base + lane;
-        const bool emit = (i < nlist) && lscore[i] >= thr && lscore[i] != 0;
-        const unsigned long long m = __ballot(emit);
-        if (emit) {
-            const int pos = slot0 + done + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
-                                              __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-            const int p = list[i];
-            const int iy = p / IW, ix = p - iy * IW;
-            // region-relative coordinates: window-local + cell offset (:822-823)
-            const int xr = ix + 3 + cj * L.wCell, yr = iy + 3 + ci * L.hCell;
-            if (pos < L.candCap)
-                out[pos] = (uint32_t)xr | ((uint32_t)yr << 12) | ((uint32_t)lscore[i] << 24);
-            else
-                atomicExch(P.status, PGORB_E_OVERFLOW);
+        __syncthreads();
+        // (4) NMS (strictly greater than all 8 neighbours; outside the interior = 0)
+        int total = 0;
+        for (int base = 0; base < nlist; base += 64) {
+            const int i = base + lane;
+            bool keep = false;
+            if (i < nlist) {
+                const int s = lscore[i];
+                if (s) {
+                    const int p = list[i];
+                    const int iy = p / IW, ix = p - iy * IW;
+                    const uint8_t* m = smap + (iy + 1) * mapPitch + ix + 1;
+                    keep = s > m[-1] && s > m[1] && s > m[-mapPitch - 1] && s > m[-mapPitch] &&
+                           s > m[-mapPitch + 1] && s > m[mapPitch - 1] && s > m[mapPitch] &&
+                           s > m[mapPitch + 1];
+                    if (!keep) lscore[i] = 0;
+                }
+            }
+            total += __popcll(__ballot(keep));
         }
-        done += __popcll(m);
+        if (total == 0) {
+            if (pass == 1) {
+                if (lane == 0) *cellCnt = 0;
+                return;
+            }
+            __syncthreads();
+            // vKeysCell.empty() -> retry at minThFAST (:812-816); clear the score map first
+            for (int base = 0; base < nlist; base += 64) {
+                const int i = base + lane;
+                if (i < nlist) {
+                    const int p = list[i];
+                    const int iy = p / IW, ix = p - iy * IW;
+                    smap[(iy + 1) * mapPitch + ix + 1] = 0;
+                }
+            }
+            __syncthreads();
+            continue;
+        }
+        // emit into this cell's slots
+        if (lane == 0) *cellCnt = total;
+        uint32_t* out = P.cellCand + (int64_t)frame * P.cellCandFrame + L.cellCandOff + (int64_t)c * L.cellCap;
+        int done = 0;
+        for (int base = 0; base < nlist; base += 64) {
+            const int i = base + lane;
+            const bool emit = (i < nlist) && lscore[i] != 0;
+            const unsigned long long m = __ballot(emit);
+            if (emit) {
+                const int pos = done + wave_prefix(m);
+                const int p = list[i];
+                const int iy = p / IW, ix = p - iy * IW;
+                // region-relative coordinates: window-local + cell offset (:822-823)
+                const int xr = ix + 3 + cj * L.wCell, yr = iy + 3 + ci * L.hCell;
+                if (pos < L.cellCap)
+                    out[pos] = (uint32_t)xr | ((uint32_t)yr << 12) | ((uint32_t)lscore[i] << 24);
+                else
+                    atomicExch(P.status, PGORB_E_OVERFLOW);          // cannot happen (see header)
+            }
+            done += __popcll(m);
+        }
+        return;
     }
 }
 
@@ -209,14 +261,14 @@ void pg_launch_fast(const PgPlan& P, int nframes, hipStream_t s)
         maxW = max(maxW, P.lvl[l].wCell + 6);
         maxH = max(maxH, P.lvl[l].hCell + 6);
     }
-    const int tilePitch = ((maxW + 3 + 3) & ~3) + 4;       // shift<=3, round up to dwords, +4 pad
+    const int TP = ((maxW + 1 + 3) & ~3) + 8;              // byte 0 pad + window + slack dwords
     const int tileRows = maxH;
     const int mapPitch = ((maxW - 6 + 2) + 3) & ~3;
     const int mapRows = maxH - 6 + 2;
     const int npixMax = (mapRows - 2) * mapPitch;
-    size_t smem = (size_t)tileRows * tilePitch + (size_t)mapRows * mapPitch;
-    smem = (smem + 15) & ~(size_t)15;
-    smem += (size_t)npixMax * 2 + (size_t)npixMax;
-    dim3 grid(P.totalCells, nframes), block(64);
-    hipLaunchKernelGGL(k_fast_cells, grid, block, smem, s, P, tilePitch, tileRows, mapPitch, mapRows);
+    size_t smem = (size_t)tileRows * TP + (size_t)mapRows * mapPitch;
+    smem += (size_t)npixMax * 2 + (size_t)npixMax + 64;
+    const int cellsPerXcd = (P.totalCells + 7) / 8;
+    dim3 grid(cellsPerXcd * 8, nframes), block(64);
+    hipLaunchKernelGGL(k_fast_cells, grid, block, smem, s, P, TP, tileRows, mapPitch, mapRows, cellsPerXcd);
 }

@@ -4,8 +4,10 @@
 //   pyramid arena   level l, frame f : u8 plane, row pitch = align64(w_l), at
 //                   lvl[l].img + f * lvl[l].fstride          (level 0 may alias the caller's
 //                   device buffer when it is 4-byte aligned -- no copy)
-//   candidate arena u32 cand[f][l][candCap_l]  packed x | y<<12 | score<<24 (region-relative
-//                   coordinates, i.e. pixel - 16, like vToDistributeKeys ORBextractor.cc:818-826)
+//   cell slots      u32 cellCand[f][l][cell][cellCap_l] + i32 cellCount[f][cell]: K2 output,
+//                   packed x | y<<12 | score<<24 (region-relative coordinates, i.e. pixel - 16,
+//                   like vToDistributeKeys ORBextractor.cc:818-826)
+//   candidate arena u32 cand[f][l][candCap_l]  the same records compacted by K3's prologue
 //   key scratch     u32 kpos[f][l][candCap_l]  quadtree: current node position of every key
 //   selection       u32 sel[f][l][selCap]      quadtree result in the reference's output order
 //   counters        i32 candCount[f][l], kpCount[f][l], status word
@@ -16,6 +18,12 @@
 
 #define PG_EDGE 16            // minBorderX = EDGE_THRESHOLD-3 (ORBextractor.cc:773)
 #define PG_MAXL PGORB_MAX_LEVELS
+
+struct PgQuadTab {            // column taps of 4 adjacent destination pixels (pyramid fast path)
+    int32_t  base_dw;         // first aligned source dword
+    uint32_t offs;            // 4 bits per pixel: byte offset of tap 0 from 4*base_dw (0..8)
+    int16_t  a0[4], a1[4];    // 11-bit coefficients of tap 0 / tap 1
+};
 
 struct PgLevel {
     // pyramid plane of this level
@@ -28,12 +36,15 @@ struct PgLevel {
     const int16_t* xalpha;    // [2*w] 11-bit coefficients
     const int32_t* yofs;      // [2*h] clamped source rows of the two taps
     const int16_t* ybeta;     // [2*h]
+    const PgQuadTab* qtab;    // [ceil(w/4)] or null when a quad spans more than 3 source dwords
     // cell grid (ORBextractor.cc:781-787)
     int32_t  nCols, nRows, wCell, hCell, cellBase;
     // quadtree (ORBextractor.cc:539-563)
     int32_t  quota, nIni, selCap;
     float    hX;
     // candidate storage
+    int32_t  cellCap;         // candidate slots per cell = ceil(wCell/2)*ceil(hCell/2)
+    int64_t  cellCandOff;     // u32 offset of this level's cell slots inside a frame's slab
     int32_t  candCap;
     int64_t  candOff;         // u32 offset of (frame 0, this level) inside a frame's slab
     int64_t  selOff;          // u32 offset inside a frame's selection slab
@@ -50,7 +61,10 @@ struct PgPlan {
     int64_t  candFrame;       // u32 per frame in cand / kpos arenas
     int64_t  selFrame;        // u32 per frame in sel arena
     int64_t  nodeFrame;       // int per frame in node scratch
-    uint32_t* cand;
+    int64_t  cellCandFrame;   // u32 per frame in the per-cell slot slab
+    uint32_t* cellCand;       // K2 output: [frame][level][cell][cellCap]
+    int32_t*  cellCount;      // K2 output: [frame][totalCells]
+    uint32_t* cand;           // K3: dense candidates
     uint32_t* kpos;
     uint32_t* sel;
     int32_t*  nodeScratch;
@@ -75,3 +89,5 @@ void pg_launch_match_batch(const uint8_t* d_desc, const int32_t* d_n, int cap_pe
                            hipStream_t s);
 void pg_launch_best2(const uint8_t* d_a, int na, const uint8_t* d_b, int nb,
                      int32_t* d_best_idx, uint16_t* d_best, uint16_t* d_second, hipStream_t s);
+
+static_assert(sizeof(PgPlan) <= 4000, "PgPlan is passed by value as a kernel argument (4 KiB limit)");

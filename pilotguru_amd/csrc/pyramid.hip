@@ -66,10 +66,89 @@ __global__ __launch_bounds__(256) void k_pyr_resize_bilinear_u8(
     *reinterpret_cast<uint32_t*>(dst + (int64_t)blockIdx.z * dfstride + (int64_t)dy * dpitch + x4) = out;
 }
 
+// Fast path (scale factors up to ~2): one lane owns 4 adjacent destination columns for
+// PYR_ROWS consecutive destination rows.  Its column taps live in registers (host-built
+// PgQuadTab: first source dword, per-pixel byte offsets, 11-bit coefficients); per source row it
+// issues three aligned 32-bit loads and extracts the taps with v_alignbyte; the horizontal
+// result of a source row is kept in registers and reused by the next destination row
+// (a 1.2x down-scale needs 1.2 source rows per destination row instead of 2).
+#define PYR_ROWS 8
+
+__device__ __forceinline__ void pyr_hrow(const uint8_t* __restrict__ row, int base_dw, int last_dw,
+                                         uint32_t offs, const int a0[4], const int a1[4], int H[4])
+{
+    const uint32_t* r = reinterpret_cast<const uint32_t*>(row);
+    const uint32_t w0 = r[min(base_dw, last_dw)], w1 = r[min(base_dw + 1, last_dw)],
+                   w2 = r[min(base_dw + 2, last_dw)];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t o = (offs >> (4 * k)) & 15u;
+        const uint32_t lo = o < 4 ? w0 : (o < 8 ? w1 : w2);
+        const uint32_t hi = o < 4 ? w1 : (o < 8 ? w2 : 0u);
+        const uint32_t t = __builtin_amdgcn_alignbyte(hi, lo, o & 3u);
+        H[k] = (int)(t & 0xFF) * a0[k] + (int)((t >> 8) & 0xFF) * a1[k];      // HResizeLinear, 11-bit
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pyr_resize_quads(
+    const uint8_t* __restrict__ src, int spitch, int64_t sfstride, int sw,
+    uint8_t* __restrict__ dst, int dpitch, int64_t dfstride, int dw, int dh,
+    const PgQuadTab* __restrict__ qtab, const int32_t* __restrict__ yofs,
+    const int16_t* __restrict__ ybeta)
+{
+    const int quad = blockIdx.x * 64 + threadIdx.x;
+    const int dy0 = (blockIdx.y * 4 + threadIdx.y) * PYR_ROWS;
+    if (quad * 4 >= dw || dy0 >= dh) return;
+    const PgQuadTab T = qtab[quad];
+    int a0[4], a1[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { a0[k] = T.a0[k]; a1[k] = T.a1[k]; }
+    const int last_dw = (sw - 1) >> 2;
+    const uint8_t* sbase = src + (int64_t)blockIdx.z * sfstride;
+    uint8_t* dbase = dst + (int64_t)blockIdx.z * dfstride + quad * 4;
+    int rowA = -1, rowB = -1, HA[4] = {0, 0, 0, 0}, HB[4] = {0, 0, 0, 0};
+    const int dyEnd = min(dy0 + PYR_ROWS, dh);
+    for (int dy = dy0; dy < dyEnd; dy++) {
+        const int sy0 = yofs[2 * dy], sy1 = yofs[2 * dy + 1];          // wave-uniform
+        if (sy0 != rowA) {
+            if (sy0 == rowB) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) HA[k] = HB[k];
+            } else {
+                pyr_hrow(sbase + (int64_t)sy0 * spitch, T.base_dw, last_dw, T.offs, a0, a1, HA);
+            }
+            rowA = sy0;
+        }
+        if (sy1 != rowB) {
+            if (sy1 == rowA) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) HB[k] = HA[k];
+            } else {
+                pyr_hrow(sbase + (int64_t)sy1 * spitch, T.base_dw, last_dw, T.offs, a0, a1, HB);
+            }
+            rowB = sy1;
+        }
+        const int b0 = ybeta[2 * dy], b1 = ybeta[2 * dy + 1];
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int v = (((b0 * (HA[k] >> 4)) >> 16) + ((b1 * (HB[k] >> 4)) >> 16) + 2) >> 2;
+            out |= (uint32_t)(v & 0xFF) << (8 * k);
+        }
+        *reinterpret_cast<uint32_t*>(dbase + (int64_t)dy * dpitch) = out;
+    }
+}
+
 void pg_launch_pyramid_level(const PgPlan& P, int level, int nframes, hipStream_t s)
 {
     const PgLevel& S = P.lvl[level - 1];
     const PgLevel& D = P.lvl[level];
+    if (D.qtab) {
+        dim3 block(64, 4), grid((D.w + 255) / 256, (D.h + 4 * PYR_ROWS - 1) / (4 * PYR_ROWS), nframes);
+        hipLaunchKernelGGL(k_pyr_resize_quads, grid, block, 0, s, S.img, S.pitch, S.fstride, S.w,
+                           D.img, D.pitch, D.fstride, D.w, D.h, D.qtab, D.yofs, D.ybeta);
+        return;
+    }
     dim3 block(64, 4), grid((D.w + 255) / 256, (D.h + 3) / 4, nframes);
     hipLaunchKernelGGL(k_pyr_resize_bilinear_u8, grid, block, 0, s, S.img, S.pitch, S.fstride,
                        D.img, D.pitch, D.fstride, D.w, D.h, D.xofs, D.xofs1, D.xalpha, D.yofs,

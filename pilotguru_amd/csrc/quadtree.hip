@@ -66,11 +66,47 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const PgPlan P)
     const int l = blockIdx.x, frame = blockIdx.y;
     const PgLevel& L = P.lvl[l];
     int* kpc = &P.kpCount[frame * PG_MAXL + l];
-    int ncand = P.candCount[frame * PG_MAXL + l];
+    uint32_t* cand = P.cand + (int64_t)frame * P.candFrame + L.candOff;
+
+    // ---- prologue: compact K2's per-cell slots into a dense candidate array ---------------
+    int ncand;
+    {
+        const int ncells = L.nCols * L.nRows;
+        const int32_t* cc = P.cellCount + (int64_t)frame * P.totalCells + L.cellBase;
+        const uint32_t* slots = P.cellCand + (int64_t)frame * P.cellCandFrame + L.cellCandOff;
+        const int per = (ncells + QT_T - 1) / QT_T;
+        const int cb = tid * per, ce = min(cb + per, ncells);
+        int sum = 0;
+        for (int i = cb; i < ce; i++) sum += cc[i];
+        sh[tid] = sum;
+        __syncthreads();
+        if (tid < 64) {
+            int v0 = sh[4 * tid], v1 = sh[4 * tid + 1], v2 = sh[4 * tid + 2], v3 = sh[4 * tid + 3];
+            int s = v0 + v1 + v2 + v3, incl = s;
+            for (int d = 1; d < 64; d <<= 1) {
+                int o = __shfl_up(incl, d);
+                if (tid >= d) incl += o;
+            }
+            int ex = incl - s;
+            sh[4 * tid] = ex; sh[4 * tid + 1] = ex + v0; sh[4 * tid + 2] = ex + v0 + v1;
+            sh[4 * tid + 3] = ex + v0 + v1 + v2;
+            if (tid == 63) sh[QT_T] = incl;
+        }
+        __syncthreads();
+        int run = sh[tid];
+        ncand = sh[QT_T];
+        for (int i = cb; i < ce; i++) {
+            const int n = cc[i];
+            const uint32_t* src = slots + (int64_t)i * L.cellCap;
+            for (int j = 0; j < n; j++) cand[run + j] = src[j];
+            run += n;
+        }
+        if (tid == 0) P.candCount[frame * PG_MAXL + l] = ncand;
+        __syncthreads();
+    }
     if (ncand > L.candCap) ncand = L.candCap;
     if (ncand <= 0) { if (tid == 0) *kpc = 0; return; }
 
-    const uint32_t* cand = P.cand + (int64_t)frame * P.candFrame + L.candOff;
     uint32_t* kpos = P.kpos + (int64_t)frame * P.candFrame + L.candOff;
     int* S = P.nodeScratch + (int64_t)frame * P.nodeFrame + L.nodeOff;
     const int NC = L.nodeCap;
