@@ -230,11 +230,11 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
         V.cellCandOff = (int64_t)cellCandFrame;
         cellCandFrame += align_up((size_t)V.cellCap * V.nCols * V.nRows, 64);
         V.selOff = (int64_t)selFrame; selFrame += align_up(V.selCap, 16);
-        V.nodeOff = (int64_t)nodeFrame; nodeFrame += (size_t)V.nodeCap * 20;
+        V.nodeOff = (int64_t)nodeFrame; nodeFrame += align_up((size_t)V.nCols * V.nRows, 64);   // cell offsets
         V.scale = c->mvScaleFactor[l];
         V.patchSize = (float)(int)(31 * c->mvScaleFactor[l]);                     // :836
         selTotal += V.selCap;
-        if ((size_t)V.nodeCap * 6 * sizeof(int) > 60 * 1024)
+        if ((size_t)V.nodeCap * 24 * sizeof(int) > 150 * 1024)
             return fail(c, PGORB_E_LIMIT, "nfeatures too large for the quadtree kernel's LDS budget");
         if (V.w > 4095 + 2 * PG_EDGE || V.h > 4095 + 2 * PG_EDGE)
             return fail(c, PGORB_E_LIMIT, "level larger than 4095 px is not supported");
@@ -243,8 +243,7 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
     P.cellCandFrame = (int64_t)cellCandFrame;
     P.candFrame = (int64_t)candFrame; P.selFrame = (int64_t)selFrame; P.nodeFrame = (int64_t)nodeFrame;
     if ((rc = ensure(c, c->pyr, pyrFrame * B))) return rc;
-    if ((rc = ensure(c, c->cand, candFrame * 4 * B))) return rc;
-    if ((rc = ensure(c, c->kpos, candFrame * 4 * B))) return rc;
+    if ((rc = ensure(c, c->cand, candFrame * 8 * B))) return rc;          // uint2 key records
     if ((rc = ensure(c, c->cellCand, cellCandFrame * 4 * B))) return rc;
     if ((rc = ensure(c, c->cellCount, (size_t)cells * 4 * B + 64))) return rc;
     if ((rc = ensure(c, c->sel, selFrame * 4 * B))) return rc;
@@ -265,7 +264,7 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
         }
     }
     P.cellCand = (uint32_t*)c->cellCand.p; P.cellCount = (int32_t*)c->cellCount.p;
-    P.cand = (uint32_t*)c->cand.p; P.kpos = (uint32_t*)c->kpos.p; P.sel = (uint32_t*)c->sel.p;
+    P.cand = (uint32_t*)c->cand.p; P.kpos = nullptr; P.sel = (uint32_t*)c->sel.p;
     P.nodeScratch = (int32_t*)c->nodes.p;
     P.candCount = (int32_t*)c->counters.p;
     P.kpCount = P.candCount + (size_t)B * PG_MAXL;
@@ -625,12 +624,13 @@ int pgorb_debug_level_candidates(pgorb_ctx* c, int frame, int level, int32_t* x,
     int32_t cnt = 0;
     PG_HIP(c, hipMemcpy(&cnt, P.candCount + frame * PG_MAXL + level, 4, hipMemcpyDeviceToHost));
     if (cnt > P.lvl[level].candCap) cnt = P.lvl[level].candCap;
-    std::vector<uint32_t> buf(cnt > 0 ? cnt : 1);
+    std::vector<uint32_t> buf(cnt > 0 ? 2 * (size_t)cnt : 2);
     if (cnt > 0)
-        PG_HIP(c, hipMemcpy(buf.data(), P.cand + (int64_t)frame * P.candFrame + P.lvl[level].candOff,
-                            (size_t)cnt * 4, hipMemcpyDeviceToHost));
+        PG_HIP(c, hipMemcpy(buf.data(), P.cand + ((int64_t)frame * P.candFrame + P.lvl[level].candOff) * 2,
+                            (size_t)cnt * 8, hipMemcpyDeviceToHost));
     for (int i = 0; i < cnt && i < cap; i++) {
-        x[i] = buf[i] & 0xFFF; y[i] = (buf[i] >> 12) & 0xFFF; response[i] = buf[i] >> 24;
+        const uint32_t v = buf[2 * (size_t)i];
+        x[i] = v & 0xFFF; y[i] = (v >> 12) & 0xFFF; response[i] = v >> 24;
     }
     return cnt;
 }

@@ -16,6 +16,8 @@
 // Structure per wave:
 //  (1) the (wCell+6)x(hCell+6) window is staged into LDS with aligned 32-bit global loads,
 //      re-aligned with v_alignbyte so that interior column 0 sits on an LDS dword boundary;
+//      (a persistent-wave variant with register prefetch of the next window measured 2x slower:
+//      the per-cell scalar set-up serialises inside one wave instead of overlapping across waves)
 //  (2) each lane tests a QUAD of 4 horizontally adjacent pixels per step from 5 aligned LDS
 //      dwords (centre, left, right, 3 rows up, 3 rows down): a pixel can only be a corner if
 //      both opposite ring pairs (0,8) and (4,12) contain a darker (or a brighter) pixel; the
@@ -35,6 +37,7 @@
 // Roofline: HBM-read bound in principle (one pass over all pyramid pixels, 1 B/px);
 // algorithmic bytes per frame = sum_l w_l*h_l.
 #include "pgorb_internal.h"
+#include <stdlib.h>
 
 extern __shared__ __attribute__((aligned(16))) uint8_t pg_fast_smem[];
 
@@ -79,17 +82,21 @@ __device__ __forceinline__ int wave_prefix(unsigned long long m)
 
 // tile layout: row r at tile + r*TP; window column c at byte 1 + c, so interior column 0
 // (window column 3) is at byte 4.
+#define FAST_LIST_CAP 768          // compacted candidates held in LDS (u16 each)
+
+// (2) necessary test + compaction of interior rows [rowBeg, rowEnd).  Returns the new list
+// length, or -1 when the list could overflow (the caller then takes the chunked slow path).
 template <int QW>      // quads per row handled by consecutive lanes: 8 (IW <= 32) or 16 (IW <= 64)
-__device__ __forceinline__ int quick_pass(const uint8_t* tile, int TP, int IW, int IH, int t,
-                                          uint16_t* list, int lane)
+__device__ __forceinline__ int quick_pass(const uint8_t* tile, int TP, int IW, int rowBeg, int rowEnd,
+                                          int t, uint16_t* list, int nlist, int lane)
 {
     const int lq = lane & (QW - 1), lr = lane / QW;
     const int NQ = (IW + 3) >> 2;
-    int nlist = 0;
-    for (int row0 = 0; row0 < IH; row0 += 64 / QW) {
+    for (int row0 = rowBeg; row0 < rowEnd; row0 += 64 / QW) {
+        if (nlist > FAST_LIST_CAP - 256) return -1;          // a step adds at most 256 entries
         const int iy = row0 + lr;
         unsigned pass = 0;
-        if (iy < IH && lq < NQ) {
+        if (iy < rowEnd && lq < NQ) {
             const uint32_t* rc = reinterpret_cast<const uint32_t*>(tile + (iy + 3) * TP) + 1 + lq;
             const uint32_t* ru = reinterpret_cast<const uint32_t*>(tile + iy * TP) + 1 + lq;
             const uint32_t* rd = reinterpret_cast<const uint32_t*>(tile + (iy + 6) * TP) + 1 + lq;
@@ -101,25 +108,88 @@ __device__ __forceinline__ int quick_pass(const uint8_t* tile, int TP, int IW, i
                 const int v = (C >> (8 * i)) & 0xFF;
                 const int r0 = (D >> (8 * i)) & 0xFF, r8 = (U >> (8 * i)) & 0xFF;
                 const int r4 = (R3 >> (8 * i)) & 0xFF, r12 = (L3 >> (8 * i)) & 0xFF;
-                const int lo = v - t, hi = v + t;
-                const bool dark = (r0 < lo || r8 < lo) && (r4 < lo || r12 < lo);
-                const bool bright = (r0 > hi || r8 > hi) && (r4 > hi || r12 > hi);
-                if ((dark || bright) && 4 * lq + i < IW) pass |= 1u << i;
+                // darker: both pairs hold a pixel < v-t  <=>  max(min(r0,r8), min(r4,r12)) + t < v
+                const int dk = max(min(r0, r8), min(r4, r12)) + t;
+                const int br = min(max(r0, r8), max(r4, r12)) - t;
+                if ((dk < v || br > v) && 4 * lq + i < IW) pass |= 1u << i;
             }
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const bool p = (pass >> i) & 1;
             const unsigned long long m = __ballot(p);
-            if (p) list[nlist + wave_prefix(m)] = (uint16_t)(iy * IW + 4 * lq + i);
+            if (p) list[nlist + wave_prefix(m)] = (uint16_t)((iy << 8) | (4 * lq + i));
             nlist += __popcll(m);
         }
     }
     return nlist;
 }
 
-__global__ __launch_bounds__(64) void k_fast_cells(const PgPlan P, int TP, int tileRows,
-                                                    int mapPitch, int mapRows, int cellsPerXcd)
+// (3) exact scores for the compacted pixels -> score map
+__device__ __forceinline__ void score_list(const uint8_t* tile, int TP, uint8_t* smap, int mapPitch,
+                                           const uint16_t* list, int nlist, int t, int lane)
+{
+    for (int base = 0; base < nlist; base += 64) {
+        const int i = base + lane;
+        if (i < nlist) {
+            const int p = list[i] & 0x7FFF;
+            const int iy = p >> 8, ix = p & 0xFF;
+            const uint8_t* cp = tile + (iy + 3) * TP + 4 + ix;
+            int d[16];
+            ring_load(cp, TP, cp[0], d);
+            const int s = fast_score16(d);
+            if (s >= t) smap[(iy + 1) * mapPitch + ix + 1] = (uint8_t)s;   // else: not a corner at t
+        }
+    }
+}
+
+// 3x3 strict NMS of one pixel on the score map (outside the interior = 0); returns its score or 0
+__device__ __forceinline__ int nms_score(const uint8_t* smap, int mapPitch, int iy, int ix)
+{
+    const uint8_t* m = smap + (iy + 1) * mapPitch + ix + 1;
+    const int s = m[0];
+    const bool keep = s && s > m[-1] && s > m[1] && s > m[-mapPitch - 1] && s > m[-mapPitch] &&
+                      s > m[-mapPitch + 1] && s > m[mapPitch - 1] && s > m[mapPitch] && s > m[mapPitch + 1];
+    return keep ? s : 0;
+}
+
+// Slow path for one threshold when the candidate list would not fit in LDS (very noisy cell at
+// minThFAST): score the cell in row blocks, then run NMS over every interior pixel.
+// Leaves the score map zeroed.  Returns the number of survivors (written to `out`).
+__device__ __noinline__ int fast_pass_chunked(const uint8_t* tile, int TP, uint8_t* smap, int mapPitch,
+                                              int mapRows, int IW, int IH, int t, uint16_t* list,
+                                              uint32_t* out, int cap, int xoff, int yoff, int lane)
+{
+    __syncthreads();
+    for (int i = lane; i < (mapRows * mapPitch) >> 2; i += 64) reinterpret_cast<uint32_t*>(smap)[i] = 0;
+    __syncthreads();
+    const int rowsPer = (IW <= 32) ? 16 : 8;                 // <= 512 candidates per block
+    for (int r = 0; r < IH; r += rowsPer) {
+        const int n = (IW <= 32) ? quick_pass<8>(tile, TP, IW, r, min(r + rowsPer, IH), t, list, 0, lane)
+                                 : quick_pass<16>(tile, TP, IW, r, min(r + rowsPer, IH), t, list, 0, lane);
+        __syncthreads();
+        score_list(tile, TP, smap, mapPitch, list, n, t, lane);
+        __syncthreads();
+    }
+    int done = 0;
+    for (int iy = 0; iy < IH; iy++)
+        for (int ix = lane; ix - lane < IW; ix += 64) {
+            const int sc = ix < IW ? nms_score(smap, mapPitch, iy, ix) : 0;
+            const unsigned long long m = __ballot(sc != 0);
+            if (sc) {
+                const int pos = done + wave_prefix(m);
+                if (pos < cap) out[pos] = (uint32_t)(ix + xoff) | ((uint32_t)(iy + yoff) << 12) | ((uint32_t)sc << 24);
+            }
+            done += __popcll(m);
+        }
+    __syncthreads();
+    for (int i = lane; i < (mapRows * mapPitch) >> 2; i += 64) reinterpret_cast<uint32_t*>(smap)[i] = 0;
+    __syncthreads();
+    return done;
+}
+
+__global__ __launch_bounds__(64, 8) void k_fast_cells(const PgPlan P, int TP, int tileRows,
+                                                       int mapPitch, int mapRows, int cellsPerXcd)
 {
     const int lane = threadIdx.x;
     const int frame = blockIdx.y;
@@ -134,14 +204,11 @@ __global__ __launch_bounds__(64) void k_fast_cells(const PgPlan P, int TP, int t
     const int iniY = PG_EDGE + ci * L.hCell;
     const int iniX = PG_EDGE + cj * L.wCell;
     int32_t* cellCnt = P.cellCount + (int64_t)frame * P.totalCells + cell;
-    if (iniY >= maxBorderY - 3 || iniX >= maxBorderX - 6) {             // :794, :803
-        if (lane == 0) *cellCnt = 0;
-        return;
-    }
     const int maxX = min(iniX + L.wCell + 6, maxBorderX);
     const int maxY = min(iniY + L.hCell + 6, maxBorderY);
     const int W = maxX - iniX, H = maxY - iniY;
-    if (W < 7 || H < 7) {                                               // cv::FAST finds nothing
+    // skipped cells (:794, :803) and windows cv::FAST finds nothing in (< 7 px)
+    if (iniY >= maxBorderY - 3 || iniX >= maxBorderX - 6 || W < 7 || H < 7) {
         if (lane == 0) *cellCnt = 0;
         return;
     }
@@ -149,48 +216,48 @@ __global__ __launch_bounds__(64) void k_fast_cells(const PgPlan P, int TP, int t
 
     uint8_t* tile = pg_fast_smem;                                  // [tileRows][TP]
     uint8_t* smap = tile + tileRows * TP;                          // [mapRows][mapPitch], 1-px zero rim
-    uint16_t* list = reinterpret_cast<uint16_t*>(smap + mapRows * mapPitch);   // pixel ids
-    uint8_t* lscore = reinterpret_cast<uint8_t*>(list + (mapRows - 2) * mapPitch);
+    uint16_t* list = reinterpret_cast<uint16_t*>(smap + mapRows * mapPitch);   // [FAST_LIST_CAP]
 
     // (1) stage the window.  LDS dword j of a row holds window columns 4j-1 .. 4j+2.
     const uint8_t* img = L.img + (int64_t)frame * L.fstride;
     const int gx0 = iniX - 1;                       // global x of LDS byte 0
     const int ga = gx0 & ~3, sh = gx0 & 3;
     const int ndw = (W + 1 + 3) >> 2;               // dwords covering bytes 0 .. W
-    for (int i = lane; i < ndw * H; i += 64) {
-        const int r = i / ndw, q = i - r * ndw;
-        const uint32_t* g = reinterpret_cast<const uint32_t*>(img + (int64_t)(iniY + r) * L.pitch + ga) + q;
-        const uint32_t lo = g[0], hi = g[1];
-        const uint32_t v = sh == 0 ? lo : sh == 1 ? __builtin_amdgcn_alignbyte(hi, lo, 1)
-                         : sh == 2 ? __builtin_amdgcn_alignbyte(hi, lo, 2)
-                                   : __builtin_amdgcn_alignbyte(hi, lo, 3);
-        *reinterpret_cast<uint32_t*>(tile + r * TP + 4 * q) = v;
+    {
+        const int lq = lane & 15, lr = lane >> 4;       // 16 dwords x 4 rows per step
+        const uint8_t* grow = img + (int64_t)(iniY + lr) * L.pitch + ga;
+        uint8_t* trow = tile + lr * TP;
+        for (int r = lr; r < H; r += 4, grow += 4 * (int64_t)L.pitch, trow += 4 * TP)
+            for (int q = lq; q < ndw; q += 16) {
+                const uint32_t* g = reinterpret_cast<const uint32_t*>(grow) + q;
+                const uint32_t lo = g[0], hi = g[1];
+                *reinterpret_cast<uint32_t*>(trow + 4 * q) = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)sh);
+            }
     }
     for (int i = lane; i < (mapRows * mapPitch) >> 2; i += 64)
         reinterpret_cast<uint32_t*>(smap)[i] = 0;
     __syncthreads();
 
+    uint32_t* out = P.cellCand + (int64_t)frame * P.cellCandFrame + L.cellCandOff + (int64_t)c * L.cellCap;
+    const int xoff = 3 + cj * L.wCell, yoff = 3 + ci * L.hCell;   // window-local -> region-relative (:822-823)
+
     for (int pass = 0; pass < 2; pass++) {
         const int t = pass == 0 ? P.iniTh : P.minTh;
         // (2) necessary test + compaction
-        const int nlist = (IW <= 32) ? quick_pass<8>(tile, TP, IW, IH, t, list, lane)
-                                     : quick_pass<16>(tile, TP, IW, IH, t, list, lane);
+        const int nlist = (IW <= 32) ? quick_pass<8>(tile, TP, IW, 0, IH, t, list, 0, lane)
+                                     : quick_pass<16>(tile, TP, IW, 0, IH, t, list, 0, lane);
+        if (nlist < 0) {                                   // list would overflow: chunked slow path
+            const int total = fast_pass_chunked(tile, TP, smap, mapPitch, mapRows, IW, IH, t, list, out,
+                                                L.cellCap, xoff, yoff, lane);
+            if (total > 0 || pass == 1) {
+                if (lane == 0) *cellCnt = min(total, L.cellCap);
+                return;
+            }
+            continue;
+        }
         __syncthreads();
         // (3) exact scores for the compacted pixels
-        for (int base = 0; base < nlist; base += 64) {
-            const int i = base + lane;
-            if (i < nlist) {
-                const int p = list[i];
-                const int iy = p / IW, ix = p - iy * IW;
-                const uint8_t* cp = tile + (iy + 3) * TP + 4 + ix;
-                int d[16];
-                ring_load(cp, TP, cp[0], d);
-                int s = fast_score16(d);
-                s = (s >= t) ? s : 0;                    // not a corner at this threshold
-                lscore[i] = (uint8_t)s;
-                if (s) smap[(iy + 1) * mapPitch + ix + 1] = (uint8_t)s;
-            }
-        }
+        score_list(tile, TP, smap, mapPitch, list, nlist, t, lane);
         __syncthreads();
         // (4) NMS (strictly greater than all 8 neighbours; outside the interior = 0)
         int total = 0;
@@ -198,16 +265,9 @@ __global__ __launch_bounds__(64) void k_fast_cells(const PgPlan P, int TP, int t
             const int i = base + lane;
             bool keep = false;
             if (i < nlist) {
-                const int s = lscore[i];
-                if (s) {
-                    const int p = list[i];
-                    const int iy = p / IW, ix = p - iy * IW;
-                    const uint8_t* m = smap + (iy + 1) * mapPitch + ix + 1;
-                    keep = s > m[-1] && s > m[1] && s > m[-mapPitch - 1] && s > m[-mapPitch] &&
-                           s > m[-mapPitch + 1] && s > m[mapPitch - 1] && s > m[mapPitch] &&
-                           s > m[mapPitch + 1];
-                    if (!keep) lscore[i] = 0;
-                }
+                const int p = list[i];
+                keep = nms_score(smap, mapPitch, p >> 8, p & 0xFF) != 0;
+                if (keep) list[i] = (uint16_t)(p | 0x8000);          // iy < 64: bit 15 is free
             }
             total += __popcll(__ballot(keep));
         }
@@ -221,9 +281,8 @@ __global__ __launch_bounds__(64) void k_fast_cells(const PgPlan P, int TP, int t
             for (int base = 0; base < nlist; base += 64) {
                 const int i = base + lane;
                 if (i < nlist) {
-                    const int p = list[i];
-                    const int iy = p / IW, ix = p - iy * IW;
-                    smap[(iy + 1) * mapPitch + ix + 1] = 0;
+                    const int p = list[i] & 0x7FFF;
+                    smap[((p >> 8) + 1) * mapPitch + (p & 0xFF) + 1] = 0;
                 }
             }
             __syncthreads();
@@ -231,20 +290,18 @@ __global__ __launch_bounds__(64) void k_fast_cells(const PgPlan P, int TP, int t
         }
         // emit into this cell's slots
         if (lane == 0) *cellCnt = total;
-        uint32_t* out = P.cellCand + (int64_t)frame * P.cellCandFrame + L.cellCandOff + (int64_t)c * L.cellCap;
         int done = 0;
         for (int base = 0; base < nlist; base += 64) {
             const int i = base + lane;
-            const bool emit = (i < nlist) && lscore[i] != 0;
+            const bool emit = (i < nlist) && (list[i] & 0x8000);
             const unsigned long long m = __ballot(emit);
             if (emit) {
                 const int pos = done + wave_prefix(m);
-                const int p = list[i];
-                const int iy = p / IW, ix = p - iy * IW;
-                // region-relative coordinates: window-local + cell offset (:822-823)
-                const int xr = ix + 3 + cj * L.wCell, yr = iy + 3 + ci * L.hCell;
+                const int p = list[i] & 0x7FFF;
+                const int iy = p >> 8, ix = p & 0xFF;
+                const uint32_t sc = smap[(iy + 1) * mapPitch + ix + 1];
                 if (pos < L.cellCap)
-                    out[pos] = (uint32_t)xr | ((uint32_t)yr << 12) | ((uint32_t)lscore[i] << 24);
+                    out[pos] = (uint32_t)(ix + xoff) | ((uint32_t)(iy + yoff) << 12) | (sc << 24);
                 else
                     atomicExch(P.status, PGORB_E_OVERFLOW);          // cannot happen (see header)
             }
@@ -261,13 +318,12 @@ void pg_launch_fast(const PgPlan& P, int nframes, hipStream_t s)
         maxW = max(maxW, P.lvl[l].wCell + 6);
         maxH = max(maxH, P.lvl[l].hCell + 6);
     }
-    const int TP = ((maxW + 1 + 3) & ~3) + 8;              // byte 0 pad + window + slack dwords
+    const int TP = (maxW + 5 + 3) & ~3;                    // byte 0 pad + window + quick-test over-read
     const int tileRows = maxH;
     const int mapPitch = ((maxW - 6 + 2) + 3) & ~3;
     const int mapRows = maxH - 6 + 2;
-    const int npixMax = (mapRows - 2) * mapPitch;
-    size_t smem = (size_t)tileRows * TP + (size_t)mapRows * mapPitch;
-    smem += (size_t)npixMax * 2 + (size_t)npixMax + 64;
+    size_t smem = (size_t)tileRows * TP + (size_t)mapRows * mapPitch + FAST_LIST_CAP * 2 + 16;
+    if (const char* e = getenv("PGORB_FAST_EXTRA_LDS")) smem += (size_t)atoi(e);   // occupancy experiments
     const int cellsPerXcd = (P.totalCells + 7) / 8;
     dim3 grid(cellsPerXcd * 8, nframes), block(64);
     hipLaunchKernelGGL(k_fast_cells, grid, block, smem, s, P, TP, tileRows, mapPitch, mapRows, cellsPerXcd);

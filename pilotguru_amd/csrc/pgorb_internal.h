@@ -7,8 +7,8 @@
 //   cell slots      u32 cellCand[f][l][cell][cellCap_l] + i32 cellCount[f][cell]: K2 output,
 //                   packed x | y<<12 | score<<24 (region-relative coordinates, i.e. pixel - 16,
 //                   like vToDistributeKeys ORBextractor.cc:818-826)
-//   candidate arena u32 cand[f][l][candCap_l]  the same records compacted by K3's prologue
-//   key scratch     u32 kpos[f][l][candCap_l]  quadtree: current node position of every key
+//   key records     uint2 keys[f][l][candCap_l] = {packed candidate, node position | quadrant<<28}:
+//                   K2's records compacted by K3's prologue + the quadtree's per-key state
 //   selection       u32 sel[f][l][selCap]      quadtree result in the reference's output order
 //   counters        i32 candCount[f][l], kpCount[f][l], status word
 #pragma once
@@ -64,8 +64,8 @@ struct PgPlan {
     int64_t  cellCandFrame;   // u32 per frame in the per-cell slot slab
     uint32_t* cellCand;       // K2 output: [frame][level][cell][cellCap]
     int32_t*  cellCount;      // K2 output: [frame][totalCells]
-    uint32_t* cand;           // K3: dense candidates
-    uint32_t* kpos;
+    uint32_t* cand;           // K3: dense uint2 key records (2 u32 per key)
+    uint32_t* kpos;           // (unused)
     uint32_t* sel;
     int32_t*  nodeScratch;
     int32_t*  candCount;      // [frame][PG_MAXL]
