@@ -108,9 +108,9 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
                                                   uint8_t* __restrict__ desc, int cap_per_frame,
                                                   int32_t* __restrict__ n_out)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t raw[DW_N * DW_PITCH];
-    __shared__ __attribute__((aligned(16))) uint16_t hbuf[DW_N * DH_PITCH];
-    __shared__ __attribute__((aligned(16))) uint8_t blur[DH_N * DB_PITCH];
+    __shared__ __attribute__((aligned(16))) uint8_t raw[DW_N * DW_PITCH];       // 2064 B
+    __shared__ __attribute__((aligned(16))) uint16_t hbuf[DW_N * DH_PITCH];     // 3440 B
+    uint8_t* blur = raw;          // the blurred tile (37 x 40 B) reuses the raw window once the row pass is done
 
     const int lane = threadIdx.x;
     const int frame = blockIdx.y;
@@ -154,17 +154,26 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
         }
     }
     __syncthreads();
-    const uint8_t* rw = raw;                   // rw[r*DW_PITCH + c], (r,c) in 0..42, centre (21,21)
+
 
     // ---- IC_Angle: integer moments over the radius-15 disc (:77-104) -------------------
+    // One task = one aligned dword (4 pixels) of one disc row; v_dot4_u32_u8 against per-row
+    // weight dwords: (u+15) inside the disc / 0 outside, and the 0/1 disc mask.
     int m10 = 0, m01 = 0;
-    for (int i = lane; i < 31 * 31; i += 64) {
-        const int vy = i / 31 - 15, ux = i - (i / 31) * 31 - 15;
-        if (abs(ux) <= pg_umax[abs(vy)]) {
-            const int val = rw[(DW_R + vy) * DW_PITCH + DW_R + ux];
-            m10 += ux * val;
-            m01 += vy * val;
+    for (int i = lane; i < 31 * 9; i += 64) {
+        const int r = i / 9, q = i - r * 9;                     // r = v+15, dword q+1 = columns 4q+4 ..
+        const int vy = r - 15;
+        const uint32_t val = *reinterpret_cast<const uint32_t*>(raw + (DW_R + vy) * DW_PITCH + 4 * (q + 1));
+        const int dmax = pg_umax[abs(vy)];
+        uint32_t wu = 0, wm = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int ux = 4 * (q + 1) + k - DW_R;
+            if (abs(ux) <= dmax) { wu |= (uint32_t)(ux + 15) << (8 * k); wm |= 1u << (8 * k); }
         }
+        const int sv = (int)__builtin_amdgcn_udot4(val, wm, 0u, false);          // sum of disc pixels
+        m10 += (int)__builtin_amdgcn_udot4(val, wu, 0u, false) - 15 * sv;        // sum u * I
+        m01 += vy * sv;                                                           // sum v * I
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -174,22 +183,22 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
     const float angle = pg_fast_atan2((float)m01, (float)m10);
 
     // ---- 7x7 Gaussian, fixed point, separable (OpenCV 2.4 8U path, Appendix A4) ---------
-    // row pass: a lane produces 4 adjacent sums from 3 aligned LDS dwords (10 source bytes)
+    // row pass: a lane produces 4 adjacent sums from 3 aligned LDS dwords; each sum is two
+    // v_dot4_u32_u8 against the packed taps (K0..K3) and (K4,K5,K6,0)
+    const uint32_t KA = (uint32_t)G.k0 | ((uint32_t)G.k1 << 8) | ((uint32_t)G.k2 << 16) | ((uint32_t)G.k3 << 24);
+    const uint32_t KB = (uint32_t)G.k2 | ((uint32_t)G.k1 << 8) | ((uint32_t)G.k0 << 16);
     for (int i = lane; i < DW_N * 10; i += 64) {
         const int r = i / 10, q = i - r * 10;
         const uint32_t* s = reinterpret_cast<const uint32_t*>(raw + r * DW_PITCH) + q;
         const uint32_t w0 = s[0], w1 = s[1], w2 = s[2];
-        int b[10];
-#pragma unroll
-        for (int k = 0; k < 4; k++) { b[k] = (w0 >> (8 * k)) & 0xFF; b[4 + k] = (w1 >> (8 * k)) & 0xFF; }
-        b[8] = w2 & 0xFF; b[9] = (w2 >> 8) & 0xFF;
         uint32_t o[4];
+        o[0] = __builtin_amdgcn_udot4(w0, KA, __builtin_amdgcn_udot4(w1, KB, 0u, false), false);
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-            o[k] = (uint32_t)(G.k0 * (b[k] + b[k + 6]) + G.k1 * (b[k + 1] + b[k + 5]) +
-                              G.k2 * (b[k + 2] + b[k + 4]) + G.k3 * b[k + 3]);     // <= 257*255
+        for (int k = 1; k < 4; k++)
+            o[k] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, (uint32_t)k), KA,
+                       __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, (uint32_t)k), KB, 0u, false), false);
         uint32_t* d = reinterpret_cast<uint32_t*>(hbuf + r * DH_PITCH + 4 * q);
-        d[0] = o[0] | (o[1] << 16);
+        d[0] = o[0] | (o[1] << 16);                               // each sum <= 257*255 = 65535
         d[1] = o[2] | (o[3] << 16);
     }
     __syncthreads();

@@ -50,54 +50,82 @@ __global__ __launch_bounds__(MT_T) void k_hamming_matrix(const uint8_t* __restri
     }
 }
 
-// best / second-best over all train descriptors for 64 queries per block
+// best / second-best over all train descriptors for 64 queries per workgroup.  The workgroup
+// is MT_WAVES waves: wave w scans the w-th contiguous slice of the train set for the SAME 64
+// queries (its own LDS tile), then wave 0 merges the partial results in slice order, which
+// preserves "first minimum wins" (strict '<', ORBmatcher.cc:443-458).
+#define MT_WAVES 4
+#define MT_SLICE_TILE 128     // train descriptors staged per wave and LDS tile (4 KiB)
+
 __device__ __forceinline__ void best2_scan(const uint8_t* a, int na, const uint8_t* b, int nb,
                                            int32_t* best_idx, uint16_t* best, uint16_t* second,
-                                           uint4* tile)
+                                           uint4* tiles, int* part)
 {
-    const int i = blockIdx.x * MT_T + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = blockIdx.x * MT_T + lane;
     uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
     if (i < na) {
         q0 = reinterpret_cast<const uint4*>(a + (int64_t)i * 32)[0];
         q1 = reinterpret_cast<const uint4*>(a + (int64_t)i * 32)[1];
     }
+    const int per = (nb + MT_WAVES - 1) / MT_WAVES;
+    const int jb = wv * per, je = min(jb + per, nb);
+    uint4* tile = tiles + wv * 2 * MT_SLICE_TILE;
     int b1 = 65535, b2 = 65535, bi = -1;
-    for (int j0 = 0; j0 < nb; j0 += MT_TILE) {
-        __syncthreads();
-        stage_tile(tile, b, j0, nb, threadIdx.x, MT_T);
-        __syncthreads();
-        const int cnt = min(MT_TILE, nb - j0);
+    for (int j0 = jb; j0 < je; j0 += MT_SLICE_TILE) {          // waves run independently: wave-local sync only
+        const int cnt = min(MT_SLICE_TILE, je - j0);
+        const uint4* src = reinterpret_cast<const uint4*>(b + (int64_t)j0 * 32);
+        __builtin_amdgcn_wave_barrier();
+        for (int k = lane; k < 2 * cnt; k += 64) tile[k] = src[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         for (int j = 0; j < cnt; j++) {
             const int d = pg_hamming256(q0, q1, tile[2 * j], tile[2 * j + 1]);
             if (d < b1) { b2 = b1; b1 = d; bi = j0 + j; }
             else if (d < b2) b2 = d;
         }
     }
-    if (i < na) { best_idx[i] = bi; best[i] = (uint16_t)b1; second[i] = (uint16_t)b2; }
+    part[(wv * 64 + lane) * 3 + 0] = b1;
+    part[(wv * 64 + lane) * 3 + 1] = b2;
+    part[(wv * 64 + lane) * 3 + 2] = bi;
+    __syncthreads();
+    if (wv == 0 && i < na) {
+        int m1 = 65535, m2 = 65535, mi = -1;
+#pragma unroll
+        for (int w = 0; w < MT_WAVES; w++) {
+            const int p1 = part[(w * 64 + lane) * 3], p2 = part[(w * 64 + lane) * 3 + 1], pi = part[(w * 64 + lane) * 3 + 2];
+            if (p1 < m1) { m2 = min(m1, p2); m1 = p1; mi = pi; }      // new best; old best and p2 compete for second
+            else m2 = min(m2, p1);                                     // p1 >= m1: candidate for second (p2 >= p1)
+        }
+        best_idx[i] = mi; best[i] = (uint16_t)m1; second[i] = (uint16_t)m2;
+    }
 }
 
-__global__ __launch_bounds__(MT_T) void k_hamming_best2(const uint8_t* __restrict__ a, int na,
+__global__ __launch_bounds__(MT_T * MT_WAVES) void k_hamming_best2(const uint8_t* __restrict__ a, int na,
                                                          const uint8_t* __restrict__ b, int nb,
                                                          int32_t* best_idx, uint16_t* best, uint16_t* second)
 {
-    __shared__ uint4 tile[2 * MT_TILE];
-    best2_scan(a, na, b, nb, best_idx, best, second, tile);
+    __shared__ uint4 tiles[MT_WAVES * 2 * MT_SLICE_TILE];
+    __shared__ int part[MT_WAVES * 64 * 3];
+    best2_scan(a, na, b, nb, best_idx, best, second, tiles, part);
 }
 
-__global__ __launch_bounds__(MT_T) void k_match_batch(const uint8_t* __restrict__ desc,
+__global__ __launch_bounds__(MT_T * MT_WAVES) void k_match_batch(const uint8_t* __restrict__ desc,
                                                        const int32_t* __restrict__ n, int cap,
                                                        const int32_t* __restrict__ pq,
                                                        const int32_t* __restrict__ pt,
                                                        int32_t* best_idx, uint16_t* best, uint16_t* second)
 {
-    __shared__ uint4 tile[2 * MT_TILE];
+    __shared__ uint4 tiles[MT_WAVES * 2 * MT_SLICE_TILE];
+    __shared__ int part[MT_WAVES * 64 * 3];
     const int p = blockIdx.y;
     const int fq = pq[p], ft = pt[p];
     const int na = min(n[fq], cap), nb = min(n[ft], cap);
     if ((int)blockIdx.x * MT_T >= na) return;
     const int64_t o = (int64_t)p * cap;
     best2_scan(desc + (int64_t)fq * cap * 32, na, desc + (int64_t)ft * cap * 32, nb,
-               best_idx + o, best + o, second + o, tile);
+               best_idx + o, best + o, second + o, tiles, part);
 }
 
 void pg_launch_hamming_matrix(const uint8_t* d_a, int na, const uint8_t* d_b, int nb,
@@ -114,7 +142,7 @@ void pg_launch_best2(const uint8_t* d_a, int na, const uint8_t* d_b, int nb,
                      int32_t* d_best_idx, uint16_t* d_best, uint16_t* d_second, hipStream_t s)
 {
     if (na <= 0) return;
-    dim3 grid((na + MT_T - 1) / MT_T), block(MT_T);
+    dim3 grid((na + MT_T - 1) / MT_T), block(MT_T * MT_WAVES);
     hipLaunchKernelGGL(k_hamming_best2, grid, block, 0, s, d_a, na, d_b, nb, d_best_idx, d_best, d_second);
 }
 
@@ -123,7 +151,7 @@ void pg_launch_match_batch(const uint8_t* d_desc, const int32_t* d_n, int cap_pe
                            int32_t* d_best_idx, uint16_t* d_best, uint16_t* d_second, hipStream_t s)
 {
     if (npairs <= 0) return;
-    dim3 grid((cap_per_frame + MT_T - 1) / MT_T, npairs), block(MT_T);
+    dim3 grid((cap_per_frame + MT_T - 1) / MT_T, npairs), block(MT_T * MT_WAVES);
     hipLaunchKernelGGL(k_match_batch, grid, block, 0, s, d_desc, d_n, cap_per_frame, d_pq, d_pt,
                        d_best_idx, d_best, d_second);
 }
