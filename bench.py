@@ -124,6 +124,25 @@ def main():
         blob = synth_vocabulary_blob(k=10, L=5, seed=7) if rank == 0 else None
         vocab = pgd.broadcast_vocabulary(blob, 0, dev)
         vocab_bytes = int(vocab.numel())
+        # every rank makes the received blob resident in its context and transforms the same
+        # probe descriptors; the word ids must agree across ranks (config 4's criterion)
+        import ctypes as C
+        ext._check(ext._L.pgorb_vocab_upload_device(ext._h, C.c_void_p(vocab.data_ptr()), vocab.numel(),
+                                                    C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        g = torch.Generator().manual_seed(1234)
+        probe = torch.randint(0, 256, (2048, 32), generator=g, dtype=torch.uint8).to(dev)
+        pw = torch.empty(2048, dtype=torch.int32, device=dev)
+        pwt = torch.empty(2048, dtype=torch.float64, device=dev)
+        pn = torch.empty(2048, dtype=torch.int32, device=dev)
+        ext._check(ext._L.pgorb_bow_transform_device(
+            ext._h, C.c_void_p(probe.data_ptr()), 2048, 4, C.c_void_p(pw.data_ptr()), C.c_void_p(pwt.data_ptr()),
+            C.c_void_p(pn.data_ptr()), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        sig = torch.stack([pw.to(torch.int64).sum(), (pw.to(torch.int64) * torch.arange(2048, device=dev)).sum(),
+                           pn.to(torch.int64).sum()])
+        sigs = [torch.empty_like(sig) for _ in range(world)]
+        dist.all_gather(sigs, sig)
+        if not all(torch.equal(sigs[0], x) for x in sigs):
+            raise SystemExit("BoW words differ across ranks after the vocabulary broadcast")
 
     def step():
         ext.extract_batch_device(frames, kps, desc, n)

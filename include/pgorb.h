@@ -130,6 +130,51 @@ int  pgorb_match_batch_device(pgorb_ctx* ctx, const uint8_t* d_desc, const int32
                               int32_t* d_best_idx, uint16_t* d_best, uint16_t* d_second,
                               void* hip_stream);
 
+/* ---- ORB vocabulary (DBoW2 TemplatedVocabulary<FORB::TDescriptor, FORB>) -----------------
+ *   pgorb_vocab_load_text     ORBVocabulary(text_file) -> TemplatedVocabulary::loadFromTextFile
+ *                             thirdparty/orb-slam2/src/ORBVocabulary.cc:7-9,
+ *                             thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1337-1420
+ *   pgorb_bow_transform*      TemplatedVocabulary::transform(feature, word_id, weight, nid,
+ *                             levelsup)  TemplatedVocabulary.h:1217-1259 for every feature
+ *   pgorb_bow_vectors         the accumulation part of transform(features, BowVector&,
+ *                             FeatureVector&, levelsup)  TemplatedVocabulary.h:1126-1194 with
+ *                             BowVector::addWeight/normalize (BowVector.cpp:34-84) and
+ *                             FeatureVector::addFeature (FeatureVector.cpp:31-45), called from
+ *                             Frame::ComputeBoW (thirdparty/orb-slam2/src/Frame.cc:399-406)
+ * A vocabulary is a flat little-endian blob (layout in pilotguru_amd/vocab.py and bow.hip) so
+ * that one rank can parse it and broadcast it to its peers with a single RCCL broadcast.
+ * Deviation from the reference loader: empty lines are skipped (the reference appends a bogus
+ * root child with an uninitialised descriptor for a trailing newline). */
+typedef struct pgorb_vocab pgorb_vocab;
+int  pgorb_vocab_load_text(const char* path, pgorb_vocab** out);
+int  pgorb_vocab_from_blob(const void* blob, int64_t nbytes, pgorb_vocab** out);   /* copies */
+int  pgorb_vocab_blob(const pgorb_vocab* v, const void** blob, int64_t* nbytes);
+int  pgorb_vocab_info(const pgorb_vocab* v, int* k, int* L, int* nnodes, int* nwords,
+                      int* scoring, int* weighting);
+void pgorb_vocab_free(pgorb_vocab* v);
+/* Make a vocabulary resident on the context's GPU (host blob: H2D copy; device blob, e.g. the
+ * receive buffer of the broadcast: D2D copy on `hip_stream`). */
+int  pgorb_vocab_upload(pgorb_ctx* ctx, const pgorb_vocab* v);
+int  pgorb_vocab_upload_device(pgorb_ctx* ctx, const void* d_blob, int64_t nbytes, void* hip_stream);
+/* Per-feature word id, word weight and the ancestor node at level L - levelsup (0 = root).
+ * Host buffers / device buffers + stream. */
+int  pgorb_bow_transform(pgorb_ctx* ctx, const uint8_t* desc, int n, int levelsup,
+                         uint32_t* word, double* weight, uint32_t* node);
+int  pgorb_bow_transform_device(pgorb_ctx* ctx, const uint8_t* d_desc, int n, int levelsup,
+                                uint32_t* d_word, double* d_weight, uint32_t* d_node,
+                                void* hip_stream);
+/* Host: BowVector (ascending word ids, L1-normalised when the scoring type says so) and
+ * FeatureVector (ascending node ids, feature indices in feature order) from the per-feature
+ * results.  bow_* need n entries, fv_node/fv_start n+1 entries, fv_feat n entries.
+ * scoring: 0 = L1_NORM ... (BowVector.h:36-53); weighting 0 = TF_IDF, 1 = TF. */
+int  pgorb_bow_vectors(int n, const uint32_t* word, const double* weight, const uint32_t* node,
+                       int scoring, int weighting,
+                       uint32_t* bow_id, double* bow_val, int* n_bow,
+                       uint32_t* fv_node, int32_t* fv_start, uint32_t* fv_feat, int* n_fv);
+/* L1Scoring::score(v1, v2), ScoringObject.cpp:23-60 (host). */
+double pgorb_bow_score_l1(const uint32_t* id1, const double* val1, int n1,
+                          const uint32_t* id2, const double* val2, int n2);
+
 /* Per-stage device timing with HIP events recorded on the launch stream around the kernel
  * groups of every *_device call: stage 0 = pyramid chain (K1, nlevels-1 launches), 1 = FAST
  * cells (K2), 2 = quadtree (K3), 3 = orientation+blur+rBRIEF (K4-6), 4 = Hamming match (K7).

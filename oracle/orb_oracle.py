@@ -80,6 +80,14 @@ def lib():
         L.orc_hamming_matrix.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_hamming_best2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_vocab_load_text.restype = C.c_void_p
+        L.orc_vocab_load_text.argtypes = [C.c_char_p]
+        L.orc_vocab_free.argtypes = [C.c_void_p]
+        L.orc_vocab_info.argtypes = [C.c_void_p, i32p, i32p, i32p, i32p]
+        L.orc_bow_transform_one.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_bow_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7
+        L.orc_bow_score_l1.restype = C.c_double
+        L.orc_bow_score_l1.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         _lib = L
     return _lib
 
@@ -259,3 +267,82 @@ def hamming_best2(a, b):
     b2 = np.zeros(len(a), np.uint16)
     lib().orc_hamming_best2(_p(a), len(a), _p(b), len(b), _p(bi), _p(b1), _p(b2))
     return bi, b1, b2
+
+
+# ---------------------------------------------------------------- DBoW2 vocabulary oracle
+class VocabOracle:
+    """TemplatedVocabulary<FORB> restated (oracle/bow_oracle.c)."""
+
+    def __init__(self, text_path):
+        self.L_ = lib()
+        self.h = self.L_.orc_vocab_load_text(text_path.encode())
+        if not self.h:
+            raise ValueError("cannot load vocabulary %s" % text_path)
+        k, L, nn, nw = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        self.L_.orc_vocab_info(self.h, C.byref(k), C.byref(L), C.byref(nn), C.byref(nw))
+        self.k, self.L, self.nnodes, self.nwords = k.value, L.value, nn.value, nw.value
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L_.orc_vocab_free(self.h)
+            self.h = None
+
+    def transform_features(self, desc, levelsup):
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        n = len(desc)
+        word = np.zeros(n, np.uint32)
+        weight = np.zeros(n, np.float64)
+        node = np.zeros(n, np.uint32)
+        for i in range(n):
+            self.L_.orc_bow_transform_one(self.h, C.c_void_p(desc[i].ctypes.data), levelsup,
+                                          C.c_void_p(word[i:].ctypes.data), C.c_void_p(weight[i:].ctypes.data),
+                                          C.c_void_p(node[i:].ctypes.data))
+        return word, weight, node
+
+    def transform(self, desc, levelsup):
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        n = len(desc)
+        bid, bval = np.zeros(n + 1, np.uint32), np.zeros(n + 1, np.float64)
+        fnode, fstart, ffeat = np.zeros(n + 1, np.uint32), np.zeros(n + 2, np.int32), np.zeros(n + 1, np.uint32)
+        nb, nf = C.c_int32(), C.c_int32()
+        self.L_.orc_bow_transform(self.h, _p(desc), n, levelsup, _p(bid), _p(bval), C.cast(C.byref(nb), C.c_void_p),
+                                  _p(fnode), _p(fstart), _p(ffeat), C.cast(C.byref(nf), C.c_void_p))
+        nb, nf = nb.value, nf.value
+        return (bid[:nb].copy(), bval[:nb].copy()), (fnode[:nf].copy(), fstart[:nf + 1].copy(), ffeat[:fstart[nf]].copy())
+
+
+def bow_score_l1(a, b):
+    (i1, v1), (i2, v2) = a, b
+    i1, i2 = np.ascontiguousarray(i1, np.uint32), np.ascontiguousarray(i2, np.uint32)
+    v1, v2 = np.ascontiguousarray(v1, np.float64), np.ascontiguousarray(v2, np.float64)
+    return lib().orc_bow_score_l1(_p(i1), _p(v1), len(i1), _p(i2), _p(v2), len(i2))
+
+
+_REF = os.path.join(_HERE, "_ref", "libdbow2_ref.so")
+
+
+def ref_dbow2():
+    """The REAL reference BowVector/FeatureVector code (oracle/Makefile.ref), or None."""
+    if not os.path.exists(_REF):
+        if os.path.isdir("/root/reference"):
+            subprocess.check_call(["make", "-C", _HERE, "-f", "Makefile.ref"], stdout=subprocess.DEVNULL)
+        else:
+            return None
+    R = C.CDLL(_REF)
+    R.ref_bow_vectors.argtypes = [C.c_int] + [C.c_void_p] * 10
+    return R
+
+
+def ref_bow_vectors(word, weight, node):
+    R = ref_dbow2()
+    n = len(word)
+    word = np.ascontiguousarray(word, np.uint32)
+    weight = np.ascontiguousarray(weight, np.float64)
+    node = np.ascontiguousarray(node, np.uint32)
+    bid, bval = np.zeros(n + 1, np.uint32), np.zeros(n + 1, np.float64)
+    fnode, fstart, ffeat = np.zeros(n + 1, np.uint32), np.zeros(n + 2, np.int32), np.zeros(n + 1, np.uint32)
+    nb, nf = C.c_int32(), C.c_int32()
+    R.ref_bow_vectors(n, _p(word), _p(weight), _p(node), _p(bid), _p(bval), C.cast(C.byref(nb), C.c_void_p),
+                      _p(fnode), _p(fstart), _p(ffeat), C.cast(C.byref(nf), C.c_void_p))
+    nb, nf = nb.value, nf.value
+    return (bid[:nb].copy(), bval[:nb].copy()), (fnode[:nf].copy(), fstart[:nf + 1].copy(), ffeat[:fstart[nf]].copy())

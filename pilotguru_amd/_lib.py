@@ -21,6 +21,9 @@ SYMBOLS = (
     "pgorb_hamming_matrix", "pgorb_hamming_best2", "pgorb_match_batch_device",
     "pgorb_debug_level_size", "pgorb_debug_level_image", "pgorb_debug_level_candidates",
     "pgorb_debug_level_keypoints", "pgorb_profile_begin", "pgorb_profile_read",
+    "pgorb_vocab_load_text", "pgorb_vocab_from_blob", "pgorb_vocab_blob", "pgorb_vocab_info",
+    "pgorb_vocab_free", "pgorb_vocab_upload", "pgorb_vocab_upload_device", "pgorb_bow_transform",
+    "pgorb_bow_transform_device", "pgorb_bow_vectors", "pgorb_bow_score_l1",
 )
 
 
@@ -83,8 +86,21 @@ def lib():
     L.pgorb_debug_level_keypoints.argtypes = [vp, C.c_int, C.c_int]
     L.pgorb_profile_begin.argtypes = [vp, C.c_int]
     L.pgorb_profile_read.argtypes = [vp, C.POINTER(C.c_double)]
+    L.pgorb_vocab_load_text.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.pgorb_vocab_from_blob.argtypes = [vp, C.c_int64, C.POINTER(vp)]
+    L.pgorb_vocab_blob.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64)]
+    L.pgorb_vocab_info.argtypes = [vp] + [i32p] * 6
+    L.pgorb_vocab_free.restype = None
+    L.pgorb_vocab_free.argtypes = [vp]
+    L.pgorb_vocab_upload.argtypes = [vp, vp]
+    L.pgorb_vocab_upload_device.argtypes = [vp, vp, C.c_int64, vp]
+    L.pgorb_bow_transform.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp]
+    L.pgorb_bow_transform_device.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
+    L.pgorb_bow_vectors.argtypes = [C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, vp, i32p, vp, vp, vp, i32p]
+    L.pgorb_bow_score_l1.restype = C.c_double
+    L.pgorb_bow_score_l1.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int]
     for name in SYMBOLS:
-        if name not in ("pgorb_destroy", "pgorb_last_error"):
+        if name not in ("pgorb_destroy", "pgorb_last_error", "pgorb_vocab_free", "pgorb_bow_score_l1"):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L

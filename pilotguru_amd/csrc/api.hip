@@ -41,7 +41,8 @@ struct pgorb_ctx {
     bool planValid = false;
     // device memory
     Arena pyr, cand, kpos, sel, nodes, counters, tables, cellCand, cellCount;
-    Arena stageKps, stageDesc, stageN, stageA, stageB, stageOut;
+    Arena stageKps, stageDesc, stageN, stageA, stageB, stageOut, vocab;
+    int vocabK = 0, vocabL = 0, vocabNodes = 0;
     int lastFrames = 0;
     bool lastAliased = false;
     // stage profiling (HIP events on the launch stream)
@@ -308,6 +309,42 @@ int run_batch(pgorb_ctx* c, const uint8_t* d_gray, bool resident_in_level0, int 
 
 }  // namespace
 
+// ---- helpers used by bow.hip ---------------------------------------------------------------
+int pg_ctx_fail(pgorb_ctx* c, int code, const char* msg) { return fail(c, code, "%s", msg); }
+int pg_ctx_device(pgorb_ctx* c) { return c->prm.device; }
+int pg_ctx_stage(pgorb_ctx* c, int which, size_t bytes, void** p)
+{
+    Arena* a = which == 0 ? &c->stageA : which == 1 ? &c->stageB : &c->stageOut;
+    PG_HIP(c, hipSetDevice(c->prm.device));
+    int rc = ensure(c, *a, bytes);
+    if (rc) return rc;
+    *p = a->p;
+    return 0;
+}
+int pg_ctx_vocab_store(pgorb_ctx* c, const void* src, size_t nbytes, bool src_on_device, hipStream_t s)
+{
+    PG_HIP(c, hipSetDevice(c->prm.device));
+    int32_t hdr[16];
+    if (src_on_device) {
+        PG_HIP(c, hipMemcpyAsync(hdr, src, 64, hipMemcpyDeviceToHost, s));
+        PG_HIP(c, hipStreamSynchronize(s));
+    } else memcpy(hdr, src, 64);
+    if (hdr[0] != 0x43564750 || hdr[1] != 1 || hdr[4] < 1)
+        return fail(c, PGORB_E_ARG, "not a pgorb vocabulary blob");
+    int rc = ensure(c, c->vocab, nbytes);
+    if (rc) return rc;
+    if (src_on_device) PG_HIP(c, hipMemcpyAsync(c->vocab.p, src, nbytes, hipMemcpyDeviceToDevice, s));
+    else PG_HIP(c, hipMemcpy(c->vocab.p, src, nbytes, hipMemcpyHostToDevice));
+    c->vocabK = hdr[2]; c->vocabL = hdr[3]; c->vocabNodes = hdr[4];
+    return 0;
+}
+int pg_ctx_vocab_get(pgorb_ctx* c, const uint8_t** d_blob, int* k, int* L, int* nnodes)
+{
+    if (!c->vocab.p || !c->vocabNodes) return fail(c, PGORB_E_ARG, "no vocabulary uploaded");
+    *d_blob = (const uint8_t*)c->vocab.p; *k = c->vocabK; *L = c->vocabL; *nnodes = c->vocabNodes;
+    return 0;
+}
+
 extern "C" {
 
 int pgorb_create(const pgorb_params* p, pgorb_ctx** out)
@@ -365,7 +402,7 @@ void pgorb_destroy(pgorb_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->prm.device);
     Arena* all[] = {&c->cellCand, &c->cellCount, &c->pyr, &c->cand, &c->kpos, &c->sel, &c->nodes, &c->counters, &c->tables,
-                    &c->stageKps, &c->stageDesc, &c->stageN, &c->stageA, &c->stageB, &c->stageOut};
+                    &c->stageKps, &c->stageDesc, &c->stageN, &c->stageA, &c->stageB, &c->stageOut, &c->vocab};
     for (Arena* a : all) if (a->p) (void)hipFree(a->p);
     for (hipEvent_t e : c->evExtract) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->evMatch) (void)hipEventDestroy(e);

@@ -98,3 +98,107 @@ def synth_vocabulary_blob(k=10, L=5, seed=7):
     import torch
     desc, weight, parent = synth_vocabulary(k, L, seed)
     return torch.from_numpy(pack_vocabulary(k, L, desc, weight, parent).copy())
+
+
+def write_vocabulary_text(path, k, L, desc, weight, parent, scoring=0, weighting=0, trailing_newline=False):
+    """Write the DBoW2 text format (TemplatedVocabulary::saveToTextFile layout,
+    TemplatedVocabulary.h:1424-1447): header `k L scoring weighting`, then per node (file order,
+    root omitted) `parent isLeaf d0 .. d31 weight`.  No trailing newline by default: the
+    reference loader turns one into a bogus node."""
+    n = len(parent)
+    nchild = np.bincount(np.asarray(parent[1:], np.int64), minlength=n)
+    lines = ["%d %d %d %d" % (k, L, scoring, weighting)]
+    for i in range(1, n):
+        lines.append("%d %d %s %s" % (parent[i], 1 if nchild[i] == 0 else 0,
+                                      " ".join(str(int(b)) for b in desc[i]), repr(float(weight[i]))))
+    with open(path, "w") as f:
+        f.write("\n".join(lines))
+        if trailing_newline:
+            f.write("\n")
+
+
+class ORBVocabulary:
+    """Mirror of ORB_SLAM2::ORBVocabulary = DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>
+    (thirdparty/orb-slam2/include/ORBVocabulary.h:29-34): load from the text format or from a
+    packed blob, upload to an extractor context, transform descriptors."""
+
+    def __init__(self, text_file=None, blob=None):
+        import ctypes as C
+        from . import _lib
+        self._L = _lib.lib()
+        h = C.c_void_p()
+        if text_file is not None:
+            rc = self._L.pgorb_vocab_load_text(str(text_file).encode(), C.byref(h))
+        else:
+            blob = np.ascontiguousarray(blob, np.uint8)
+            rc = self._L.pgorb_vocab_from_blob(C.c_void_p(blob.ctypes.data), blob.size, C.byref(h))
+        if rc != 0:
+            raise ValueError("vocabulary loading failure (rc=%d)" % rc)       # CHECK-fails in the reference
+        self._h = h
+        vals = [C.c_int32() for _ in range(6)]
+        self._L.pgorb_vocab_info(h, *[C.byref(x) for x in vals])
+        self.k, self.L, self.nnodes, self.nwords, self.scoring, self.weighting = [x.value for x in vals]
+        self._ctx = None
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.pgorb_vocab_free(self._h)
+            self._h = None
+
+    def blob(self):
+        import ctypes as C
+        p, n = C.c_void_p(), C.c_int64()
+        self._L.pgorb_vocab_blob(self._h, C.byref(p), C.byref(n))
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value,)).copy()
+
+    def upload(self, extractor):
+        extractor._check(self._L.pgorb_vocab_upload(extractor._h, self._h))
+        self._ctx = extractor
+
+    def transform_features(self, descriptors, levelsup):
+        """Per-feature (word id, weight, node id at level L-levelsup) -- computed on the GPU."""
+        import ctypes as C
+        d = np.ascontiguousarray(descriptors, np.uint8).reshape(-1, 32)
+        n = len(d)
+        word, weight, node = np.zeros(n, np.uint32), np.zeros(n, np.float64), np.zeros(n, np.uint32)
+        e = self._ctx
+        e._check(self._L.pgorb_bow_transform(e._h, C.c_void_p(d.ctypes.data), n, levelsup, C.c_void_p(word.ctypes.data),
+                                             C.c_void_p(weight.ctypes.data), C.c_void_p(node.ctypes.data)))
+        return word, weight, node
+
+    def transform(self, descriptors, levelsup=4):
+        """transform(features, BowVector&, FeatureVector&, levelsup): returns
+        ((word_ids, values), (node_ids, starts, feature_indices))."""
+        word, weight, node = self.transform_features(descriptors, levelsup)
+        return bow_vectors(word, weight, node, self.scoring, self.weighting)
+
+
+def bow_vectors(word, weight, node, scoring=0, weighting=0):
+    import ctypes as C
+    from . import _lib
+    L = _lib.lib()
+    n = len(word)
+    word = np.ascontiguousarray(word, np.uint32)
+    weight = np.ascontiguousarray(weight, np.float64)
+    node = np.ascontiguousarray(node, np.uint32)
+    bid, bval = np.zeros(n + 1, np.uint32), np.zeros(n + 1, np.float64)
+    fnode, fstart, ffeat = np.zeros(n + 1, np.uint32), np.zeros(n + 2, np.int32), np.zeros(n + 1, np.uint32)
+    nb, nf = C.c_int32(), C.c_int32()
+    p = lambda a: C.c_void_p(a.ctypes.data)
+    rc = L.pgorb_bow_vectors(n, p(word), p(weight), p(node), scoring, weighting, p(bid), p(bval), C.byref(nb),
+                             p(fnode), p(fstart), p(ffeat), C.byref(nf))
+    if rc != 0:
+        raise ValueError("pgorb_bow_vectors rc=%d" % rc)
+    nb, nf = nb.value, nf.value
+    end = int(fstart[nf]) if n else 0
+    return (bid[:nb].copy(), bval[:nb].copy()), (fnode[:nf].copy(), fstart[:nf + 1].copy(), ffeat[:end].copy())
+
+
+def bow_score_l1(a, b):
+    import ctypes as C
+    from . import _lib
+    (i1, v1), (i2, v2) = a, b
+    i1, i2 = np.ascontiguousarray(i1, np.uint32), np.ascontiguousarray(i2, np.uint32)
+    v1, v2 = np.ascontiguousarray(v1, np.float64), np.ascontiguousarray(v2, np.float64)
+    p = lambda x: C.c_void_p(x.ctypes.data)
+    return _lib.lib().pgorb_bow_score_l1(p(i1), p(v1), len(i1), p(i2), p(v2), len(i2))

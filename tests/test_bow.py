@@ -1,0 +1,119 @@
+"""DBoW2 vocabulary path: text loader, blob, BowVector/FeatureVector accumulation (pinned
+against the REAL reference BowVector.cpp/FeatureVector.cpp via oracle/_ref), and the GPU
+tree descent against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from pilotguru_amd import vocab as V
+
+
+def _vocab_file(tmp_path, k=4, L=3, seed=1, trailing_newline=False):
+    desc, weight, parent = V.synth_vocabulary(k, L, seed)
+    # a few stop words (weight 0) so the "w > 0" branch is exercised
+    weight[-3:] = 0.0
+    path = os.path.join(str(tmp_path), "voc.txt")
+    V.write_vocabulary_text(path, k, L, desc, weight, parent, trailing_newline=trailing_newline)
+    return path, desc, weight, parent
+
+
+def test_text_loader_matches_oracle_and_python_pack(tmp_path, oracle):
+    path, desc, weight, parent = _vocab_file(tmp_path, trailing_newline=True)   # trailing newline is skipped
+    voc = V.ORBVocabulary(text_file=path)
+    ora = oracle.VocabOracle(path)
+    assert (voc.k, voc.L, voc.nnodes, voc.nwords) == (ora.k, ora.L, ora.nnodes, ora.nwords) == (4, 3, 85, 64)
+    assert np.array_equal(voc.blob(), V.pack_vocabulary(4, 3, desc, weight, parent))
+    # blob round trip through the C ABI
+    voc2 = V.ORBVocabulary(blob=voc.blob())
+    assert np.array_equal(voc2.blob(), voc.blob())
+    with pytest.raises(ValueError):
+        V.ORBVocabulary(text_file=os.path.join(str(tmp_path), "missing.txt"))
+    with pytest.raises(ValueError):
+        V.ORBVocabulary(blob=np.zeros(128, np.uint8))
+
+
+def test_bow_vectors_match_real_reference_code(oracle):
+    """pgorb_bow_vectors (product, host) == reference BowVector::addWeight/normalize and
+    FeatureVector::addFeature, bit for bit (oracle/_ref built from /root/reference)."""
+    if oracle.ref_dbow2() is None:
+        pytest.skip("oracle/_ref/libdbow2_ref.so not built and /root/reference absent")
+    rng = np.random.RandomState(3)
+    for n in (0, 1, 7, 500, 2000):
+        word = rng.randint(0, 300, n).astype(np.uint32)
+        wtab = np.round(rng.uniform(0.0, 9.0, 300), 5)
+        wtab[rng.randint(0, 300, 20)] = 0.0                   # stop words
+        weight = wtab[word]
+        node = (word // 7).astype(np.uint32)
+        got = V.bow_vectors(word, weight, node, scoring=0, weighting=0)
+        ref = oracle.ref_bow_vectors(word, weight, node)
+        for g, r in zip(got[0] + got[1], ref[0] + ref[1]):
+            assert g.dtype == r.dtype and g.tobytes() == r.tobytes()
+        if n:
+            assert abs(got[0][1].sum() - 1.0) < 1e-12           # L1 normalised
+
+
+def test_oracle_transform_vs_product_host_accumulation(tmp_path, oracle):
+    path, desc, weight, parent = _vocab_file(tmp_path)
+    ora = oracle.VocabOracle(path)
+    rng = np.random.RandomState(5)
+    feats = rng.randint(0, 256, (300, 32)).astype(np.uint8)
+    word, w, node = ora.transform_features(feats, levelsup=2)
+    (bid, bval), (fn, fs, ff) = ora.transform(feats, levelsup=2)
+    got = V.bow_vectors(word, w, node, 0, 0)
+    assert np.array_equal(got[0][0], bid) and got[0][1].tobytes() == bval.tobytes()
+    assert np.array_equal(got[1][0], fn) and np.array_equal(got[1][1], fs) and np.array_equal(got[1][2], ff)
+    # FeatureVector keys are nodes at depth L - levelsup = 1: children of the root
+    assert set(fn.tolist()) <= set(np.nonzero(parent == 0)[0].tolist())
+    # L1 score: identical vectors score 1, disjoint vectors 0; product == oracle
+    a = got[0]
+    assert abs(V.bow_score_l1(a, a) - 1.0) < 1e-12
+    b = (a[0] + 100000, a[1])
+    assert V.bow_score_l1(a, b) == 0.0
+    feats2 = feats.copy()
+    feats2[:150] = rng.randint(0, 256, (150, 32))
+    c = V.bow_vectors(*ora.transform_features(feats2, 2), 0, 0)[0]
+    assert V.bow_score_l1(a, c) == oracle.bow_score_l1(a, c)
+    assert 0.0 < V.bow_score_l1(a, c) < 1.0
+
+
+@pytest.mark.gpu
+def test_gpu_bow_transform_matches_oracle(tmp_path, oracle):
+    import pilotguru_amd as pg
+    path, desc, weight, parent = _vocab_file(tmp_path, k=6, L=4, seed=9)
+    ora = oracle.VocabOracle(path)
+    voc = V.ORBVocabulary(text_file=path)
+    ext = pg.ORBextractor(500, 1.2, 8, 20, 7, max_width=320, max_height=240)
+    voc.upload(ext)
+    rng = np.random.RandomState(11)
+    feats = rng.randint(0, 256, (1500, 32)).astype(np.uint8)
+    feats[:200] = desc[rng.randint(1, len(desc), 200)]        # exact node descriptors: distance-0 ties
+    for levelsup in (4, 2, 0, 7):
+        word, w, node = voc.transform_features(feats, levelsup)
+        oword, ow, onode = ora.transform_features(feats, levelsup)
+        assert np.array_equal(word, oword) and w.tobytes() == ow.tobytes() and np.array_equal(node, onode)
+    (bid, bval), fv = voc.transform(feats, levelsup=4)
+    (obid, obval), ofv = ora.transform(feats, levelsup=4)
+    assert np.array_equal(bid, obid) and bval.tobytes() == obval.tobytes()
+    for g, r in zip(fv, ofv):
+        assert np.array_equal(g, r)
+
+
+@pytest.mark.gpu
+def test_gpu_vocab_upload_from_device_blob(oracle, tmp_path):
+    """The multi-GPU path: the blob arrives in device memory (broadcast receive buffer)."""
+    import ctypes as C
+    import torch
+    import pilotguru_amd as pg
+    path, desc, weight, parent = _vocab_file(tmp_path, k=5, L=3, seed=2)
+    voc = V.ORBVocabulary(text_file=path)
+    ext = pg.ORBextractor(500, 1.2, 8, 20, 7, max_width=320, max_height=240)
+    t = torch.from_numpy(voc.blob()).cuda()
+    ext._check(ext._L.pgorb_vocab_upload_device(ext._h, C.c_void_p(t.data_ptr()), t.numel(),
+                                                C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    voc._ctx = ext
+    rng = np.random.RandomState(1)
+    feats = rng.randint(0, 256, (100, 32)).astype(np.uint8)
+    word, w, node = voc.transform_features(feats, 4)
+    oword, ow, onode = oracle.VocabOracle(path).transform_features(feats, 4)
+    assert np.array_equal(word, oword) and np.array_equal(node, onode) and w.tobytes() == ow.tobytes()
