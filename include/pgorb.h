@@ -130,6 +130,50 @@ int  pgorb_match_batch_device(pgorb_ctx* ctx, const uint8_t* d_desc, const int32
                               int32_t* d_best_idx, uint16_t* d_best, uint16_t* d_second,
                               void* hip_stream);
 
+/* ---- Frame grid + guided matcher for initialisation ---------------------------------------
+ *   pgorb_frame_grid*            Frame::AssignFeaturesToGrid / PosInGrid
+ *                                thirdparty/orb-slam2/src/Frame.cc:234-249, 386-396 (64 x 48 grid,
+ *                                include/Frame.h:37-38) as CSR: cell = col*48 + row,
+ *                                start[3073], idx[] in insertion (= keypoint) order
+ *   pgorb_search_for_initialization*   ORBmatcher::SearchForInitialization(F1, F2,
+ *                                vbPrevMatched, vnMatches12, windowSize)
+ *                                src/ORBmatcher.cc:407-522 incl. GetFeaturesInArea
+ *                                (Frame.cc:331-384), TH_LOW = 50, the nnratio test, the
+ *                                30-bin rotation histogram and ComputeThreeMaxima (:1605-1646)
+ * Keypoints are taken as already undistorted (pilotguru calibrations with k1 == 0 skip
+ * cv::undistortPoints, Frame.cc:410-414) and the bounds are the image rectangle
+ * (Frame.cc:461-466): pass min_x = 0, max_x = cols, min_y = 0, max_y = rows.
+ * The batched device forms work on the layout of pgorb_extract_batch_device. */
+#define PGORB_GRID_COLS 64
+#define PGORB_GRID_ROWS 48
+#define PGORB_GRID_CELLS (PGORB_GRID_COLS * PGORB_GRID_ROWS)
+int  pgorb_frame_grid(pgorb_ctx* ctx, const pgorb_keypoint* kps, int n,
+                      float min_x, float max_x, float min_y, float max_y,
+                      int32_t* grid_start /*[3073]*/, int32_t* grid_idx /*[n]*/);
+int  pgorb_frame_grid_batch_device(pgorb_ctx* ctx, const pgorb_keypoint* d_kps, const int32_t* d_n,
+                                   int nframes, int cap_per_frame,
+                                   float min_x, float max_x, float min_y, float max_y,
+                                   int32_t* d_grid_start /*[nframes][3073]*/,
+                                   int32_t* d_grid_idx /*[nframes][cap]*/, void* hip_stream);
+/* prev_matched: float[2*n1] in/out (vbPrevMatched); matches12: int32[n1] out (-1 = none);
+ * returns nmatches (>= 0) or an error code. */
+int  pgorb_search_for_initialization(pgorb_ctx* ctx,
+                                     const pgorb_keypoint* kps1, const uint8_t* desc1, int n1,
+                                     const pgorb_keypoint* kps2, const uint8_t* desc2, int n2,
+                                     float min_x, float max_x, float min_y, float max_y,
+                                     float* prev_matched, int32_t* matches12,
+                                     int window_size, float nnratio, int check_orientation);
+/* pair p: F1 = frame pair_f1[p], F2 = frame pair_f2[p]; d_prev_matched / d_matches12 are
+ * [npairs][cap]; d_nmatches[npairs]. */
+int  pgorb_search_for_initialization_batch_device(pgorb_ctx* ctx, const pgorb_keypoint* d_kps,
+                                     const uint8_t* d_desc, const int32_t* d_n, int cap_per_frame,
+                                     const int32_t* d_grid_start, const int32_t* d_grid_idx,
+                                     const int32_t* d_pair_f1, const int32_t* d_pair_f2, int npairs,
+                                     float min_x, float max_x, float min_y, float max_y,
+                                     float* d_prev_matched, int32_t* d_matches12, int32_t* d_nmatches,
+                                     int window_size, float nnratio, int check_orientation,
+                                     void* hip_stream);
+
 /* ---- ORB vocabulary (DBoW2 TemplatedVocabulary<FORB::TDescriptor, FORB>) -----------------
  *   pgorb_vocab_load_text     ORBVocabulary(text_file) -> TemplatedVocabulary::loadFromTextFile
  *                             thirdparty/orb-slam2/src/ORBVocabulary.cc:7-9,

@@ -1,0 +1,161 @@
+/* oracle/match_oracle.c -- CPU oracle for the Frame grid and ORBmatcher::SearchForInitialization.
+ * TEST INFRASTRUCTURE (see orb_oracle.h).  Restates, line by line (paths under
+ * /root/reference/thirdparty/orb-slam2):
+ *   Frame::AssignFeaturesToGrid / PosInGrid     src/Frame.cc:234-249, 386-396
+ *   Frame::GetFeaturesInArea                    src/Frame.cc:331-384
+ *   ORBmatcher::SearchForInitialization         src/ORBmatcher.cc:407-522
+ *   ORBmatcher::ComputeThreeMaxima              src/ORBmatcher.cc:1605-1646
+ * for undistorted == raw keypoints (pilotguru's calibration path with k1 == 0,
+ * src/Frame.cc:408-438) and image bounds (0, cols, 0, rows) (src/Frame.cc:461-466).
+ */
+#include "orb_oracle.h"
+#include <limits.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define GRID_COLS 64          /* include/Frame.h:37-38 */
+#define GRID_ROWS 48
+#define HISTO_LENGTH 30       /* src/ORBmatcher.cc:38-40 */
+#define TH_LOW 50
+
+/* CSR grid: cell = ix*GRID_ROWS + iy; start[GRID_COLS*GRID_ROWS+1]; idx[n] keeps insertion order */
+void orc_frame_grid(const orc_keypoint* kps, int n, float minX, float maxX, float minY, float maxY,
+                    int32_t* start, int32_t* idx)
+{
+    const float invW = (float)GRID_COLS / (maxX - minX);         /* Frame.cc:216-217 */
+    const float invH = (float)GRID_ROWS / (maxY - minY);
+    const int ncell = GRID_COLS * GRID_ROWS;
+    int* cell = (int*)malloc(sizeof(int) * (n + 1));
+    memset(start, 0, sizeof(int32_t) * (ncell + 1));
+    for (int i = 0; i < n; i++) {
+        const int posX = (int)roundf((kps[i].x - minX) * invW);   /* PosInGrid, Frame.cc:388-389 */
+        const int posY = (int)roundf((kps[i].y - minY) * invH);
+        cell[i] = (posX < 0 || posX >= GRID_COLS || posY < 0 || posY >= GRID_ROWS) ? -1 : posX * GRID_ROWS + posY;
+        if (cell[i] >= 0) start[cell[i] + 1]++;
+    }
+    for (int c = 0; c < ncell; c++) start[c + 1] += start[c];
+    int* fill = (int*)calloc(ncell, sizeof(int));
+    for (int i = 0; i < n; i++)
+        if (cell[i] >= 0) idx[start[cell[i]] + fill[cell[i]]++] = i;
+    free(fill); free(cell);
+}
+
+/* Frame::GetFeaturesInArea, Frame.cc:331-384.  Returns the number of indices written. */
+int orc_features_in_area(const orc_keypoint* kps, const int32_t* start, const int32_t* idx,
+                         float minX, float maxX, float minY, float maxY,
+                         float x, float y, float r, int minLevel, int maxLevel, int32_t* out)
+{
+    const float invW = (float)GRID_COLS / (maxX - minX);
+    const float invH = (float)GRID_ROWS / (maxY - minY);
+    int n = 0;
+    int nMinCellX = (int)floorf((x - minX - r) * invW); if (nMinCellX < 0) nMinCellX = 0;
+    if (nMinCellX >= GRID_COLS) return 0;
+    int nMaxCellX = (int)ceilf((x - minX + r) * invW); if (nMaxCellX > GRID_COLS - 1) nMaxCellX = GRID_COLS - 1;
+    if (nMaxCellX < 0) return 0;
+    int nMinCellY = (int)floorf((y - minY - r) * invH); if (nMinCellY < 0) nMinCellY = 0;
+    if (nMinCellY >= GRID_ROWS) return 0;
+    int nMaxCellY = (int)ceilf((y - minY + r) * invH); if (nMaxCellY > GRID_ROWS - 1) nMaxCellY = GRID_ROWS - 1;
+    if (nMaxCellY < 0) return 0;
+    const int bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+        for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+            const int c = ix * GRID_ROWS + iy;
+            for (int j = start[c]; j < start[c + 1]; j++) {
+                const orc_keypoint* kp = &kps[idx[j]];
+                if (bCheckLevels) {
+                    if (kp->octave < minLevel) continue;
+                    if (maxLevel >= 0 && kp->octave > maxLevel) continue;
+                }
+                const float distx = kp->x - x, disty = kp->y - y;
+                if (fabsf(distx) < r && fabsf(disty) < r) out[n++] = idx[j];
+            }
+        }
+    return n;
+}
+
+/* ORBmatcher::ComputeThreeMaxima, ORBmatcher.cc:1605-1646 (histogram given as bin sizes) */
+static void three_maxima(const int* histo, int L, int* ind1, int* ind2, int* ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = histo[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; *ind3 = *ind2; *ind2 = *ind1; *ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; *ind3 = *ind2; *ind2 = i; }
+        else if (s > max3) { max3 = s; *ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { *ind2 = -1; *ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { *ind3 = -1; }
+}
+
+/* ORBmatcher::SearchForInitialization, ORBmatcher.cc:407-522.  prev_matched: float[2*n1] in/out
+ * (vbPrevMatched); matches12: int32[n1] out.  Returns nmatches. */
+int orc_search_for_initialization(const orc_keypoint* kps1, const uint8_t* desc1, int n1,
+                                  const orc_keypoint* kps2, const uint8_t* desc2, int n2,
+                                  const int32_t* grid2_start, const int32_t* grid2_idx,
+                                  float minX, float maxX, float minY, float maxY,
+                                  float* prev_matched, int32_t* matches12,
+                                  int windowSize, float nnratio, int checkOrientation)
+{
+    int nmatches = 0;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    int* rotBin = (int*)malloc(sizeof(int) * (n1 + 1));          /* bin an i1 was pushed to, or -1 */
+    for (int i = 0; i < n1; i++) rotBin[i] = -1;
+    const float factor = 1.0f / HISTO_LENGTH;
+    int* vMatchedDistance = (int*)malloc(sizeof(int) * (n2 + 1));
+    int* vnMatches21 = (int*)malloc(sizeof(int) * (n2 + 1));
+    for (int i = 0; i < n2; i++) { vMatchedDistance[i] = INT_MAX; vnMatches21[i] = -1; }
+    int32_t* vIndices2 = (int32_t*)malloc(sizeof(int32_t) * (n2 + 1));
+
+    for (int i1 = 0; i1 < n1; i1++) {
+        const int level1 = kps1[i1].octave;
+        if (level1 > 0) continue;
+        const int nind = orc_features_in_area(kps2, grid2_start, grid2_idx, minX, maxX, minY, maxY,
+                                              prev_matched[2 * i1], prev_matched[2 * i1 + 1],
+                                              (float)windowSize, level1, level1, vIndices2);
+        if (nind == 0) continue;
+        const uint8_t* d1 = desc1 + 32 * (size_t)i1;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (int k = 0; k < nind; k++) {
+            const int i2 = vIndices2[k];
+            const int dist = orc_descriptor_distance(d1, desc2 + 32 * (size_t)i2);
+            if (vMatchedDistance[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= TH_LOW) {
+            if (bestDist < (float)bestDist2 * nnratio) {
+                if (vnMatches21[bestIdx2] >= 0) { matches12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+                matches12[i1] = bestIdx2;
+                vnMatches21[bestIdx2] = i1;
+                vMatchedDistance[bestIdx2] = bestDist;
+                nmatches++;
+                if (checkOrientation) {
+                    float rot = kps1[i1].angle - kps2[bestIdx2].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)roundf(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotBin[i1] = bin;
+                }
+            }
+        }
+    }
+    if (checkOrientation) {
+        int histo[HISTO_LENGTH] = {0};
+        for (int i = 0; i < n1; i++) if (rotBin[i] >= 0) histo[rotBin[i]]++;
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(histo, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i1 = 0; i1 < n1; i1++) {
+            const int b = rotBin[i1];
+            if (b < 0 || b == ind1 || b == ind2 || b == ind3) continue;
+            if (matches12[i1] >= 0) { matches12[i1] = -1; nmatches--; }
+        }
+    }
+    for (int i1 = 0; i1 < n1; i1++)                                /* :516-519 */
+        if (matches12[i1] >= 0) {
+            prev_matched[2 * i1] = kps2[matches12[i1]].x;
+            prev_matched[2 * i1 + 1] = kps2[matches12[i1]].y;
+        }
+    free(rotBin); free(vMatchedDistance); free(vnMatches21); free(vIndices2);
+    return nmatches;
+}

@@ -80,6 +80,13 @@ def lib():
         L.orc_hamming_matrix.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_hamming_best2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_frame_grid.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        L.orc_features_in_area.restype = C.c_int
+        L.orc_features_in_area.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_float] * 7 + [C.c_int, C.c_int, C.c_void_p]
+        L.orc_search_for_initialization.restype = C.c_int
+        L.orc_search_for_initialization.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                                    C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
+                                                    C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int]
         L.orc_vocab_load_text.restype = C.c_void_p
         L.orc_vocab_load_text.argtypes = [C.c_char_p]
         L.orc_vocab_free.argtypes = [C.c_void_p]
@@ -346,3 +353,36 @@ def ref_bow_vectors(word, weight, node):
                       _p(fnode), _p(fstart), _p(ffeat), C.cast(C.byref(nf), C.c_void_p))
     nb, nf = nb.value, nf.value
     return (bid[:nb].copy(), bval[:nb].copy()), (fnode[:nf].copy(), fstart[:nf + 1].copy(), ffeat[:fstart[nf]].copy())
+
+
+# ---------------------------------------------------------------- Frame grid + guided matcher oracle
+def frame_grid(kps, bounds):
+    kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE)
+    start = np.zeros(64 * 48 + 1, np.int32)
+    idx = np.zeros(max(len(kps), 1), np.int32)
+    lib().orc_frame_grid(_p(kps), len(kps), bounds[0], bounds[1], bounds[2], bounds[3], _p(start), _p(idx))
+    return start, idx[:start[-1]].copy()
+
+
+def features_in_area(kps, grid, bounds, x, y, r, min_level, max_level):
+    kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE)
+    out = np.zeros(len(kps) + 1, np.int32)
+    n = lib().orc_features_in_area(_p(kps), _p(grid[0]), _p(grid[1]), bounds[0], bounds[1], bounds[2], bounds[3],
+                                   x, y, r, min_level, max_level, _p(out))
+    return out[:n].copy()
+
+
+def search_for_initialization(kps1, desc1, kps2, desc2, bounds, prev_matched, window_size=100, nnratio=0.9,
+                              check_orientation=True):
+    kps1 = np.ascontiguousarray(kps1, KEYPOINT_DTYPE)
+    kps2 = np.ascontiguousarray(kps2, KEYPOINT_DTYPE)
+    desc1 = np.ascontiguousarray(desc1, np.uint8)
+    desc2 = np.ascontiguousarray(desc2, np.uint8)
+    g2 = frame_grid(kps2, bounds)
+    idx = np.ascontiguousarray(np.concatenate([g2[1], np.zeros(1, np.int32)]))
+    prev = np.ascontiguousarray(prev_matched, np.float32).copy()
+    m12 = np.full(max(len(kps1), 1), -1, np.int32)
+    nm = lib().orc_search_for_initialization(_p(kps1), _p(desc1), len(kps1), _p(kps2), _p(desc2), len(kps2),
+                                             _p(g2[0]), _p(idx), bounds[0], bounds[1], bounds[2], bounds[3],
+                                             _p(prev), _p(m12), window_size, nnratio, int(check_orientation))
+    return nm, m12[:len(kps1)].copy(), prev

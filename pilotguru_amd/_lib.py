@@ -24,6 +24,8 @@ SYMBOLS = (
     "pgorb_vocab_load_text", "pgorb_vocab_from_blob", "pgorb_vocab_blob", "pgorb_vocab_info",
     "pgorb_vocab_free", "pgorb_vocab_upload", "pgorb_vocab_upload_device", "pgorb_bow_transform",
     "pgorb_bow_transform_device", "pgorb_bow_vectors", "pgorb_bow_score_l1",
+    "pgorb_frame_grid", "pgorb_frame_grid_batch_device", "pgorb_search_for_initialization",
+    "pgorb_search_for_initialization_batch_device",
 )
 
 
@@ -86,6 +88,12 @@ def lib():
     L.pgorb_debug_level_keypoints.argtypes = [vp, C.c_int, C.c_int]
     L.pgorb_profile_begin.argtypes = [vp, C.c_int]
     L.pgorb_profile_read.argtypes = [vp, C.POINTER(C.c_double)]
+    f4 = [C.c_float] * 4
+    L.pgorb_frame_grid.argtypes = [vp, vp, C.c_int] + f4 + [vp, vp]
+    L.pgorb_frame_grid_batch_device.argtypes = [vp, vp, vp, C.c_int, C.c_int] + f4 + [vp, vp, vp]
+    L.pgorb_search_for_initialization.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int] + f4 + [vp, vp, C.c_int, C.c_float, C.c_int]
+    L.pgorb_search_for_initialization_batch_device.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int] + f4 + \
+        [vp, vp, vp, C.c_int, C.c_float, C.c_int, vp]
     L.pgorb_vocab_load_text.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.pgorb_vocab_from_blob.argtypes = [vp, C.c_int64, C.POINTER(vp)]
     L.pgorb_vocab_blob.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64)]

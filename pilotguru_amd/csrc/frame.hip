@@ -1,0 +1,371 @@
+// frame.hip -- Frame grid (a12) and ORBmatcher::SearchForInitialization (a10) on gfx950.
+//
+// Restates (thirdparty/orb-slam2):
+//   Frame::AssignFeaturesToGrid / PosInGrid   src/Frame.cc:234-249, 386-396
+//   Frame::GetFeaturesInArea                  src/Frame.cc:331-384
+//   ORBmatcher::SearchForInitialization       src/ORBmatcher.cc:407-522
+//   ORBmatcher::ComputeThreeMaxima            src/ORBmatcher.cc:1605-1646
+//
+// The matcher is sequential over F1's keypoints by construction: whether candidate i2 is
+// considered depends on vMatchedDistance[i2], which earlier keypoints wrote (:445-446, :469).
+// So one 64-lane wave owns one frame pair and walks i1 in order; everything inside one i1 is
+// wave-parallel: lanes gather the grid cells of the search window (CSR ranges, wave prefix sum
+// -> candidate list in the reference's (column, row, insertion) order), lanes evaluate the
+// 256-bit Hamming distance of one candidate each (the query descriptor is wave-uniform), and a
+// wave argmin on (distance << 16 | list position) reproduces "first minimum wins" (:448-457).
+// All per-pair state (vMatchedDistance, vnMatches21, vnMatches12, histogram bins) lives in LDS.
+// Throughput comes from pairs in parallel; the path is used a few times per ride.
+#include "pgorb_internal.h"
+
+#define GRID_COLS PGORB_GRID_COLS
+#define GRID_ROWS PGORB_GRID_ROWS
+#define GRID_CELLS PGORB_GRID_CELLS
+#define HISTO_LENGTH 30
+#define TH_LOW 50
+
+int pg_ctx_fail(pgorb_ctx* c, int code, const char* msg);
+int pg_ctx_stage(pgorb_ctx* c, int which, size_t bytes, void** p);
+int pg_ctx_device(pgorb_ctx* c);
+
+__device__ __forceinline__ int grid_cell_of(const pgorb_keypoint& kp, float minX, float minY, float invW, float invH)
+{
+    const int posX = (int)roundf(__fmul_rn(__fsub_rn(kp.x, minX), invW));       // PosInGrid (:388-389)
+    const int posY = (int)roundf(__fmul_rn(__fsub_rn(kp.y, minY), invH));
+    return (posX < 0 || posX >= GRID_COLS || posY < 0 || posY >= GRID_ROWS) ? -1 : posX * GRID_ROWS + posY;
+}
+
+__global__ __launch_bounds__(256) void k_frame_grid(const pgorb_keypoint* __restrict__ kps,
+                                                     const int32_t* __restrict__ nper, int cap,
+                                                     float minX, float minY, float invW, float invH,
+                                                     int32_t* __restrict__ gstart, int32_t* __restrict__ gidx)
+{
+    __shared__ int cnt[GRID_CELLS];
+    __shared__ int part[256 + 1];
+    __shared__ int cellOf[256];
+    const int tid = threadIdx.x, f = blockIdx.x;
+    const int n = min(nper[f], cap);
+    const pgorb_keypoint* K = kps + (int64_t)f * cap;
+    int32_t* start = gstart + (int64_t)f * (GRID_CELLS + 1);
+    int32_t* idx = gidx + (int64_t)f * cap;
+    for (int c = tid; c < GRID_CELLS; c += 256) cnt[c] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const int c = grid_cell_of(K[i], minX, minY, invW, invH);
+        if (c >= 0) atomicAdd(&cnt[c], 1);
+    }
+    __syncthreads();
+    // exclusive scan of the 3072 counters: 12 per thread
+    {
+        const int b = tid * 12;
+        int sum = 0;
+        for (int c = b; c < b + 12; c++) sum += cnt[c];
+        part[tid] = sum;
+        __syncthreads();
+        if (tid == 0) { int run = 0; for (int t = 0; t < 256; t++) { const int v = part[t]; part[t] = run; run += v; } part[256] = run; }
+        __syncthreads();
+        int run = part[tid];
+        for (int c = b; c < b + 12; c++) { const int v = cnt[c]; cnt[c] = run; start[c] = run; run += v; }
+        if (tid == 255) start[GRID_CELLS] = part[256];
+    }
+    __syncthreads();
+    // stable placement: chunks of 256 keypoints in index order (mGrid[..].push_back(i), :246-247)
+    for (int base = 0; base < n; base += 256) {
+        const int i = base + tid;
+        const int c = (i < n) ? grid_cell_of(K[i], minX, minY, invW, invH) : -1;
+        cellOf[tid] = c;
+        __syncthreads();
+        int pos = -1;
+        if (c >= 0) {
+            int rank = 0;
+            for (int t = 0; t < tid; t++) rank += (cellOf[t] == c);
+            pos = cnt[c] + rank;
+        }
+        __syncthreads();
+        if (c >= 0) { atomicAdd(&cnt[c], 1); idx[pos] = i; }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, d));
+    return v;
+}
+
+extern __shared__ __attribute__((aligned(16))) uint8_t pg_sfi_smem[];
+
+__global__ __launch_bounds__(64) void k_search_for_initialization(
+    const pgorb_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc, const int32_t* __restrict__ nper,
+    int cap, const int32_t* __restrict__ gstart, const int32_t* __restrict__ gidx,
+    const int32_t* __restrict__ pairF1, const int32_t* __restrict__ pairF2,
+    float minX, float minY, float invW, float invH,
+    float* __restrict__ prevMatched, int32_t* __restrict__ matches12out, int32_t* __restrict__ nmatchesOut,
+    int windowSize, float nnratio, int checkOrientation)
+{
+    const int lane = threadIdx.x, p = blockIdx.x;
+    const int f1 = pairF1[p], f2 = pairF2[p];
+    const int n1 = min(nper[f1], cap), n2 = min(nper[f2], cap);
+    const pgorb_keypoint* K1 = kps + (int64_t)f1 * cap;
+    const pgorb_keypoint* K2 = kps + (int64_t)f2 * cap;
+    const uint8_t* D1 = desc + (int64_t)f1 * cap * 32;
+    const uint8_t* D2 = desc + (int64_t)f2 * cap * 32;
+    const int32_t* start2 = gstart + (int64_t)f2 * (GRID_CELLS + 1);
+    const int32_t* idx2 = gidx + (int64_t)f2 * cap;
+    float* prev = prevMatched + (int64_t)p * cap * 2;
+    int32_t* m12out = matches12out + (int64_t)p * cap;
+
+    uint16_t* matchedDist = reinterpret_cast<uint16_t*>(pg_sfi_smem);      // [cap] vMatchedDistance (0xFFFF = INT_MAX)
+    int16_t* m21 = reinterpret_cast<int16_t*>(matchedDist + cap);          // [cap] vnMatches21
+    int16_t* m12 = m21 + cap;                                              // [cap] vnMatches12
+    uint16_t* candList = reinterpret_cast<uint16_t*>(m12 + cap);           // [cap] vIndices2
+    int8_t* rotBin = reinterpret_cast<int8_t*>(candList + cap);            // [cap] bin an i1 was pushed to
+    for (int i = lane; i < cap; i += 64) { matchedDist[i] = 0xFFFF; m21[i] = -1; m12[i] = -1; rotBin[i] = -1; }
+    __syncthreads();
+
+    const float r = (float)windowSize;
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nmatches = 0;
+    for (int i1 = 0; i1 < n1; i1++) {
+        const pgorb_keypoint kp1 = K1[i1];
+        if (kp1.octave > 0) continue;                                       // :424-426
+        const int level1 = kp1.octave;
+        const float x = prev[2 * i1], y = prev[2 * i1 + 1];
+        // GetFeaturesInArea(x, y, r, level1, level1)  (Frame.cc:336-350)
+        const int nMinCellX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, minX), r), invW)));
+        if (nMinCellX >= GRID_COLS) continue;
+        const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, minX), r), invW)));
+        if (nMaxCellX < 0) continue;
+        const int nMinCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, minY), r), invH)));
+        if (nMinCellY >= GRID_ROWS) continue;
+        const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, minY), r), invH)));
+        if (nMaxCellY < 0) continue;
+        const int ncy = nMaxCellY - nMinCellY + 1;
+        const int T = max(0, (nMaxCellX - nMinCellX + 1)) * max(0, ncy);
+        // gather the window's cell ranges into the candidate list, in (ix, iy, j) order
+        int M = 0;
+        for (int base = 0; base < T; base += 64) {
+            const int t = base + lane;
+            int s = 0, cnt = 0;
+            if (t < T) {
+                const int ix = nMinCellX + t / ncy, iy = nMinCellY + t % ncy;
+                const int c = ix * GRID_ROWS + iy;
+                s = start2[c]; cnt = start2[c + 1] - s;
+            }
+            const int incl = wave_incl_scan(cnt, lane);
+            const int off = M + incl - cnt;
+            for (int j = 0; j < cnt; j++) candList[off + j] = (uint16_t)idx2[s + j];
+            M += __shfl(incl, 63);
+        }
+        __syncthreads();
+        if (M == 0) continue;                                               // vIndices2.empty() (before filtering it can only be larger)
+        // distances: one candidate per lane
+        const uint4 q0 = reinterpret_cast<const uint4*>(D1 + (int64_t)i1 * 32)[0];
+        const uint4 q1 = reinterpret_cast<const uint4*>(D1 + (int64_t)i1 * 32)[1];
+        unsigned b1key = 0xFFFFFFFFu;          // (dist << 16 | list position) of this lane's best
+        int b2 = 0x7fffffff;                   // this lane's second-smallest distance
+        for (int k = lane; k < M; k += 64) {
+            const int i2 = candList[k];
+            const pgorb_keypoint kp2 = K2[i2];
+            // bCheckLevels is true for minLevel = maxLevel = 0 (Frame.cc:354): octave must equal level1
+            if (kp2.octave < level1 || kp2.octave > level1) continue;
+            const float distx = __fsub_rn(kp2.x, x), disty = __fsub_rn(kp2.y, y);
+            if (!(fabsf(distx) < r && fabsf(disty) < r)) continue;
+            const uint4 d0 = reinterpret_cast<const uint4*>(D2 + (int64_t)i2 * 32)[0];
+            const uint4 d1 = reinterpret_cast<const uint4*>(D2 + (int64_t)i2 * 32)[1];
+            const int dist = __popc(q0.x ^ d0.x) + __popc(q0.y ^ d0.y) + __popc(q0.z ^ d0.z) + __popc(q0.w ^ d0.w) +
+                             __popc(q1.x ^ d1.x) + __popc(q1.y ^ d1.y) + __popc(q1.z ^ d1.z) + __popc(q1.w ^ d1.w);
+            if ((int)matchedDist[i2] <= dist) continue;                     // :445-446
+            const unsigned key = ((unsigned)dist << 16) | (unsigned)k;
+            if (key < b1key) { if (b1key != 0xFFFFFFFFu) b2 = min(b2, (int)(b1key >> 16)); b1key = key; }
+            else b2 = min(b2, dist);
+        }
+        const unsigned wkey = wave_min_u32(b1key);
+        if (wkey != 0xFFFFFFFFu) {
+            const int bestDist = (int)(wkey >> 16);
+            const int bestIdx2 = candList[wkey & 0xFFFF];
+            // second best: the other lanes' best, the winning lane's second
+            const unsigned mine = (b1key == wkey) ? (unsigned)b2 : (b1key == 0xFFFFFFFFu ? 0x7fffffffu : (b1key >> 16));
+            const unsigned lane2 = wave_min_u32(min(mine, (unsigned)b2));
+            const float bestDist2 = (lane2 >= 0x7fffffffu) ? 2147483648.0f : (float)(int)lane2;   // (float)INT_MAX
+            if (bestDist <= TH_LOW && (float)bestDist < __fmul_rn(bestDist2, nnratio)) {          // :460-462
+                int bin = -1;
+                if (checkOrientation) {                                      // :473-483
+                    float rot = __fsub_rn(kp1.angle, K2[bestIdx2].angle);
+                    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                    bin = (int)roundf(__fmul_rn(rot, factor));
+                    if (bin == HISTO_LENGTH) bin = 0;
+                }
+                const int old = m21[bestIdx2];
+                if (old >= 0) nmatches--;                                    // :464-468
+                nmatches++;
+                if (lane == 0) {
+                    if (old >= 0) m12[old] = -1;
+                    m12[i1] = (int16_t)bestIdx2;
+                    m21[bestIdx2] = (int16_t)i1;
+                    matchedDist[bestIdx2] = (uint16_t)bestDist;
+                    rotBin[i1] = (int8_t)bin;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (checkOrientation) {
+        // histogram sizes = number of pushes per bin (a displaced i1 stays in its list, :481)
+        int h = 0;                                                           // lane b < 30 counts bin b
+        for (int i = 0; i < n1; i++) h += (rotBin[i] == lane);
+        int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+        for (int i = 0; i < HISTO_LENGTH; i++) {                             // ComputeThreeMaxima (:1605-1646)
+            const int s = __shfl(h, i);
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        int removed = 0;
+        for (int i = lane; i < n1; i += 64) {
+            const int b = rotBin[i];
+            if (b >= 0 && b != ind1 && b != ind2 && b != ind3 && m12[i] >= 0) { m12[i] = -1; removed++; }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) removed += __shfl_xor(removed, d);
+        nmatches -= removed;
+        __syncthreads();
+    }
+    for (int i = lane; i < n1; i += 64) {                                    // :516-519
+        const int m = m12[i];
+        m12out[i] = m;
+        if (m >= 0) { prev[2 * i] = K2[m].x; prev[2 * i + 1] = K2[m].y; }
+    }
+    if (lane == 0) nmatchesOut[p] = nmatches;
+}
+
+extern "C" {
+
+int pgorb_frame_grid_batch_device(pgorb_ctx* c, const pgorb_keypoint* d_kps, const int32_t* d_n, int nframes,
+                                  int cap, float min_x, float max_x, float min_y, float max_y,
+                                  int32_t* d_grid_start, int32_t* d_grid_idx, void* stream)
+{
+    if (!c) return PGORB_E_ARG;
+    if (!d_kps || !d_n || nframes < 1 || cap < 1 || !d_grid_start || !d_grid_idx || !(max_x > min_x) || !(max_y > min_y))
+        return pg_ctx_fail(c, PGORB_E_ARG, "bad argument to pgorb_frame_grid_batch_device");
+    if (hipSetDevice(pg_ctx_device(c)) != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "hipSetDevice failed");
+    const float invW = (float)GRID_COLS / (max_x - min_x), invH = (float)GRID_ROWS / (max_y - min_y);   // Frame.cc:216-217
+    hipLaunchKernelGGL(k_frame_grid, dim3(nframes), dim3(256), 0, (hipStream_t)stream, d_kps, d_n, cap, min_x, min_y,
+                       invW, invH, d_grid_start, d_grid_idx);
+    if (hipGetLastError() != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "k_frame_grid launch failed");
+    return 0;
+}
+
+int pgorb_search_for_initialization_batch_device(pgorb_ctx* c, const pgorb_keypoint* d_kps, const uint8_t* d_desc,
+                                    const int32_t* d_n, int cap, const int32_t* d_grid_start,
+                                    const int32_t* d_grid_idx, const int32_t* d_pair_f1, const int32_t* d_pair_f2,
+                                    int npairs, float min_x, float max_x, float min_y, float max_y,
+                                    float* d_prev_matched, int32_t* d_matches12, int32_t* d_nmatches,
+                                    int window_size, float nnratio, int check_orientation, void* stream)
+{
+    if (!c) return PGORB_E_ARG;
+    if (!d_kps || !d_desc || !d_n || cap < 1 || !d_grid_start || !d_grid_idx || npairs < 0 ||
+        (npairs && (!d_pair_f1 || !d_pair_f2 || !d_prev_matched || !d_matches12 || !d_nmatches)) ||
+        !(max_x > min_x) || !(max_y > min_y) || window_size < 0)
+        return pg_ctx_fail(c, PGORB_E_ARG, "bad argument to pgorb_search_for_initialization_batch_device");
+    if (cap > 16000) return pg_ctx_fail(c, PGORB_E_LIMIT, "more than 16000 keypoints per frame");
+    if (!npairs) return 0;
+    if (hipSetDevice(pg_ctx_device(c)) != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "hipSetDevice failed");
+    const float invW = (float)GRID_COLS / (max_x - min_x), invH = (float)GRID_ROWS / (max_y - min_y);
+    const size_t lds = (size_t)cap * 9 + 64;
+    static size_t configured = 0;
+    if (lds > configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_for_initialization),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        configured = lds;
+    }
+    hipLaunchKernelGGL(k_search_for_initialization, dim3(npairs), dim3(64), lds, (hipStream_t)stream, d_kps, d_desc,
+                       d_n, cap, d_grid_start, d_grid_idx, d_pair_f1, d_pair_f2, min_x, min_y, invW, invH,
+                       d_prev_matched, d_matches12, d_nmatches, window_size, nnratio, check_orientation);
+    if (hipGetLastError() != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "k_search_for_initialization launch failed");
+    return 0;
+}
+
+int pgorb_frame_grid(pgorb_ctx* c, const pgorb_keypoint* kps, int n, float min_x, float max_x, float min_y,
+                     float max_y, int32_t* grid_start, int32_t* grid_idx)
+{
+    if (!c) return PGORB_E_ARG;
+    if (n < 0 || (n && (!kps || !grid_idx)) || !grid_start) return pg_ctx_fail(c, PGORB_E_ARG, "bad argument to pgorb_frame_grid");
+    const int cap = n > 0 ? n : 1;
+    void* d;
+    int rc = pg_ctx_stage(c, 0, (size_t)cap * sizeof(pgorb_keypoint) + 64 + (size_t)(GRID_CELLS + 1) * 4 + (size_t)cap * 4, &d);
+    if (rc) return rc;
+    pgorb_keypoint* dk = (pgorb_keypoint*)d;
+    int32_t* dn = (int32_t*)((uint8_t*)d + (((size_t)cap * sizeof(pgorb_keypoint) + 15) & ~(size_t)15));
+    int32_t* ds = dn + 4;
+    int32_t* di = ds + GRID_CELLS + 1;
+    if (n && hipMemcpy(dk, kps, (size_t)n * sizeof(pgorb_keypoint), hipMemcpyHostToDevice) != hipSuccess)
+        return pg_ctx_fail(c, PGORB_E_HIP, "hipMemcpy failed");
+    if (hipMemcpy(dn, &n, 4, hipMemcpyHostToDevice) != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "hipMemcpy failed");
+    if ((rc = pgorb_frame_grid_batch_device(c, dk, dn, 1, cap, min_x, max_x, min_y, max_y, ds, di, 0))) return rc;
+    if (hipMemcpy(grid_start, ds, (size_t)(GRID_CELLS + 1) * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        (n && hipMemcpy(grid_idx, di, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess))
+        return pg_ctx_fail(c, PGORB_E_HIP, "hipMemcpy failed");
+    return 0;
+}
+
+int pgorb_search_for_initialization(pgorb_ctx* c, const pgorb_keypoint* kps1, const uint8_t* desc1, int n1,
+                                    const pgorb_keypoint* kps2, const uint8_t* desc2, int n2,
+                                    float min_x, float max_x, float min_y, float max_y, float* prev_matched,
+                                    int32_t* matches12, int window_size, float nnratio, int check_orientation)
+{
+    if (!c) return PGORB_E_ARG;
+    if (n1 < 0 || n2 < 0 || (n1 && (!kps1 || !desc1 || !prev_matched || !matches12)) || (n2 && (!kps2 || !desc2)))
+        return pg_ctx_fail(c, PGORB_E_ARG, "bad argument to pgorb_search_for_initialization");
+    if (n1 == 0) return 0;
+    const int cap = (n1 > n2 ? n1 : n2) > 0 ? (n1 > n2 ? n1 : n2) : 1;
+    // one staging slab: 2 frames of kps + desc, counts, grids, pair ids, prev, matches, nmatches
+    const size_t szK = (((size_t)2 * cap * sizeof(pgorb_keypoint)) + 63) & ~(size_t)63;
+    const size_t szD = (((size_t)2 * cap * 32) + 63) & ~(size_t)63;
+    const size_t szG = (((size_t)2 * (GRID_CELLS + 1) * 4) + 63) & ~(size_t)63;
+    const size_t szI = (((size_t)2 * cap * 4) + 63) & ~(size_t)63;
+    const size_t szP = (((size_t)cap * 8) + 63) & ~(size_t)63;
+    const size_t szM = (((size_t)cap * 4) + 63) & ~(size_t)63;
+    void* d;
+    int rc = pg_ctx_stage(c, 0, szK + szD + szG + szI + szP + szM + 256, &d);
+    if (rc) return rc;
+    uint8_t* b = (uint8_t*)d;
+    pgorb_keypoint* dk = (pgorb_keypoint*)b; b += szK;
+    uint8_t* dd = b; b += szD;
+    int32_t* dgs = (int32_t*)b; b += szG;
+    int32_t* dgi = (int32_t*)b; b += szI;
+    float* dp = (float*)b; b += szP;
+    int32_t* dm = (int32_t*)b; b += szM;
+    int32_t* dmisc = (int32_t*)b;            // n[2], f1, f2, nmatches
+    const int32_t misc[5] = {n1, n2, 0, 1, 0};
+    bool ok = hipMemcpy(dk, kps1, (size_t)n1 * sizeof(pgorb_keypoint), hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(dd, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice) == hipSuccess &&
+              (!n2 || (hipMemcpy(dk + cap, kps2, (size_t)n2 * sizeof(pgorb_keypoint), hipMemcpyHostToDevice) == hipSuccess &&
+                       hipMemcpy(dd + (size_t)cap * 32, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice) == hipSuccess)) &&
+              hipMemcpy(dp, prev_matched, (size_t)n1 * 8, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(dmisc, misc, sizeof(misc), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) return pg_ctx_fail(c, PGORB_E_HIP, "hipMemcpy H2D failed");
+    if ((rc = pgorb_frame_grid_batch_device(c, dk, dmisc, 2, cap, min_x, max_x, min_y, max_y, dgs, dgi, 0))) return rc;
+    if ((rc = pgorb_search_for_initialization_batch_device(c, dk, dd, dmisc, cap, dgs, dgi, dmisc + 2, dmisc + 3, 1,
+                                                           min_x, max_x, min_y, max_y, dp, dm, dmisc + 4, window_size,
+                                                           nnratio, check_orientation, 0))) return rc;
+    int32_t nm = 0;
+    ok = hipMemcpy(prev_matched, dp, (size_t)n1 * 8, hipMemcpyDeviceToHost) == hipSuccess &&
+         hipMemcpy(matches12, dm, (size_t)n1 * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+         hipMemcpy(&nm, dmisc + 4, 4, hipMemcpyDeviceToHost) == hipSuccess;
+    if (!ok) return pg_ctx_fail(c, PGORB_E_HIP, "hipMemcpy D2H failed");
+    return nm;
+}
+
+}  // extern "C"

@@ -209,8 +209,50 @@ class ORBextractor:
         return bi, b1, b2
 
 
+class Frame:
+    """The part of ORB_SLAM2::Frame the front end needs (thirdparty/orb-slam2/include/Frame.h):
+    mvKeys (== mvKeysUndistorted for k1 == 0), mDescriptors, the image bounds and the 64x48 grid
+    (AssignFeaturesToGrid, src/Frame.cc:234-249), built on the GPU."""
+
+    def __init__(self, extractor, image):
+        self.ext = extractor
+        self.mvKeys, self.mDescriptors = extractor(image)
+        self.mvKeysUndistorted = self.mvKeys
+        self.N = len(self.mvKeys)
+        h, w = image.shape
+        self.bounds = (0.0, float(w), 0.0, float(h))          # mnMinX, mnMaxX, mnMinY, mnMaxY (Frame.cc:461-466)
+        self.grid_start = np.zeros(64 * 48 + 1, np.int32)
+        self.grid_idx = np.zeros(max(self.N, 1), np.int32)
+        if self.N:
+            extractor._check(extractor._L.pgorb_frame_grid(extractor._h, _p(self.mvKeys), self.N, *self.bounds,
+                                                           _p(self.grid_start), _p(self.grid_idx)))
+
+    def grid_cell(self, col, row):
+        """mGrid[col][row] as an index array."""
+        c = col * 48 + row
+        return self.grid_idx[self.grid_start[c]:self.grid_start[c + 1]]
+
+
 class ORBmatcher:
-    """Static helper mirroring ORBmatcher::DescriptorDistance (ORBmatcher.h:44)."""
+    """ORBmatcher(nnratio, checkOri) (thirdparty/orb-slam2/include/ORBmatcher.h:40-44)."""
+
+    TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30               # src/ORBmatcher.cc:38-40
+
+    def __init__(self, nnratio=0.6, checkOri=True):
+        self.mfNNratio, self.mbCheckOrientation = float(nnratio), bool(checkOri)
+
+    def SearchForInitialization(self, F1, F2, vbPrevMatched, windowSize=10):
+        """(nmatches, vnMatches12); vbPrevMatched ([N1,2] float32) is updated in place, as in
+        src/ORBmatcher.cc:407-522."""
+        ext = F1.ext
+        prev = np.ascontiguousarray(vbPrevMatched, np.float32)
+        m12 = np.full(max(F1.N, 1), -1, np.int32)
+        nm = ext._check(ext._L.pgorb_search_for_initialization(
+            ext._h, _p(F1.mvKeysUndistorted), _p(F1.mDescriptors), F1.N,
+            _p(F2.mvKeysUndistorted), _p(F2.mDescriptors), F2.N, *F2.bounds, _p(prev), _p(m12),
+            int(windowSize), self.mfNNratio, int(self.mbCheckOrientation)))
+        vbPrevMatched[...] = prev
+        return nm, m12[:F1.N].copy()
 
     @staticmethod
     def DescriptorDistance(a, b):

@@ -1,0 +1,110 @@
+"""Frame grid (a12) and ORBmatcher::SearchForInitialization (a10): oracle self-checks on CPU,
+GPU parity against the oracle."""
+import numpy as np
+import pytest
+
+from pilotguru_amd.synth import synth_ride
+
+
+def _frames(oracle, w=640, h=480, nf=1500, n=2, seed=4, dx=7, dy=3):
+    ride = synth_ride(seed, w, h, n, dx=dx, dy=dy)
+    ora = oracle.OrbOracle(nf, 1.2, 8, 20, 7)
+    return ride, [ora.extract(ride[i]) for i in range(n)]
+
+
+def test_oracle_grid_and_area_query(oracle):
+    ride, fr = _frames(oracle)
+    kps, desc = fr[0]
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    start, idx = oracle.frame_grid(kps, bounds)
+    assert start[-1] == len(kps) and sorted(idx.tolist()) == list(range(len(kps)))
+    for c in (0, 100, 1500, 3071):                              # insertion order inside a cell
+        cell = idx[start[c]:start[c + 1]]
+        assert np.all(np.diff(cell) > 0)
+    col = np.floor((kps["x"] - 0.0) * np.float32(64 / 640.0) + 0.5).astype(int)      # round(), positive
+    row = np.floor((kps["y"] - 0.0) * np.float32(48 / 480.0) + 0.5).astype(int)
+    for i in (0, 5, len(kps) - 1):
+        c = col[i] * 48 + row[i]
+        assert i in idx[start[c]:start[c + 1]]
+    # brute-force area query, level 0 only
+    got = oracle.features_in_area(kps, (start, idx), bounds, 300.0, 200.0, 100.0, 0, 0)
+    want = [i for i in range(len(kps)) if kps["octave"][i] == 0 and abs(kps["x"][i] - 300) < 100 and abs(kps["y"][i] - 200) < 100]
+    assert sorted(got.tolist()) == want
+    # an out-of-image query returns nothing
+    assert len(oracle.features_in_area(kps, (start, idx), bounds, 5000.0, 200.0, 100.0, 0, 0)) == 0
+
+
+def test_oracle_search_for_initialization_finds_the_shift(oracle):
+    ride, fr = _frames(oracle)
+    (k1, d1), (k2, d2) = fr
+    prev = np.stack([k1["x"], k1["y"]], 1)
+    nm, m12, prev2 = oracle.search_for_initialization(k1, d1, k2, d2, (0.0, 640.0, 0.0, 480.0), prev)
+    assert nm == int((m12 >= 0).sum()) and nm > 100
+    lvl0 = k1["octave"] == 0
+    assert np.all(m12[~lvl0] == -1)                              # only level-0 keypoints are matched
+    dxy = np.stack([k2["x"][m12[m12 >= 0]] - k1["x"][m12 >= 0], k2["y"][m12[m12 >= 0]] - k1["y"][m12 >= 0]], 1)
+    assert np.median(dxy[:, 0]) == -7 and np.median(dxy[:, 1]) == -3   # frame 1 = scene shifted by (7,3)
+    assert len(set(m12[m12 >= 0].tolist())) == nm                # one-to-one
+    assert np.array_equal(prev2[m12 >= 0], np.stack([k2["x"], k2["y"]], 1)[m12[m12 >= 0]])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ratio,ori,win", [(0.9, True, 100), (0.7, False, 40), (0.9, True, 8)])
+def test_gpu_grid_and_search_for_initialization(oracle, ratio, ori, win):
+    import pilotguru_amd as pg
+    w, h, nf = 640, 480, 1500
+    ride = synth_ride(4, w, h, 2, dx=7, dy=3)
+    ext = pg.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    F1, F2 = pg.Frame(ext, ride[0]), pg.Frame(ext, ride[1])
+    for F in (F1, F2):
+        start, idx = oracle.frame_grid(F.mvKeys, F.bounds)
+        assert np.array_equal(F.grid_start, start) and np.array_equal(F.grid_idx[:len(idx)], idx)
+    prev = np.stack([F1.mvKeys["x"], F1.mvKeys["y"]], 1).astype(np.float32)
+    onm, om12, oprev = oracle.search_for_initialization(F1.mvKeys, F1.mDescriptors, F2.mvKeys, F2.mDescriptors,
+                                                        F2.bounds, prev, win, ratio, ori)
+    m = pg.ORBmatcher(ratio, ori)
+    nm, m12 = m.SearchForInitialization(F1, F2, prev, win)
+    assert nm == onm and np.array_equal(m12, om12)
+    assert prev.tobytes() == oprev.tobytes()
+    # second call with the updated vbPrevMatched (what MonocularInitialization does frame after frame)
+    onm2, om12b, oprev2 = oracle.search_for_initialization(F1.mvKeys, F1.mDescriptors, F2.mvKeys, F2.mDescriptors,
+                                                           F2.bounds, oprev, win, ratio, ori)
+    nm2, m12b = m.SearchForInitialization(F1, F2, prev, win)
+    assert nm2 == onm2 and np.array_equal(m12b, om12b) and prev.tobytes() == oprev2.tobytes()
+
+
+@pytest.mark.gpu
+def test_gpu_search_for_initialization_batch_device(oracle):
+    import ctypes as C
+    import torch
+    import pilotguru_amd as pg
+    w, h, nf, B = 640, 480, 1000, 3
+    ride = synth_ride(8, w, h, B, dx=5, dy=2)
+    ext = pg.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B)
+    kps, desc, n = ext.extract_batch_device(torch.from_numpy(ride).cuda())
+    cap = kps.shape[1]
+    gs = torch.empty((B, 3073), dtype=torch.int32, device="cuda")
+    gi = torch.empty((B, cap), dtype=torch.int32, device="cuda")
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    ext._check(ext._L.pgorb_frame_grid_batch_device(ext._h, p(kps), p(n), B, cap, 0.0, float(w), 0.0, float(h), p(gs), p(gi), s))
+    f1 = torch.tensor([0, 1], dtype=torch.int32, device="cuda")
+    f2 = torch.tensor([1, 2], dtype=torch.int32, device="cuda")
+    prev = kps[:2, :, :2].contiguous().clone()
+    m12 = torch.empty((2, cap), dtype=torch.int32, device="cuda")
+    nm = torch.empty(2, dtype=torch.int32, device="cuda")
+    ext._check(ext._L.pgorb_search_for_initialization_batch_device(
+        ext._h, p(kps), p(desc), p(n), cap, p(gs), p(gi), p(f1), p(f2), 2, 0.0, float(w), 0.0, float(h),
+        p(prev), p(m12), p(nm), 100, 0.9, 1, s))
+    torch.cuda.synchronize()
+    nh = n.cpu().numpy()
+    kh = kps.cpu().numpy().view(np.uint8).reshape(B, cap, 28)
+    dh = desc.cpu().numpy()
+    for pi, (a, b) in enumerate(((0, 1), (1, 2))):
+        ka = kh[a, :nh[a]].copy().view(oracle.KEYPOINT_DTYPE).reshape(-1)
+        kb = kh[b, :nh[b]].copy().view(oracle.KEYPOINT_DTYPE).reshape(-1)
+        pv = np.stack([ka["x"], ka["y"]], 1)
+        onm, om12, oprev = oracle.search_for_initialization(ka, dh[a, :nh[a]], kb, dh[b, :nh[b]], (0.0, float(w), 0.0, float(h)), pv)
+        assert int(nm[pi]) == onm
+        assert np.array_equal(m12[pi, :nh[a]].cpu().numpy(), om12)
+        assert prev[pi, :nh[a]].cpu().numpy().tobytes() == oprev.tobytes()
