@@ -108,6 +108,17 @@ int  pgorb_extract_batch_device(pgorb_ctx* ctx, const uint8_t* d_gray, int nfram
                                 int w, int h, int stride, int64_t frame_stride,
                                 pgorb_keypoint* d_kps, uint8_t* d_desc, int cap_per_frame,
                                 int32_t* d_n, void* hip_stream);
+/* Colour ingest: Tracking::GrabImageMonocular's cvtColor (src/Tracking.cc:247-260) fused in
+ * front of the extractor.  d_img = nframes interleaved 8-bit images with `channels` = 3 or 4
+ * bytes per pixel, rgb_order != 0 for R,G,B(,A) (Camera_RGB: 1), 0 for B,G,R(,A).
+ * gray = (R*4899 + G*9617 + B*1868 + 8192) >> 14 (OpenCV 2.4 CV_RGB2GRAY, 8U).  The grey
+ * planes are written straight into the context's pyramid level 0. */
+int  pgorb_extract_batch_color_device(pgorb_ctx* ctx, const uint8_t* d_img, int nframes,
+                                      int w, int h, int stride, int64_t frame_stride,
+                                      int channels, int rgb_order,
+                                      pgorb_keypoint* d_kps, uint8_t* d_desc, int cap_per_frame,
+                                      int32_t* d_n, void* hip_stream);
+
 /* Device status word of the last *_device call: 0 or PGORB_E_OVERFLOW.  Synchronises. */
 int  pgorb_check_async(pgorb_ctx* ctx, void* hip_stream);
 

@@ -25,7 +25,7 @@ SYMBOLS = (
     "pgorb_vocab_free", "pgorb_vocab_upload", "pgorb_vocab_upload_device", "pgorb_bow_transform",
     "pgorb_bow_transform_device", "pgorb_bow_vectors", "pgorb_bow_score_l1",
     "pgorb_frame_grid", "pgorb_frame_grid_batch_device", "pgorb_search_for_initialization",
-    "pgorb_search_for_initialization_batch_device",
+    "pgorb_search_for_initialization_batch_device", "pgorb_extract_batch_color_device",
 )
 
 
@@ -78,6 +78,8 @@ def lib():
     L.pgorb_extract_batch_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64,
                                              vp, vp, C.c_int, vp, vp]
     L.pgorb_check_async.argtypes = [vp, vp]
+    L.pgorb_extract_batch_color_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int,
+                                                   vp, vp, C.c_int, vp, vp]
     L.pgorb_descriptor_distance.argtypes = [vp, vp]
     L.pgorb_hamming_matrix.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp]
     L.pgorb_hamming_best2.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp]

@@ -458,6 +458,21 @@ int pgorb_extract_batch_device(pgorb_ctx* c, const uint8_t* d_gray, int nframes,
                      cap_per_frame, d_n, (hipStream_t)stream);
 }
 
+int pgorb_extract_batch_color_device(pgorb_ctx* c, const uint8_t* d_img, int nframes, int w, int h, int stride,
+                                     int64_t frame_stride, int channels, int rgb_order, pgorb_keypoint* d_kps,
+                                     uint8_t* d_desc, int cap_per_frame, int32_t* d_n, void* stream)
+{
+    if (!c) return PGORB_E_ARG;
+    if (!d_img || !d_kps || !d_desc || !d_n || nframes < 1 || w < 1 || h < 1 || (channels != 3 && channels != 4) ||
+        stride < w * channels || cap_per_frame < 1)
+        return fail(c, PGORB_E_ARG, "bad argument to pgorb_extract_batch_color_device");
+    PG_HIP(c, hipSetDevice(c->prm.device));
+    int rc = make_plan(c, w, h, nframes);
+    if (rc) return rc;
+    pg_launch_color_to_gray(c->plan, d_img, stride, frame_stride, channels, rgb_order, nframes, (hipStream_t)stream);
+    return run_batch(c, nullptr, true, nframes, w, h, w, 0, d_kps, d_desc, cap_per_frame, d_n, (hipStream_t)stream);
+}
+
 int pgorb_check_async(pgorb_ctx* c, void* stream)
 {
     if (!c) return PGORB_E_ARG;

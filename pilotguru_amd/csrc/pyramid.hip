@@ -28,6 +28,37 @@ __global__ __launch_bounds__(256) void k_copy_level0(const uint8_t* __restrict__
     *reinterpret_cast<uint32_t*>(dst + (int64_t)blockIdx.z * dfstride + (int64_t)y * pitch + x4) = v;
 }
 
+// cvtColor RGB/BGR(A) -> GRAY, 8U fixed point (OpenCV 2.4 color.cpp RGB2Gray<uchar>: yuv_shift 14,
+// coefficients R 4899, G 9617, B 1868), 4 pixels per lane, written into the level-0 plane.
+__global__ __launch_bounds__(256) void k_color_to_gray(const uint8_t* __restrict__ src, int stride,
+                                                        int64_t sfstride, int cn, int rIdx,
+                                                        uint8_t* __restrict__ dst, int pitch,
+                                                        int64_t dfstride, int w, int h)
+{
+    const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x4 >= w || y >= h) return;
+    const uint8_t* s = src + (int64_t)blockIdx.z * sfstride + (int64_t)y * stride + (int64_t)x4 * cn;
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (x4 + k < w) {
+            const uint8_t* px = s + k * cn;
+            const int R = px[rIdx], G = px[1], B = px[2 - rIdx];
+            v |= (uint32_t)((R * 4899 + G * 9617 + B * 1868 + 8192) >> 14) << (8 * k);
+        }
+    *reinterpret_cast<uint32_t*>(dst + (int64_t)blockIdx.z * dfstride + (int64_t)y * pitch + x4) = v;
+}
+
+void pg_launch_color_to_gray(const PgPlan& P, const uint8_t* src, int stride, int64_t fstride, int channels,
+                             int rgb_order, int nframes, hipStream_t s)
+{
+    const PgLevel& L = P.lvl[0];
+    dim3 block(64, 4), grid((L.w + 255) / 256, (L.h + 3) / 4, nframes);
+    hipLaunchKernelGGL(k_color_to_gray, grid, block, 0, s, src, stride, fstride, channels, rgb_order ? 0 : 2,
+                       L.img, L.pitch, L.fstride, L.w, L.h);
+}
+
 void pg_launch_copy_level0(const PgPlan& P, const uint8_t* src, int stride, int64_t fstride,
                            int nframes, hipStream_t s)
 {

@@ -1,0 +1,276 @@
+// optical_trajectories.cc -- the drop-in CLI surface of pilotguru's optical_trajectories
+// (src/optical_trajectories.cc:36-114) over libpgorb, FRONT-END MODE.
+//
+// Same flags as the reference (vocabulary_file, camera_settings, out_dir, in_video, visualize,
+// vertical_flip, horizontal_flip, output_per_segment_videos, rotation_smooth_sigma; gflags
+// syntax --flag=value / --flag value / --noflag) and the same three CHECKs (:77-79).  What runs
+// per frame is the part of the reference this project rebuilds: ORB extraction
+// (Frame::ExtractORB), Frame::ComputeBoW, the 64x48 grid and ORBmatcher(0.9,true)
+// .SearchForInitialization(previous, current, ..., 100) (Tracking.cc:596-597).  The SLAM back
+// end (Tracking/LocalMapping/LoopClosing, pose estimation) is out of scope, so instead of
+// trajectory-<k>.json (which needs poses) the run writes <out_dir>/frontend-<k>.json; the
+// trajectory JSON writer is exercised with --trajectory_in=<poses.txt> (see trajectory_json.hpp).
+// No libav here: --in_video takes a .y4m (Y plane), a printf pattern of PGM files
+// (frames/%06d.pgm) or a headerless .gray file sized by Camera_width/Camera_height.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "orb_extractor.hpp"
+#include "trajectory_json.hpp"
+
+namespace {
+
+struct Flags {
+    std::string vocabulary_file, camera_settings, out_dir, in_video, trajectory_in, dump_features;
+    bool visualize = true, vertical_flip = false, horizontal_flip = false, output_per_segment_videos = false;
+    long long rotation_smooth_sigma = -1;
+    int device = 0, batch = 8, max_frames = -1;
+};
+
+[[noreturn]] void check_failed(const char* what)
+{
+    fprintf(stderr, "Check failed: %s\n", what);             // glog CHECK aborts; we exit non-zero
+    exit(EXIT_FAILURE);
+}
+
+bool parse_flags(int argc, char** argv, Flags& F)
+{
+    std::map<std::string, std::string*> str = {{"vocabulary_file", &F.vocabulary_file}, {"camera_settings", &F.camera_settings},
+        {"out_dir", &F.out_dir}, {"in_video", &F.in_video}, {"trajectory_in", &F.trajectory_in}, {"dump_features", &F.dump_features}};
+    std::map<std::string, bool*> bl = {{"visualize", &F.visualize}, {"vertical_flip", &F.vertical_flip},
+        {"horizontal_flip", &F.horizontal_flip}, {"output_per_segment_videos", &F.output_per_segment_videos}};
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        if (a.rfind("--", 0) == 0) a = a.substr(2); else if (a.rfind("-", 0) == 0) a = a.substr(1); else return false;
+        std::string name = a, val; bool has = false;
+        const size_t eq = a.find('=');
+        if (eq != std::string::npos) { name = a.substr(0, eq); val = a.substr(eq + 1); has = true; }
+        if (bl.count(name)) { *bl[name] = !has || (val != "false" && val != "0" && val != "no"); continue; }
+        if (name.rfind("no", 0) == 0 && bl.count(name.substr(2))) { *bl[name.substr(2)] = false; continue; }
+        if (!has) { if (i + 1 >= argc) return false; val = argv[++i]; }
+        if (str.count(name)) *str[name] = val;
+        else if (name == "rotation_smooth_sigma") F.rotation_smooth_sigma = atoll(val.c_str());
+        else if (name == "device") F.device = atoi(val.c_str());
+        else if (name == "batch") F.batch = atoi(val.c_str());
+        else if (name == "max_frames") F.max_frames = atoi(val.c_str());
+        else { fprintf(stderr, "ERROR: unknown command line flag '%s'\n", name.c_str()); return false; }
+    }
+    return true;
+}
+
+// OpenCV FileStorage YAML as written by calibrate.cc:504-544: "key: value" lines
+std::map<std::string, double> read_settings(const std::string& path)
+{
+    std::map<std::string, double> m;
+    std::ifstream f(path);
+    if (!f.good()) check_failed("camera_settings file is readable");
+    std::string line;
+    while (std::getline(f, line)) {
+        const size_t c = line.find(':');
+        if (c == std::string::npos || line[0] == '%' || line[0] == '-') continue;
+        std::string k = line.substr(0, c), v = line.substr(c + 1);
+        k.erase(0, k.find_first_not_of(" \t")); k.erase(k.find_last_not_of(" \t") + 1);
+        char* e = nullptr;
+        const double d = strtod(v.c_str(), &e);
+        if (e != v.c_str()) m[k] = d;
+    }
+    return m;
+}
+
+struct FrameSource {                  // ImageSequenceSource (include/io/image_sequence_reader.hpp:23-28), grey only
+    std::string path; int w = 0, h = 0; double fps = 30; long frame = 0;
+    FILE* fp = nullptr; bool y4m = false, pattern = false; size_t y4mFrameBytes = 0;
+    bool open(const std::string& p, int sw, int sh, double f)
+    {
+        path = p; fps = f;
+        if (p.find('%') != std::string::npos) { pattern = true; return true; }
+        fp = fopen(p.c_str(), "rb");
+        if (!fp) return false;
+        if (p.size() > 4 && p.substr(p.size() - 4) == ".y4m") {
+            y4m = true;
+            char hdr[512]; if (!fgets(hdr, sizeof(hdr), fp)) return false;
+            int chroma = 420; char* t = strtok(hdr, " \n");
+            while (t) {
+                if (t[0] == 'W') w = atoi(t + 1); else if (t[0] == 'H') h = atoi(t + 1);
+                else if (t[0] == 'F') { int a = 30, b = 1; if (sscanf(t + 1, "%d:%d", &a, &b) == 2 && b) fps = (double)a / b; }
+                else if (t[0] == 'C') chroma = !strncmp(t + 1, "mono", 4) ? 400 : !strncmp(t + 1, "444", 3) ? 444 : !strncmp(t + 1, "422", 3) ? 422 : 420;
+                t = strtok(nullptr, " \n");
+            }
+            const size_t y = (size_t)w * h;
+            y4mFrameBytes = chroma == 400 ? y : chroma == 444 ? 3 * y : chroma == 422 ? 2 * y : y + 2 * ((size_t)((w + 1) / 2) * ((h + 1) / 2));
+            return w > 0 && h > 0;
+        }
+        w = sw; h = sh;
+        return w > 0 && h > 0;
+    }
+    bool next(std::vector<uint8_t>& gray, long long* time_usec, long long* frame_id)
+    {
+        if (pattern) {
+            char name[1024]; snprintf(name, sizeof(name), path.c_str(), (int)frame);
+            FILE* f = fopen(name, "rb");
+            if (!f) return false;
+            char magic[3] = {0}; int maxv = 0;
+            if (fscanf(f, "%2s %d %d %d", magic, &w, &h, &maxv) != 4 || strcmp(magic, "P5") || maxv != 255) { fclose(f); return false; }
+            fgetc(f);
+            gray.resize((size_t)w * h);
+            const bool ok = fread(gray.data(), 1, gray.size(), f) == gray.size();
+            fclose(f);
+            if (!ok) return false;
+        } else if (y4m) {
+            char line[64];
+            if (!fgets(line, sizeof(line), fp) || strncmp(line, "FRAME", 5)) return false;
+            std::vector<uint8_t> buf(y4mFrameBytes);
+            if (fread(buf.data(), 1, buf.size(), fp) != buf.size()) return false;
+            gray.assign(buf.begin(), buf.begin() + (size_t)w * h);
+        } else {
+            gray.resize((size_t)w * h);
+            if (fread(gray.data(), 1, gray.size(), fp) != gray.size()) return false;
+        }
+        *frame_id = frame;
+        *time_usec = (long long)llround((double)frame * 1e6 / fps);
+        frame++;
+        return true;
+    }
+};
+
+void flip(std::vector<uint8_t>& g, int w, int h, bool vertical, bool horizontal)
+{
+    if (vertical) for (int y = 0; y < h / 2; y++) std::swap_ranges(g.begin() + (size_t)y * w, g.begin() + (size_t)(y + 1) * w, g.begin() + (size_t)(h - 1 - y) * w);
+    if (horizontal) for (int y = 0; y < h; y++) std::reverse(g.begin() + (size_t)y * w, g.begin() + (size_t)(y + 1) * w);
+}
+
+int write_trajectory_from_text(const Flags& F)
+{
+    // fixture format: first line 6 plane doubles; then per point:
+    // time_usec is_lost frame_id tx ty tz qw qx qy qz dir_x dir_y turn_angle
+    std::ifstream f(F.trajectory_in);
+    if (!f.good()) check_failed("trajectory_in file is readable");
+    double plane[6];
+    for (double& v : plane) f >> v;
+    std::vector<pgorb::PoseWithTimestamp> traj; std::vector<double> dirs, turns;
+    for (;;) {
+        pgorb::PoseWithTimestamp p; long long t, id; int lost; double dx, dy, turn;
+        if (!(f >> t >> lost >> id >> p.pose.translation[0] >> p.pose.translation[1] >> p.pose.translation[2] >> p.pose.qw >>
+              p.pose.qx >> p.pose.qy >> p.pose.qz >> dx >> dy >> turn)) break;
+        p.time_usec = t; p.is_lost = lost != 0; p.frame_id = id;
+        traj.push_back(p); dirs.push_back(dx); dirs.push_back(dy); turns.push_back(turn);
+    }
+    const std::string out = F.out_dir + "/trajectory-0.json";            // TrajectoryOutFileName (:65-70)
+    std::ofstream o(out);
+    if (!o.good()) check_failed("out_dir is writable");
+    o << pgorb::trajectory_to_json(plane, traj, dirs.data(), turns.data(), 0) << std::endl;   // dump(2) << endl (:108-109)
+    return EXIT_SUCCESS;
+}
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    Flags F;
+    if (!parse_flags(argc, argv, F)) return EXIT_FAILURE;
+    if (!F.trajectory_in.empty()) return write_trajectory_from_text(F);
+    if (F.vocabulary_file.empty()) check_failed("!FLAGS_vocabulary_file.empty()");     // :77
+    if (F.camera_settings.empty()) check_failed("!FLAGS_camera_settings.empty()");     // :78
+    if (F.in_video.empty()) check_failed("!FLAGS_in_video.empty()");                   // :79
+
+    std::map<std::string, double> S = read_settings(F.camera_settings);
+    auto get = [&](const char* k, double d) { return S.count(k) ? S[k] : d; };
+    // underscore keys of this fork (Tracking.cc:131-135); defaults as written by calibrate.cc:518-532
+    const int nFeatures = (int)get("ORBextractor_nFeatures", 2000), nLevels = (int)get("ORBextractor_nLevels", 8);
+    const float scaleFactor = (float)get("ORBextractor_scaleFactor", 1.2);
+    const int iniTh = (int)get("ORBextractor_iniThFAST", 20), minTh = (int)get("ORBextractor_minThFAST", 7);
+
+    FrameSource src;
+    if (!src.open(F.in_video, (int)get("Camera_width", 0), (int)get("Camera_height", 0), get("Camera_fps", 30.0)))
+        check_failed("input video opens (y4m, PGM pattern or .gray + Camera_width/Camera_height)");
+
+    pgorb_vocab* voc = nullptr;
+    if (pgorb_vocab_load_text(F.vocabulary_file.c_str(), &voc) != PGORB_OK)           // ORBVocabulary.cc:8 CHECK
+        check_failed("vocabulary loads (ORB vocabulary text file)");
+    int vk, vL, vn, vw, vs, vwt; pgorb_vocab_info(voc, &vk, &vL, &vn, &vw, &vs, &vwt);
+
+    const int B = std::max(1, F.batch);
+    std::vector<std::vector<uint8_t>> frames(B);
+    std::vector<long long> tus(B), ids(B);
+    pgorb::ORBextractor* ext = nullptr;
+    pgorb::Frame prev; bool havePrev = false;
+    std::vector<float> prevMatched;
+    std::ostringstream js;
+    js << "{\n  \"frames\": [";
+    FILE* dump = F.dump_features.empty() ? nullptr : fopen(F.dump_features.c_str(), "wb");
+    long total = 0; bool first = true;
+    for (;;) {
+        int nb = 0;
+        while (nb < B && (F.max_frames < 0 || total + nb < F.max_frames) && src.next(frames[nb], &tus[nb], &ids[nb])) {
+            flip(frames[nb], src.w, src.h, F.vertical_flip, F.horizontal_flip);
+            nb++;
+        }
+        if (!nb) break;
+        if (!ext) {
+            ext = new pgorb::ORBextractor(nFeatures, scaleFactor, nLevels, iniTh, minTh, src.w, src.h, B, F.device);
+            if (pgorb_vocab_upload(ext->context(), voc) != PGORB_OK) check_failed("vocabulary upload");
+        }
+        const int cap = pgorb_max_keypoints(ext->context(), src.w, src.h);
+        if (cap < 0) check_failed("frame size usable for the ORB cell grid");
+        std::vector<pgorb_keypoint> kps((size_t)nb * cap); std::vector<uint8_t> desc((size_t)nb * cap * 32); std::vector<int> n(nb);
+        std::vector<const uint8_t*> ptrs(nb);
+        for (int i = 0; i < nb; i++) ptrs[i] = frames[i].data();
+        if (pgorb_extract_batch(ext->context(), ptrs.data(), nb, src.w, src.h, src.w, kps.data(), desc.data(), cap, n.data()) != PGORB_OK)
+            check_failed(pgorb_last_error(ext->context()));
+        for (int i = 0; i < nb; i++) {
+            pgorb::Frame cur;
+            cur.mvKeysUndistorted.assign(kps.begin() + (size_t)i * cap, kps.begin() + (size_t)i * cap + n[i]);
+            cur.mDescriptors.assign(desc.begin() + (size_t)i * cap * 32, desc.begin() + ((size_t)i * cap + n[i]) * 32);
+            cur.mnMaxX = (float)src.w; cur.mnMaxY = (float)src.h;
+            // Frame::ComputeBoW: transform(descriptors, BowVec, FeatVec, 4)  (Frame.cc:399-406)
+            std::vector<uint32_t> word(n[i]), node(n[i]), bid(n[i] + 1), fnode(n[i] + 1), ffeat(n[i] + 1);
+            std::vector<double> wt(n[i]), bval(n[i] + 1); std::vector<int32_t> fstart(n[i] + 2);
+            int nbow = 0, nfv = 0;
+            if (n[i]) {
+                if (pgorb_bow_transform(ext->context(), cur.mDescriptors.data(), n[i], 4, word.data(), wt.data(), node.data()) != PGORB_OK)
+                    check_failed(pgorb_last_error(ext->context()));
+                pgorb_bow_vectors(n[i], word.data(), wt.data(), node.data(), vs, vwt, bid.data(), bval.data(), &nbow,
+                                  fnode.data(), fstart.data(), ffeat.data(), &nfv);
+            }
+            int nmatches = -1;
+            if (havePrev) {                              // MonocularInitialization's matcher call (Tracking.cc:596-597)
+                pgorb::ORBmatcher matcher(ext->context(), 0.9f, true);
+                prevMatched.resize((size_t)prev.N() * 2);
+                for (int k = 0; k < prev.N(); k++) { prevMatched[2 * k] = prev.mvKeysUndistorted[k].x; prevMatched[2 * k + 1] = prev.mvKeysUndistorted[k].y; }
+                std::vector<int32_t> m12;
+                nmatches = matcher.SearchForInitialization(prev, cur, prevMatched, m12, 100);
+            }
+            js << (first ? "\n" : ",\n") << "    {\"frame_id\": " << ids[i] << ", \"time_usec\": " << tus[i] << ", \"n_keypoints\": " << n[i]
+               << ", \"n_bow_words\": " << nbow << ", \"n_feature_nodes\": " << nfv << ", \"n_matches_prev\": " << nmatches << "}";
+            first = false;
+            if (dump) {
+                const int32_t hdr[2] = {(int32_t)ids[i], n[i]};
+                fwrite(hdr, 4, 2, dump);
+                fwrite(cur.mvKeysUndistorted.data(), sizeof(pgorb_keypoint), n[i], dump);
+                fwrite(cur.mDescriptors.data(), 32, n[i], dump);
+            }
+            prev = cur; havePrev = true;
+        }
+        total += nb;
+    }
+    js << "\n  ],\n  \"orb\": {\"nFeatures\": " << nFeatures << ", \"nLevels\": " << nLevels << ", \"iniThFAST\": " << iniTh
+       << ", \"minThFAST\": " << minTh << "},\n  \"vocabulary\": {\"k\": " << vk << ", \"L\": " << vL << ", \"nodes\": " << vn << ", \"words\": " << vw
+       << "}\n}";
+    if (dump) fclose(dump);
+    const std::string out = (F.out_dir.empty() ? std::string(".") : F.out_dir) + "/frontend-0.json";
+    std::ofstream o(out);
+    if (!o.good()) check_failed("out_dir is writable");
+    o << js.str() << std::endl;
+    fprintf(stderr, "optical_trajectories (front-end mode): %ld frames -> %s\n", total, out.c_str());
+    delete ext;
+    pgorb_vocab_free(voc);
+    return EXIT_SUCCESS;
+}

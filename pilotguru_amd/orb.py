@@ -135,6 +135,23 @@ class ORBextractor:
             cap, C.c_void_p(n_out.data_ptr()), C.c_void_p(s)))
         return kps_out, desc_out, n_out
 
+    def extract_batch_color_device(self, frames_rgb, rgb_order=True, stream=None):
+        """`frames_rgb`: CUDA(HIP) torch uint8 tensor [B, H, W, C], C = 3 or 4; fuses
+        Tracking::GrabImageMonocular's cvtColor (Tracking.cc:247-260) in front of the extractor."""
+        import torch
+        B, H, W, Cn = frames_rgb.shape
+        cap = self.max_keypoints(W, H)
+        dev = frames_rgb.device
+        kps = torch.empty((B, cap, 7), dtype=torch.float32, device=dev)
+        desc = torch.empty((B, cap, 32), dtype=torch.uint8, device=dev)
+        n = torch.empty((B,), dtype=torch.int32, device=dev)
+        s = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+        self._check(self._L.pgorb_extract_batch_color_device(
+            self._h, C.c_void_p(frames_rgb.data_ptr()), B, W, H, frames_rgb.stride(1), frames_rgb.stride(0), Cn,
+            int(bool(rgb_order)), C.c_void_p(kps.data_ptr()), C.c_void_p(desc.data_ptr()), cap,
+            C.c_void_p(n.data_ptr()), C.c_void_p(s)))
+        return kps, desc, n
+
     def check_async(self, stream=None):
         import torch
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream

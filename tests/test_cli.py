@@ -1,0 +1,94 @@
+"""The optical_trajectories-compatible CLI (pilotguru_amd/host/optical_trajectories, C++ over the
+C ABI): flag surface and CHECKs of src/optical_trajectories.cc:36-79, the trajectory JSON
+writer (src/io/json_converters.cc:6-96 + nlohmann dump(2)) against a committed fixture, and
+-- on the GPU -- the front-end run against the Python path."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CLI = os.path.join(ROOT, "pilotguru_amd", "host", "optical_trajectories")
+
+
+def _cli(*args):
+    return subprocess.run([CLI] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+
+
+def test_cli_checks_required_flags():
+    assert os.path.exists(CLI), "build it: make -C pilotguru_amd/csrc"
+    r = _cli()
+    assert r.returncode != 0 and "!FLAGS_vocabulary_file.empty()" in r.stderr          # :77
+    r = _cli("--vocabulary_file=v.txt")
+    assert r.returncode != 0 and "!FLAGS_camera_settings.empty()" in r.stderr          # :78
+    r = _cli("--vocabulary_file=v.txt", "--camera_settings", "c.yml")
+    assert r.returncode != 0 and "!FLAGS_in_video.empty()" in r.stderr                 # :79
+    r = _cli("--no_such_flag=1")
+    assert r.returncode != 0 and "unknown command line flag" in r.stderr
+    # boolean forms of gflags are accepted up to the first failing CHECK
+    r = _cli("--novisualize", "--vertical_flip", "--horizontal_flip=false", "--output_per_segment_videos",
+             "--rotation_smooth_sigma=5", "--out_dir=/tmp")
+    assert "unknown command line flag" not in r.stderr
+
+
+def test_trajectory_json_writer_matches_fixture(tmp_path):
+    r = _cli("--trajectory_in=" + os.path.join(HERE, "golden", "trajectory_in.txt"), "--out_dir=" + str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    got = open(os.path.join(str(tmp_path), "trajectory-0.json")).read()
+    want = open(os.path.join(HERE, "golden", "trajectory_expected.json")).read()
+    assert got == want
+    d = json.loads(got)                                               # schema of json_converters.cc:56-96
+    assert sorted(d) == ["plane", "trajectory"]
+    p = d["trajectory"][1]
+    assert sorted(p) == ["angular_velocity", "frame_id", "is_lost", "planar_direction", "pose", "time_usec"]
+    assert sorted(p["pose"]) == ["rotation", "translation"] and sorted(p["pose"]["rotation"]) == ["w", "x", "y", "z"]
+    assert d["trajectory"][0]["angular_velocity"] == 0 and '"angular_velocity": 0,' in got   # integer 0 (:83)
+    assert abs(p["angular_velocity"] - 0.01 / (0.033333 + 1e-10)) < 1e-12
+
+
+@pytest.mark.gpu
+def test_cli_front_end_run_matches_python_path(tmp_path, oracle):
+    import pilotguru_amd as pg
+    from pilotguru_amd import vocab as V
+    from pilotguru_amd.synth import synth_ride
+    w, h, nfr, nf = 480, 360, 5, 800
+    ride = synth_ride(12, w, h, nfr, dx=4, dy=2)
+    d = str(tmp_path)
+    for i in range(nfr):
+        with open(os.path.join(d, "%06d.pgm" % i), "wb") as f:
+            f.write(b"P5\n%d %d\n255\n" % (w, h) + ride[i].tobytes())
+    with open(os.path.join(d, "cam.yml"), "w") as f:                 # keys as written by calibrate.cc:504-544
+        f.write("%YAML:1.0\n---\nCamera_fps: 25.\nORBextractor_nFeatures: 800\nORBextractor_scaleFactor: 1.2\n"
+                "ORBextractor_nLevels: 8\nORBextractor_iniThFAST: 20\nORBextractor_minThFAST: 7\n")
+    desc, weight, parent = V.synth_vocabulary(5, 4, seed=3)
+    V.write_vocabulary_text(os.path.join(d, "voc.txt"), 5, 4, desc, weight, parent)
+    r = _cli("--vocabulary_file=" + os.path.join(d, "voc.txt"), "--camera_settings=" + os.path.join(d, "cam.yml"),
+             "--in_video=" + os.path.join(d, "%06d.pgm"), "--out_dir=" + d, "--novisualize", "--batch=2",
+             "--dump_features=" + os.path.join(d, "feat.bin"))
+    assert r.returncode == 0, r.stderr
+    out = json.load(open(os.path.join(d, "frontend-0.json")))
+    assert [fr["frame_id"] for fr in out["frames"]] == list(range(nfr))
+    assert out["frames"][2]["time_usec"] == 80000                    # 2 / 25 fps
+    ext = pg.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    voc = V.ORBVocabulary(text_file=os.path.join(d, "voc.txt"))
+    voc.upload(ext)
+    raw = open(os.path.join(d, "feat.bin"), "rb").read()
+    off, prevF = 0, None
+    for i in range(nfr):
+        fid, n = np.frombuffer(raw, np.int32, 2, off); off += 8
+        F = pg.Frame(ext, ride[i])
+        assert fid == i and n == F.N == out["frames"][i]["n_keypoints"]
+        assert raw[off:off + 28 * n] == F.mvKeys.tobytes(); off += 28 * n
+        assert raw[off:off + 32 * n] == F.mDescriptors.tobytes(); off += 32 * n
+        (bid, bval), fv = voc.transform(F.mDescriptors, 4)
+        assert out["frames"][i]["n_bow_words"] == len(bid) and out["frames"][i]["n_feature_nodes"] == len(fv[0])
+        if prevF is not None:
+            prev = np.stack([prevF.mvKeys["x"], prevF.mvKeys["y"]], 1).astype(np.float32)
+            nm, _ = pg.ORBmatcher(0.9, True).SearchForInitialization(prevF, F, prev, 100)
+            assert out["frames"][i]["n_matches_prev"] == nm and nm > 50
+        else:
+            assert out["frames"][i]["n_matches_prev"] == -1
+        prevF = F

@@ -139,3 +139,23 @@ def test_errors_and_edge_cases():
     assert e.value.code == PGORB_E_LIMIT
     with pytest.raises(TypeError):
         ext(np.zeros((240, 320), np.float32))
+
+
+@pytest.mark.parametrize("cn,rgb", [(3, True), (3, False), (4, True)])
+def test_color_ingest_matches_cvtcolor_then_extract(oracle, cn, rgb):
+    """GrabImageMonocular: cvtColor(RGB/BGR(A) -> GRAY) then the extractor (Tracking.cc:247-265)."""
+    import torch
+    w, h, nf = 324, 244, 300
+    rng = np.random.RandomState(cn * 2 + rgb)
+    base = synth_scene(21, w, h).astype(np.int32)
+    img = np.stack([np.clip(base + rng.randint(-20, 21, base.shape), 0, 255) for _ in range(cn)], 2).astype(np.uint8)
+    rgb_img = img[..., :3] if rgb else img[..., 2::-1]
+    gray = oracle.rgb_to_gray(np.ascontiguousarray(rgb_img))
+    ext = _make(nf, w, h)
+    kps, desc, n = ext.extract_batch_color_device(torch.from_numpy(img[None]).cuda(), rgb_order=rgb)
+    ext.check_async()
+    assert np.array_equal(ext.debug_level_image(0, 0), gray)
+    okp, odesc = oracle.OrbOracle(nf, 1.2, 8, 20, 7).extract(gray)
+    n0 = int(n[0])
+    assert n0 == len(okp) and kps[0, :n0].cpu().numpy().tobytes() == okp.tobytes()
+    assert np.array_equal(desc[0, :n0].cpu().numpy(), odesc)
