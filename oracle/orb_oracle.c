@@ -217,6 +217,12 @@ int orc_fast9_nms(const uint8_t* img, int w, int h, int stride, int threshold,
         for (int x = 3; x < w - 3; x++) {
             const uint8_t* p = img + (size_t)y * stride + x;
             int v = p[0], d[25];
+            {   /* any 9-arc holds a pixel of every opposite pair: cheap reject (same result) */
+                const int lo = v - threshold, hi = v + threshold;
+                const int r0 = p[3 * stride], r8 = p[-3 * stride], r4 = p[3], r12 = p[-3];
+                if (!(((r0 < lo || r8 < lo) && (r4 < lo || r12 < lo)) ||
+                      ((r0 > hi || r8 > hi) && (r4 > hi || r12 > hi)))) continue;
+            }
             for (int k = 0; k < 25; k++)
                 d[k] = v - p[k_ring[k & 15][1] * stride + k_ring[k & 15][0]];
             if (fast_is_corner(d, threshold))
@@ -520,16 +526,20 @@ void orc_gaussian_blur7(const uint8_t* src, int w, int h, int sstride,
         const uint8_t* s = src + (size_t)y * sstride;
         for (int x = 0; x < w; x++) {
             int acc = 0;
-            for (int i = 0; i < 7; i++) acc += K[i] * s[reflect101(x + i - 3, w)];
+            if (x >= 3 && x + 3 < w)
+                acc = K[0] * (s[x - 3] + s[x + 3]) + K[1] * (s[x - 2] + s[x + 2]) + K[2] * (s[x - 1] + s[x + 1]) + K[3] * s[x];
+            else
+                for (int i = 0; i < 7; i++) acc += K[i] * s[reflect101(x + i - 3, w)];
             R[(size_t)y * w + x] = acc;
         }
     }
     const int wvec = w & ~3;          /* SSE2 column pass covers x < wvec */
     for (int y = 0; y < h; y++) {
         uint8_t* d = dst + (size_t)y * dstride;
+        const int* rr[7];
+        for (int i = 0; i < 7; i++) rr[i] = R + (size_t)reflect101(y + i - 3, h) * w;
         for (int x = 0; x < w; x++) {
-            int C = 0;
-            for (int i = 0; i < 7; i++) C += K[i] * R[(size_t)reflect101(y + i - 3, h) * w + x];
+            int C = K[0] * (rr[0][x] + rr[6][x]) + K[1] * (rr[1][x] + rr[5][x]) + K[2] * (rr[2][x] + rr[4][x]) + K[3] * rr[3][x];
             int v = (C + 32768) >> 16;                 /* FixedPtCastEx: half up */
             if (tie_mode == 0 && x < wvec && (C & 0xFFFF) == 0x8000)
                 v &= ~1;                                /* cvtps2dq: tie -> even  */

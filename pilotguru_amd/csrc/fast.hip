@@ -195,11 +195,11 @@ __global__ __launch_bounds__(64, 8) void k_fast_cells(const PgPlan P, int TP, in
     const int frame = blockIdx.y;
     const int cell = (blockIdx.x & 7) * cellsPerXcd + (blockIdx.x >> 3);      // XCD-contiguous
     if (cell >= P.totalCells) return;
-    int l = 0;
-    while (l + 1 < P.nlevels && cell >= P.lvl[l + 1].cellBase) l++;
+    // one load instead of a dependent search through the per-level cell bases
+    const uint32_t ct = P.cellTab[cell];                 // level | cell row << 4 | cell col << 16
+    const int l = ct & 15, ci = (ct >> 4) & 0xFFF, cj = ct >> 16;
     const PgLevel& L = P.lvl[l];
     const int c = cell - L.cellBase;
-    const int ci = c / L.nCols, cj = c - ci * L.nCols;
     const int maxBorderX = L.w - PG_EDGE, maxBorderY = L.h - PG_EDGE;
     const int iniY = PG_EDGE + ci * L.hCell;
     const int iniX = PG_EDGE + cj * L.wCell;
@@ -219,6 +219,8 @@ __global__ __launch_bounds__(64, 8) void k_fast_cells(const PgPlan P, int TP, in
     uint16_t* list = reinterpret_cast<uint16_t*>(smap + mapRows * mapPitch);   // [FAST_LIST_CAP]
 
     // (1) stage the window.  LDS dword j of a row holds window columns 4j-1 .. 4j+2.
+    // All global loads are issued before anything waits on them (the score map is zeroed in
+    // their shadow); lane (lr = lane>>4, lq = lane&15) owns dword lq of rows lr, lr+4, ...
     const uint8_t* img = L.img + (int64_t)frame * L.fstride;
     const int gx0 = iniX - 1;                       // global x of LDS byte 0
     const int ga = gx0 & ~3, sh = gx0 & 3;
@@ -227,15 +229,35 @@ __global__ __launch_bounds__(64, 8) void k_fast_cells(const PgPlan P, int TP, in
         const int lq = lane & 15, lr = lane >> 4;       // 16 dwords x 4 rows per step
         const uint8_t* grow = img + (int64_t)(iniY + lr) * L.pitch + ga;
         uint8_t* trow = tile + lr * TP;
-        for (int r = lr; r < H; r += 4, grow += 4 * (int64_t)L.pitch, trow += 4 * TP)
-            for (int q = lq; q < ndw; q += 16) {
-                const uint32_t* g = reinterpret_cast<const uint32_t*>(grow) + q;
-                const uint32_t lo = g[0], hi = g[1];
-                *reinterpret_cast<uint32_t*>(trow + 4 * q) = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)sh);
+        if (H <= 48 && ndw <= 16) {
+            uint2 pre[12];
+            const bool act = lq < ndw;
+#pragma unroll
+            for (int k = 0; k < 12; k++) {
+                const int r = lr + 4 * k;
+                pre[k] = (act && r < H) ? *reinterpret_cast<const uint2*>(grow + (int64_t)(4 * k) * L.pitch + 4 * lq)
+                                        : make_uint2(0u, 0u);
             }
+            for (int i = lane; i < (mapRows * mapPitch) >> 2; i += 64)
+                reinterpret_cast<uint32_t*>(smap)[i] = 0;
+#pragma unroll
+            for (int k = 0; k < 12; k++) {
+                const int r = lr + 4 * k;
+                if (act && r < H)
+                    *reinterpret_cast<uint32_t*>(trow + (4 * k) * TP + 4 * lq) =
+                        __builtin_amdgcn_alignbyte(pre[k].y, pre[k].x, (uint32_t)sh);
+            }
+        } else {
+            for (int r = lr; r < H; r += 4, grow += 4 * (int64_t)L.pitch, trow += 4 * TP)
+                for (int q = lq; q < ndw; q += 16) {
+                    const uint32_t* g = reinterpret_cast<const uint32_t*>(grow) + q;
+                    const uint32_t lo = g[0], hi = g[1];
+                    *reinterpret_cast<uint32_t*>(trow + 4 * q) = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)sh);
+                }
+            for (int i = lane; i < (mapRows * mapPitch) >> 2; i += 64)
+                reinterpret_cast<uint32_t*>(smap)[i] = 0;
+        }
     }
-    for (int i = lane; i < (mapRows * mapPitch) >> 2; i += 64)
-        reinterpret_cast<uint32_t*>(smap)[i] = 0;
     __syncthreads();
 
     uint32_t* out = P.cellCand + (int64_t)frame * P.cellCandFrame + L.cellCandOff + (int64_t)c * L.cellCap;

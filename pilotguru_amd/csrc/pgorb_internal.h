@@ -64,6 +64,7 @@ struct PgPlan {
     int64_t  cellCandFrame;   // u32 per frame in the per-cell slot slab
     uint32_t* cellCand;       // K2 output: [frame][level][cell][cellCap]
     int32_t*  cellCount;      // K2 output: [frame][totalCells]
+    const uint32_t* cellTab;  // [totalCells] level | cell row << 4 | cell col << 16
     uint32_t* cand;           // K3: dense uint2 key records (2 u32 per key)
     uint32_t* kpos;           // (unused)
     uint32_t* sel;
