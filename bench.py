@@ -208,6 +208,16 @@ def main():
         rk = max(cands, key=lambda s: stage_ms[s])
         launches = 7 if rk == "pyramid" else 1
         ach = (abytes[rk] * B / launches) / (stage_ms[rk] / launches * 1e-3) / 1e9
+        kname = {"pyramid": "k_pyr_resize_quads", "fast": "k_fast_cells", "describe": "k_describe",
+                 "match": "k_match_batch"}[rk]
+        traffic = None                                  # HBM bytes per launch from the committed PMC passes
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if tr["workload"] == {"width": W, "height": H, "features": NF, "batch": B}:
+                k = tr["kernels"][kname]
+                traffic = (2.0 * k["fetch_kb"] + k["write_kb"]) * 1024.0
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "frames/sec ORB extract+match, 1080p @ 2000 kp/frame",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -219,11 +229,9 @@ def main():
                                    % (W, H, NF, B),
                        "batch": B, "keypoints_per_frame": nkp, "parallelism": "frames-sharded x%d" % world,
                        "vocab_broadcast_bytes": vocab_bytes},
-            "roofline": {"bound": "hbm", "kernel": {"pyramid": "k_pyr_resize_bilinear_u8",
-                                                     "fast": "k_fast_cells", "describe": "k_describe",
-                                                     "match": "k_match_batch"}[rk],
+            "roofline": {"bound": "hbm", "kernel": kname,
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": abytes[rk] * B / launches,
                          "launch_ms": stage_ms[rk] / launches},
             "stage_ms_per_step": stage_ms, "dominant_stage": dom,

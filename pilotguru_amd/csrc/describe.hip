@@ -114,7 +114,10 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
 
     const int lane = threadIdx.x;
     const int frame = blockIdx.y;
-    int idx = blockIdx.x;
+    // XCD-contiguous keypoint ranges: consecutive workgroups go to consecutive XCDs, so give XCD x
+    // the x-th eighth of the frame's keypoint list (neighbours in the list are neighbours in the
+    // image: their 43x43 windows share L2 lines)
+    int idx = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     // locate (level, index in level) from the per-level keypoint counts
     const int32_t* kpc = P.kpCount + frame * PG_MAXL;
     int l = 0, total = 0, before = 0, found = -1, j = 0;
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
         if (found < 0 && idx < total + c) { found = q; before = total; }
         total += c;
     }
-    if (blockIdx.x == 0 && lane == 0) n_out[frame] = total;
+    if (blockIdx.x == 0 && lane == 0) n_out[frame] = total;      // (idx == 0 as well)
     if (found < 0) return;
     l = found; j = idx - before;
     const PgLevel& L = P.lvl[l];
@@ -294,6 +297,6 @@ void pg_launch_describe(const PgPlan& P, int nframes, pgorb_keypoint* d_kps, uin
                         int cap_per_frame, int32_t* d_n, hipStream_t s)
 {
     static const PgGauss7 G = pg_gauss7();
-    dim3 grid(P.selTotal, nframes), block(64);
+    dim3 grid((P.selTotal + 7) & ~7, nframes), block(64);
     hipLaunchKernelGGL(k_describe, grid, block, 0, s, P, G, d_kps, d_desc, cap_per_frame, d_n);
 }
