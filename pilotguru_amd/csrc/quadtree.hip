@@ -77,7 +77,7 @@ __device__ __forceinline__ int qt_quadrant(const int4 b, uint32_t cv)
     return (x < midX) ? ((y < midY) ? 0 : 2) : ((y < midY) ? 1 : 3);      // n1 n3 / n2 n4 (:515-526)
 }
 
-__global__ __launch_bounds__(QT_T) void k_quadtree(const PgPlan P)
+__global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P)
 {
     __shared__ int sh[QT_W + 8];
     extern __shared__ __attribute__((aligned(16))) int qt_lds[];     // 24 ints per node
