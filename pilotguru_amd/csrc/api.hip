@@ -168,7 +168,7 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
 
     // --- resize tables ---
     std::vector<uint8_t> tab;
-    struct TabOff { size_t xofs, xofs1, xalpha, yofs, ybeta, qtab; bool hasQ; } toff[PG_MAXL];
+    struct TabOff { size_t xofs, xofs1, xalpha, yofs, ybeta, qtab, yrel, qtab2; bool hasQ, hasY, hasQ2; } toff[PG_MAXL];
     for (int l = 1; l < L; l++) {
         std::vector<int32_t> xo, xo1, yo; std::vector<int16_t> xa, yb;
         build_resize_tables(g[l - 1].w, g[l - 1].h, g[l].w, g[l].h, xo, xo1, xa, yo, yb);
@@ -204,6 +204,36 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
         }
         toff[l].hasQ = ok;
         toff[l].qtab = put(qt.data(), qt.size() * sizeof(PgQuadTab));
+        // 8-byte-window table: xb = first tap of the quad (clamped so the window stays inside the row)
+        std::vector<PgQuadTab2> q2(nq);
+        bool ok2 = g[l - 1].w >= 8;
+        for (int q = 0; q < nq && ok2; q++) {
+            PgQuadTab2& T = q2[q];
+            memset(&T, 0, sizeof(T));
+            T.xb = std::min(xo[4 * q], g[l - 1].w - 8);
+            for (int k = 0; k < 4; k++) {
+                const int dx = 4 * q + k;
+                if (dx >= g[l].w) { T.sel[k] = 0x0c0c0c0cu; continue; }
+                const int o0 = xo[dx] - T.xb, o1 = xo1[dx] - T.xb;
+                if (o0 < 0 || o0 > 7 || o1 < 0 || o1 > 7) { ok2 = false; break; }
+                T.sel[k] = (uint32_t)o0 | (0x0cu << 8) | ((uint32_t)o1 << 16) | (0x0cu << 24);
+                T.coef[k] = (uint32_t)(uint16_t)xa[2 * dx] | ((uint32_t)(uint16_t)xa[2 * dx + 1] << 16);
+                if (xa[2 * dx] < 0 || xa[2 * dx + 1] < 0) ok2 = false;
+            }
+        }
+        toff[l].hasQ2 = ok2;
+        toff[l].qtab2 = put(q2.data(), q2.size() * sizeof(PgQuadTab2));
+        // row pattern for the 4-rows-per-lane kernel: r0(dy) - r0(group base) - d in {0,1}, r1 - r0 in {0,1}
+        std::vector<uint8_t> yr(g[l].h, 0);
+        bool oky = true;
+        for (int dy = 0; dy < g[l].h; dy++) {
+            const int base = yo[2 * (dy & ~3)], d = dy & 3;
+            const int e0 = yo[2 * dy] - base - d, e1 = yo[2 * dy + 1] - yo[2 * dy];
+            if (e0 < 0 || e0 > 1 || e1 < 0 || e1 > 1) oky = false;
+            yr[dy] = (uint8_t)((e0 & 1) | ((e1 & 1) << 1));
+        }
+        toff[l].hasY = oky;
+        toff[l].yrel = put(yr.data(), yr.size());
     }
     if ((rc = ensure(c, c->tables, tab.size() + 16))) return rc;
     if (!tab.empty()) PG_HIP(c, hipMemcpy(c->tables.p, tab.data(), tab.size(), hipMemcpyHostToDevice));
@@ -262,6 +292,8 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
             V.yofs = (const int32_t*)(t + toff[l].yofs);
             V.ybeta = (const int16_t*)(t + toff[l].ybeta);
             V.qtab = toff[l].hasQ ? (const PgQuadTab*)(t + toff[l].qtab) : nullptr;
+            V.yrel = toff[l].hasY ? (t + toff[l].yrel) : nullptr;
+            V.qtab2 = toff[l].hasQ2 ? (const PgQuadTab2*)(t + toff[l].qtab2) : nullptr;
         }
     }
     P.cellCand = (uint32_t*)c->cellCand.p; P.cellCount = (int32_t*)c->cellCount.p;

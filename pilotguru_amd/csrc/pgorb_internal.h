@@ -25,6 +25,12 @@ struct PgQuadTab {            // column taps of 4 adjacent destination pixels (p
     int16_t  a0[4], a1[4];    // 11-bit coefficients of tap 0 / tap 1
 };
 
+struct PgQuadTab2 {           // pyramid 4x4 fast path: one unaligned 8-byte window per quad and row
+    int32_t  xb;              // byte offset of the window in a source row (<= sw - 8)
+    uint32_t sel[4];          // v_perm_b32 selectors: tap0 -> bits 0..7, tap1 -> bits 16..23
+    uint32_t coef[4];         // a0 | a1 << 16 (11-bit coefficients)
+};
+
 struct PgLevel {
     // pyramid plane of this level
     uint8_t* img;             // frame 0 plane
@@ -37,6 +43,8 @@ struct PgLevel {
     const int32_t* yofs;      // [2*h] clamped source rows of the two taps
     const int16_t* ybeta;     // [2*h]
     const PgQuadTab* qtab;    // [ceil(w/4)] or null when a quad spans more than 3 source dwords
+    const PgQuadTab2* qtab2;  // [ceil(w/4)] or null when a quad's taps do not fit one 8-byte window
+    const uint8_t* yrel;      // [h] row pattern of the 4x4 fast path, or null when it does not apply
     // cell grid (ORBextractor.cc:781-787)
     int32_t  nCols, nRows, wCell, hCell, cellBase;
     // quadtree (ORBextractor.cc:539-563)

@@ -170,10 +170,88 @@ __global__ __launch_bounds__(256) void k_pyr_resize_quads(
     }
 }
 
+// Fast path for down-scales up to 1.25x (the ORB pyramid's 1.2): a lane owns 4 destination
+// columns x 4 destination rows.
+//  * Those rows need at most 6 consecutive source rows (row r0(d) is base+d or base+d+1, r1 is r0
+//    or r0+1 -- verified on the host, yrel[]), so all loads are issued before anything waits.
+//  * Per source row ONE unaligned 8-byte load starting at the quad's first tap covers all eight
+//    taps; v_perm_b32 with a per-lane selector packs (tap0, tap1) of a pixel into two u16 and
+//    v_dot2_u32_u16 against the packed 11-bit coefficients is HResizeLinear -- 2 instructions
+//    per pixel and row.
+//  * The vertical blend picks its two rows with wave-uniform branches (4 patterns).
+typedef unsigned short pg_us2 __attribute__((ext_vector_type(2)));
+struct __attribute__((packed, aligned(1))) PgU2 { uint32_t x, y; };
+
+template <int D, int F>
+__device__ __forceinline__ uint32_t pyr_vrow(const int (&H)[6][4], int b0, int b1)
+{
+    constexpr int iA = D + (F & 1), iB = iA + ((F >> 1) & 1);
+    uint32_t out = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int v = ((__mul24(b0, H[iA][j]) >> 16) + (__mul24(b1, H[iB][j]) >> 16) + 2) >> 2;   // VResizeLinear
+        out |= (uint32_t)(v & 0xFF) << (8 * j);
+    }
+    return out;
+}
+
+template <int D>
+__device__ __forceinline__ void pyr_store_row(const int (&H)[6][4], int dy, int dh, const uint8_t* yrel,
+                                              const int16_t* ybeta, uint8_t* dbase, int dpitch)
+{
+    if (dy >= dh) return;
+    const int f = yrel[dy];                                            // wave-uniform
+    const int b0 = ybeta[2 * dy], b1 = ybeta[2 * dy + 1];
+    uint32_t out;
+    if (f == 0) out = pyr_vrow<D, 0>(H, b0, b1);
+    else if (f == 1) out = pyr_vrow<D, 1>(H, b0, b1);
+    else if (f == 2) out = pyr_vrow<D, 2>(H, b0, b1);
+    else out = pyr_vrow<D, 3>(H, b0, b1);
+    *reinterpret_cast<uint32_t*>(dbase + (int64_t)dy * dpitch) = out;
+}
+
+__global__ __launch_bounds__(256) void k_pyr_resize_rows4(
+    const uint8_t* __restrict__ src, int spitch, int64_t sfstride, int sh,
+    uint8_t* __restrict__ dst, int dpitch, int64_t dfstride, int dw, int dh,
+    const PgQuadTab2* __restrict__ qtab, const int32_t* __restrict__ yofs,
+    const int16_t* __restrict__ ybeta, const uint8_t* __restrict__ yrel)
+{
+    const int quad = blockIdx.x * 64 + threadIdx.x;
+    const int dy0 = (blockIdx.y * 4 + threadIdx.y) * 4;
+    if (quad * 4 >= dw || dy0 >= dh) return;
+    const PgQuadTab2 T = qtab[quad];
+    const int sFirst = yofs[2 * dy0];                                  // wave-uniform
+    const uint8_t* sbase = src + (int64_t)blockIdx.z * sfstride + T.xb;
+    PgU2 w[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+        w[k] = *reinterpret_cast<const PgU2*>(sbase + (int64_t)min(sFirst + k, sh - 1) * spitch);
+    int H[6][4];
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t taps = __builtin_amdgcn_perm(w[k].y, w[k].x, T.sel[j]);      // tap0 | tap1 << 16
+            H[k][j] = (int)(__builtin_amdgcn_udot2(__builtin_bit_cast(pg_us2, taps),
+                                                   __builtin_bit_cast(pg_us2, T.coef[j]), 0u, false) >> 4);
+        }
+    uint8_t* dbase = dst + (int64_t)blockIdx.z * dfstride + quad * 4;
+    pyr_store_row<0>(H, dy0 + 0, dh, yrel, ybeta, dbase, dpitch);
+    pyr_store_row<1>(H, dy0 + 1, dh, yrel, ybeta, dbase, dpitch);
+    pyr_store_row<2>(H, dy0 + 2, dh, yrel, ybeta, dbase, dpitch);
+    pyr_store_row<3>(H, dy0 + 3, dh, yrel, ybeta, dbase, dpitch);
+}
+
 void pg_launch_pyramid_level(const PgPlan& P, int level, int nframes, hipStream_t s)
 {
     const PgLevel& S = P.lvl[level - 1];
     const PgLevel& D = P.lvl[level];
+    if (D.qtab2 && D.yrel) {
+        dim3 block(64, 4), grid((D.w + 255) / 256, (D.h + 15) / 16, nframes);
+        hipLaunchKernelGGL(k_pyr_resize_rows4, grid, block, 0, s, S.img, S.pitch, S.fstride, S.h,
+                           D.img, D.pitch, D.fstride, D.w, D.h, D.qtab2, D.yofs, D.ybeta, D.yrel);
+        return;
+    }
     if (D.qtab) {
         dim3 block(64, 4), grid((D.w + 255) / 256, (D.h + 4 * PYR_ROWS - 1) / (4 * PYR_ROWS), nframes);
         hipLaunchKernelGGL(k_pyr_resize_quads, grid, block, 0, s, S.img, S.pitch, S.fstride, S.w,
