@@ -25,14 +25,34 @@ __device__ static const int8_t pg_pattern31[256 * 4] = {
 #include "orb_pattern31.inc"
 };
 
-// circular patch row half-widths, ORBextractor.cc:452-469 evaluated
-__device__ static const int8_t pg_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+// (circular patch row half-widths umax, ORBextractor.cc:452-469, are baked into pg_make_moment_tab)
+
+struct PgMomentTab { uint32_t wu[31 * 9], wm[31 * 9]; };
+// per (disc row v+15, window dword q+1): packed byte weights (u+15 inside the disc, else 0) and
+// the 0/1 disc mask, for v_dot4_u32_u8
+constexpr PgMomentTab pg_make_moment_tab()
+{
+    constexpr int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+    PgMomentTab t = {};
+    for (int r = 0; r < 31; r++)
+        for (int q = 0; q < 9; q++) {
+            const int vy = r - 15, dmax = umax[vy < 0 ? -vy : vy];
+            uint32_t wu = 0, wm = 0;
+            for (int k = 0; k < 4; k++) {
+                const int ux = 4 * (q + 1) + k - 21;
+                if ((ux < 0 ? -ux : ux) <= dmax) { wu |= (uint32_t)(ux + 15) << (8 * k); wm |= 1u << (8 * k); }
+            }
+            t.wu[r * 9 + q] = wu; t.wm[r * 9 + q] = wm;
+        }
+    return t;
+}
+__device__ static const PgMomentTab pg_moment_tab = pg_make_moment_tab();
 
 #define DW_R 21               // window radius: 18 (taps) + 3 (blur)
 #define DW_N 43               // window side
 #define DW_PITCH 48
 #define DH_N 37               // blurred side
-#define DH_PITCH 40           // u16 row pitch of the horizontal pass (even: read as dwords)
+#define DH_PITCH 40           // columns per packed row pair of the horizontal pass
 #define DB_PITCH 40
 
 __device__ __forceinline__ int pg_reflect101(int p, int n)
@@ -109,7 +129,7 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
                                                   int32_t* __restrict__ n_out)
 {
     __shared__ __attribute__((aligned(16))) uint8_t raw[DW_N * DW_PITCH];       // 2064 B
-    __shared__ __attribute__((aligned(16))) uint16_t hbuf[DW_N * DH_PITCH];     // 3440 B
+    __shared__ __attribute__((aligned(16))) uint32_t hbuf[22 * DH_PITCH];       // 3520 B: [row pair][column]
     uint8_t* blur = raw;          // the blurred tile (37 x 40 B) reuses the raw window once the row pass is done
 
     const int lane = threadIdx.x;
@@ -139,16 +159,14 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
     // ---- stage the raw 43x43 window: window column 0 lands on an LDS dword boundary --------
     const int x0 = x - DW_R, y0 = y - DW_R;
     if (x0 >= 0 && y0 >= 0 && x0 + 52 <= w && y + DW_R < h) {   // 12 dwords + 1 stay inside the row
-        const int xa = x0 & ~3, sh = x0 & 3;
-        for (int i = lane; i < 12 * DW_N; i += 64) {
-            const int r = i / 12, q = i - r * 12;
-            const uint32_t* g = reinterpret_cast<const uint32_t*>(img + (int64_t)(y0 + r) * L.pitch + xa) + q;
-            const uint32_t lo = g[0], hi = g[1];
-            const uint32_t v = sh == 0 ? lo : sh == 1 ? __builtin_amdgcn_alignbyte(hi, lo, 1)
-                             : sh == 2 ? __builtin_amdgcn_alignbyte(hi, lo, 2)
-                                       : __builtin_amdgcn_alignbyte(hi, lo, 3);
-            *reinterpret_cast<uint32_t*>(raw + r * DW_PITCH + 4 * q) = v;
-        }
+        const int xa = x0 & ~3;
+        const uint32_t sh = (uint32_t)(x0 & 3);
+        const int lq = lane % 12, lr = lane / 12;               // 12 dwords x 5 rows per step
+        if (lr < 5)
+            for (int r = lr; r < DW_N; r += 5) {
+                const uint2 g = *reinterpret_cast<const uint2*>(img + (int64_t)(y0 + r) * L.pitch + xa + 4 * lq);
+                *reinterpret_cast<uint32_t*>(raw + r * DW_PITCH + 4 * lq) = __builtin_amdgcn_alignbyte(g.y, g.x, sh);
+            }
     } else {                                   // BORDER_REFLECT_101 (:1085)
         for (int i = lane; i < DW_N * DW_PITCH; i += 64) {
             const int r = i / DW_PITCH, c = i - r * DW_PITCH;
@@ -158,25 +176,16 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
     }
     __syncthreads();
 
-
     // ---- IC_Angle: integer moments over the radius-15 disc (:77-104) -------------------
-    // One task = one aligned dword (4 pixels) of one disc row; v_dot4_u32_u8 against per-row
-    // weight dwords: (u+15) inside the disc / 0 outside, and the 0/1 disc mask.
+    // One task = one aligned dword (4 pixels) of one disc row; v_dot4_u32_u8 against the
+    // precomputed per-(row, dword) weights: (u+15) inside the disc / 0 outside, and the disc mask.
     int m10 = 0, m01 = 0;
     for (int i = lane; i < 31 * 9; i += 64) {
         const int r = i / 9, q = i - r * 9;                     // r = v+15, dword q+1 = columns 4q+4 ..
-        const int vy = r - 15;
-        const uint32_t val = *reinterpret_cast<const uint32_t*>(raw + (DW_R + vy) * DW_PITCH + 4 * (q + 1));
-        const int dmax = pg_umax[abs(vy)];
-        uint32_t wu = 0, wm = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int ux = 4 * (q + 1) + k - DW_R;
-            if (abs(ux) <= dmax) { wu |= (uint32_t)(ux + 15) << (8 * k); wm |= 1u << (8 * k); }
-        }
-        const int sv = (int)__builtin_amdgcn_udot4(val, wm, 0u, false);          // sum of disc pixels
-        m10 += (int)__builtin_amdgcn_udot4(val, wu, 0u, false) - 15 * sv;        // sum u * I
-        m01 += vy * sv;                                                           // sum v * I
+        const uint32_t val = *reinterpret_cast<const uint32_t*>(raw + (DW_R - 15 + r) * DW_PITCH + 4 * (q + 1));
+        const int sv = (int)__builtin_amdgcn_udot4(val, pg_moment_tab.wm[i], 0u, false);        // sum of disc pixels
+        m10 += (int)__builtin_amdgcn_udot4(val, pg_moment_tab.wu[i], 0u, false) - 15 * sv;      // sum u * I
+        m01 += (r - 15) * sv;                                                                   // sum v * I
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -186,53 +195,77 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
     const float angle = pg_fast_atan2((float)m01, (float)m10);
 
     // ---- 7x7 Gaussian, fixed point, separable (OpenCV 2.4 8U path, Appendix A4) ---------
-    // row pass: a lane produces 4 adjacent sums from 3 aligned LDS dwords; each sum is two
-    // v_dot4_u32_u8 against the packed taps (K0..K3) and (K4,K5,K6,0)
+    // row pass: a task = 4 adjacent columns of a PAIR of rows; each sum is two v_dot4_u32_u8
+    // against the packed taps (K0..K3) and (K4,K5,K6,0); the sums of the two rows are stored
+    // packed (row r | row r+1 << 16) so the column pass can use v_dot2_u32_u16.
     const uint32_t KA = (uint32_t)G.k0 | ((uint32_t)G.k1 << 8) | ((uint32_t)G.k2 << 16) | ((uint32_t)G.k3 << 24);
     const uint32_t KB = (uint32_t)G.k2 | ((uint32_t)G.k1 << 8) | ((uint32_t)G.k0 << 16);
-    for (int i = lane; i < DW_N * 10; i += 64) {
-        const int r = i / 10, q = i - r * 10;
-        const uint32_t* s = reinterpret_cast<const uint32_t*>(raw + r * DW_PITCH) + q;
-        const uint32_t w0 = s[0], w1 = s[1], w2 = s[2];
-        uint32_t o[4];
-        o[0] = __builtin_amdgcn_udot4(w0, KA, __builtin_amdgcn_udot4(w1, KB, 0u, false), false);
+    uint32_t* hT = hbuf;                                       // [22 row pairs][DH_PITCH columns]
+    for (int i = lane; i < 22 * 10; i += 64) {
+        const int rp = i / 10, q = i - rp * 10;
+        uint32_t o[2][4];
 #pragma unroll
-        for (int k = 1; k < 4; k++)
-            o[k] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, (uint32_t)k), KA,
-                       __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, (uint32_t)k), KB, 0u, false), false);
-        uint32_t* d = reinterpret_cast<uint32_t*>(hbuf + r * DH_PITCH + 4 * q);
-        d[0] = o[0] | (o[1] << 16);                               // each sum <= 257*255 = 65535
-        d[1] = o[2] | (o[3] << 16);
+        for (int rr = 0; rr < 2; rr++) {
+            const int r = min(2 * rp + rr, DW_N - 1);          // pair 21 = (row 42, unused)
+            const uint32_t* s = reinterpret_cast<const uint32_t*>(raw + r * DW_PITCH) + q;
+            const uint32_t w0 = s[0], w1 = s[1], w2 = s[2];
+            o[rr][0] = __builtin_amdgcn_udot4(w0, KA, __builtin_amdgcn_udot4(w1, KB, 0u, false), false);
+#pragma unroll
+            for (int k = 1; k < 4; k++)
+                o[rr][k] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, (uint32_t)k), KA,
+                               __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, (uint32_t)k), KB, 0u, false), false);
+        }
+        uint4 st;                                               // each sum <= 257*255 = 65535
+        st.x = o[0][0] | (o[1][0] << 16); st.y = o[0][1] | (o[1][1] << 16);
+        st.z = o[0][2] | (o[1][2] << 16); st.w = o[0][3] | (o[1][3] << 16);
+        *reinterpret_cast<uint4*>(hT + rp * DH_PITCH + 4 * q) = st;
     }
     __syncthreads();
-    // column pass: a lane owns 2 adjacent columns and slides down 13 output rows
+    // column pass: a lane owns 2 adjacent columns and one of three row segments that start on an
+    // even row (0..13, 14..25, 26..36); per pair of output rows it slides one packed row pair in.
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const us2 K01 = __builtin_bit_cast(us2, (uint32_t)G.k0 | ((uint32_t)G.k1 << 16));
+    const us2 K23 = __builtin_bit_cast(us2, (uint32_t)G.k2 | ((uint32_t)G.k3 << 16));
+    const us2 K45 = __builtin_bit_cast(us2, (uint32_t)G.k2 | ((uint32_t)G.k1 << 16));
     const int wvec = w & ~3;
     {
         const int cp = lane % 19, sg = lane / 19;                 // 19 column pairs x 3 segments
         if (sg < 3) {
-            const int rbeg = 13 * sg, rend = min(rbeg + 13, DH_N);
-            const uint32_t* s = reinterpret_cast<const uint32_t*>(hbuf + rbeg * DH_PITCH) + cp;
-            uint32_t win[7];
+            const int rbeg = sg == 0 ? 0 : (sg == 1 ? 14 : 26), rend = sg == 0 ? 14 : (sg == 1 ? 26 : DH_N);
+            const uint2* s = reinterpret_cast<const uint2*>(hT + (rbeg >> 1) * DH_PITCH) + cp;     // columns 2cp, 2cp+1
+            uint2 P0 = s[0], P1 = s[DH_PITCH / 2], P2 = s[2 * (DH_PITCH / 2)];
+            const int pmax = 21 - (rbeg >> 1);                     // last existing row pair, relative
 #pragma unroll
-            for (int k = 0; k < 6; k++) win[k + 1] = s[k * (DH_PITCH / 2)];
-            for (int r = rbeg; r < rend; r++) {
+            for (int j = 0; j < 7; j++) {
+                const uint2 P3 = s[min(j + 3, pmax) * (DH_PITCH / 2)];
+                const int ye = rbeg + 2 * j;
+                if (ye < rend) {
+                    uint32_t outE = 0, outO = 0;
 #pragma unroll
-                for (int k = 0; k < 6; k++) win[k] = win[k + 1];
-                win[6] = s[(r - rbeg + 6) * (DH_PITCH / 2)];
-                uint32_t outp = 0;
-#pragma unroll
-                for (int hf = 0; hf < 2; hf++) {
-                    const int sft = 16 * hf;
-                    const int C = G.k0 * (int)(((win[0] >> sft) & 0xFFFF) + ((win[6] >> sft) & 0xFFFF)) +
-                                  G.k1 * (int)(((win[1] >> sft) & 0xFFFF) + ((win[5] >> sft) & 0xFFFF)) +
-                                  G.k2 * (int)(((win[2] >> sft) & 0xFFFF) + ((win[4] >> sft) & 0xFFFF)) +
-                                  G.k3 * (int)((win[3] >> sft) & 0xFFFF);
-                    int v = (C + 32768) >> 16;                   // FixedPtCastEx: half up
-                    if (P.tieMode == 0 && (C & 0xFFFF) == 0x8000 && (x - 18 + 2 * cp + hf) < wvec)
-                        v &= ~1;                                 // SSE2 column pass: tie -> even
-                    outp |= (uint32_t)min(v, 255) << (8 * hf);
+                    for (int hf = 0; hf < 2; hf++) {
+                        const uint32_t p0 = hf ? P0.y : P0.x, p1 = hf ? P1.y : P1.x, p2 = hf ? P2.y : P2.x, p3 = hf ? P3.y : P3.x;
+                        const int xabs = x - 18 + 2 * cp + hf;
+                        // even output row: rows (y, y+1), (y+2, y+3), (y+4, y+5), y+6
+                        uint32_t C = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, p0), K01, (uint32_t)G.k0 * (p3 & 0xFFFFu), false);
+                        C = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, p1), K23, C, false);
+                        C = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, p2), K45, C, false);
+                        int v = (int)((C + 32768u) >> 16);                 // FixedPtCastEx: half up
+                        if (P.tieMode == 0 && (C & 0xFFFFu) == 0x8000u && xabs < wvec) v &= ~1;   // SSE2: tie -> even
+                        outE |= (uint32_t)min(v, 255) << (8 * hf);
+                        // odd output row: rows (y+1, y+2), (y+3, y+4), (y+5, y+6), y+7
+                        const uint32_t a0 = __builtin_amdgcn_alignbit(p1, p0, 16), a1 = __builtin_amdgcn_alignbit(p2, p1, 16),
+                                       a2 = __builtin_amdgcn_alignbit(p3, p2, 16);
+                        uint32_t Co = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a0), K01, (uint32_t)G.k0 * (p3 >> 16), false);
+                        Co = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a1), K23, Co, false);
+                        Co = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a2), K45, Co, false);
+                        int vo = (int)((Co + 32768u) >> 16);
+                        if (P.tieMode == 0 && (Co & 0xFFFFu) == 0x8000u && xabs < wvec) vo &= ~1;
+                        outO |= (uint32_t)min(vo, 255) << (8 * hf);
+                    }
+                    *reinterpret_cast<uint16_t*>(blur + ye * DB_PITCH + 2 * cp) = (uint16_t)outE;
+                    if (ye + 1 < rend) *reinterpret_cast<uint16_t*>(blur + (ye + 1) * DB_PITCH + 2 * cp) = (uint16_t)outO;
                 }
-                *reinterpret_cast<uint16_t*>(blur + r * DB_PITCH + 2 * cp) = (uint16_t)outp;
+                P0 = P1; P1 = P2; P2 = P3;
             }
         }
     }

@@ -21,7 +21,7 @@
 //  (2) each lane tests a QUAD of 4 horizontally adjacent pixels per step from 5 aligned LDS
 //      dwords (centre, left, right, 3 rows up, 3 rows down): a pixel can only be a corner if
 //      both opposite ring pairs (0,8) and (4,12) contain a darker (or a brighter) pixel; the
-//      few percent that pass are compacted into an LDS list with ballot/mbcnt;
+//      few percent that pass are compacted into an LDS list with ONE wave prefix sum per pass;
 //  (3) exact 16-ring scores (min3/max3 sliding arcs) for the compacted list, all lanes busy;
 //  (4) NMS on an LDS score map; survivors go to the cell's own fixed slot range of the
 //      (frame, level) candidate slab plus a per-cell count -- no atomics (a single device-scope
@@ -84,16 +84,20 @@ __device__ __forceinline__ int wave_prefix(unsigned long long m)
 // (window column 3) is at byte 4.
 #define FAST_LIST_CAP 768          // compacted candidates held in LDS (u16 each)
 
-// (2) necessary test + compaction of interior rows [rowBeg, rowEnd).  Returns the new list
-// length, or -1 when the list could overflow (the caller then takes the chunked slow path).
+// (2) necessary test + compaction of interior rows [rowBeg, rowEnd).  Each lane tests one quad
+// per step and keeps the 4 result bits of every step in a 64-bit register; ONE wave prefix sum
+// at the end turns the per-lane popcounts into list offsets (the list order is irrelevant: NMS
+// works on the score map).  Returns the list length, or -1 when the list would overflow (the
+// caller then takes the chunked slow path).
 template <int QW>      // quads per row handled by consecutive lanes: 8 (IW <= 32) or 16 (IW <= 64)
 __device__ __forceinline__ int quick_pass(const uint8_t* tile, int TP, int IW, int rowBeg, int rowEnd,
-                                          int t, uint16_t* list, int nlist, int lane)
+                                          int t, uint16_t* list, int lane)
 {
     const int lq = lane & (QW - 1), lr = lane / QW;
     const int NQ = (IW + 3) >> 2;
-    for (int row0 = rowBeg; row0 < rowEnd; row0 += 64 / QW) {
-        if (nlist > FAST_LIST_CAP - 256) return -1;          // a step adds at most 256 entries
+    unsigned long long bits = 0ull;                     // step s -> bits 4s .. 4s+3
+    int step = 0;
+    for (int row0 = rowBeg; row0 < rowEnd; row0 += 64 / QW, step++) {
         const int iy = row0 + lr;
         unsigned pass = 0;
         if (iy < rowEnd && lq < NQ) {
@@ -114,13 +118,23 @@ __device__ __forceinline__ int quick_pass(const uint8_t* tile, int TP, int IW, i
                 if ((dk < v || br > v) && 4 * lq + i < IW) pass |= 1u << i;
             }
         }
+        bits |= (unsigned long long)pass << (4 * step);
+    }
+    const int cnt = __popcll(bits);
+    int incl = cnt;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const bool p = (pass >> i) & 1;
-            const unsigned long long m = __ballot(p);
-            if (p) list[nlist + wave_prefix(m)] = (uint16_t)((iy << 8) | (4 * lq + i));
-            nlist += __popcll(m);
-        }
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    const int nlist = __shfl(incl, 63);
+    if (nlist > FAST_LIST_CAP) return -1;
+    int off = incl - cnt;
+    while (bits) {
+        const int bpos = __ffsll((long long)bits) - 1;
+        bits &= bits - 1;
+        const int iy = rowBeg + (bpos >> 2) * (64 / QW) + lr;
+        list[off++] = (uint16_t)((iy << 8) | (4 * lq + (bpos & 3)));
     }
     return nlist;
 }
@@ -165,8 +179,8 @@ __device__ __noinline__ int fast_pass_chunked(const uint8_t* tile, int TP, uint8
     __syncthreads();
     const int rowsPer = (IW <= 32) ? 16 : 8;                 // <= 512 candidates per block
     for (int r = 0; r < IH; r += rowsPer) {
-        const int n = (IW <= 32) ? quick_pass<8>(tile, TP, IW, r, min(r + rowsPer, IH), t, list, 0, lane)
-                                 : quick_pass<16>(tile, TP, IW, r, min(r + rowsPer, IH), t, list, 0, lane);
+        const int n = (IW <= 32) ? quick_pass<8>(tile, TP, IW, r, min(r + rowsPer, IH), t, list, lane)
+                                 : quick_pass<16>(tile, TP, IW, r, min(r + rowsPer, IH), t, list, lane);
         __syncthreads();
         score_list(tile, TP, smap, mapPitch, list, n, t, lane);
         __syncthreads();
@@ -266,8 +280,8 @@ __global__ __launch_bounds__(64, 8) void k_fast_cells(const PgPlan P, int TP, in
     for (int pass = 0; pass < 2; pass++) {
         const int t = pass == 0 ? P.iniTh : P.minTh;
         // (2) necessary test + compaction
-        const int nlist = (IW <= 32) ? quick_pass<8>(tile, TP, IW, 0, IH, t, list, 0, lane)
-                                     : quick_pass<16>(tile, TP, IW, 0, IH, t, list, 0, lane);
+        const int nlist = (IW <= 32) ? quick_pass<8>(tile, TP, IW, 0, IH, t, list, lane)
+                                     : quick_pass<16>(tile, TP, IW, 0, IH, t, list, lane);
         if (nlist < 0) {                                   // list would overflow: chunked slow path
             const int total = fast_pass_chunked(tile, TP, smap, mapPitch, mapRows, IW, IH, t, list, out,
                                                 L.cellCap, xoff, yoff, lane);
