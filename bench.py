@@ -118,7 +118,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("PGORB_BENCH_FORCE_DIST"):    # the env switch exercises the N>1 code on one GPU
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
 
@@ -141,7 +141,7 @@ def main():
 
     # the one collective of this path: broadcast the (synthetic) ORB vocabulary root -> peers
     vocab_bytes = 0
-    if world > 1:
+    if dist is not None:
         from pilotguru_amd import dist as pgd
         from pilotguru_amd.vocab import synth_vocabulary_blob
         blob = synth_vocabulary_blob(k=10, L=5, seed=7) if rank == 0 else None
@@ -237,7 +237,7 @@ def main():
             "stage_ms_per_step": stage_ms, "dominant_stage": dom,
             "whole_path_algorithmic_GBps": sum(abytes.values()) * fps / world / 1e9,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:            # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(W, H, NF)
             out["speedup_vs_cpu_all_cores"] = fps / out["cpu_baseline"]["value"]
             out["speedup_vs_cpu_per_core"] = fps / out["cpu_baseline"]["per_core"]

@@ -40,7 +40,7 @@ struct pgorb_ctx {
     int planW = 0, planH = 0, planBatch = 0;
     bool planValid = false;
     // device memory
-    Arena pyr, cand, kpos, sel, nodes, counters, tables, cellCand, cellCount, cellTab;
+    Arena pyr, cand, sel, nodes, counters, tables, cellCand, cellCount, cellTab;
     Arena stageKps, stageDesc, stageN, stageA, stageB, stageOut, vocab;
     int vocabK = 0, vocabL = 0, vocabNodes = 0;
     int lastFrames = 0;
@@ -307,7 +307,7 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
         PG_HIP(c, hipMemcpy(c->cellTab.p, ct.data(), ct.size() * 4, hipMemcpyHostToDevice));
         P.cellTab = (const uint32_t*)c->cellTab.p;
     }
-    P.cand = (uint32_t*)c->cand.p; P.kpos = nullptr; P.sel = (uint32_t*)c->sel.p;
+    P.cand = (uint32_t*)c->cand.p; P.sel = (uint32_t*)c->sel.p;
     P.nodeScratch = (int32_t*)c->nodes.p;
     P.candCount = (int32_t*)c->counters.p;
     P.kpCount = P.candCount + (size_t)B * PG_MAXL;
@@ -443,7 +443,7 @@ void pgorb_destroy(pgorb_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->prm.device);
-    Arena* all[] = {&c->cellTab, &c->cellCand, &c->cellCount, &c->pyr, &c->cand, &c->kpos, &c->sel, &c->nodes, &c->counters, &c->tables,
+    Arena* all[] = {&c->cellTab, &c->cellCand, &c->cellCount, &c->pyr, &c->cand, &c->sel, &c->nodes, &c->counters, &c->tables,
                     &c->stageKps, &c->stageDesc, &c->stageN, &c->stageA, &c->stageB, &c->stageOut, &c->vocab};
     for (Arena* a : all) if (a->p) (void)hipFree(a->p);
     for (hipEvent_t e : c->evExtract) (void)hipEventDestroy(e);

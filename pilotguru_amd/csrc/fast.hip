@@ -359,7 +359,8 @@ void pg_launch_fast(const PgPlan& P, int nframes, hipStream_t s)
     const int mapPitch = ((maxW - 6 + 2) + 3) & ~3;
     const int mapRows = maxH - 6 + 2;
     size_t smem = (size_t)tileRows * TP + (size_t)mapRows * mapPitch + FAST_LIST_CAP * 2 + 16;
-    if (const char* e = getenv("PGORB_FAST_EXTRA_LDS")) smem += (size_t)atoi(e);   // occupancy experiments
+    // profiling knob: extra LDS per wave lowers occupancy (occupancy sweep)
+    if (const char* e = getenv("PGORB_FAST_EXTRA_LDS")) smem += (size_t)atoi(e);
     const int cellsPerXcd = (P.totalCells + 7) / 8;
     dim3 grid(cellsPerXcd * 8, nframes), block(64);
     hipLaunchKernelGGL(k_fast_cells, grid, block, smem, s, P, TP, tileRows, mapPitch, mapRows, cellsPerXcd);

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(64) void k_search_for_initialization(
 {
     const int lane = threadIdx.x, p = blockIdx.x;
     const int f1 = pairF1[p], f2 = pairF2[p];
-    const int n1 = min(nper[f1], cap), n2 = min(nper[f2], cap);
+    const int n1 = min(nper[f1], cap);
     const pgorb_keypoint* K1 = kps + (int64_t)f1 * cap;
     const pgorb_keypoint* K2 = kps + (int64_t)f2 * cap;
     const uint8_t* D1 = desc + (int64_t)f1 * cap * 32;

@@ -66,7 +66,7 @@ struct PgPlan {
     PgLevel  lvl[PG_MAXL];
     int32_t  nlevels, totalCells, iniTh, minTh, tieMode;
     int32_t  selTotal;        // sum of selCap over levels (= per-frame keypoint bound)
-    int64_t  candFrame;       // u32 per frame in cand / kpos arenas
+    int64_t  candFrame;       // key records per frame in the cand arena
     int64_t  selFrame;        // u32 per frame in sel arena
     int64_t  nodeFrame;       // int per frame in node scratch
     int64_t  cellCandFrame;   // u32 per frame in the per-cell slot slab
@@ -74,7 +74,6 @@ struct PgPlan {
     int32_t*  cellCount;      // K2 output: [frame][totalCells]
     const uint32_t* cellTab;  // [totalCells] level | cell row << 4 | cell col << 16
     uint32_t* cand;           // K3: dense uint2 key records (2 u32 per key)
-    uint32_t* kpos;           // (unused)
     uint32_t* sel;
     int32_t*  nodeScratch;
     int32_t*  candCount;      // [frame][PG_MAXL]
