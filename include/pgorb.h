@@ -185,6 +185,41 @@ int  pgorb_search_for_initialization_batch_device(pgorb_ctx* ctx, const pgorb_ke
                                      int window_size, float nnratio, int check_orientation,
                                      void* hip_stream);
 
+/* ---- Guided matchers of the tracking thread (next tier of SURVEY.md 8a row a11) -------------
+ *   pgorb_search_by_projection_points   ORBmatcher::SearchByProjection(Frame &F, const
+ *       vector<MapPoint*> &vpMapPoints, float th)  src/ORBmatcher.cc:46-131 incl.
+ *       RadiusByViewingCos :133-139 -- the local-map matcher of Tracking::SearchLocalPoints
+ *       (src/Tracking.cc:1134-1184).  Per map point the caller passes what MapPoint carries after
+ *       Frame::isInFrustum: mbTrackInView && !isBad() (valid), mTrackProjX/Y, mnTrackScaleLevel,
+ *       mTrackViewCos, GetDescriptor(), Observations() > 0.
+ *   pgorb_search_by_projection_frame    the matching loop of ORBmatcher::SearchByProjection(Frame
+ *       &CurrentFrame, const Frame &LastFrame, float th, bool bMono)  src/ORBmatcher.cc:1355-1474
+ *       for bMono = true, given the projections (u, v) of the last frame's map points into the
+ *       current frame (the cv::Mat pose arithmetic of :1343-1377 stays with the caller, who owns
+ *       the poses): valid = has a map point && !outlier && invzc >= 0 && inside the image
+ *       bounds; octave/angle of the last frame's keypoint; best match only, TH_HIGH, rotation
+ *       histogram + ComputeThreeMaxima.
+ * Common state: kp_has_point[i] != 0 when the frame's keypoint i already holds a map point with
+ * Observations() > 0 before the call (:79-81 / :1397-1399); assigned[i] receives the index of the
+ * query (map point) written to F.mvpMapPoints[i] by this call, or -1.  Queries are processed in
+ * order (each assignment changes what later queries may take), one 64-lane wave per frame. */
+int  pgorb_search_by_projection_points(pgorb_ctx* ctx,
+        const pgorb_keypoint* kps, const uint8_t* desc, int n,            /* the frame F             */
+        float min_x, float max_x, float min_y, float max_y,
+        const uint8_t* kp_has_point,                                      /* [n]                     */
+        int npoints, const uint8_t* valid, const float* proj_x, const float* proj_y,
+        const int32_t* level, const float* view_cos, const uint8_t* point_desc,
+        const uint8_t* point_has_obs, float th, float nnratio,
+        int32_t* assigned /*[n]*/);                                       /* returns nmatches        */
+int  pgorb_search_by_projection_frame(pgorb_ctx* ctx,
+        const pgorb_keypoint* kps, const uint8_t* desc, int n,            /* CurrentFrame            */
+        float min_x, float max_x, float min_y, float max_y,
+        const uint8_t* kp_has_point,
+        int nlast, const uint8_t* valid, const float* u, const float* v,
+        const int32_t* last_octave, const float* last_angle, const uint8_t* point_desc,
+        const uint8_t* point_has_obs, float th, int check_orientation,
+        int32_t* assigned /*[n]*/);                                       /* returns nmatches        */
+
 /* ---- ORB vocabulary (DBoW2 TemplatedVocabulary<FORB::TDescriptor, FORB>) -----------------
  *   pgorb_vocab_load_text     ORBVocabulary(text_file) -> TemplatedVocabulary::loadFromTextFile
  *                             thirdparty/orb-slam2/src/ORBVocabulary.cc:7-9,

@@ -159,3 +159,111 @@ int orc_search_for_initialization(const orc_keypoint* kps1, const uint8_t* desc1
     free(rotBin); free(vMatchedDistance); free(vnMatches21); free(vIndices2);
     return nmatches;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, float th)
+ * src/ORBmatcher.cc:46-131, RadiusByViewingCos :133-139.  MapPoint fields as arrays:
+ * valid = mbTrackInView && !isBad(); proj_x/y = mTrackProjX/Y; level = mnTrackScaleLevel;
+ * view_cos = mTrackViewCos; pdesc = GetDescriptor(); pobs = Observations() > 0.
+ * kp_has_point[i]: F.mvpMapPoints[i] holds a point with Observations() > 0 before the call.
+ * assigned[i] = index of the map point written to F.mvpMapPoints[i] by this call, or -1. */
+#define TH_HIGH 100
+int orc_search_by_projection_points(const orc_keypoint* kps, const uint8_t* desc, int n,
+                                    const int32_t* grid_start, const int32_t* grid_idx,
+                                    float minX, float maxX, float minY, float maxY,
+                                    const float* scale_factors, const uint8_t* kp_has_point,
+                                    int npoints, const uint8_t* valid, const float* proj_x, const float* proj_y,
+                                    const int32_t* level, const float* view_cos, const uint8_t* pdesc,
+                                    const uint8_t* pobs, float th, float nnratio, int32_t* assigned)
+{
+    int nmatches = 0;
+    uint8_t* taken = (uint8_t*)malloc(n + 1);
+    for (int i = 0; i < n; i++) { taken[i] = kp_has_point ? (kp_has_point[i] != 0) : 0; assigned[i] = -1; }
+    int32_t* vIndices = (int32_t*)malloc(sizeof(int32_t) * (n + 1));
+    const int bFactor = th != 1.0;
+    for (int iMP = 0; iMP < npoints; iMP++) {
+        if (!valid[iMP]) continue;
+        const int nPredictedLevel = level[iMP];
+        float r = ((double)view_cos[iMP] > 0.998) ? 2.5f : 4.0f;
+        if (bFactor) r *= th;
+        const int nind = orc_features_in_area(kps, grid_start, grid_idx, minX, maxX, minY, maxY, proj_x[iMP], proj_y[iMP],
+                                              r * scale_factors[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel, vIndices);
+        if (nind == 0) continue;
+        const uint8_t* d = pdesc + 32 * (size_t)iMP;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int k = 0; k < nind; k++) {
+            const int idx = vIndices[k];
+            if (taken[idx]) continue;
+            const int dist = orc_descriptor_distance(d, desc + 32 * (size_t)idx);
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = kps[idx].octave; bestIdx = idx; }
+            else if (dist < bestDist2) { bestLevel2 = kps[idx].octave; bestDist2 = dist; }
+        }
+        if (bestDist <= TH_HIGH) {
+            if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+            assigned[bestIdx] = iMP;
+            taken[bestIdx] = pobs[iMP] != 0;
+            nmatches++;
+        }
+    }
+    free(taken); free(vIndices);
+    return nmatches;
+}
+
+/* The matching loop of ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame,
+ * float th, bool bMono = true), src/ORBmatcher.cc:1355-1474, given the projections (u, v) of the
+ * last frame's map points (valid = pMP && !outlier && invzc >= 0 && inside the bounds). */
+int orc_search_by_projection_frame(const orc_keypoint* kps, const uint8_t* desc, int n,
+                                   const int32_t* grid_start, const int32_t* grid_idx,
+                                   float minX, float maxX, float minY, float maxY,
+                                   const float* scale_factors, const uint8_t* kp_has_point,
+                                   int nlast, const uint8_t* valid, const float* u, const float* v,
+                                   const int32_t* last_octave, const float* last_angle, const uint8_t* pdesc,
+                                   const uint8_t* pobs, float th, int checkOrientation, int32_t* assigned)
+{
+    int nmatches = 0;
+    uint8_t* taken = (uint8_t*)malloc(n + 1);
+    for (int i = 0; i < n; i++) { taken[i] = kp_has_point ? (kp_has_point[i] != 0) : 0; assigned[i] = -1; }
+    int32_t* vIndices2 = (int32_t*)malloc(sizeof(int32_t) * (n + 1));
+    int* histBin = (int*)malloc(sizeof(int) * (nlast + 1));       /* rotHist as (bin, bestIdx2) per push */
+    int* histIdx = (int*)malloc(sizeof(int) * (nlast + 1));
+    int npush = 0;
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int i = 0; i < nlast; i++) {
+        if (!valid[i]) continue;
+        const int nLastOctave = last_octave[i];
+        const float radius = th * scale_factors[nLastOctave];
+        const int nind = orc_features_in_area(kps, grid_start, grid_idx, minX, maxX, minY, maxY, u[i], v[i], radius,
+                                              nLastOctave - 1, nLastOctave + 1, vIndices2);
+        if (nind == 0) continue;
+        const uint8_t* dMP = pdesc + 32 * (size_t)i;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int k = 0; k < nind; k++) {
+            const int i2 = vIndices2[k];
+            if (taken[i2]) continue;
+            const int dist = orc_descriptor_distance(dMP, desc + 32 * (size_t)i2);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= TH_HIGH) {
+            assigned[bestIdx2] = i;
+            taken[bestIdx2] = pobs[i] != 0;
+            nmatches++;
+            if (checkOrientation) {
+                float rot = last_angle[i] - kps[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                histBin[npush] = bin; histIdx[npush] = bestIdx2; npush++;
+            }
+        }
+    }
+    if (checkOrientation) {
+        int histo[HISTO_LENGTH] = {0};
+        for (int k = 0; k < npush; k++) histo[histBin[k]]++;
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(histo, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int k = 0; k < npush; k++)
+            if (histBin[k] != ind1 && histBin[k] != ind2 && histBin[k] != ind3) { assigned[histIdx[k]] = -1; nmatches--; }
+    }
+    free(taken); free(vIndices2); free(histBin); free(histIdx);
+    return nmatches;
+}

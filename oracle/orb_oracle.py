@@ -87,6 +87,12 @@ def lib():
         L.orc_search_for_initialization.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                                     C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
                                                     C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int]
+        L.orc_search_by_projection_points.restype = C.c_int
+        L.orc_search_by_projection_points.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p] + [C.c_float] * 4 + \
+            [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_float, C.c_float, C.c_void_p]
+        L.orc_search_by_projection_frame.restype = C.c_int
+        L.orc_search_by_projection_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p] + [C.c_float] * 4 + \
+            [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_float, C.c_int, C.c_void_p]
         L.orc_vocab_load_text.restype = C.c_void_p
         L.orc_vocab_load_text.argtypes = [C.c_char_p]
         L.orc_vocab_free.argtypes = [C.c_void_p]
@@ -386,3 +392,38 @@ def search_for_initialization(kps1, desc1, kps2, desc2, bounds, prev_matched, wi
                                              _p(g2[0]), _p(idx), bounds[0], bounds[1], bounds[2], bounds[3],
                                              _p(prev), _p(m12), window_size, nnratio, int(check_orientation))
     return nm, m12[:len(kps1)].copy(), prev
+
+
+def _prep(kps, desc, bounds, kp_has_point):
+    kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    g = frame_grid(kps, bounds)
+    idx = np.ascontiguousarray(np.concatenate([g[1], np.zeros(1, np.int32)]))
+    has = np.ascontiguousarray(kp_has_point if kp_has_point is not None else np.zeros(len(kps), np.uint8), np.uint8)
+    return kps, desc, g[0], idx, has
+
+
+def search_by_projection_points(kps, desc, bounds, scale_factors, kp_has_point, valid, proj_x, proj_y, level, view_cos,
+                                pdesc, pobs, th, nnratio):
+    kps, desc, gs, gi, has = _prep(kps, desc, bounds, kp_has_point)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    a = [np.ascontiguousarray(valid, np.uint8), np.ascontiguousarray(proj_x, np.float32), np.ascontiguousarray(proj_y, np.float32),
+         np.ascontiguousarray(level, np.int32), np.ascontiguousarray(view_cos, np.float32), np.ascontiguousarray(pdesc, np.uint8),
+         np.ascontiguousarray(pobs, np.uint8)]
+    out = np.full(max(len(kps), 1), -1, np.int32)
+    nm = lib().orc_search_by_projection_points(_p(kps), _p(desc), len(kps), _p(gs), _p(gi), *bounds, _p(sf), _p(has), len(a[0]),
+                                               *[_p(x) for x in a], th, nnratio, _p(out))
+    return nm, out[:len(kps)].copy()
+
+
+def search_by_projection_frame(kps, desc, bounds, scale_factors, kp_has_point, valid, u, v, last_octave, last_angle, pdesc,
+                               pobs, th, check_orientation=True):
+    kps, desc, gs, gi, has = _prep(kps, desc, bounds, kp_has_point)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    a = [np.ascontiguousarray(valid, np.uint8), np.ascontiguousarray(u, np.float32), np.ascontiguousarray(v, np.float32),
+         np.ascontiguousarray(last_octave, np.int32), np.ascontiguousarray(last_angle, np.float32),
+         np.ascontiguousarray(pdesc, np.uint8), np.ascontiguousarray(pobs, np.uint8)]
+    out = np.full(max(len(kps), 1), -1, np.int32)
+    nm = lib().orc_search_by_projection_frame(_p(kps), _p(desc), len(kps), _p(gs), _p(gi), *bounds, _p(sf), _p(has), len(a[0]),
+                                              *[_p(x) for x in a], th, int(check_orientation), _p(out))
+    return nm, out[:len(kps)].copy()

@@ -16,6 +16,8 @@
 // All per-pair state (vMatchedDistance, vnMatches21, vnMatches12, histogram bins) lives in LDS.
 // Throughput comes from pairs in parallel; the path is used a few times per ride.
 #include "pgorb_internal.h"
+#include <algorithm>
+#include <vector>
 
 #define GRID_COLS PGORB_GRID_COLS
 #define GRID_ROWS PGORB_GRID_ROWS
@@ -250,6 +252,150 @@ __global__ __launch_bounds__(64) void k_search_for_initialization(
     if (lane == 0) nmatchesOut[p] = nmatches;
 }
 
+// ---- SearchByProjection (local map points / last frame), src/ORBmatcher.cc:46-131, 1355-1474 ----
+// One wave per frame; queries in order.  mode 0: best + second with the same-level ratio test
+// (:83-125); mode 1: best only + rotation histogram (:1390-1469).
+struct PgProjQuery {
+    const uint8_t* valid; const float* x; const float* y; const float* radius;
+    const int32_t* minLevel; const int32_t* maxLevel; const float* angle;
+    const uint8_t* desc; const uint8_t* hasObs;
+};
+
+#define TH_HIGH 100
+
+__global__ __launch_bounds__(64) void k_search_by_projection(
+    const pgorb_keypoint* __restrict__ K, const uint8_t* __restrict__ D, int n,
+    const int32_t* __restrict__ gstart, const int32_t* __restrict__ gidx,
+    float minX, float minY, float invW, float invH, const uint8_t* __restrict__ kpHasPoint,
+    PgProjQuery Q, int nq, int mode, float nnratio, int checkOrientation,
+    int32_t* __restrict__ assignedOut, int32_t* __restrict__ nmatchesOut)
+{
+    const int lane = threadIdx.x;
+    // state in LDS: taken[i] = keypoint i holds a point with observations (before or by this
+    // call); asg[i] = query assigned to keypoint i by this call; candList = vIndices;
+    // rotBin[q] / qBest[q] = histogram bin and keypoint of accepted query q (mode 1)
+    uint8_t* taken = pg_sfi_smem;                                         // [n]
+    int32_t* asg = reinterpret_cast<int32_t*>(pg_sfi_smem + ((n + 15) & ~15));      // [n]
+    uint16_t* candList = reinterpret_cast<uint16_t*>(asg + n);            // [n]
+    uint16_t* qBest = candList + n;                                       // [nq]
+    int8_t* rotBin = reinterpret_cast<int8_t*>(qBest + nq);               // [nq]
+    for (int i = lane; i < n; i += 64) { taken[i] = kpHasPoint ? (kpHasPoint[i] != 0) : 0; asg[i] = -1; }
+    if (mode == 1) for (int i = lane; i < nq; i += 64) rotBin[i] = -1;
+    __syncthreads();
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nmatches = 0;
+    for (int q = 0; q < nq; q++) {
+        if (!Q.valid[q]) continue;
+        const float x = Q.x[q], y = Q.y[q], r = Q.radius[q];
+        const int minLevel = Q.minLevel[q], maxLevel = Q.maxLevel[q];
+        // GetFeaturesInArea(x, y, r, minLevel, maxLevel)  (Frame.cc:336-350)
+        const int nMinCellX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, minX), r), invW)));
+        if (nMinCellX >= GRID_COLS) continue;
+        const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, minX), r), invW)));
+        if (nMaxCellX < 0) continue;
+        const int nMinCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, minY), r), invH)));
+        if (nMinCellY >= GRID_ROWS) continue;
+        const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, minY), r), invH)));
+        if (nMaxCellY < 0) continue;
+        const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+        const int ncy = nMaxCellY - nMinCellY + 1;
+        const int T = max(0, (nMaxCellX - nMinCellX + 1)) * max(0, ncy);
+        int M = 0;
+        for (int base = 0; base < T; base += 64) {
+            const int t = base + lane;
+            int s = 0, cnt = 0;
+            if (t < T) {
+                const int c = (nMinCellX + t / ncy) * GRID_ROWS + nMinCellY + t % ncy;
+                s = gstart[c]; cnt = gstart[c + 1] - s;
+            }
+            const int incl = wave_incl_scan(cnt, lane);
+            const int off = M + incl - cnt;
+            for (int j = 0; j < cnt; j++) candList[off + j] = (uint16_t)gidx[s + j];
+            M += __shfl(incl, 63);
+        }
+        __syncthreads();
+        if (M == 0) continue;
+        const uint4 q0 = reinterpret_cast<const uint4*>(Q.desc + (int64_t)q * 32)[0];
+        const uint4 q1 = reinterpret_cast<const uint4*>(Q.desc + (int64_t)q * 32)[1];
+        unsigned b1key = 0xFFFFFFFFu, b2key = 0xFFFFFFFFu;     // (dist << 16 | list position): two smallest of this lane
+        for (int k = lane; k < M; k += 64) {
+            const int i2 = candList[k];
+            const pgorb_keypoint kp2 = K[i2];
+            if (bCheckLevels) {
+                if (kp2.octave < minLevel) continue;
+                if (maxLevel >= 0 && kp2.octave > maxLevel) continue;
+            }
+            if (!(fabsf(__fsub_rn(kp2.x, x)) < r && fabsf(__fsub_rn(kp2.y, y)) < r)) continue;
+            if (taken[i2]) continue;                           // mvpMapPoints[idx] with Observations() > 0
+            const uint4 d0 = reinterpret_cast<const uint4*>(D + (int64_t)i2 * 32)[0];
+            const uint4 d1 = reinterpret_cast<const uint4*>(D + (int64_t)i2 * 32)[1];
+            const int dist = __popc(q0.x ^ d0.x) + __popc(q0.y ^ d0.y) + __popc(q0.z ^ d0.z) + __popc(q0.w ^ d0.w) +
+                             __popc(q1.x ^ d1.x) + __popc(q1.y ^ d1.y) + __popc(q1.z ^ d1.z) + __popc(q1.w ^ d1.w);
+            const unsigned key = ((unsigned)dist << 16) | (unsigned)k;
+            if (key < b1key) { b2key = b1key; b1key = key; } else if (key < b2key) b2key = key;
+        }
+        // the two smallest keys of the wave = best and second in (distance, scan order)
+        const unsigned w1 = wave_min_u32(b1key);
+        if (w1 != 0xFFFFFFFFu && (int)(w1 >> 16) < 256) {      // bestDist starts at 256 (:74 / :1390)
+            const unsigned w2 = wave_min_u32(b1key == w1 ? b2key : b1key);
+            const int bestDist = (int)(w1 >> 16), bestIdx = candList[w1 & 0xFFFF];
+            bool accept = false;
+            int bin = -1;
+            if (mode == 0) {
+                const bool has2 = (w2 != 0xFFFFFFFFu) && (int)(w2 >> 16) < 256;
+                const int bestDist2 = has2 ? (int)(w2 >> 16) : 256;
+                const int bestLevel = K[bestIdx].octave;
+                const int bestLevel2 = has2 ? K[candList[w2 & 0xFFFF]].octave : -1;
+                if (bestDist <= TH_HIGH)                       // :113-123
+                    accept = !(bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(nnratio, (float)bestDist2));
+            } else {
+                accept = bestDist <= TH_HIGH;                  // :1421
+                if (accept && checkOrientation) {              // :1426-1436
+                    float rot = __fsub_rn(Q.angle[q], K[bestIdx].angle);
+                    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                    bin = (int)roundf(__fmul_rn(rot, factor));
+                    if (bin == HISTO_LENGTH) bin = 0;
+                }
+            }
+            if (accept) {
+                nmatches++;
+                if (lane == 0) {
+                    asg[bestIdx] = q;                          // F.mvpMapPoints[bestIdx] = pMP
+                    taken[bestIdx] = Q.hasObs[q] != 0;
+                    if (mode == 1) { rotBin[q] = (int8_t)bin; qBest[q] = (uint16_t)bestIdx; }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (mode == 1 && checkOrientation) {                       // :1443-1469
+        int h = 0;
+        for (int i = 0; i < nq; i++) h += (rotBin[i] == lane);
+        int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            const int s = __shfl(h, i);
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        // rotHist[bin] holds bestIdx2 of every accepted query; every entry of a rejected bin resets
+        // its keypoint to NULL and is counted out once (:1458-1465)
+        int removed = 0;
+        for (int i = lane; i < nq; i += 64) {
+            const int b = rotBin[i];
+            if (b >= 0 && b != ind1 && b != ind2 && b != ind3) { asg[qBest[i]] = -1; removed++; }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) removed += __shfl_xor(removed, d);
+        nmatches -= removed;
+        __syncthreads();
+    }
+    for (int i = lane; i < n; i += 64) assignedOut[i] = asg[i];
+    if (lane == 0) *nmatchesOut = nmatches;
+}
+
 extern "C" {
 
 int pgorb_frame_grid_batch_device(pgorb_ctx* c, const pgorb_keypoint* d_kps, const int32_t* d_n, int nframes,
@@ -295,6 +441,116 @@ int pgorb_search_for_initialization_batch_device(pgorb_ctx* c, const pgorb_keypo
                        d_prev_matched, d_matches12, d_nmatches, window_size, nnratio, check_orientation);
     if (hipGetLastError() != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "k_search_for_initialization launch failed");
     return 0;
+}
+
+static int pg_search_by_projection_host(pgorb_ctx* c, int mode, const pgorb_keypoint* kps, const uint8_t* desc, int n,
+                                        float min_x, float max_x, float min_y, float max_y, const uint8_t* kp_has_point,
+                                        int nq, const uint8_t* valid, const float* qx, const float* qy,
+                                        const float* radius, const int32_t* minLevel, const int32_t* maxLevel,
+                                        const float* angle, const uint8_t* qdesc, const uint8_t* qobs, float nnratio,
+                                        int check_orientation, int32_t* assigned)
+{
+    if (n < 0 || nq < 0 || (n && (!kps || !desc || !assigned)) || (nq && (!valid || !qx || !qy || !qdesc || !qobs)) ||
+        !(max_x > min_x) || !(max_y > min_y))
+        return pg_ctx_fail(c, PGORB_E_ARG, "bad argument to pgorb_search_by_projection_*");
+    for (int i = 0; i < n; i++) assigned[i] = -1;
+    if (!n || !nq) return 0;
+    if (n > 16000 || nq > 16000) return pg_ctx_fail(c, PGORB_E_LIMIT, "more than 16000 keypoints / queries");
+    auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
+    const size_t oK = 0, oD = oK + al((size_t)n * sizeof(pgorb_keypoint)), oGS = oD + al((size_t)n * 32),
+                 oGI = oGS + al((size_t)(GRID_CELLS + 1) * 4), oH = oGI + al((size_t)n * 4), oV = oH + al(n),
+                 oX = oV + al(nq), oY = oX + al((size_t)nq * 4), oR = oY + al((size_t)nq * 4), oMin = oR + al((size_t)nq * 4),
+                 oMax = oMin + al((size_t)nq * 4), oA = oMax + al((size_t)nq * 4), oQD = oA + al((size_t)nq * 4),
+                 oO = oQD + al((size_t)nq * 32), oAs = oO + al(nq), oN = oAs + al((size_t)n * 4), total = oN + 64;
+    void* dv;
+    int rc = pg_ctx_stage(c, 0, total, &dv);
+    if (rc) return rc;
+    uint8_t* d = (uint8_t*)dv;
+    std::vector<uint8_t> zeros((size_t)std::max(n, nq) * 4, 0);
+    bool ok = hipMemcpy(d + oK, kps, (size_t)n * sizeof(pgorb_keypoint), hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(d + oD, desc, (size_t)n * 32, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(d + oH, kp_has_point ? kp_has_point : zeros.data(), n, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(d + oV, valid, nq, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(d + oX, qx, (size_t)nq * 4, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(d + oY, qy, (size_t)nq * 4, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(d + oR, radius, (size_t)nq * 4, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(d + oMin, minLevel, (size_t)nq * 4, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(d + oMax, maxLevel, (size_t)nq * 4, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(d + oA, angle ? (const void*)angle : (const void*)zeros.data(), (size_t)nq * 4, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(d + oQD, qdesc, (size_t)nq * 32, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(d + oO, qobs, nq, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(d + oN, &n, 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) return pg_ctx_fail(c, PGORB_E_HIP, "hipMemcpy H2D failed");
+    if ((rc = pgorb_frame_grid_batch_device(c, (pgorb_keypoint*)(d + oK), (int32_t*)(d + oN), 1, n, min_x, max_x, min_y,
+                                            max_y, (int32_t*)(d + oGS), (int32_t*)(d + oGI), 0))) return rc;
+    const float invW = (float)GRID_COLS / (max_x - min_x), invH = (float)GRID_ROWS / (max_y - min_y);
+    PgProjQuery Q = {d + oV, (float*)(d + oX), (float*)(d + oY), (float*)(d + oR), (int32_t*)(d + oMin), (int32_t*)(d + oMax),
+                     (float*)(d + oA), d + oQD, d + oO};
+    const size_t lds = (size_t)((n + 15) & ~15) + (size_t)n * 6 + (size_t)nq * 3 + 64;
+    static size_t configured = 0;
+    if (lds > configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_by_projection),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        configured = lds;
+    }
+    hipLaunchKernelGGL(k_search_by_projection, dim3(1), dim3(64), lds, 0, (pgorb_keypoint*)(d + oK), d + oD, n,
+                       (int32_t*)(d + oGS), (int32_t*)(d + oGI), min_x, min_y, invW, invH, d + oH, Q, nq, mode, nnratio,
+                       check_orientation, (int32_t*)(d + oAs), (int32_t*)(d + oN));
+    if (hipGetLastError() != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "k_search_by_projection launch failed");
+    int32_t nm = 0;
+    ok = hipMemcpy(assigned, d + oAs, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+         hipMemcpy(&nm, d + oN, 4, hipMemcpyDeviceToHost) == hipSuccess;
+    if (!ok) return pg_ctx_fail(c, PGORB_E_HIP, "hipMemcpy D2H failed");
+    return nm;
+}
+
+int pgorb_search_by_projection_points(pgorb_ctx* c, const pgorb_keypoint* kps, const uint8_t* desc, int n, float min_x,
+                                      float max_x, float min_y, float max_y, const uint8_t* kp_has_point, int npoints,
+                                      const uint8_t* valid, const float* proj_x, const float* proj_y, const int32_t* level,
+                                      const float* view_cos, const uint8_t* point_desc, const uint8_t* point_has_obs,
+                                      float th, float nnratio, int32_t* assigned)
+{
+    if (!c) return PGORB_E_ARG;
+    if (npoints < 0 || (npoints && (!level || !view_cos))) return pg_ctx_fail(c, PGORB_E_ARG, "bad argument");
+    const int L = pgorb_levels(c);
+    std::vector<float> sf(L + 1), radius(npoints > 0 ? npoints : 1);
+    std::vector<int32_t> lo(npoints > 0 ? npoints : 1), hi(npoints > 0 ? npoints : 1);
+    std::vector<uint8_t> ok(npoints > 0 ? npoints : 1);
+    pgorb_scale_tables(c, sf.data(), nullptr, nullptr, nullptr);
+    const bool bFactor = th != 1.0;                                      // :50
+    for (int i = 0; i < npoints; i++) {
+        ok[i] = valid[i] && level[i] >= 0 && level[i] < L;
+        float r = ((double)view_cos[i] > 0.998) ? 2.5f : 4.0f;           // RadiusByViewingCos (:133-139)
+        if (bFactor) r *= th;                                            // :65-66
+        radius[i] = r * sf[ok[i] ? level[i] : 0];                        // r*F.mvScaleFactors[nPredictedLevel] (:69)
+        lo[i] = level[i] - 1; hi[i] = level[i];
+    }
+    return pg_search_by_projection_host(c, 0, kps, desc, n, min_x, max_x, min_y, max_y, kp_has_point, npoints, ok.data(),
+                                        proj_x, proj_y, radius.data(), lo.data(), hi.data(), nullptr, point_desc,
+                                        point_has_obs, nnratio, 0, assigned);
+}
+
+int pgorb_search_by_projection_frame(pgorb_ctx* c, const pgorb_keypoint* kps, const uint8_t* desc, int n, float min_x,
+                                     float max_x, float min_y, float max_y, const uint8_t* kp_has_point, int nlast,
+                                     const uint8_t* valid, const float* u, const float* v, const int32_t* last_octave,
+                                     const float* last_angle, const uint8_t* point_desc, const uint8_t* point_has_obs,
+                                     float th, int check_orientation, int32_t* assigned)
+{
+    if (!c) return PGORB_E_ARG;
+    if (nlast < 0 || (nlast && (!last_octave || !last_angle))) return pg_ctx_fail(c, PGORB_E_ARG, "bad argument");
+    const int L = pgorb_levels(c);
+    std::vector<float> sf(L + 1), radius(nlast > 0 ? nlast : 1);
+    std::vector<int32_t> lo(nlast > 0 ? nlast : 1), hi(nlast > 0 ? nlast : 1);
+    std::vector<uint8_t> ok(nlast > 0 ? nlast : 1);
+    pgorb_scale_tables(c, sf.data(), nullptr, nullptr, nullptr);
+    for (int i = 0; i < nlast; i++) {
+        ok[i] = valid[i] && last_octave[i] >= 0 && last_octave[i] < L;
+        radius[i] = th * sf[ok[i] ? last_octave[i] : 0];                 // :1383
+        lo[i] = last_octave[i] - 1; hi[i] = last_octave[i] + 1;          // :1392 (neither forward nor backward: mono)
+    }
+    return pg_search_by_projection_host(c, 1, kps, desc, n, min_x, max_x, min_y, max_y, kp_has_point, nlast, ok.data(), u, v,
+                                        radius.data(), lo.data(), hi.data(), last_angle, point_desc, point_has_obs, 0.f,
+                                        check_orientation, assigned);
 }
 
 int pgorb_frame_grid(pgorb_ctx* c, const pgorb_keypoint* kps, int n, float min_x, float max_x, float min_y,

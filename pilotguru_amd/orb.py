@@ -250,6 +250,21 @@ class Frame:
         return self.grid_idx[self.grid_start[c]:self.grid_start[c + 1]]
 
 
+class MapPoints:
+    """What the matchers read from a set of ORB_SLAM2::MapPoint (thirdparty/orb-slam2/include/
+    MapPoint.h) as arrays: valid (mbTrackInView && !isBad()), projection, predicted level, viewing
+    cosine, representative descriptor, Observations() > 0."""
+
+    def __init__(self, valid, proj_x, proj_y, level, view_cos, descriptors, has_obs):
+        self.valid = np.ascontiguousarray(valid, np.uint8)
+        self.proj_x = np.ascontiguousarray(proj_x, np.float32)
+        self.proj_y = np.ascontiguousarray(proj_y, np.float32)
+        self.level = np.ascontiguousarray(level, np.int32)
+        self.view_cos = np.ascontiguousarray(view_cos, np.float32)
+        self.descriptors = np.ascontiguousarray(descriptors, np.uint8).reshape(-1, 32)
+        self.has_obs = np.ascontiguousarray(has_obs, np.uint8)
+
+
 class ORBmatcher:
     """ORBmatcher(nnratio, checkOri) (thirdparty/orb-slam2/include/ORBmatcher.h:40-44)."""
 
@@ -257,6 +272,35 @@ class ORBmatcher:
 
     def __init__(self, nnratio=0.6, checkOri=True):
         self.mfNNratio, self.mbCheckOrientation = float(nnratio), bool(checkOri)
+
+    def SearchByProjection(self, F, points, th, kp_has_point=None):
+        """SearchByProjection(Frame &F, const vector<MapPoint*>&, th) (src/ORBmatcher.cc:46-131).
+        Returns (nmatches, assigned) with assigned[i] = index into `points` written to
+        F.mvpMapPoints[i], or -1."""
+        ext = F.ext
+        has = np.ascontiguousarray(kp_has_point if kp_has_point is not None else np.zeros(max(F.N, 1), np.uint8), np.uint8)
+        out = np.full(max(F.N, 1), -1, np.int32)
+        nm = ext._check(ext._L.pgorb_search_by_projection_points(
+            ext._h, _p(F.mvKeysUndistorted), _p(F.mDescriptors), F.N, *F.bounds, _p(has), len(points.valid),
+            _p(points.valid), _p(points.proj_x), _p(points.proj_y), _p(points.level), _p(points.view_cos),
+            _p(points.descriptors), _p(points.has_obs), float(th), self.mfNNratio, _p(out)))
+        return nm, out[:F.N].copy()
+
+    def SearchByProjectionLastFrame(self, CurrentFrame, valid, u, v, last_octave, last_angle, point_desc, point_has_obs,
+                                    th, kp_has_point=None):
+        """The matching loop of SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th,
+        bMono=true) (src/ORBmatcher.cc:1355-1474) for given projections (u, v)."""
+        ext = CurrentFrame.ext
+        F = CurrentFrame
+        has = np.ascontiguousarray(kp_has_point if kp_has_point is not None else np.zeros(max(F.N, 1), np.uint8), np.uint8)
+        a = [np.ascontiguousarray(valid, np.uint8), np.ascontiguousarray(u, np.float32), np.ascontiguousarray(v, np.float32),
+             np.ascontiguousarray(last_octave, np.int32), np.ascontiguousarray(last_angle, np.float32),
+             np.ascontiguousarray(point_desc, np.uint8), np.ascontiguousarray(point_has_obs, np.uint8)]
+        out = np.full(max(F.N, 1), -1, np.int32)
+        nm = ext._check(ext._L.pgorb_search_by_projection_frame(
+            ext._h, _p(F.mvKeysUndistorted), _p(F.mDescriptors), F.N, *F.bounds, _p(has), len(a[0]),
+            *[_p(x) for x in a], float(th), int(self.mbCheckOrientation), _p(out)))
+        return nm, out[:F.N].copy()
 
     def SearchForInitialization(self, F1, F2, vbPrevMatched, windowSize=10):
         """(nmatches, vnMatches12); vbPrevMatched ([N1,2] float32) is updated in place, as in

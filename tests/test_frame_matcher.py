@@ -108,3 +108,71 @@ def test_gpu_search_for_initialization_batch_device(oracle):
         assert int(nm[pi]) == onm
         assert np.array_equal(m12[pi, :nh[a]].cpu().numpy(), om12)
         assert prev[pi, :nh[a]].cpu().numpy().tobytes() == oprev.tobytes()
+
+
+def _synthetic_map_points(F1keys, F1desc, shift, rng, drop=0.2, dup=0.1):
+    """Map points 'seen' in frame 1, projected into frame 2 (= frame 1 shifted by `shift`), with
+    jitter, a few invalid ones, a few without observations and duplicated descriptors (ties)."""
+    n = len(F1keys)
+    sel = rng.permutation(n)[: int(n * (1 - drop))]
+    sel = np.concatenate([sel, sel[: int(n * dup)]])                       # duplicates compete for the same keypoint
+    px = F1keys["x"][sel] - shift[0] + rng.uniform(-1.5, 1.5, len(sel)).astype(np.float32)
+    py = F1keys["y"][sel] - shift[1] + rng.uniform(-1.5, 1.5, len(sel)).astype(np.float32)
+    valid = (rng.uniform(size=len(sel)) > 0.05).astype(np.uint8)
+    view_cos = np.where(rng.uniform(size=len(sel)) > 0.5, 0.9995, 0.9).astype(np.float32)
+    has_obs = (rng.uniform(size=len(sel)) > 0.1).astype(np.uint8)
+    return sel, valid, px.astype(np.float32), py.astype(np.float32), F1keys["octave"][sel].astype(np.int32), view_cos, F1desc[sel], has_obs
+
+
+def test_oracle_search_by_projection_consistency(oracle):
+    ride, fr = _frames(oracle, nf=1200)
+    (k1, d1), (k2, d2) = fr
+    rng = np.random.RandomState(3)
+    sel, valid, px, py, lvl, vc, pd, obs = _synthetic_map_points(k1, d1, (7, 3), rng)
+    sf = oracle.OrbOracle(1200).scale_factors
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    nm, asg = oracle.search_by_projection_points(k2, d2, bounds, sf, None, valid, px, py, lvl, vc, pd, obs, 3.0, 0.8)
+    assert nm > 300 and nm >= int((asg >= 0).sum())              # a point without observations can be overwritten
+    good = asg >= 0
+    assert np.all(valid[asg[good]] == 1)
+    # assigned keypoints lie within the search radius of their point and in the allowed levels
+    r = np.where(vc[asg[good]] > 0.998, 2.5, 4.0) * 3.0 * sf[lvl[asg[good]]]
+    assert np.all(np.abs(k2["x"][good] - px[asg[good]]) < r) and np.all(np.abs(k2["y"][good] - py[asg[good]]) < r)
+    assert np.all((k2["octave"][good] == lvl[asg[good]]) | (k2["octave"][good] == lvl[asg[good]] - 1))
+    nm2, asg2 = oracle.search_by_projection_frame(k2, d2, bounds, sf, None, valid, px, py, lvl, k1["angle"][sel], pd, obs, 15.0)
+    assert nm2 > 300 and nm2 <= int(valid.sum())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("th,ratio", [(3.0, 0.8), (1.0, 0.8), (5.0, 0.6)])
+def test_gpu_search_by_projection_points(oracle, th, ratio):
+    import pilotguru_amd as pg
+    w, h, nf = 640, 480, 1200
+    ride = synth_ride(4, w, h, 2, dx=7, dy=3)
+    ext = pg.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    F1, F2 = pg.Frame(ext, ride[0]), pg.Frame(ext, ride[1])
+    rng = np.random.RandomState(5)
+    sel, valid, px, py, lvl, vc, pd, obs = _synthetic_map_points(F1.mvKeys, F1.mDescriptors, (7, 3), rng)
+    has = (rng.uniform(size=F2.N) > 0.9).astype(np.uint8)         # some keypoints already hold a point
+    onm, oasg = oracle.search_by_projection_points(F2.mvKeys, F2.mDescriptors, F2.bounds, ext.GetScaleFactors(), has,
+                                                   valid, px, py, lvl, vc, pd, obs, th, ratio)
+    nm, asg = pg.ORBmatcher(ratio, True).SearchByProjection(F2, pg.MapPoints(valid, px, py, lvl, vc, pd, obs), th, has)
+    assert nm == onm and np.array_equal(asg, oasg) and nm > 100
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("th,ori", [(15.0, True), (7.0, False), (30.0, True)])
+def test_gpu_search_by_projection_last_frame(oracle, th, ori):
+    import pilotguru_amd as pg
+    w, h, nf = 640, 480, 1200
+    ride = synth_ride(4, w, h, 2, dx=7, dy=3)
+    ext = pg.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    F1, F2 = pg.Frame(ext, ride[0]), pg.Frame(ext, ride[1])
+    rng = np.random.RandomState(6)
+    sel, valid, px, py, lvl, vc, pd, obs = _synthetic_map_points(F1.mvKeys, F1.mDescriptors, (7, 3), rng)
+    ang = F1.mvKeys["angle"][sel].copy()
+    ang[::7] = (ang[::7] + 100.0) % 360.0                          # some rotation-inconsistent matches
+    onm, oasg = oracle.search_by_projection_frame(F2.mvKeys, F2.mDescriptors, F2.bounds, ext.GetScaleFactors(), None,
+                                                  valid, px, py, lvl, ang, pd, obs, th, ori)
+    nm, asg = pg.ORBmatcher(0.9, ori).SearchByProjectionLastFrame(F2, valid, px, py, lvl, ang, pd, obs, th)
+    assert nm == onm and np.array_equal(asg, oasg) and nm > 100
