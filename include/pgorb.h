@@ -220,6 +220,19 @@ int  pgorb_search_by_projection_frame(pgorb_ctx* ctx,
         const uint8_t* point_has_obs, float th, int check_orientation,
         int32_t* assigned /*[n]*/);                                       /* returns nmatches        */
 
+/*   pgorb_search_by_bow   ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame &F, vector<MapPoint*>
+ *       &vpMapPointMatches)  src/ORBmatcher.cc:161-290 (Tracking::TrackReferenceKeyFrame,
+ *       src/Tracking.cc:758; relocalisation :1359).  Both FeatureVectors come as the CSR arrays
+ *       pgorb_bow_vectors produces (ascending node ids).  kf_point_valid[i] = the key frame's
+ *       keypoint i has a map point that is not bad.  matches[j] = key-frame keypoint index whose
+ *       map point was written to vpMapPointMatches[j], or -1.  Returns nmatches. */
+int  pgorb_search_by_bow(pgorb_ctx* ctx,
+        const uint8_t* kf_desc, const float* kf_angle, const uint8_t* kf_point_valid, int nkf,
+        const uint32_t* kf_fv_node, const int32_t* kf_fv_start, const uint32_t* kf_fv_feat, int kf_nfv,
+        const uint8_t* f_desc, const float* f_angle, int nf,
+        const uint32_t* f_fv_node, const int32_t* f_fv_start, const uint32_t* f_fv_feat, int f_nfv,
+        float nnratio, int check_orientation, int32_t* matches /*[nf]*/);
+
 /* ---- ORB vocabulary (DBoW2 TemplatedVocabulary<FORB::TDescriptor, FORB>) -----------------
  *   pgorb_vocab_load_text     ORBVocabulary(text_file) -> TemplatedVocabulary::loadFromTextFile
  *                             thirdparty/orb-slam2/src/ORBVocabulary.cc:7-9,

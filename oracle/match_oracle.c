@@ -267,3 +267,66 @@ int orc_search_by_projection_frame(const orc_keypoint* kps, const uint8_t* desc,
     free(taken); free(vIndices2); free(histBin); free(histIdx);
     return nmatches;
 }
+
+/* ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches),
+ * src/ORBmatcher.cc:161-290.  FeatureVectors as CSR (ascending nodes).  matches[j] = key-frame
+ * keypoint whose map point went to vpMapPointMatches[j], or -1.  Returns nmatches. */
+int orc_search_by_bow(const uint8_t* kf_desc, const float* kf_angle, const uint8_t* kf_point_valid, int nkf,
+                      const uint32_t* aNode, const int32_t* aStart, const uint32_t* aFeat, int nA,
+                      const uint8_t* f_desc, const float* f_angle, int nf,
+                      const uint32_t* bNode, const int32_t* bStart, const uint32_t* bFeat, int nB,
+                      float nnratio, int checkOrientation, int32_t* matches)
+{
+    int nmatches = 0;
+    for (int i = 0; i < nf; i++) matches[i] = -1;
+    int* histBin = (int*)malloc(sizeof(int) * (nf + 1));
+    int* histIdx = (int*)malloc(sizeof(int) * (nf + 1));
+    int npush = 0;
+    const float factor = 1.0f / HISTO_LENGTH;
+    int a = 0, b = 0;
+    while (a < nA && b < nB) {
+        if (aNode[a] == bNode[b]) {
+            for (int ia = aStart[a]; ia < aStart[a + 1]; ia++) {
+                const unsigned realIdxKF = aFeat[ia];
+                if (!kf_point_valid[realIdxKF]) continue;
+                const uint8_t* dKF = kf_desc + 32 * (size_t)realIdxKF;
+                int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+                for (int ib = bStart[b]; ib < bStart[b + 1]; ib++) {
+                    const unsigned realIdxF = bFeat[ib];
+                    if (matches[realIdxF] >= 0) continue;
+                    const int dist = orc_descriptor_distance(dKF, f_desc + 32 * (size_t)realIdxF);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = (int)realIdxF; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 <= TH_LOW) {
+                    if ((float)bestDist1 < nnratio * (float)bestDist2) {
+                        matches[bestIdxF] = (int32_t)realIdxKF;
+                        if (checkOrientation) {
+                            float rot = kf_angle[realIdxKF] - f_angle[bestIdxF];
+                            if (rot < 0.0) rot += 360.0f;
+                            int bin = (int)roundf(rot * factor);
+                            if (bin == HISTO_LENGTH) bin = 0;
+                            histBin[npush] = bin; histIdx[npush] = bestIdxF; npush++;
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            a++; b++;
+        } else if (aNode[a] < bNode[b]) {
+            while (a < nA && aNode[a] < bNode[b]) a++;                   /* lower_bound */
+        } else {
+            while (b < nB && bNode[b] < aNode[a]) b++;
+        }
+    }
+    if (checkOrientation) {
+        int histo[HISTO_LENGTH] = {0};
+        for (int k = 0; k < npush; k++) histo[histBin[k]]++;
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(histo, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int k = 0; k < npush; k++)
+            if (histBin[k] != ind1 && histBin[k] != ind2 && histBin[k] != ind3) { matches[histIdx[k]] = -1; nmatches--; }
+    }
+    free(histBin); free(histIdx);
+    return nmatches;
+}

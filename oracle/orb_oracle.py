@@ -93,6 +93,9 @@ def lib():
         L.orc_search_by_projection_frame.restype = C.c_int
         L.orc_search_by_projection_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p] + [C.c_float] * 4 + \
             [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_float, C.c_int, C.c_void_p]
+        L.orc_search_by_bow.restype = C.c_int
+        L.orc_search_by_bow.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 2 + [C.c_int] + \
+            [C.c_void_p] * 3 + [C.c_int, C.c_float, C.c_int, C.c_void_p]
         L.orc_vocab_load_text.restype = C.c_void_p
         L.orc_vocab_load_text.argtypes = [C.c_char_p]
         L.orc_vocab_free.argtypes = [C.c_void_p]
@@ -427,3 +430,16 @@ def search_by_projection_frame(kps, desc, bounds, scale_factors, kp_has_point, v
     nm = lib().orc_search_by_projection_frame(_p(kps), _p(desc), len(kps), _p(gs), _p(gi), *bounds, _p(sf), _p(has), len(a[0]),
                                               *[_p(x) for x in a], th, int(check_orientation), _p(out))
     return nm, out[:len(kps)].copy()
+
+
+def search_by_bow(kf_desc, kf_angle, kf_valid, kf_fv, f_desc, f_angle, f_fv, nnratio, check_orientation=True):
+    kf_desc = np.ascontiguousarray(kf_desc, np.uint8); f_desc = np.ascontiguousarray(f_desc, np.uint8)
+    kf_angle = np.ascontiguousarray(kf_angle, np.float32); f_angle = np.ascontiguousarray(f_angle, np.float32)
+    kf_valid = np.ascontiguousarray(kf_valid, np.uint8)
+    A = [np.ascontiguousarray(kf_fv[0], np.uint32), np.ascontiguousarray(kf_fv[1], np.int32), np.ascontiguousarray(kf_fv[2], np.uint32)]
+    B = [np.ascontiguousarray(f_fv[0], np.uint32), np.ascontiguousarray(f_fv[1], np.int32), np.ascontiguousarray(f_fv[2], np.uint32)]
+    out = np.full(max(len(f_desc), 1), -1, np.int32)
+    nm = lib().orc_search_by_bow(_p(kf_desc), _p(kf_angle), _p(kf_valid), len(kf_desc), _p(A[0]), _p(A[1]), _p(A[2]), len(A[0]),
+                                 _p(f_desc), _p(f_angle), len(f_desc), _p(B[0]), _p(B[1]), _p(B[2]), len(B[0]),
+                                 nnratio, int(check_orientation), _p(out))
+    return nm, out[:len(f_desc)].copy()

@@ -396,7 +396,144 @@ __global__ __launch_bounds__(64) void k_search_by_projection(
     if (lane == 0) *nmatchesOut = nmatches;
 }
 
+// ---- SearchByBoW(KeyFrame*, Frame&), src/ORBmatcher.cc:161-290 -----------------------------------
+// One wave per (key frame, frame) pair: merge-join of the two node lists; inside a common node the
+// key frame's features are visited in order (each assignment removes a candidate for the later
+// ones, :211-212) and the frame's features of that node are scanned one per lane.
+__global__ __launch_bounds__(64) void k_search_by_bow(
+    const uint8_t* __restrict__ kfDesc, const float* __restrict__ kfAngle, const uint8_t* __restrict__ kfValid,
+    const uint32_t* __restrict__ aNode, const int32_t* __restrict__ aStart, const uint32_t* __restrict__ aFeat, int nA,
+    const uint8_t* __restrict__ fDesc, const float* __restrict__ fAngle, int nf,
+    const uint32_t* __restrict__ bNode, const int32_t* __restrict__ bStart, const uint32_t* __restrict__ bFeat, int nB,
+    float nnratio, int checkOrientation, int32_t* __restrict__ matchesOut, int32_t* __restrict__ nmatchesOut)
+{
+    const int lane = threadIdx.x;
+    int32_t* asg = reinterpret_cast<int32_t*>(pg_sfi_smem);               // [nf] vpMapPointMatches (as KF index)
+    int8_t* rotBin = reinterpret_cast<int8_t*>(asg + nf);                 // [nf]
+    for (int i = lane; i < nf; i += 64) { asg[i] = -1; rotBin[i] = -1; }
+    __syncthreads();
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nmatches = 0, a = 0, b = 0;
+    while (a < nA && b < nB) {                                            // :185-252
+        const uint32_t na = aNode[a], nb = bNode[b];
+        if (na < nb) { a++; continue; }                                   // lower_bound on a sorted list
+        if (nb < na) { b++; continue; }
+        const int a0 = aStart[a], a1 = aStart[a + 1], b0 = bStart[b], b1 = bStart[b + 1];
+        for (int ia = a0; ia < a1; ia++) {
+            const int realIdxKF = (int)aFeat[ia];
+            if (!kfValid[realIdxKF]) continue;                            // !pMP || pMP->isBad()
+            const uint4 q0 = reinterpret_cast<const uint4*>(kfDesc + (int64_t)realIdxKF * 32)[0];
+            const uint4 q1 = reinterpret_cast<const uint4*>(kfDesc + (int64_t)realIdxKF * 32)[1];
+            unsigned b1key = 0xFFFFFFFFu, b2key = 0xFFFFFFFFu;
+            for (int k = b0 + lane; k < b1; k += 64) {
+                const int realIdxF = (int)bFeat[k];
+                if (asg[realIdxF] >= 0) continue;                         // vpMapPointMatches[realIdxF]
+                const uint4 d0 = reinterpret_cast<const uint4*>(fDesc + (int64_t)realIdxF * 32)[0];
+                const uint4 d1 = reinterpret_cast<const uint4*>(fDesc + (int64_t)realIdxF * 32)[1];
+                const int dist = __popc(q0.x ^ d0.x) + __popc(q0.y ^ d0.y) + __popc(q0.z ^ d0.z) + __popc(q0.w ^ d0.w) +
+                                 __popc(q1.x ^ d1.x) + __popc(q1.y ^ d1.y) + __popc(q1.z ^ d1.z) + __popc(q1.w ^ d1.w);
+                const unsigned key = ((unsigned)dist << 16) | (unsigned)(k - b0);
+                if (key < b1key) { b2key = b1key; b1key = key; } else if (key < b2key) b2key = key;
+            }
+            const unsigned w1 = wave_min_u32(b1key);
+            if (w1 != 0xFFFFFFFFu && (int)(w1 >> 16) < 256) {             // bestDist1 starts at 256
+                const unsigned w2 = wave_min_u32(b1key == w1 ? b2key : b1key);
+                const int bestDist1 = (int)(w1 >> 16);
+                const int bestDist2 = (w2 != 0xFFFFFFFFu && (int)(w2 >> 16) < 256) ? (int)(w2 >> 16) : 256;
+                const int bestIdxF = (int)bFeat[b0 + (int)(w1 & 0xFFFF)];
+                if (bestDist1 <= TH_LOW && (float)bestDist1 < __fmul_rn(nnratio, (float)bestDist2)) {   // :233-235
+                    int bin = -1;
+                    if (checkOrientation) {                               // :241-250
+                        float rot = __fsub_rn(kfAngle[realIdxKF], fAngle[bestIdxF]);
+                        if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                        bin = (int)roundf(__fmul_rn(rot, factor));
+                        if (bin == HISTO_LENGTH) bin = 0;
+                    }
+                    nmatches++;
+                    if (lane == 0) { asg[bestIdxF] = realIdxKF; rotBin[bestIdxF] = (int8_t)bin; }
+                }
+            }
+            __syncthreads();
+        }
+        a++; b++;
+    }
+    if (checkOrientation) {                                               // :256-277
+        int h = 0;
+        for (int i = 0; i < nf; i++) h += (rotBin[i] == lane);
+        int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            const int s = __shfl(h, i);
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        int removed = 0;
+        for (int i = lane; i < nf; i += 64) {
+            const int bb = rotBin[i];
+            if (bb >= 0 && bb != ind1 && bb != ind2 && bb != ind3) { asg[i] = -1; removed++; }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) removed += __shfl_xor(removed, d);
+        nmatches -= removed;
+        __syncthreads();
+    }
+    for (int i = lane; i < nf; i += 64) matchesOut[i] = asg[i];
+    if (lane == 0) *nmatchesOut = nmatches;
+}
+
 extern "C" {
+
+int pgorb_search_by_bow(pgorb_ctx* c, const uint8_t* kf_desc, const float* kf_angle, const uint8_t* kf_point_valid, int nkf,
+                        const uint32_t* kf_fv_node, const int32_t* kf_fv_start, const uint32_t* kf_fv_feat, int kf_nfv,
+                        const uint8_t* f_desc, const float* f_angle, int nf, const uint32_t* f_fv_node,
+                        const int32_t* f_fv_start, const uint32_t* f_fv_feat, int f_nfv, float nnratio,
+                        int check_orientation, int32_t* matches)
+{
+    if (!c) return PGORB_E_ARG;
+    if (nkf < 0 || nf < 0 || kf_nfv < 0 || f_nfv < 0 || (nf && !matches) ||
+        (nkf && (!kf_desc || !kf_angle || !kf_point_valid)) || (nf && (!f_desc || !f_angle)) ||
+        (kf_nfv && (!kf_fv_node || !kf_fv_start || !kf_fv_feat)) || (f_nfv && (!f_fv_node || !f_fv_start || !f_fv_feat)))
+        return pg_ctx_fail(c, PGORB_E_ARG, "bad argument to pgorb_search_by_bow");
+    for (int i = 0; i < nf; i++) matches[i] = -1;
+    if (!nkf || !nf || !kf_nfv || !f_nfv) return 0;
+    if (nf > 16000 || nkf > 16000) return pg_ctx_fail(c, PGORB_E_LIMIT, "more than 16000 keypoints");
+    const int nfeatA = kf_fv_start[kf_nfv], nfeatB = f_fv_start[f_nfv];
+    auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
+    size_t off = 0;
+    auto place = [&](size_t bytes) { const size_t o = off; off += al(bytes); return o; };
+    const size_t oKD = place((size_t)nkf * 32), oKA = place((size_t)nkf * 4), oKV = place(nkf), oAN = place((size_t)kf_nfv * 4),
+                 oAS = place((size_t)(kf_nfv + 1) * 4), oAF = place((size_t)nfeatA * 4 + 4), oFD = place((size_t)nf * 32),
+                 oFA = place((size_t)nf * 4), oBN = place((size_t)f_nfv * 4), oBS = place((size_t)(f_nfv + 1) * 4),
+                 oBF = place((size_t)nfeatB * 4 + 4), oM = place((size_t)nf * 4), oNM = place(64);
+    void* dv;
+    int rc = pg_ctx_stage(c, 0, off, &dv);
+    if (rc) return rc;
+    uint8_t* d = (uint8_t*)dv;
+    auto up = [&](size_t o, const void* p, size_t n) { return n == 0 || hipMemcpy(d + o, p, n, hipMemcpyHostToDevice) == hipSuccess; };
+    if (!(up(oKD, kf_desc, (size_t)nkf * 32) && up(oKA, kf_angle, (size_t)nkf * 4) && up(oKV, kf_point_valid, nkf) &&
+          up(oAN, kf_fv_node, (size_t)kf_nfv * 4) && up(oAS, kf_fv_start, (size_t)(kf_nfv + 1) * 4) && up(oAF, kf_fv_feat, (size_t)nfeatA * 4) &&
+          up(oFD, f_desc, (size_t)nf * 32) && up(oFA, f_angle, (size_t)nf * 4) && up(oBN, f_fv_node, (size_t)f_nfv * 4) &&
+          up(oBS, f_fv_start, (size_t)(f_nfv + 1) * 4) && up(oBF, f_fv_feat, (size_t)nfeatB * 4)))
+        return pg_ctx_fail(c, PGORB_E_HIP, "hipMemcpy H2D failed");
+    const size_t lds = (size_t)nf * 5 + 64;
+    static size_t configured = 0;
+    if (lds > configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_by_bow), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        configured = lds;
+    }
+    hipLaunchKernelGGL(k_search_by_bow, dim3(1), dim3(64), lds, 0, d + oKD, (const float*)(d + oKA), d + oKV,
+                       (const uint32_t*)(d + oAN), (const int32_t*)(d + oAS), (const uint32_t*)(d + oAF), kf_nfv, d + oFD,
+                       (const float*)(d + oFA), nf, (const uint32_t*)(d + oBN), (const int32_t*)(d + oBS),
+                       (const uint32_t*)(d + oBF), f_nfv, nnratio, check_orientation, (int32_t*)(d + oM), (int32_t*)(d + oNM));
+    if (hipGetLastError() != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "k_search_by_bow launch failed");
+    int32_t nm = 0;
+    if (hipMemcpy(matches, d + oM, (size_t)nf * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(&nm, d + oNM, 4, hipMemcpyDeviceToHost) != hipSuccess)
+        return pg_ctx_fail(c, PGORB_E_HIP, "hipMemcpy D2H failed");
+    return nm;
+}
 
 int pgorb_frame_grid_batch_device(pgorb_ctx* c, const pgorb_keypoint* d_kps, const int32_t* d_n, int nframes,
                                   int cap, float min_x, float max_x, float min_y, float max_y,

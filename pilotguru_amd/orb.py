@@ -302,6 +302,25 @@ class ORBmatcher:
             *[_p(x) for x in a], float(th), int(self.mbCheckOrientation), _p(out)))
         return nm, out[:F.N].copy()
 
+    def SearchByBoW(self, ext, kf_desc, kf_angle, kf_point_valid, kf_featvec, F, f_featvec):
+        """SearchByBoW(KeyFrame* pKF, Frame &F, vpMapPointMatches) (src/ORBmatcher.cc:161-290).
+        Feature vectors are the (nodes, starts, features) triples of ORBVocabulary.transform().
+        Returns (nmatches, matches) with matches[j] = key-frame keypoint index or -1."""
+        kd = np.ascontiguousarray(kf_desc, np.uint8).reshape(-1, 32)
+        ka = np.ascontiguousarray(kf_angle, np.float32)
+        kv = np.ascontiguousarray(kf_point_valid, np.uint8)
+        A = [np.ascontiguousarray(kf_featvec[0], np.uint32), np.ascontiguousarray(kf_featvec[1], np.int32),
+             np.ascontiguousarray(kf_featvec[2], np.uint32)]
+        B = [np.ascontiguousarray(f_featvec[0], np.uint32), np.ascontiguousarray(f_featvec[1], np.int32),
+             np.ascontiguousarray(f_featvec[2], np.uint32)]
+        fa = np.ascontiguousarray(F.mvKeys["angle"], np.float32)
+        out = np.full(max(F.N, 1), -1, np.int32)
+        nm = ext._check(ext._L.pgorb_search_by_bow(
+            ext._h, _p(kd), _p(ka), _p(kv), len(kd), _p(A[0]), _p(A[1]), _p(A[2]), len(A[0]),
+            _p(F.mDescriptors), _p(fa), F.N, _p(B[0]), _p(B[1]), _p(B[2]), len(B[0]),
+            self.mfNNratio, int(self.mbCheckOrientation), _p(out)))
+        return nm, out[:F.N].copy()
+
     def SearchForInitialization(self, F1, F2, vbPrevMatched, windowSize=10):
         """(nmatches, vnMatches12); vbPrevMatched ([N1,2] float32) is updated in place, as in
         src/ORBmatcher.cc:407-522."""

@@ -176,3 +176,29 @@ def test_gpu_search_by_projection_last_frame(oracle, th, ori):
                                                   valid, px, py, lvl, ang, pd, obs, th, ori)
     nm, asg = pg.ORBmatcher(0.9, ori).SearchByProjectionLastFrame(F2, valid, px, py, lvl, ang, pd, obs, th)
     assert nm == onm and np.array_equal(asg, oasg) and nm > 100
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ratio,ori", [(0.7, True), (0.9, False)])
+def test_gpu_search_by_bow(tmp_path, oracle, ratio, ori):
+    """TrackReferenceKeyFrame: ComputeBoW on both frames, then SearchByBoW(keyframe, frame)."""
+    import os
+    import pilotguru_amd as pg
+    from pilotguru_amd import vocab as V
+    w, h, nf = 640, 480, 1200
+    ride = synth_ride(4, w, h, 2, dx=3, dy=1)
+    ext = pg.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    KF, F = pg.Frame(ext, ride[0]), pg.Frame(ext, ride[1])
+    desc, weight, parent = V.synth_vocabulary(6, 4, seed=4)
+    path = os.path.join(str(tmp_path), "voc.txt")
+    V.write_vocabulary_text(path, 6, 4, desc, weight, parent)
+    voc = V.ORBVocabulary(text_file=path)
+    voc.upload(ext)
+    _, fvK = voc.transform(KF.mDescriptors, 2)                   # nodes 2 levels above the leaves
+    _, fvF = voc.transform(F.mDescriptors, 2)
+    rng = np.random.RandomState(8)
+    valid = (rng.uniform(size=KF.N) > 0.3).astype(np.uint8)       # key-frame keypoints that carry a good map point
+    onm, om = oracle.search_by_bow(KF.mDescriptors, KF.mvKeys["angle"], valid, fvK, F.mDescriptors, F.mvKeys["angle"], fvF, ratio, ori)
+    nm, mt = pg.ORBmatcher(ratio, ori).SearchByBoW(ext, KF.mDescriptors, KF.mvKeys["angle"], valid, fvK, F, fvF)
+    assert nm == onm and np.array_equal(mt, om) and nm > 50
+    assert np.all(valid[mt[mt >= 0]] == 1) and len(set(mt[mt >= 0].tolist())) <= nm
