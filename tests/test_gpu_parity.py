@@ -203,3 +203,42 @@ def test_batch_properties_at_bench_size():
     torch.cuda.synchronize()
     best = b1[0, :n[4]].cpu().numpy().view(np.uint16)
     assert (best == 0).mean() > 0.15 and np.median(best) < 40
+
+
+@pytest.mark.parametrize("scale,nlevels,ini,mn,nf", [(1.5, 4, 20, 7, 600), (2.0, 3, 15, 5, 400), (1.2, 1, 20, 7, 300),
+                                                      (1.1, 6, 30, 10, 700), (1.25, 5, 20, 7, 500)])
+def test_other_pyramid_parameters_bit_exact(oracle, scale, nlevels, ini, mn, nf):
+    """Non-default ORBextractor parameters: other scale factors take the generic pyramid kernels
+    (the 4x4 fast path only covers down-scales <= 1.25), other thresholds, a single level."""
+    import pilotguru_amd as pg
+    w, h = 612, 452
+    img = synth_scene(31, w, h)
+    ora = oracle.OrbOracle(nf, scale, nlevels, ini, mn)
+    okp, odesc = ora.extract(img)
+    ext = pg.ORBextractor(nf, scale, nlevels, ini, mn, max_width=w, max_height=h)
+    kp, desc = ext(img)
+    for l in range(nlevels):
+        assert np.array_equal(ext.debug_level_image(0, l), ora.level_image(l)), "pyramid level %d" % l
+    assert len(kp) == len(okp) and kp.tobytes() == okp.tobytes() and np.array_equal(desc, odesc)
+
+
+def test_blur_tie_mode_switch(oracle):
+    """blur_tie_mode = 1 (scalar half-up everywhere) against the oracle's tie_mode 1."""
+    import pilotguru_amd as pg
+    w, h, nf = 400, 300, 500
+    img = synth_scene(17, w, h)
+    okp, odesc = oracle.OrbOracle(nf, 1.2, 8, 20, 7, blur_tie_mode=1).extract(img)
+    kp, desc = pg.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, blur_tie_mode=1)(img)
+    assert kp.tobytes() == okp.tobytes() and np.array_equal(desc, odesc)
+
+
+def test_context_reuse_across_frame_sizes(oracle):
+    """One context, several frame sizes in a row (plan rebuild), then back."""
+    import pilotguru_amd as pg
+    ext = pg.ORBextractor(400, 1.2, 8, 20, 7, max_width=640, max_height=480)
+    ora = oracle.OrbOracle(400, 1.2, 8, 20, 7)
+    for (w, h, seed) in ((640, 480, 1), (322, 250, 2), (640, 480, 1), (500, 300, 3)):
+        img = synth_scene(seed, w, h)
+        kp, desc = ext(img)
+        okp, odesc = ora.extract(img)
+        assert kp.tobytes() == okp.tobytes() and np.array_equal(desc, odesc)
