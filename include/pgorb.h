@@ -155,6 +155,19 @@ int  pgorb_match_batch_device(pgorb_ctx* ctx, const uint8_t* d_desc, const int32
  * cv::undistortPoints, Frame.cc:410-414) and the bounds are the image rectangle
  * (Frame.cc:461-466): pass min_x = 0, max_x = cols, min_y = 0, max_y = rows.
  * The batched device forms work on the layout of pgorb_extract_batch_device. */
+/*   pgorb_undistort_keypoints*   Frame::UndistortKeyPoints (src/Frame.cc:408-438) =
+ *       cv::undistortPoints(pts, pts, mK, mDistCoef, Mat(), mK): camera = {fx, fy, cx, cy},
+ *       dist = {k1, k2, p1, p2, k3} (as float, like mK / mDistCoef).  k1 == 0 copies the
+ *       keypoints unchanged (:410-414).  Only pt.x / pt.y change.
+ *   pgorb_image_bounds           Frame::ComputeImageBounds (src/Frame.cc:440-467): bounds =
+ *       {mnMinX, mnMaxX, mnMinY, mnMaxY} from the four undistorted image corners. */
+int  pgorb_undistort_keypoints(pgorb_ctx* ctx, const pgorb_keypoint* kps, int n,
+                               const float camera[4], const float dist[5], pgorb_keypoint* out);
+int  pgorb_undistort_keypoints_batch_device(pgorb_ctx* ctx, const pgorb_keypoint* d_kps,
+                               const int32_t* d_n, int nframes, int cap_per_frame,
+                               const float camera[4], const float dist[5],
+                               pgorb_keypoint* d_out, void* hip_stream);
+int  pgorb_image_bounds(int cols, int rows, const float camera[4], const float dist[5], float bounds[4]);
 #define PGORB_GRID_COLS 64
 #define PGORB_GRID_ROWS 48
 #define PGORB_GRID_CELLS (PGORB_GRID_COLS * PGORB_GRID_ROWS)

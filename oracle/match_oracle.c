@@ -330,3 +330,46 @@ int orc_search_by_bow(const uint8_t* kf_desc, const float* kf_angle, const uint8
     free(histBin); free(histIdx);
     return nmatches;
 }
+
+/* cv2.4: cv::undistortPoints(src, dst, K, distCoeffs, Mat(), K) (imgproc/undistort.cpp,
+ * cvUndistortPoints: 5 fixed-point iterations in double), as called by Frame::UndistortKeyPoints
+ * (src/Frame.cc:408-438) and Frame::ComputeImageBounds (:440-467).  PARITY UNPINNED (OpenCV). */
+static void undistort_point(const double K[4], const double k[5], float px, float py, float* ox, float* oy)
+{
+    const double fx = K[0], fy = K[1], cx = K[2], cy = K[3], ifx = 1. / fx, ify = 1. / fy;
+    double x = px, y = py, x0, y0;
+    x0 = x = (x - cx) * ifx;
+    y0 = y = (y - cy) * ify;
+    for (int j = 0; j < 5; j++) {
+        double r2 = x * x + y * y;
+        double icdist = 1. / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+        double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x);
+        double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    double xx = fx * x + 0. * y + cx;
+    double yy = 0. * x + fy * y + cy;
+    double ww = 1. / (0. * x + 0. * y + 1.);
+    *ox = (float)(xx * ww); *oy = (float)(yy * ww);
+}
+void orc_undistort_keypoints(const orc_keypoint* kps, int n, const float camera[4], const float dist[5], orc_keypoint* out)
+{
+    const double K[4] = {camera[0], camera[1], camera[2], camera[3]};
+    const double k[5] = {dist[0], dist[1], dist[2], dist[3], dist[4]};
+    for (int i = 0; i < n; i++) {
+        out[i] = kps[i];
+        if (dist[0] != 0.0f) undistort_point(K, k, kps[i].x, kps[i].y, &out[i].x, &out[i].y);
+    }
+}
+void orc_image_bounds(int cols, int rows, const float camera[4], const float dist[5], float bounds[4])
+{
+    if (dist[0] == 0.0f) { bounds[0] = 0; bounds[1] = (float)cols; bounds[2] = 0; bounds[3] = (float)rows; return; }
+    const double K[4] = {camera[0], camera[1], camera[2], camera[3]};
+    const double k[5] = {dist[0], dist[1], dist[2], dist[3], dist[4]};
+    float ux[4], uy[4];
+    const float cxs[4] = {0, (float)cols, 0, (float)cols}, cys[4] = {0, 0, (float)rows, (float)rows};
+    for (int i = 0; i < 4; i++) undistort_point(K, k, cxs[i], cys[i], &ux[i], &uy[i]);
+    bounds[0] = fminf(ux[0], ux[2]); bounds[1] = fmaxf(ux[1], ux[3]);
+    bounds[2] = fminf(uy[0], uy[1]); bounds[3] = fmaxf(uy[2], uy[3]);
+}

@@ -96,6 +96,8 @@ def lib():
         L.orc_search_by_bow.restype = C.c_int
         L.orc_search_by_bow.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 2 + [C.c_int] + \
             [C.c_void_p] * 3 + [C.c_int, C.c_float, C.c_int, C.c_void_p]
+        L.orc_undistort_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_image_bounds.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_vocab_load_text.restype = C.c_void_p
         L.orc_vocab_load_text.argtypes = [C.c_char_p]
         L.orc_vocab_free.argtypes = [C.c_void_p]
@@ -443,3 +445,18 @@ def search_by_bow(kf_desc, kf_angle, kf_valid, kf_fv, f_desc, f_angle, f_fv, nnr
                                  _p(f_desc), _p(f_angle), len(f_desc), _p(B[0]), _p(B[1]), _p(B[2]), len(B[0]),
                                  nnratio, int(check_orientation), _p(out))
     return nm, out[:len(f_desc)].copy()
+
+
+def undistort_keypoints(kps, camera, dist):
+    kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE)
+    cam = np.ascontiguousarray(camera, np.float32); d = np.ascontiguousarray(dist, np.float32)
+    out = np.zeros_like(kps)
+    lib().orc_undistort_keypoints(_p(kps), len(kps), _p(cam), _p(d), _p(out))
+    return out
+
+
+def image_bounds(cols, rows, camera, dist):
+    cam = np.ascontiguousarray(camera, np.float32); d = np.ascontiguousarray(dist, np.float32)
+    b = np.zeros(4, np.float32)
+    lib().orc_image_bounds(cols, rows, _p(cam), _p(d), _p(b))
+    return tuple(float(x) for x in b)

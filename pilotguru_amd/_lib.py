@@ -27,6 +27,7 @@ SYMBOLS = (
     "pgorb_frame_grid", "pgorb_frame_grid_batch_device", "pgorb_search_for_initialization",
     "pgorb_search_for_initialization_batch_device", "pgorb_extract_batch_color_device",
     "pgorb_search_by_projection_points", "pgorb_search_by_projection_frame", "pgorb_search_by_bow",
+    "pgorb_undistort_keypoints", "pgorb_undistort_keypoints_batch_device", "pgorb_image_bounds",
 )
 
 
@@ -101,6 +102,9 @@ def lib():
     L.pgorb_search_by_projection_frame.argtypes = [vp, vp, vp, C.c_int] + f4 + [vp, C.c_int] + [vp] * 7 + [C.c_float, C.c_int, vp]
     L.pgorb_search_by_bow.argtypes = [vp] + [vp] * 3 + [C.c_int] + [vp] * 3 + [C.c_int] + [vp] * 2 + [C.c_int] + [vp] * 3 + \
         [C.c_int, C.c_float, C.c_int, vp]
+    L.pgorb_undistort_keypoints.argtypes = [vp, vp, C.c_int, vp, vp, vp]
+    L.pgorb_undistort_keypoints_batch_device.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
+    L.pgorb_image_bounds.argtypes = [C.c_int, C.c_int, vp, vp, vp]
     L.pgorb_vocab_load_text.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.pgorb_vocab_from_blob.argtypes = [vp, C.c_int64, C.POINTER(vp)]
     L.pgorb_vocab_blob.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64)]

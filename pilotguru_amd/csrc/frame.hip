@@ -483,7 +483,118 @@ __global__ __launch_bounds__(64) void k_search_by_bow(
     if (lane == 0) *nmatchesOut = nmatches;
 }
 
+// ---- cv::undistortPoints (OpenCV 2.4 imgproc/undistort.cpp cvUndistortPoints), 5 fixed-point
+// iterations in double, R = identity, P = K.  Same operation order on host and device, no FMA.
+struct PgCamera { double fx, fy, cx, cy, ifx, ify, k1, k2, p1, p2, k3; };
+
+__host__ __device__ inline void pg_undistort_point(const PgCamera& C, float px, float py, float* ox, float* oy)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+#define PGM(a, b) __dmul_rn((a), (b))
+#define PGA(a, b) __dadd_rn((a), (b))
+#define PGS(a, b) __dsub_rn((a), (b))
+#define PGD(a, b) __ddiv_rn((a), (b))
+#else
+#define PGM(a, b) ((a) * (b))
+#define PGA(a, b) ((a) + (b))
+#define PGS(a, b) ((a) - (b))
+#define PGD(a, b) ((a) / (b))
+#endif
+    double x = (double)px, y = (double)py;
+    const double x0 = x = PGM(PGS(x, C.cx), C.ifx);
+    const double y0 = y = PGM(PGS(y, C.cy), C.ify);
+    for (int j = 0; j < 5; j++) {
+        const double r2 = PGA(PGM(x, x), PGM(y, y));
+        // icdist = (1 + ((k[7]*r2 + k[6])*r2 + k[5])*r2) / (1 + ((k[4]*r2 + k[1])*r2 + k[0])*r2), k5..k7 = 0
+        const double icdist = PGD(1.0, PGA(1.0, PGM(PGA(PGM(PGA(PGM(C.k3, r2), C.k2), r2), C.k1), r2)));
+        const double deltaX = PGA(PGM(PGM(PGM(2.0, C.p1), x), y), PGM(C.p2, PGA(r2, PGM(PGM(2.0, x), x))));
+        const double deltaY = PGA(PGM(C.p1, PGA(r2, PGM(PGM(2.0, y), y))), PGM(PGM(PGM(2.0, C.p2), x), y));
+        x = PGM(PGS(x0, deltaX), icdist);
+        y = PGM(PGS(y0, deltaY), icdist);
+    }
+    // RR = P * R = K: xx = fx*x + 0*y + cx, ww = 1/(0*x + 0*y + 1)
+    const double xx = PGA(PGA(PGM(C.fx, x), PGM(0.0, y)), C.cx);
+    const double yy = PGA(PGA(PGM(0.0, x), PGM(C.fy, y)), C.cy);
+    const double ww = PGD(1.0, PGA(PGA(PGM(0.0, x), PGM(0.0, y)), 1.0));
+    *ox = (float)PGM(xx, ww);
+    *oy = (float)PGM(yy, ww);
+#undef PGM
+#undef PGA
+#undef PGS
+#undef PGD
+}
+
+static PgCamera pg_make_camera(const float camera[4], const float dist[5])
+{
+    PgCamera C;
+    C.fx = camera[0]; C.fy = camera[1]; C.cx = camera[2]; C.cy = camera[3];
+    C.ifx = 1. / C.fx; C.ify = 1. / C.fy;
+    C.k1 = dist[0]; C.k2 = dist[1]; C.p1 = dist[2]; C.p2 = dist[3]; C.k3 = dist[4];
+    return C;
+}
+
+__global__ __launch_bounds__(256) void k_undistort_keypoints(const pgorb_keypoint* __restrict__ in,
+                                                              const int32_t* __restrict__ nper, int cap,
+                                                              PgCamera C, int identity, pgorb_keypoint* __restrict__ out)
+{
+    const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= min(nper[f], cap)) return;
+    pgorb_keypoint k = in[(int64_t)f * cap + i];
+    if (!identity) pg_undistort_point(C, k.x, k.y, &k.x, &k.y);
+    out[(int64_t)f * cap + i] = k;
+}
+
 extern "C" {
+
+int pgorb_undistort_keypoints_batch_device(pgorb_ctx* c, const pgorb_keypoint* d_kps, const int32_t* d_n, int nframes,
+                                           int cap, const float camera[4], const float dist[5], pgorb_keypoint* d_out,
+                                           void* stream)
+{
+    if (!c) return PGORB_E_ARG;
+    if (!d_kps || !d_n || !d_out || nframes < 1 || cap < 1 || !camera || !dist)
+        return pg_ctx_fail(c, PGORB_E_ARG, "bad argument to pgorb_undistort_keypoints_batch_device");
+    if (hipSetDevice(pg_ctx_device(c)) != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "hipSetDevice failed");
+    hipLaunchKernelGGL(k_undistort_keypoints, dim3((cap + 255) / 256, nframes), dim3(256), 0, (hipStream_t)stream, d_kps, d_n,
+                       cap, pg_make_camera(camera, dist), dist[0] == 0.0f ? 1 : 0, d_out);      // Frame.cc:410
+    if (hipGetLastError() != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "k_undistort_keypoints launch failed");
+    return 0;
+}
+
+int pgorb_undistort_keypoints(pgorb_ctx* c, const pgorb_keypoint* kps, int n, const float camera[4], const float dist[5],
+                              pgorb_keypoint* out)
+{
+    if (!c) return PGORB_E_ARG;
+    if (n < 0 || (n && (!kps || !out)) || !camera || !dist) return pg_ctx_fail(c, PGORB_E_ARG, "bad argument to pgorb_undistort_keypoints");
+    if (!n) return 0;
+    void* dv;
+    int rc = pg_ctx_stage(c, 0, (size_t)2 * n * sizeof(pgorb_keypoint) + 128, &dv);
+    if (rc) return rc;
+    pgorb_keypoint* din = (pgorb_keypoint*)dv;
+    pgorb_keypoint* dout = din + n;
+    int32_t* dn = (int32_t*)(((uintptr_t)(dout + n) + 63) & ~(uintptr_t)63);
+    if (hipMemcpy(din, kps, (size_t)n * sizeof(pgorb_keypoint), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dn, &n, 4, hipMemcpyHostToDevice) != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "hipMemcpy H2D failed");
+    if ((rc = pgorb_undistort_keypoints_batch_device(c, din, dn, 1, n, camera, dist, dout, 0))) return rc;
+    if (hipMemcpy(out, dout, (size_t)n * sizeof(pgorb_keypoint), hipMemcpyDeviceToHost) != hipSuccess)
+        return pg_ctx_fail(c, PGORB_E_HIP, "hipMemcpy D2H failed");
+    return 0;
+}
+
+int pgorb_image_bounds(int cols, int rows, const float camera[4], const float dist[5], float bounds[4])
+{
+    if (cols < 1 || rows < 1 || !camera || !dist || !bounds) return PGORB_E_ARG;
+    if (dist[0] == 0.0f) {                                     // Frame.cc:461-466
+        bounds[0] = 0.0f; bounds[1] = (float)cols; bounds[2] = 0.0f; bounds[3] = (float)rows;
+        return 0;
+    }
+    const PgCamera C = pg_make_camera(camera, dist);
+    const float cx[4] = {0.0f, (float)cols, 0.0f, (float)cols}, cy[4] = {0.0f, 0.0f, (float)rows, (float)rows};
+    float ux[4], uy[4];
+    for (int i = 0; i < 4; i++) pg_undistort_point(C, cx[i], cy[i], &ux[i], &uy[i]);
+    bounds[0] = std::min(ux[0], ux[2]); bounds[1] = std::max(ux[1], ux[3]);     // Frame.cc:455-458
+    bounds[2] = std::min(uy[0], uy[1]); bounds[3] = std::max(uy[2], uy[3]);
+    return 0;
+}
 
 int pgorb_search_by_bow(pgorb_ctx* c, const uint8_t* kf_desc, const float* kf_angle, const uint8_t* kf_point_valid, int nkf,
                         const uint32_t* kf_fv_node, const int32_t* kf_fv_start, const uint32_t* kf_fv_feat, int kf_nfv,

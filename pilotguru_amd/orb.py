@@ -231,18 +231,33 @@ class Frame:
     mvKeys (== mvKeysUndistorted for k1 == 0), mDescriptors, the image bounds and the 64x48 grid
     (AssignFeaturesToGrid, src/Frame.cc:234-249), built on the GPU."""
 
-    def __init__(self, extractor, image):
+    def __init__(self, extractor, image, camera=None, dist_coef=None):
+        """camera = (fx, fy, cx, cy), dist_coef = (k1, k2, p1, p2[, k3]) like mK / mDistCoef; without
+        them (or with k1 == 0) the keypoints are used as they are (Frame.cc:410-414)."""
         self.ext = extractor
         self.mvKeys, self.mDescriptors = extractor(image)
-        self.mvKeysUndistorted = self.mvKeys
         self.N = len(self.mvKeys)
         h, w = image.shape
-        self.bounds = (0.0, float(w), 0.0, float(h))          # mnMinX, mnMaxX, mnMinY, mnMaxY (Frame.cc:461-466)
+        L = extractor._L
+        if camera is not None and dist_coef is not None and float(dist_coef[0]) != 0.0:
+            cam = np.ascontiguousarray(camera, np.float32)
+            dc = np.zeros(5, np.float32)
+            dc[:len(dist_coef)] = dist_coef
+            self.mvKeysUndistorted = np.zeros_like(self.mvKeys)                      # UndistortKeyPoints (Frame.cc:408-438)
+            if self.N:
+                extractor._check(L.pgorb_undistort_keypoints(extractor._h, _p(self.mvKeys), self.N, _p(cam), _p(dc),
+                                                             _p(self.mvKeysUndistorted)))
+            b = np.zeros(4, np.float32)
+            L.pgorb_image_bounds(w, h, _p(cam), _p(dc), _p(b))                       # ComputeImageBounds (Frame.cc:440-467)
+            self.bounds = tuple(float(x) for x in b)
+        else:
+            self.mvKeysUndistorted = self.mvKeys
+            self.bounds = (0.0, float(w), 0.0, float(h))      # mnMinX, mnMaxX, mnMinY, mnMaxY (Frame.cc:461-466)
         self.grid_start = np.zeros(64 * 48 + 1, np.int32)
         self.grid_idx = np.zeros(max(self.N, 1), np.int32)
         if self.N:
-            extractor._check(extractor._L.pgorb_frame_grid(extractor._h, _p(self.mvKeys), self.N, *self.bounds,
-                                                           _p(self.grid_start), _p(self.grid_idx)))
+            extractor._check(L.pgorb_frame_grid(extractor._h, _p(self.mvKeysUndistorted), self.N, *self.bounds,
+                                                _p(self.grid_start), _p(self.grid_idx)))
 
     def grid_cell(self, col, row):
         """mGrid[col][row] as an index array."""

@@ -202,3 +202,53 @@ def test_gpu_search_by_bow(tmp_path, oracle, ratio, ori):
     nm, mt = pg.ORBmatcher(ratio, ori).SearchByBoW(ext, KF.mDescriptors, KF.mvKeys["angle"], valid, fvK, F, fvF)
     assert nm == onm and np.array_equal(mt, om) and nm > 50
     assert np.all(valid[mt[mt >= 0]] == 1) and len(set(mt[mt >= 0].tolist())) <= nm
+
+
+def test_image_bounds_and_undistortion_oracle_properties(oracle):
+    """cv::undistortPoints restatement: the fixed-point iteration inverts the distortion model."""
+    from pilotguru_amd import _lib
+    import ctypes as C
+    cam, dist = (700.0, 690.0, 322.5, 238.25), (-0.25, 0.08, 0.001, -0.0007, 0.0)
+    b = oracle.image_bounds(640, 480, cam, dist)
+    assert b[0] < 0 and b[1] > 640 and b[2] < 0 and b[3] > 480       # barrel distortion: corners move outwards
+    assert oracle.image_bounds(640, 480, cam, (0, 0, 0, 0, 0)) == (0.0, 640.0, 0.0, 480.0)
+    got = np.zeros(4, np.float32)
+    p = lambda a: C.c_void_p(np.ascontiguousarray(a).ctypes.data)
+    camf, df = np.array(cam, np.float32), np.array(dist, np.float32)
+    assert _lib.lib().pgorb_image_bounds(640, 480, C.c_void_p(camf.ctypes.data), C.c_void_p(df.ctypes.data), C.c_void_p(got.ctypes.data)) == 0
+    assert tuple(float(x) for x in got) == b                          # host function == oracle, bit for bit
+    k = np.zeros(50, oracle.KEYPOINT_DTYPE)
+    rng = np.random.RandomState(1)
+    k["x"], k["y"] = rng.uniform(0, 640, 50), rng.uniform(0, 480, 50)
+    u = oracle.undistort_keypoints(k, cam, dist)
+    # forward model on the undistorted points reproduces the distorted ones
+    x = (u["x"].astype(np.float64) - cam[2]) / cam[0]; y = (u["y"].astype(np.float64) - cam[3]) / cam[1]
+    r2 = x * x + y * y
+    cd = 1 + ((dist[4] * r2 + dist[1]) * r2 + dist[0]) * r2
+    xd = x * cd + 2 * dist[2] * x * y + dist[3] * (r2 + 2 * x * x)
+    yd = y * cd + dist[2] * (r2 + 2 * y * y) + 2 * dist[3] * x * y
+    assert np.allclose(xd * cam[0] + cam[2], k["x"], atol=2e-2) and np.allclose(yd * cam[1] + cam[3], k["y"], atol=2e-2)
+
+
+@pytest.mark.gpu
+def test_gpu_undistort_and_distorted_frame_pipeline(oracle):
+    """Frame constructor with a calibrated camera (k1 != 0): UndistortKeyPoints, ComputeImageBounds,
+    AssignFeaturesToGrid on the undistorted keypoints, then SearchForInitialization."""
+    import pilotguru_amd as pg
+    w, h, nf = 640, 480, 1200
+    cam, dist = (700.0, 690.0, 322.5, 238.25), (-0.25, 0.08, 0.001, -0.0007, 0.0)
+    ride = synth_ride(4, w, h, 2, dx=7, dy=3)
+    ext = pg.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    F1, F2 = pg.Frame(ext, ride[0], cam, dist), pg.Frame(ext, ride[1], cam, dist)
+    for F in (F1, F2):
+        ou = oracle.undistort_keypoints(F.mvKeys, cam, dist)
+        assert F.mvKeysUndistorted.tobytes() == ou.tobytes()
+        assert F.bounds == oracle.image_bounds(w, h, cam, dist)
+        start, idx = oracle.frame_grid(ou, F.bounds)
+        assert np.array_equal(F.grid_start, start) and np.array_equal(F.grid_idx[:len(idx)], idx)
+        assert start[-1] <= F.N                                   # PosInGrid may drop keypoints outside the bounds
+    prev = np.stack([F1.mvKeysUndistorted["x"], F1.mvKeysUndistorted["y"]], 1).astype(np.float32)
+    onm, om12, oprev = oracle.search_for_initialization(F1.mvKeysUndistorted, F1.mDescriptors, F2.mvKeysUndistorted,
+                                                        F2.mDescriptors, F2.bounds, prev, 100, 0.9, True)
+    nm, m12 = pg.ORBmatcher(0.9, True).SearchForInitialization(F1, F2, prev, 100)
+    assert nm == onm and np.array_equal(m12, om12) and prev.tobytes() == oprev.tobytes() and nm > 100
