@@ -139,6 +139,9 @@ def test_errors_and_edge_cases():
     assert e.value.code == PGORB_E_LIMIT
     with pytest.raises(TypeError):
         ext(np.zeros((240, 320), np.float32))
+    with pytest.raises(PgorbError) as e:                 # aspect < 0.5: DistributeOctTree's nIni would be 0 (:543)
+        _make(100, 320, 240)(np.zeros((180, 100), np.uint8))
+    assert e.value.code == PGORB_E_TOOSMALL
 
 
 @pytest.mark.parametrize("cn,rgb", [(3, True), (3, False), (4, True)])
@@ -242,3 +245,33 @@ def test_context_reuse_across_frame_sizes(oracle):
         kp, desc = ext(img)
         okp, odesc = ora.extract(img)
         assert kp.tobytes() == okp.tobytes() and np.array_equal(desc, odesc)
+
+
+@pytest.mark.parametrize("w,h,nlevels,nf", [(700, 100, 3, 300), (100, 150, 2, 120), (1000, 64, 1, 200)])
+def test_extreme_aspect_ratios_and_tall_cells(oracle, w, h, nlevels, nf):
+    """Panoramic / narrow frames: many quadtree roots (nIni = round(W/H), ORBextractor.cc:543),
+    single cell rows with cells up to 59 px (the kernel's generic staging path and 16-quad rows)."""
+    import pilotguru_amd as pg
+    img = synth_scene(40 + nlevels, w, h)
+    ora = oracle.OrbOracle(nf, 1.2, nlevels, 20, 7)
+    okp, odesc = ora.extract(img)
+    ext = pg.ORBextractor(nf, 1.2, nlevels, 20, 7, max_width=w, max_height=h)
+    kp, desc = ext(img)
+    for l in range(nlevels):
+        x, y, r = ext.debug_level_candidates(0, l)
+        oc = ora.level_candidates(l)
+        assert sorted(zip(y.tolist(), x.tolist(), r.tolist())) == sorted(zip(oc["y"].tolist(), oc["x"].tolist(), oc["response"].tolist()))
+        assert ext.debug_level_keypoints(0, l) == ora.level_keypoints(l)
+    assert len(kp) == len(okp) > 0 and kp.tobytes() == okp.tobytes() and np.array_equal(desc, odesc)
+
+
+def test_noise_image_takes_the_chunked_fast_path(oracle):
+    """Pure noise: nearly every pixel passes the quick test at minThFAST in cells that have no
+    iniThFAST corner -> the candidate list overflows its LDS capacity -> chunked slow path."""
+    import pilotguru_amd as pg
+    rng = np.random.RandomState(0)
+    w, h, nf = 400, 300, 500
+    img = (128 + rng.randint(-9, 10, (h, w))).astype(np.uint8)      # +-9 noise: corners at 7 but none at 20
+    okp, odesc = oracle.OrbOracle(nf, 1.2, 8, 20, 7).extract(img)
+    kp, desc = pg.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h)(img)
+    assert len(okp) > 100 and kp.tobytes() == okp.tobytes() and np.array_equal(desc, odesc)
