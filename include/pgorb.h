@@ -93,6 +93,11 @@ int  pgorb_features_per_level(const pgorb_ctx* ctx, int32_t* out);
  * <0 when the frame is unusable (PGORB_E_TOOSMALL / PGORB_E_LIMIT). */
 int  pgorb_max_keypoints(const pgorb_ctx* ctx, int w, int h);
 
+/* Page-locked host memory for frames / results: host-buffer entry points run at PCIe speed when
+ * their buffers come from here (pageable memory is staged by the driver at a fraction of it). */
+void* pgorb_host_alloc(int64_t bytes);
+void  pgorb_host_free(void* p);
+
 /* One frame, host buffers.  gray: h rows of `stride` bytes.  kps[cap], desc[cap*32]. */
 int  pgorb_extract(pgorb_ctx* ctx, const uint8_t* gray, int w, int h, int stride,
                    pgorb_keypoint* kps, uint8_t* desc, int cap, int* n);

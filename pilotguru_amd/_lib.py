@@ -28,6 +28,7 @@ SYMBOLS = (
     "pgorb_search_for_initialization_batch_device", "pgorb_extract_batch_color_device",
     "pgorb_search_by_projection_points", "pgorb_search_by_projection_frame", "pgorb_search_by_bow",
     "pgorb_undistort_keypoints", "pgorb_undistort_keypoints_batch_device", "pgorb_image_bounds",
+    "pgorb_host_alloc", "pgorb_host_free",
 )
 
 
@@ -105,6 +106,10 @@ def lib():
     L.pgorb_undistort_keypoints.argtypes = [vp, vp, C.c_int, vp, vp, vp]
     L.pgorb_undistort_keypoints_batch_device.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     L.pgorb_image_bounds.argtypes = [C.c_int, C.c_int, vp, vp, vp]
+    L.pgorb_host_alloc.restype = vp
+    L.pgorb_host_alloc.argtypes = [C.c_int64]
+    L.pgorb_host_free.restype = None
+    L.pgorb_host_free.argtypes = [vp]
     L.pgorb_vocab_load_text.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.pgorb_vocab_from_blob.argtypes = [vp, C.c_int64, C.POINTER(vp)]
     L.pgorb_vocab_blob.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64)]
@@ -119,7 +124,8 @@ def lib():
     L.pgorb_bow_score_l1.restype = C.c_double
     L.pgorb_bow_score_l1.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int]
     for name in SYMBOLS:
-        if name not in ("pgorb_destroy", "pgorb_last_error", "pgorb_vocab_free", "pgorb_bow_score_l1"):
+        if name not in ("pgorb_destroy", "pgorb_last_error", "pgorb_vocab_free", "pgorb_bow_score_l1",
+                        "pgorb_host_alloc", "pgorb_host_free"):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L

@@ -42,6 +42,8 @@ struct pgorb_ctx {
     // device memory
     Arena pyr, cand, sel, nodes, counters, tables, cellCand, cellCount, cellTab;
     Arena stageKps, stageDesc, stageN, stageA, stageB, stageOut, vocab;
+    void* pinned = nullptr;                   // page-locked bounce buffer for bulk result download
+    size_t pinnedBytes = 0;
     int vocabK = 0, vocabL = 0, vocabNodes = 0;
     int lastFrames = 0;
     bool lastAliased = false;
@@ -446,6 +448,7 @@ void pgorb_destroy(pgorb_ctx* c)
     Arena* all[] = {&c->cellTab, &c->cellCand, &c->cellCount, &c->pyr, &c->cand, &c->sel, &c->nodes, &c->counters, &c->tables,
                     &c->stageKps, &c->stageDesc, &c->stageN, &c->stageA, &c->stageB, &c->stageOut, &c->vocab};
     for (Arena* a : all) if (a->p) (void)hipFree(a->p);
+    if (c->pinned) (void)hipHostFree(c->pinned);
     for (hipEvent_t e : c->evExtract) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->evMatch) (void)hipEventDestroy(e);
     delete c;
@@ -558,16 +561,37 @@ int pgorb_extract_batch(pgorb_ctx* c, const uint8_t* const* gray, int nframes, i
     for (int f = 0; f < nframes; f++)
         if (cnt[f] > cap)
             return fail(c, PGORB_E_CAP, "frame %d has %d keypoints, capacity %d", f, cnt[f], cap);
+    // one bulk download of the used part of the staging slabs into page-locked memory, then scatter
+    const size_t kBytes = (size_t)nframes * need * sizeof(pgorb_keypoint), dBytes = (size_t)nframes * need * 32;
+    if (c->pinnedBytes < kBytes + dBytes) {
+        if (c->pinned) (void)hipHostFree(c->pinned);
+        c->pinned = nullptr; c->pinnedBytes = 0;
+        const size_t want = ((size_t)c->prm.max_batch * need * (sizeof(pgorb_keypoint) + 32) + 4095) & ~(size_t)4095;
+        PG_HIP(c, hipHostMalloc(&c->pinned, want, hipHostMallocDefault));
+        c->pinnedBytes = want;
+    }
+    uint8_t* hk = (uint8_t*)c->pinned;
+    uint8_t* hd = hk + kBytes;
+    PG_HIP(c, hipMemcpyAsync(hk, c->stageKps.p, kBytes, hipMemcpyDeviceToHost, 0));
+    PG_HIP(c, hipMemcpyAsync(hd, c->stageDesc.p, dBytes, hipMemcpyDeviceToHost, 0));
+    PG_HIP(c, hipStreamSynchronize(0));
     for (int f = 0; f < nframes; f++) {
         n[f] = cnt[f];
         if (!cnt[f]) continue;
-        PG_HIP(c, hipMemcpy(kps + (size_t)f * cap, (pgorb_keypoint*)c->stageKps.p + (size_t)f * need,
-                            (size_t)cnt[f] * sizeof(pgorb_keypoint), hipMemcpyDeviceToHost));
-        PG_HIP(c, hipMemcpy(desc + (size_t)f * cap * 32, (uint8_t*)c->stageDesc.p + (size_t)f * need * 32,
-                            (size_t)cnt[f] * 32, hipMemcpyDeviceToHost));
+        memcpy(kps + (size_t)f * cap, hk + (size_t)f * need * sizeof(pgorb_keypoint), (size_t)cnt[f] * sizeof(pgorb_keypoint));
+        memcpy(desc + (size_t)f * cap * 32, hd + (size_t)f * need * 32, (size_t)cnt[f] * 32);
     }
     return 0;
 }
+
+void* pgorb_host_alloc(int64_t bytes)
+{
+    void* p = nullptr;
+    if (bytes <= 0 || hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void pgorb_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 int pgorb_extract(pgorb_ctx* c, const uint8_t* gray, int w, int h, int stride, pgorb_keypoint* kps,
                   uint8_t* desc, int cap, int* n)
