@@ -638,6 +638,7 @@ int pgorb_hamming_best2(pgorb_ctx* c, const uint8_t* a, int na, const uint8_t* b
     if (!c) return PGORB_E_ARG;
     if (na < 0 || nb < 0 || (na && (!a || !best_idx || !best || !second)) || (nb && !b))
         return fail(c, PGORB_E_ARG, "bad argument to pgorb_hamming_best2");
+    if (nb >= (1 << 20)) return fail(c, PGORB_E_LIMIT, "more than 2^20 train descriptors");
     if (!na) return 0;
     PG_HIP(c, hipSetDevice(c->prm.device));
     int rc;

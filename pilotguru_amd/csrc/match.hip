@@ -50,16 +50,21 @@ __global__ __launch_bounds__(MT_T) void k_hamming_matrix(const uint8_t* __restri
     }
 }
 
-// best / second-best over all train descriptors for 64 queries per workgroup.  The workgroup
+// best / second-best over all train descriptors (nb < 2^20) for 64 queries per workgroup.  The workgroup
 // is MT_WAVES waves: wave w scans the w-th contiguous slice of the train set for the SAME 64
 // queries (its own LDS tile), then wave 0 merges the partial results in slice order, which
 // preserves "first minimum wins" (strict '<', ORBmatcher.cc:443-458).
 #define MT_WAVES 4
 #define MT_SLICE_TILE 128     // train descriptors staged per wave and LDS tile (4 KiB)
 
+// key = distance << 20 | train index: the two smallest keys of a query are its best and second
+// best in (distance, first index) order, i.e. exactly the reference's strict-'<' scan; 4 VALU per
+// candidate instead of a compare/select chain.
+#define MT_IDX_BITS 20
+
 __device__ __forceinline__ void best2_scan(const uint8_t* a, int na, const uint8_t* b, int nb,
                                            int32_t* best_idx, uint16_t* best, uint16_t* second,
-                                           uint4* tiles, int* part)
+                                           uint4* tiles, unsigned* part)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int i = blockIdx.x * MT_T + lane;
@@ -71,7 +76,7 @@ __device__ __forceinline__ void best2_scan(const uint8_t* a, int na, const uint8
     const int per = (nb + MT_WAVES - 1) / MT_WAVES;
     const int jb = wv * per, je = min(jb + per, nb);
     uint4* tile = tiles + wv * 2 * MT_SLICE_TILE;
-    int b1 = 65535, b2 = 65535, bi = -1;
+    unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;                // two smallest keys of this slice
     for (int j0 = jb; j0 < je; j0 += MT_SLICE_TILE) {          // waves run independently: wave-local sync only
         const int cnt = min(MT_SLICE_TILE, je - j0);
         const uint4* src = reinterpret_cast<const uint4*>(b + (int64_t)j0 * 32);
@@ -81,24 +86,26 @@ __device__ __forceinline__ void best2_scan(const uint8_t* a, int na, const uint8
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         for (int j = 0; j < cnt; j++) {
-            const int d = pg_hamming256(q0, q1, tile[2 * j], tile[2 * j + 1]);
-            if (d < b1) { b2 = b1; b1 = d; bi = j0 + j; }
-            else if (d < b2) b2 = d;
+            const unsigned d = (unsigned)pg_hamming256(q0, q1, tile[2 * j], tile[2 * j + 1]);
+            const unsigned key = (d << MT_IDX_BITS) | (unsigned)(j0 + j);
+            k2 = min(k2, max(k1, key));
+            k1 = min(k1, key);
         }
     }
-    part[(wv * 64 + lane) * 3 + 0] = b1;
-    part[(wv * 64 + lane) * 3 + 1] = b2;
-    part[(wv * 64 + lane) * 3 + 2] = bi;
+    part[(wv * 64 + lane) * 2 + 0] = k1;
+    part[(wv * 64 + lane) * 2 + 1] = k2;
     __syncthreads();
     if (wv == 0 && i < na) {
-        int m1 = 65535, m2 = 65535, mi = -1;
+        unsigned m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;
 #pragma unroll
-        for (int w = 0; w < MT_WAVES; w++) {
-            const int p1 = part[(w * 64 + lane) * 3], p2 = part[(w * 64 + lane) * 3 + 1], pi = part[(w * 64 + lane) * 3 + 2];
-            if (p1 < m1) { m2 = min(m1, p2); m1 = p1; mi = pi; }      // new best; old best and p2 compete for second
-            else m2 = min(m2, p1);                                     // p1 >= m1: candidate for second (p2 >= p1)
+        for (int w = 0; w < 2 * MT_WAVES; w++) {
+            const unsigned key = part[(w >> 1) * 128 + lane * 2 + (w & 1)];
+            m2 = min(m2, max(m1, key));
+            m1 = min(m1, key);
         }
-        best_idx[i] = mi; best[i] = (uint16_t)m1; second[i] = (uint16_t)m2;
+        best_idx[i] = (m1 == 0xFFFFFFFFu) ? -1 : (int32_t)(m1 & ((1u << MT_IDX_BITS) - 1));
+        best[i] = (m1 == 0xFFFFFFFFu) ? (uint16_t)65535 : (uint16_t)(m1 >> MT_IDX_BITS);
+        second[i] = (m2 == 0xFFFFFFFFu) ? (uint16_t)65535 : (uint16_t)(m2 >> MT_IDX_BITS);
     }
 }
 
@@ -107,7 +114,7 @@ __global__ __launch_bounds__(MT_T * MT_WAVES) void k_hamming_best2(const uint8_t
                                                          int32_t* best_idx, uint16_t* best, uint16_t* second)
 {
     __shared__ uint4 tiles[MT_WAVES * 2 * MT_SLICE_TILE];
-    __shared__ int part[MT_WAVES * 64 * 3];
+    __shared__ unsigned part[MT_WAVES * 64 * 2];
     best2_scan(a, na, b, nb, best_idx, best, second, tiles, part);
 }
 
@@ -118,7 +125,7 @@ __global__ __launch_bounds__(MT_T * MT_WAVES) void k_match_batch(const uint8_t* 
                                                        int32_t* best_idx, uint16_t* best, uint16_t* second)
 {
     __shared__ uint4 tiles[MT_WAVES * 2 * MT_SLICE_TILE];
-    __shared__ int part[MT_WAVES * 64 * 3];
+    __shared__ unsigned part[MT_WAVES * 64 * 2];
     const int p = blockIdx.y;
     const int fq = pq[p], ft = pt[p];
     const int na = min(n[fq], cap), nb = min(n[ft], cap);
