@@ -23,7 +23,7 @@
 //   * one pass over the keys per generation: the pass that moves keys to their new node also
 //     counts them into that node's quadrants for the next generation (LDS atomics).
 //
-// The prologue compacts K2's per-cell candidate slots (one wave per cell, lanes = slots) into
+// The prologue compacts K2's per-cell candidate slots (one thread per cell) into
 // the dense 8-byte key records {packed candidate, node position | quadrant << 28}.
 //
 // Integer/compare work on ~1e4 keys; latency-bound, not bandwidth-bound.  Throughput comes
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P)
 {
     __shared__ int sh[QT_W + 8];
     extern __shared__ __attribute__((aligned(16))) int qt_lds[];     // 24 ints per node
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x;
     // grid = (frames, levels): the heavy level-0 problems of all frames are dispatched first and
     // spread over all CUs (with level as the fast index every 8th workgroup -- always the same
     // 32 CUs under round-robin dispatch -- got all the level-0 work)
@@ -115,10 +115,19 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P)
         __syncthreads();
         ncand = qt_scan_excl(cellOff, ncells, sh);
         if (ncand > L.candCap) ncand = L.candCap;               // cannot happen (capacity is exact)
-        for (int c = wv; c < ncells; c += QT_W) {
-            const int n = cc[c], off = cellOff[c];
-            for (int j = lane; j < n; j += 64)
-                if (off + j < L.candCap) keys[off + j] = make_uint2(slots[(int64_t)c * L.cellCap + j], 0u);
+        // one thread per cell (a cell holds ~10 records); loads of a cell are issued 4 at a time.
+        // (A wave-per-cell loop serialised ncells/16 dependent global round trips: it WAS the kernel.)
+        for (int c = tid; c < ncells; c += QT_T) {
+            const int n = min(cc[c], L.cellCap), off = cellOff[c];
+            const uint32_t* src = slots + (int64_t)c * L.cellCap;
+            for (int j = 0; j < n; j += 4) {
+                uint32_t v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) v[u] = (j + u < n) ? src[j + u] : 0u;
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (j + u < n && off + j + u < L.candCap) keys[off + j + u] = make_uint2(v[u], 0u);
+            }
         }
         if (tid == 0) P.candCount[frame * PG_MAXL + l] = ncand;
         __syncthreads();
@@ -265,18 +274,28 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P)
         // counted into that node's quadrants (cnt4 of the next generation)
         for (int i = tid; i < 4 * size; i += QT_T) cnt4[i] = 0;
         __syncthreads();
-        for (int i = tid; i < ncand; i += QT_T) {
-            const uint2 k = keys[i];
-            const int pos = k.y & QT_POS_MASK, q = k.y >> 28;
-            const int r = rnk[pos];
-            const int np = (r >= 0 && r <= jstar) ? newpos4[4 * pos + q] : tailpos[pos];
-            uint32_t rec = (uint32_t)np;
-            if (!last && cntB[np] > 1) {
-                const int q2 = qt_quadrant(bndB[np], k.x);
-                atomicAdd(&cnt4[np * 4 + q2], 1);
-                rec |= (uint32_t)q2 << 28;
+        // 4 keys per thread and step: the four independent global loads are in flight together
+        // (one key per step left this pass bound by L2 latency)
+        for (int i0 = tid; i0 < ncand; i0 += 4 * QT_T) {
+            uint2 kk[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int i = i0 + u * QT_T; kk[u] = (i < ncand) ? keys[i] : make_uint2(0u, 0u); }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = i0 + u * QT_T;
+                if (i >= ncand) break;
+                const uint2 k = kk[u];
+                const int pos = k.y & QT_POS_MASK, q = k.y >> 28;
+                const int r = rnk[pos];
+                const int np = (r >= 0 && r <= jstar) ? newpos4[4 * pos + q] : tailpos[pos];
+                uint32_t rec = (uint32_t)np;
+                if (!last && cntB[np] > 1) {
+                    const int q2 = qt_quadrant(bndB[np], k.x);
+                    atomicAdd(&cnt4[np * 4 + q2], 1);
+                    rec |= (uint32_t)q2 << 28;
+                }
+                keys[i].y = rec;
             }
-            keys[i].y = rec;
         }
         __syncthreads();
         { int4* t4 = bndA; bndA = bndB; bndB = t4; int* t1 = cntA; cntA = cntB; cntB = t1; }
@@ -286,12 +305,19 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P)
     for (int p = tid; p < size; p += QT_T) best[p] = 0ull;
     __syncthreads();
     const int wCell = L.wCell, hCell = L.hCell, nCols = L.nCols;
-    for (int i = tid; i < ncand; i += QT_T) {
-        const uint2 k = keys[i];
-        const int x = (k.x & 0xFFF) - 3, y = ((k.x >> 12) & 0xFFF) - 3;
-        const int cj = x / wCell, ci = y / hCell;
-        const uint32_t rank = (uint32_t)(((ci * nCols + cj) * hCell + (y - ci * hCell)) * wCell + (x - cj * wCell));
-        atomicMax(&best[k.y & QT_POS_MASK], ((unsigned long long)(k.x >> 24) << 32) | (0xFFFFFFFFu - rank));
+    for (int i0 = tid; i0 < ncand; i0 += 4 * QT_T) {
+        uint2 kk[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int i = i0 + u * QT_T; kk[u] = (i < ncand) ? keys[i] : make_uint2(0u, 0u); }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (i0 + u * QT_T >= ncand) break;
+            const uint2 k = kk[u];
+            const int x = (k.x & 0xFFF) - 3, y = ((k.x >> 12) & 0xFFF) - 3;
+            const int cj = x / wCell, ci = y / hCell;
+            const uint32_t rank = (uint32_t)(((ci * nCols + cj) * hCell + (y - ci * hCell)) * wCell + (x - cj * wCell));
+            atomicMax(&best[k.y & QT_POS_MASK], ((unsigned long long)(k.x >> 24) << 32) | (0xFFFFFFFFu - rank));
+        }
     }
     __syncthreads();
     uint32_t* sel = P.sel + (int64_t)frame * P.selFrame + L.selOff;
