@@ -267,7 +267,7 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
         V.scale = c->mvScaleFactor[l];
         V.patchSize = (float)(int)(31 * c->mvScaleFactor[l]);                     // :836
         selTotal += V.selCap;
-        if ((size_t)V.nodeCap * 24 * sizeof(int) > 150 * 1024)
+        if ((size_t)std::max(V.nodeCap * 30, V.nCols * V.nRows + 1) * sizeof(int) > 140 * 1024)
             return fail(c, PGORB_E_LIMIT, "nfeatures too large for the quadtree kernel's LDS budget");
         if (V.w > 4095 + 2 * PG_EDGE || V.h > 4095 + 2 * PG_EDGE)
             return fail(c, PGORB_E_LIMIT, "level larger than 4095 px is not supported");

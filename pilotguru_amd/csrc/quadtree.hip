@@ -34,6 +34,11 @@
 #define QT_W (QT_T / 64)
 #define QT_POS_MASK 0x0FFFFFFFu
 
+// Wait ONCE for a batch of loads: the values become outputs of an (empty) asm statement, so the
+// compiler's waitcnt insertion stops tracking them.  Without this every later use that follows a
+// loop and a global store got a full `s_waitcnt vmcnt(0)` -- a store round trip per record.
+#define QT_SETTLE4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+
 // Exclusive prefix sum of a[0..n) in place (a in LDS or global); returns the total.
 // All threads must call.  sh: >= QT_W + 1 ints of LDS.
 __device__ int qt_scan_excl(int* a, int n, int* sh)
@@ -69,6 +74,50 @@ __device__ int qt_scan_excl(int* a, int n, int* sh)
     return total;
 }
 
+// Exclusive prefix over the threads of the block of three per-thread values at once (wave
+// shuffles + one cross-wave step, 2 barriers).  On return a/b/c hold the exclusive prefixes,
+// tot[0..2] the block totals.  sh: >= 3*QT_W + 3 ints.
+__device__ __forceinline__ void qt_scan3_threads(int& a, int& b, int& c, int* tot, int* sh)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int ia = a, ib = b, ic = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int oa = __shfl_up(ia, d), ob = __shfl_up(ib, d), oc = __shfl_up(ic, d);
+        if (lane >= d) { ia += oa; ib += ob; ic += oc; }
+    }
+    if (lane == 63) { sh[wv] = ia; sh[QT_W + wv] = ib; sh[2 * QT_W + wv] = ic; }
+    __syncthreads();
+    int pa = 0, pb = 0, pc = 0, ta = 0, tb = 0, tc = 0;
+#pragma unroll
+    for (int w = 0; w < QT_W; w++) {
+        const int va = sh[w], vb = sh[QT_W + w], vc = sh[2 * QT_W + w];
+        if (w < wv) { pa += va; pb += vb; pc += vc; }
+        ta += va; tb += vb; tc += vc;
+    }
+    a = pa + ia - a; b = pb + ib - b; c = pc + ic - c;
+    tot[0] = ta; tot[1] = tb; tot[2] = tc;
+    __syncthreads();
+}
+
+// ctr[target] += 1 for every active lane.  Keys arrive in cell order: when all active lanes of
+// the wave hit ONE counter (shallow generations: a handful of counters for ~2e4 keys, plain LDS
+// atomics on one address serialise lane by lane) a single lane adds the population count;
+// otherwise plain atomics (a per-target leader loop cost ~30 cycles per distinct target and was
+// 100 us of the level-0 workgroup).  Must be called by all lanes of the wave.
+__device__ __forceinline__ void qt_wave_count(int* ctr, int target, bool active)
+{
+    const unsigned long long todo = __ballot(active);
+    if (todo == 0) return;
+    const int leader = __ffsll((long long)todo) - 1;
+    const int t = __builtin_amdgcn_readlane(target, leader);
+    if (__ballot(active && target != t) == 0) {
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&ctr[t], __popcll(todo));
+    } else if (active) {
+        atomicAdd(&ctr[target], 1);
+    }
+}
+
 __device__ __forceinline__ int qt_quadrant(const int4 b, uint32_t cv)
 {
     const int midX = b.x + ((b.z - b.x + 1) >> 1);     // UL.x + ceil((UR.x-UL.x)/2)  (:483)
@@ -77,11 +126,74 @@ __device__ __forceinline__ int qt_quadrant(const int4 b, uint32_t cv)
     return (x < midX) ? ((y < midY) ? 0 : 2) : ((y < midY) ? 1 : 3);      // n1 n3 / n2 n4 (:515-526)
 }
 
+#ifdef PGORB_QT_TIMING
+// developer build only (make EXTRA=-DPGORB_QT_TIMING): per-phase time of workgroup (0,0) in
+// 10 ns ticks, read back by tools/experiments/qt_timing.py
+__device__ unsigned long long pg_qt_t[16];
+#define QT_TS(k) do { if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) { const unsigned long long t1_ = wall_clock64(); pg_qt_t[k] += t1_ - qt_t0; qt_t0 = t1_; } } while (0)
+#define QT_CNT(k, v) do { if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) pg_qt_t[k] += (v); } while (0)
+extern "C" int pgorb_debug_qt_times(unsigned long long* out16, int reset)
+{
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(pg_qt_t), sizeof(pg_qt_t)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(pg_qt_t), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define QT_TS(k) do {} while (0)
+#define QT_CNT(k, v) do {} while (0)
+#endif
+
+// Depth of the count pyramid for a level with nIni roots: the largest D <= 5 whose pyramid
+// (nIni * (4^(D+1)-1)/3 counters) fits QT_PYR_CAP ints of LDS.
+#define QT_PYR_CAP 4096
+__device__ __forceinline__ int qt_pyr_off(int nIni, int d) { return nIni * (((1 << (2 * d)) - 1) / 3); }
+__device__ __forceinline__ int qt_pyr_depth(int nIni)
+{
+    int D = 5;
+    while (D > 0 && qt_pyr_off(nIni, D + 1) > QT_PYR_CAP) D--;
+    return D;
+}
+
+// Depth-D descendant of the root that holds candidate cv: index r * 4^D + path, where path is the
+// sequence of DivideNode quadrants (:481-537) a key at (x, y) falls through.  Pure geometry --
+// which descendants exist as list nodes is decided from the counts alone.
+__device__ __forceinline__ int qt_leaf(uint32_t cv, float hX, int nIni, int regionH, int D)
+{
+    const int x = cv & 0xFFF, y = (cv >> 12) & 0xFFF;
+    int r = (int)__fdiv_rn((float)x, hX);                // vpIniNodes[kp.pt.x/hX]  (:569)
+    r = min(max(r, 0), nIni - 1);
+    int x0 = (int)__fmul_rn(hX, (float)r), x1 = (int)__fmul_rn(hX, (float)(r + 1)), y0 = 0, y1 = regionH;
+    int idx = r;
+    for (int d = 0; d < D; d++) {
+        const int midX = x0 + ((x1 - x0 + 1) >> 1), midY = y0 + ((y1 - y0 + 1) >> 1);
+        const bool qx = x >= midX, qy = y >= midY;
+        idx = idx * 4 + (qx ? 1 : 0) + (qy ? 2 : 0);
+        x0 = qx ? midX : x0; x1 = qx ? x1 : midX;
+        y0 = qy ? midY : y0; y1 = qy ? y1 : midY;
+    }
+    return idx;
+}
+
+// list position of the node holding the key whose depth-D descendant index is `leaf`
+// (map: pyramid-indexed, -1 where no list node sits)
+__device__ __forceinline__ int qt_walk(const int* map, int leaf, int nIni, int D)
+{
+    for (int d = 0; d <= D; d++) {
+        const int m = map[qt_pyr_off(nIni, d) + (leaf >> (2 * (D - d)))];
+        if (m >= 0) return m;
+    }
+    return 0;                                            // unreachable: list nodes partition the keys
+}
+
 __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P)
 {
-    __shared__ int sh[QT_W + 8];
-    extern __shared__ __attribute__((aligned(16))) int qt_lds[];     // 24 ints per node
-    const int tid = threadIdx.x;
+    __shared__ int sh[3 * QT_W + 8];
+    __shared__ int pyr[QT_PYR_CAP];                       // count pyramid, later the node map
+    extern __shared__ __attribute__((aligned(16))) int qt_lds[];     // max(30 ints per node, cells + 1)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#ifdef PGORB_QT_TIMING
+    unsigned long long qt_t0 = wall_clock64();
+#endif
     // grid = (frames, levels): the heavy level-0 problems of all frames are dispatched first and
     // spread over all CUs (with level as the fast index every 8th workgroup -- always the same
     // 32 CUs under round-robin dispatch -- got all the level-0 work)
@@ -94,8 +206,11 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P)
     int4* bndB = bndA + NC;
     int* cntA = reinterpret_cast<int*>(bndB + NC);
     int* cntB = cntA + NC;
-    int* cnt4 = cntB + NC;                              // [4*NC] keys per child of node p
-    int* newpos4 = cnt4 + 4 * NC;                       // [4*NC] new list position of child
+    int* pidA = cntB + NC;                              // depth << 28 | index at that depth
+    int* pidB = pidA + NC;
+    int* cnt4 = pidB + NC;                              // [4*NC] keys per child of node p
+    int* cnt4n = cnt4 + 4 * NC;                         // [4*NC] the same for the NEXT generation
+    int* newpos4 = cnt4n + 4 * NC;                      // [4*NC] new list position of child
     int* tailpos = newpos4 + 4 * NC;                    // [NC]  new position of unprocessed node
     int* rnk = tailpos + NC;                            // [NC]  processing rank or -1
     int* ord = rnk + NC;                                // [NC]  node at processing rank r
@@ -103,105 +218,211 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P)
     int* tmp = cinc + NC;                               // [NC]
     int* ecnt = tmp + NC;                               // [NC]  sizes of expandable nodes
     unsigned long long* best = reinterpret_cast<unsigned long long*>(newpos4);    // [NC] (epilogue)
+    int* cellOff = qt_lds;                              // [cells + 1] (prologue only)
 
-    // ---- prologue: compact K2's per-cell slots into dense key records -----------------------
+    const int N = L.quota;
+    const int regionH = L.h - 2 * PG_EDGE;              // maxY - minY
+    const int nIni = L.nIni;
+    const float hX = L.hX;
+    const int D = qt_pyr_depth(nIni);
+    const int pyrTotal = qt_pyr_off(nIni, D + 1);
+
+    // ---- prologue: K2's per-cell slots -> dense key records + leaf histogram ------------------
     int ncand;
     {
         const int ncells = L.nCols * L.nRows;
         const int32_t* cc = P.cellCount + (int64_t)frame * P.totalCells + L.cellBase;
         const uint32_t* slots = P.cellCand + (int64_t)frame * P.cellCandFrame + L.cellCandOff;
-        int* cellOff = P.nodeScratch + (int64_t)frame * P.nodeFrame + L.nodeOff;    // [ncells]
-        for (int i = tid; i < ncells; i += QT_T) cellOff[i] = cc[i];
+        for (int i = tid; i < ncells; i += QT_T) cellOff[i] = min(cc[i], L.cellCap);
+        for (int i = tid; i < pyrTotal; i += QT_T) pyr[i] = 0;
         __syncthreads();
         ncand = qt_scan_excl(cellOff, ncells, sh);
-        if (ncand > L.candCap) ncand = L.candCap;               // cannot happen (capacity is exact)
-        // one thread per cell (a cell holds ~10 records); loads of a cell are issued 4 at a time.
-        // (A wave-per-cell loop serialised ncells/16 dependent global round trips: it WAS the kernel.)
-        for (int c = tid; c < ncells; c += QT_T) {
-            const int n = min(cc[c], L.cellCap), off = cellOff[c];
-            const uint32_t* src = slots + (int64_t)c * L.cellCap;
-            for (int j = 0; j < n; j += 4) {
-                uint32_t v[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) v[u] = (j + u < n) ? src[j + u] : 0u;
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                    if (j + u < n && off + j + u < L.candCap) keys[off + j + u] = make_uint2(v[u], 0u);
-            }
-        }
-        if (tid == 0) P.candCount[frame * PG_MAXL + l] = ncand;
+        if (tid == 0) { cellOff[ncells] = ncand; P.candCount[frame * PG_MAXL + l] = ncand; }
         __syncthreads();
+        if (ncand <= 0) { if (tid == 0) *kpc = 0; return; }
+        QT_TS(8);
+        // One thread per OUTPUT record (cells hold 0..cellCap records, ~10 on average but 100+ in
+        // dense texture: any per-cell mapping leaves one wave with the long cells).  Record i
+        // belongs to the last cell whose offset is <= i: a binary search in LDS whose first steps
+        // are wave-uniform (broadcast reads); four searches per thread run interleaved.
+        int* hD = pyr + qt_pyr_off(nIni, D);
+        int steps = 0;
+        while ((1 << steps) < ncells) steps++;
+        for (int b0 = 0; b0 < ncand; b0 += 4 * QT_T) {
+            int lo[4], hi[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { lo[u] = 0; hi[u] = ncells - 1; }
+            for (int st = 0; st < steps; st++) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int mid = (lo[u] + hi[u] + 1) >> 1;
+                    const bool le = cellOff[mid] <= b0 + u * QT_T + tid;
+                    lo[u] = le ? mid : lo[u];
+                    hi[u] = le ? hi[u] : mid - 1;
+                }
+            }
+            uint32_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = b0 + u * QT_T + tid;
+                v[u] = (i < ncand) ? slots[(int64_t)lo[u] * L.cellCap + (i - cellOff[lo[u]])] : 0u;
+            }
+            QT_SETTLE4(v[0], v[1], v[2], v[3]);
+            // (all records are finished and stored before the first counting call: control flow
+            //  between a store and the next use of a loaded value costs a full s_waitcnt vmcnt(0))
+            int leaf[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = b0 + u * QT_T + tid;
+                leaf[u] = 0;
+                if (i < ncand) {
+                    leaf[u] = qt_leaf(v[u], hX, nIni, regionH, D);
+                    keys[i] = make_uint2(v[u], (uint32_t)leaf[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) qt_wave_count(hD, leaf[u], b0 + u * QT_T + tid < ncand);
+        }
+        __syncthreads();
+        QT_TS(9);
+        // counts of the shallower descendants
+        for (int d = D - 1; d >= 0; d--) {
+            const int* src = pyr + qt_pyr_off(nIni, d + 1);
+            int* dst = pyr + qt_pyr_off(nIni, d);
+            const int cnt = nIni << (2 * d);
+            for (int j = tid; j < cnt; j += QT_T) dst[j] = src[4 * j] + src[4 * j + 1] + src[4 * j + 2] + src[4 * j + 3];
+            __syncthreads();
+        }
     }
-    if (ncand <= 0) { if (tid == 0) *kpc = 0; return; }
-
-    const int N = L.quota;
-    const int regionH = L.h - 2 * PG_EDGE;              // maxY - minY
-    int size;
+    QT_TS(0); QT_CNT(10, ncand);
 
     // ---- initial nodes (:543-585) ------------------------------------------------------
+    int size;
     {
-        const int nIni = L.nIni;
-        const float hX = L.hX;
-        int* rootCnt = cnt4;
-        for (int i = tid; i < nIni; i += QT_T) rootCnt[i] = 0;
-        __syncthreads();
-        for (int i = tid; i < ncand; i += QT_T) {
-            const int x = keys[i].x & 0xFFF;
-            int r = (int)__fdiv_rn((float)x, hX);       // vpIniNodes[kp.pt.x/hX]  (:569)
-            r = min(max(r, 0), nIni - 1);
-            keys[i].y = (uint32_t)r;
-            atomicAdd(&rootCnt[r], 1);
-        }
-        __syncthreads();
         if (tid == 0) {
             int pos = 0;
             for (int i = 0; i < nIni; i++) {
-                if (rootCnt[i] > 0) {
+                if (pyr[i] > 0) {
                     bndA[pos] = make_int4((int)__fmul_rn(hX, (float)i), 0,
                                           (int)__fmul_rn(hX, (float)(i + 1)), regionH);
-                    cntA[pos] = rootCnt[i];
-                    tailpos[i] = pos++;
-                } else tailpos[i] = -1;
+                    cntA[pos] = pyr[i];
+                    pidA[pos] = i;
+                    pos++;
+                }
             }
             sh[QT_W + 1] = pos;
         }
         __syncthreads();
         size = sh[QT_W + 1];
-        __syncthreads();
-        for (int i = tid; i < 4 * size; i += QT_T) cnt4[i] = 0;
-        __syncthreads();
-        // move keys to the compacted root list and count quadrants for generation 1
-        for (int i = tid; i < ncand; i += QT_T) {
-            const uint2 k = keys[i];
-            const int pos = tailpos[k.y];
-            uint32_t rec = (uint32_t)pos;
-            if (cntA[pos] > 1) {
-                const int q = qt_quadrant(bndA[pos], k.x);
-                atomicAdd(&cnt4[pos * 4 + q], 1);
-                rec |= (uint32_t)q << 28;
-            }
-            keys[i].y = rec;
-        }
+        if (D >= 1)
+            for (int i = tid; i < 4 * size; i += QT_T) cnt4[i] = pyr[nIni + 4 * pidA[i >> 2] + (i & 3)];
         __syncthreads();
     }
+    QT_TS(1);
 
     // ---- generations (:594-739) ---------------------------------------------------------
-    int sorted_mode = 0;
-    bool last = false;
+    // Generation g splits depth g-1 nodes.  While g <= D the child counts come from the pyramid
+    // and no pass over the keys is needed ("pyramid mode"); deeper trees continue with one key
+    // pass per generation (keys carry node position | quadrant << 28).
+    int sorted_mode = 0, gen = 1;
+    bool last = false, pyrMode = true;
     while (!last) {
-        const int n = size, prevSize = size;
-        // processing order
-        for (int p = tid; p < n; p += QT_T) rnk[p] = (cntA[p] > 1) ? 1 : 0;
-        __syncthreads();
-        const int m = qt_scan_excl(rnk, n, sh);          // rnk[p] = list-order rank among expandable
-        for (int p = tid; p < n; p += QT_T) {
-            if (cntA[p] > 1) { tmp[rnk[p]] = p; ecnt[rnk[p]] = cntA[p]; }
-            else rnk[p] = -1;
+        if (pyrMode && gen > D) {
+            // leave pyramid mode: node map, then every key finds its node and is counted into its quadrant
+            for (int i = tid; i < pyrTotal; i += QT_T) pyr[i] = -1;
+            for (int i = tid; i < 4 * size; i += QT_T) cnt4[i] = 0;
+            __syncthreads();
+            for (int p = tid; p < size; p += QT_T) {
+                const int pid = pidA[p];
+                pyr[qt_pyr_off(nIni, pid >> 28) + (pid & QT_POS_MASK)] = p;
+            }
+            __syncthreads();
+            for (int i0 = 0; i0 < ncand; i0 += QT_T) {
+                const int i = i0 + tid;
+                bool act = i < ncand;
+                int tgt = 0;
+                if (act) {
+                    const uint2 k = keys[i];
+                    const int pos = qt_walk(pyr, (int)k.y, nIni, D);
+                    uint32_t rec = (uint32_t)pos;
+                    act = cntA[pos] > 1;
+                    if (act) {
+                        const int q = qt_quadrant(bndA[pos], k.x);
+                        tgt = pos * 4 + q;
+                        rec |= (uint32_t)q << 28;
+                    }
+                    keys[i].y = rec;
+                }
+                qt_wave_count(cnt4, tgt, act);
+            }
+            __syncthreads();
+            pyrMode = false;
         }
-        __syncthreads();
+        const int n = size, prevSize = size;
+        const bool fill = pyrMode && gen + 1 <= D;       // children get their counts from the pyramid
+        const int fillOff = qt_pyr_off(nIni, min(gen + 1, D));
+        int jstar = 0;
         if (!sorted_mode) {
-            for (int r = tid; r < m; r += QT_T) ord[r] = tmp[r];
+            // ---- breadth-first generation (:606-665): processing order == list order and every
+            // expandable node is split, so ONE fused scan places all children and all survivors.
+            const int per = (n + QT_T - 1) / QT_T;
+            const int pb = tid * per, pe = min(pb + per, n);
+            int se = 0, sc = 0, sx = 0;
+            for (int p = pb; p < pe; p++)
+                if (cntA[p] > 1) {
+                    const int c0 = cnt4[4 * p], c1 = cnt4[4 * p + 1], c2 = cnt4[4 * p + 2], c3 = cnt4[4 * p + 3];
+                    se++; sc += (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0); sx += (c0 > 1) + (c1 > 1) + (c2 > 1) + (c3 > 1);
+                }
+            int tot[3];
+            qt_scan3_threads(se, sc, sx, tot, sh);           // se, sc = exclusive prefixes of this thread's chunk
+            const int m = tot[0], Ctot = tot[1], nToExpand = tot[2];
+            size = Ctot + (n - m);
+            if (size > NC) { if (tid == 0) atomicExch(P.status, PGORB_E_OVERFLOW); size = min(size, NC); last = true; }
+            if (size >= N || size == prevSize) last = true;                        // :669
+            else if (size + 3 * nToExpand > N) sorted_mode = 1;                    // :673
+            int re = se, ce = sc;
+            for (int p = pb; p < pe; p++) {
+                if (cntA[p] > 1) {
+                    const int4 b = bndA[p];
+                    const int midX = b.x + ((b.z - b.x + 1) >> 1);
+                    const int midY = b.y + ((b.w - b.y + 1) >> 1);
+                    const int cq[4] = {cnt4[4 * p], cnt4[4 * p + 1], cnt4[4 * p + 2], cnt4[4 * p + 3]};
+                    const int c = (cq[0] > 0) + (cq[1] > 0) + (cq[2] > 0) + (cq[3] > 0);
+                    const int cidx = (int)(((uint32_t)pidA[p] & (QT_POS_MASK >> 2)) * 4u);
+                    int pos = Ctot - (ce + c);               // children of later parents are in front (:623-660)
+                    if (pos >= 0 && pos + c <= NC) {
+#pragma unroll
+                        for (int q = 3; q >= 0; q--) {       // push_front order n1..n4 => n4 first
+                            if (cq[q] <= 0) continue;
+                            bndB[pos] = make_int4((q & 1) ? midX : b.x, (q & 2) ? midY : b.y,
+                                                  (q & 1) ? b.z : midX, (q & 2) ? b.w : midY);
+                            cntB[pos] = cq[q];
+                            pidB[pos] = (int)(((uint32_t)gen << 28) | (uint32_t)(cidx + q));
+                            if (fill && cq[q] > 1) {
+                                const int* h = pyr + fillOff + (cidx + q) * 4;
+                                cnt4n[4 * pos] = h[0]; cnt4n[4 * pos + 1] = h[1]; cnt4n[4 * pos + 2] = h[2]; cnt4n[4 * pos + 3] = h[3];
+                            }
+                            newpos4[4 * p + q] = pos++;
+                        }
+                    }
+                    rnk[p] = 0; re++; ce += c;
+                } else {
+                    const int pos = min(Ctot + (p - re), NC - 1);   // single-key nodes keep their order behind
+                    bndB[pos] = bndA[p]; cntB[pos] = cntA[p]; pidB[pos] = pidA[p];
+                    tailpos[p] = pos; rnk[p] = -1;
+                }
+            }
+            QT_CNT(11, 1);
         } else {
+            // ---- "largest first" generation (:676-737) ----
+            for (int p = tid; p < n; p += QT_T) rnk[p] = (cntA[p] > 1) ? 1 : 0;
+            __syncthreads();
+            const int m = qt_scan_excl(rnk, n, sh);          // rnk[p] = list-order rank among expandable
+            for (int p = tid; p < n; p += QT_T) {
+                if (cntA[p] > 1) { tmp[rnk[p]] = p; ecnt[rnk[p]] = cntA[p]; }
+                else rnk[p] = -1;
+            }
+            __syncthreads();
             // descending size, ties: smaller list position first (see header)
             for (int i = tid; i < m; i += QT_T) {
                 const int ci = ecnt[i];
@@ -213,133 +434,182 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P)
                 ord[rank] = tmp[i];
                 rnk[tmp[i]] = rank;
             }
-        }
-        __syncthreads();
-        // inclusive sum of non-empty child counts in processing order
-        for (int r = tid; r < m; r += QT_T) {
-            const int p = ord[r];
-            cinc[r] = (cnt4[4 * p] > 0) + (cnt4[4 * p + 1] > 0) + (cnt4[4 * p + 2] > 0) + (cnt4[4 * p + 3] > 0);
-        }
-        __syncthreads();
-        qt_scan_excl(cinc, m, sh);                       // exclusive ...
-        for (int r = tid; r < m; r += QT_T) {            // ... -> inclusive
-            const int p = ord[r];
-            cinc[r] += (cnt4[4 * p] > 0) + (cnt4[4 * p + 1] > 0) + (cnt4[4 * p + 2] > 0) + (cnt4[4 * p + 3] > 0);
-        }
-        if (tid == 0) { sh[QT_W + 1] = m - 1; sh[QT_W + 2] = 0; }
-        __syncthreads();
-        if (sorted_mode) {                               // early break at N (:730)
+            __syncthreads();
+            // inclusive sum of non-empty child counts in processing order
             for (int r = tid; r < m; r += QT_T) {
+                const int p = ord[r];
+                cinc[r] = (cnt4[4 * p] > 0) + (cnt4[4 * p + 1] > 0) + (cnt4[4 * p + 2] > 0) + (cnt4[4 * p + 3] > 0);
+            }
+            __syncthreads();
+            qt_scan_excl(cinc, m, sh);                       // exclusive ...
+            for (int r = tid; r < m; r += QT_T) {            // ... -> inclusive
+                const int p = ord[r];
+                cinc[r] += (cnt4[4 * p] > 0) + (cnt4[4 * p + 1] > 0) + (cnt4[4 * p + 2] > 0) + (cnt4[4 * p + 3] > 0);
+            }
+            if (tid == 0) sh[QT_W + 1] = m - 1;
+            __syncthreads();
+            for (int r = tid; r < m; r += QT_T) {            // early break at N (:730)
                 const bool now = n + cinc[r] - (r + 1) >= N;
                 const bool before = (r > 0) && (n + cinc[r - 1] - r >= N);
                 if (now && !before) sh[QT_W + 1] = r;
             }
             __syncthreads();
-        }
-        const int jstar = sh[QT_W + 1];
-        const int Ctot = (m > 0) ? cinc[jstar] : 0;
-        // unprocessed nodes keep their relative order behind the new children
-        for (int p = tid; p < n; p += QT_T) tailpos[p] = (rnk[p] >= 0 && rnk[p] <= jstar) ? 0 : 1;
-        __syncthreads();
-        const int U = qt_scan_excl(tailpos, n, sh);
-        // write the new list
-        int myExpand = 0;
-        for (int p = tid; p < n; p += QT_T) {
-            const int r = rnk[p];
-            if (r >= 0 && r <= jstar) {
-                const int4 b = bndA[p];
-                const int midX = b.x + ((b.z - b.x + 1) >> 1);
-                const int midY = b.y + ((b.w - b.y + 1) >> 1);
-                const int c0 = cnt4[4 * p], c1 = cnt4[4 * p + 1], c2 = cnt4[4 * p + 2], c3 = cnt4[4 * p + 3];
-                int pos = Ctot - cinc[r];                // children of later-processed parents are in front
-                if (c3 > 0) { bndB[pos] = make_int4(midX, midY, b.z, b.w); cntB[pos] = c3; newpos4[4 * p + 3] = pos++; }
-                if (c2 > 0) { bndB[pos] = make_int4(b.x, midY, midX, b.w); cntB[pos] = c2; newpos4[4 * p + 2] = pos++; }
-                if (c1 > 0) { bndB[pos] = make_int4(midX, b.y, b.z, midY); cntB[pos] = c1; newpos4[4 * p + 1] = pos++; }
-                if (c0 > 0) { bndB[pos] = make_int4(b.x, b.y, midX, midY); cntB[pos] = c0; newpos4[4 * p] = pos++; }
-                myExpand += (c0 > 1) + (c1 > 1) + (c2 > 1) + (c3 > 1);
-            } else {
-                const int pos = Ctot + tailpos[p];
-                bndB[pos] = bndA[p]; cntB[pos] = cntA[p];
-                tailpos[p] = pos;
-            }
-        }
-        if (myExpand) atomicAdd(&sh[QT_W + 2], myExpand);
-        __syncthreads();
-        const int nToExpand = sh[QT_W + 2];
-        size = Ctot + U;
-        if (size > NC) { if (tid == 0) atomicExch(P.status, PGORB_E_OVERFLOW); size = NC; last = true; }
-        if (size >= N || size == prevSize) last = true;                    // :669 / :734
-        else if (!sorted_mode && size + 3 * nToExpand > N) sorted_mode = 1; // :673
-        // keys move to their new node; unless this was the last generation they are also
-        // counted into that node's quadrants (cnt4 of the next generation)
-        for (int i = tid; i < 4 * size; i += QT_T) cnt4[i] = 0;
-        __syncthreads();
-        // 4 keys per thread and step: the four independent global loads are in flight together
-        // (one key per step left this pass bound by L2 latency)
-        for (int i0 = tid; i0 < ncand; i0 += 4 * QT_T) {
-            uint2 kk[4];
+            jstar = sh[QT_W + 1];
+            const int Ctot = (m > 0) ? cinc[jstar] : 0;
+            // unprocessed nodes keep their relative order behind the new children
+            for (int p = tid; p < n; p += QT_T) tailpos[p] = (rnk[p] >= 0 && rnk[p] <= jstar) ? 0 : 1;
+            __syncthreads();
+            const int U = qt_scan_excl(tailpos, n, sh);
+            // write the new list
+            for (int p = tid; p < n; p += QT_T) {
+                const int r = rnk[p];
+                if (r >= 0 && r <= jstar) {
+                    const int4 b = bndA[p];
+                    const int midX = b.x + ((b.z - b.x + 1) >> 1);
+                    const int midY = b.y + ((b.w - b.y + 1) >> 1);
+                    const int cq[4] = {cnt4[4 * p], cnt4[4 * p + 1], cnt4[4 * p + 2], cnt4[4 * p + 3]};
+                    const int cidx = (int)(((uint32_t)pidA[p] & (QT_POS_MASK >> 2)) * 4u);
+                    int pos = Ctot - cinc[r];                // children of later-processed parents are in front
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const int i = i0 + u * QT_T; kk[u] = (i < ncand) ? keys[i] : make_uint2(0u, 0u); }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int i = i0 + u * QT_T;
-                if (i >= ncand) break;
-                const uint2 k = kk[u];
-                const int pos = k.y & QT_POS_MASK, q = k.y >> 28;
-                const int r = rnk[pos];
-                const int np = (r >= 0 && r <= jstar) ? newpos4[4 * pos + q] : tailpos[pos];
-                uint32_t rec = (uint32_t)np;
-                if (!last && cntB[np] > 1) {
-                    const int q2 = qt_quadrant(bndB[np], k.x);
-                    atomicAdd(&cnt4[np * 4 + q2], 1);
-                    rec |= (uint32_t)q2 << 28;
+                    for (int q = 3; q >= 0; q--) {
+                        if (cq[q] <= 0) continue;
+                        bndB[pos] = make_int4((q & 1) ? midX : b.x, (q & 2) ? midY : b.y,
+                                              (q & 1) ? b.z : midX, (q & 2) ? b.w : midY);
+                        cntB[pos] = cq[q];
+                        pidB[pos] = (int)(((uint32_t)gen << 28) | (uint32_t)(cidx + q));
+                        if (fill && cq[q] > 1) {
+                            const int* h = pyr + fillOff + (cidx + q) * 4;
+                            cnt4n[4 * pos] = h[0]; cnt4n[4 * pos + 1] = h[1]; cnt4n[4 * pos + 2] = h[2]; cnt4n[4 * pos + 3] = h[3];
+                        }
+                        newpos4[4 * p + q] = pos++;
+                    }
+                } else {
+                    const int pos = Ctot + tailpos[p];
+                    bndB[pos] = bndA[p]; cntB[pos] = cntA[p]; pidB[pos] = pidA[p];
+                    tailpos[p] = pos;
+                    if (fill && cntA[p] > 1) {               // not reached in this generation: counts carry over
+                        cnt4n[4 * pos] = cnt4[4 * p]; cnt4n[4 * pos + 1] = cnt4[4 * p + 1];
+                        cnt4n[4 * pos + 2] = cnt4[4 * p + 2]; cnt4n[4 * pos + 3] = cnt4[4 * p + 3];
+                    }
                 }
-                keys[i].y = rec;
+            }
+            size = Ctot + U;
+            if (size > NC) { if (tid == 0) atomicExch(P.status, PGORB_E_OVERFLOW); size = NC; last = true; }
+            if (size >= N || size == prevSize) last = true;                    // :734
+            QT_CNT(12, 1);
+        }
+        if (!pyrMode) {
+            // keys move to their new node; unless this was the last generation they are also
+            // counted into that node's quadrants for the next generation
+            for (int i = tid; i < 4 * size; i += QT_T) cnt4n[i] = 0;
+            __syncthreads();
+            // 4 keys per thread and step: the four independent global loads are in flight together
+            for (int b0 = 0; b0 < ncand; b0 += 4 * QT_T) {
+                uint2 kk[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int i = b0 + tid + u * QT_T; kk[u] = (i < ncand) ? keys[i] : make_uint2(0u, 0u); }
+        QT_SETTLE4(kk[0].x, kk[1].x, kk[2].x, kk[3].x); QT_SETTLE4(kk[0].y, kk[1].y, kk[2].y, kk[3].y);
+                int tgt[4];
+                bool act[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i = b0 + tid + u * QT_T;
+                    act[u] = i < ncand;
+                    tgt[u] = 0;
+                    if (act[u]) {
+                        const uint2 k = kk[u];
+                        const int pos = k.y & QT_POS_MASK, q = k.y >> 28;
+                        const int r = rnk[pos];
+                        const int np = (r >= 0 && r <= jstar) ? newpos4[4 * pos + q] : tailpos[pos];
+                        uint32_t rec = (uint32_t)np;
+                        act[u] = !last && cntB[np] > 1;
+                        if (act[u]) {
+                            const int q2 = qt_quadrant(bndB[np], k.x);
+                            tgt[u] = np * 4 + q2;
+                            rec |= (uint32_t)q2 << 28;
+                        }
+                        keys[i].y = rec;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) qt_wave_count(cnt4n, tgt[u], act[u]);
             }
         }
         __syncthreads();
-        { int4* t4 = bndA; bndA = bndB; bndB = t4; int* t1 = cntA; cntA = cntB; cntB = t1; }
+        QT_TS(2);
+        { int4* t4 = bndA; bndA = bndB; bndB = t4; int* t1 = cntA; cntA = cntB; cntB = t1;
+          t1 = cnt4; cnt4 = cnt4n; cnt4n = t1; t1 = pidA; pidA = pidB; pidB = t1; }
+        gen++;
     }
 
     // ---- best response per node, first in candidate order wins (:741-760) ---------------
+    // (best aliases newpos4: the generation loop ended with a barrier)
     for (int p = tid; p < size; p += QT_T) best[p] = 0ull;
+    int* leafPos = pyr + qt_pyr_off(nIni, D);             // depth-D descendant -> list position
+    if (pyrMode) {
+        for (int i = tid; i < pyrTotal; i += QT_T) pyr[i] = -1;
+        __syncthreads();
+        for (int p = tid; p < size; p += QT_T) {
+            const int pid = pidA[p];
+            pyr[qt_pyr_off(nIni, pid >> 28) + (pid & QT_POS_MASK)] = p;
+        }
+        __syncthreads();
+        for (int j = tid; j < (nIni << (2 * D)); j += QT_T) leafPos[j] = qt_walk(pyr, j, nIni, D);
+    }
     __syncthreads();
+    QT_TS(3);
+    // candidate order = (cell row, cell col, y, x); x / wCell by an exact reciprocal (x < 4096, wCell < 256)
     const int wCell = L.wCell, hCell = L.hCell, nCols = L.nCols;
-    for (int i0 = tid; i0 < ncand; i0 += 4 * QT_T) {
+    const uint32_t mW = ((1u << 20) + wCell - 1) / wCell, mH = ((1u << 20) + hCell - 1) / hCell;
+    for (int b0 = 0; b0 < ncand; b0 += 4 * QT_T) {
         uint2 kk[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const int i = i0 + u * QT_T; kk[u] = (i < ncand) ? keys[i] : make_uint2(0u, 0u); }
+        for (int u = 0; u < 4; u++) { const int i = b0 + tid + u * QT_T; kk[u] = (i < ncand) ? keys[i] : make_uint2(0u, 0u); }
+        QT_SETTLE4(kk[0].x, kk[1].x, kk[2].x, kk[3].x); QT_SETTLE4(kk[0].y, kk[1].y, kk[2].y, kk[3].y);
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            if (i0 + u * QT_T >= ncand) break;
+            const int i = b0 + tid + u * QT_T;
+            if (i >= ncand) break;
             const uint2 k = kk[u];
-            const int x = (k.x & 0xFFF) - 3, y = ((k.x >> 12) & 0xFFF) - 3;
-            const int cj = x / wCell, ci = y / hCell;
-            const uint32_t rank = (uint32_t)(((ci * nCols + cj) * hCell + (y - ci * hCell)) * wCell + (x - cj * wCell));
-            atomicMax(&best[k.y & QT_POS_MASK], ((unsigned long long)(k.x >> 24) << 32) | (0xFFFFFFFFu - rank));
+            const int pos = pyrMode ? leafPos[k.y] : (int)(k.y & QT_POS_MASK);
+            const uint32_t x = (k.x & 0xFFF) - 3, y = ((k.x >> 12) & 0xFFF) - 3;
+            const uint32_t cj = (x * mW) >> 20, ci = (y * mH) >> 20;
+            const uint32_t rank = ((ci * nCols + cj) * hCell + (y - ci * hCell)) * wCell + (x - cj * wCell);
+            atomicMax(&best[pos], ((unsigned long long)(k.x >> 24) << 32) | (0xFFFFFFFFu - rank));
         }
     }
     __syncthreads();
+    QT_TS(6);
     uint32_t* sel = P.sel + (int64_t)frame * P.selFrame + L.selOff;
     const int nsel = min(size, L.selCap);
     if (size > L.selCap && tid == 0) atomicExch(P.status, PGORB_E_OVERFLOW);
-    for (int i = tid; i < ncand; i += QT_T) {
-        const uint2 k = keys[i];
-        const int x = (k.x & 0xFFF) - 3, y = ((k.x >> 12) & 0xFFF) - 3;
-        const int cj = x / wCell, ci = y / hCell;
-        const uint32_t rank = (uint32_t)(((ci * nCols + cj) * hCell + (y - ci * hCell)) * wCell + (x - cj * wCell));
-        const unsigned long long key = ((unsigned long long)(k.x >> 24) << 32) | (0xFFFFFFFFu - rank);
-        const int pos = k.y & QT_POS_MASK;
-        if (pos < nsel && best[pos] == key) sel[pos] = k.x;
+    for (int b0 = 0; b0 < ncand; b0 += 4 * QT_T) {
+        uint2 kk[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int i = b0 + tid + u * QT_T; kk[u] = (i < ncand) ? keys[i] : make_uint2(0u, 0u); }
+        QT_SETTLE4(kk[0].x, kk[1].x, kk[2].x, kk[3].x); QT_SETTLE4(kk[0].y, kk[1].y, kk[2].y, kk[3].y);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (b0 + tid + u * QT_T >= ncand) break;
+            const uint2 k = kk[u];
+            const uint32_t x = (k.x & 0xFFF) - 3, y = ((k.x >> 12) & 0xFFF) - 3;
+            const uint32_t cj = (x * mW) >> 20, ci = (y * mH) >> 20;
+            const uint32_t rank = ((ci * nCols + cj) * hCell + (y - ci * hCell)) * wCell + (x - cj * wCell);
+            const unsigned long long key = ((unsigned long long)(k.x >> 24) << 32) | (0xFFFFFFFFu - rank);
+            const int pos = pyrMode ? leafPos[k.y] : (int)(k.y & QT_POS_MASK);
+            if (pos < nsel && best[pos] == key) sel[pos] = k.x;
+        }
     }
     if (tid == 0) *kpc = nsel;
+    QT_TS(7);
 }
 
 void pg_launch_quadtree(const PgPlan& P, int nframes, hipStream_t s)
 {
-    int ncMax = 0;
-    for (int l = 0; l < P.nlevels; l++) ncMax = max(ncMax, P.lvl[l].nodeCap);
-    const size_t lds = (size_t)ncMax * 24 * sizeof(int);
+    int need = 0;
+    for (int l = 0; l < P.nlevels; l++)
+        need = max(need, max(P.lvl[l].nodeCap * 30, P.lvl[l].nCols * P.lvl[l].nRows + 1));
+    const size_t lds = (size_t)need * sizeof(int);
     static size_t configured = 0;
     if (lds > configured) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree),

@@ -275,3 +275,48 @@ def test_noise_image_takes_the_chunked_fast_path(oracle):
     okp, odesc = oracle.OrbOracle(nf, 1.2, 8, 20, 7).extract(img)
     kp, desc = pg.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h)(img)
     assert len(okp) > 100 and kp.tobytes() == okp.tobytes() and np.array_equal(desc, odesc)
+
+
+def _clustered_frame(w, h, patch, grid):
+    """Flat frame with grid x grid textured patches: few candidates, packed tightly."""
+    img = np.full((h, w), 90, np.uint8)
+    tex = synth_scene(patch + grid, patch, patch)
+    for gy in range(grid):
+        for gx in range(grid):
+            y0 = 40 + gy * (h - 80 - patch) // max(grid - 1, 1) if grid > 1 else h // 3
+            x0 = 40 + gx * (w - 80 - patch) // max(grid - 1, 1) if grid > 1 else w // 2 + 17
+            img[y0:y0 + patch, x0:x0 + patch] = tex
+    return img
+
+
+@pytest.mark.parametrize("w,h,nf,patch,grid", [(960, 540, 1500, 120, 1), (1280, 720, 2000, 140, 2), (640, 480, 1000, 200, 1)])
+def test_clustered_corners_deep_quadtree(oracle, w, h, nf, patch, grid):
+    """Corners only inside small textured patches of a flat frame, fewer than the quota: every
+    node is split down to single keys, several of which share one depth-5 descendant of a root
+    (15 x 17 px at 960 x 540) -- deeper than the kernel's count pyramid, so it leaves pyramid
+    mode and continues with per-generation key passes (DistributeOctTree, ORBextractor.cc:594-739)."""
+    import pilotguru_amd as pg
+    img = _clustered_frame(w, h, patch, grid)
+    ora = oracle.OrbOracle(nf, 1.2, 8, 20, 7)
+    okp, odesc = ora.extract(img)
+    ext = pg.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    kp, desc = ext(img)
+    for l in range(8):
+        assert ext.debug_level_keypoints(0, l) == ora.level_keypoints(l), "quadtree count level %d" % l
+    assert len(okp) > 200 and kp.tobytes() == okp.tobytes() and np.array_equal(desc, odesc)
+    # pigeonhole: level-0 keypoints outnumber the depth-5 descendants the patches can touch
+    lvl0 = okp[okp["octave"] == 0]
+    leaf_w, leaf_h = w / (round(w / h) * 32.0), h / 32.0
+    assert len(lvl0) > grid * grid * (patch / leaf_w + 1) * (patch / leaf_h + 1)
+
+
+@pytest.mark.parametrize("w,h,nf", [(1600, 200, 800), (2000, 120, 600), (3000, 96, 500)])
+def test_many_roots_shallow_count_pyramid(oracle, w, h, nf):
+    """nIni = round(W/H) of 8 / 20 / 50+ roots: the count pyramid is only 4 / 3 / 2 levels deep
+    for these (LDS budget), so the switch to key passes happens in earlier generations."""
+    import pilotguru_amd as pg
+    img = synth_scene(77, w, h)
+    ora = oracle.OrbOracle(nf, 1.2, 2, 20, 7)
+    okp, odesc = ora.extract(img)
+    kp, desc = pg.ORBextractor(nf, 1.2, 2, 20, 7, max_width=w, max_height=h)(img)
+    assert len(okp) > 100 and kp.tobytes() == okp.tobytes() and np.array_equal(desc, odesc)
