@@ -123,6 +123,30 @@ __device__ __forceinline__ void pg_sincos_f(float angle, float* s_out, float* c_
 
 struct PgGauss7 { int k0, k1, k2, k3; };     // K[0]=K[6]=k0 ... K[3]=k3 (8-bit fixed point)
 
+typedef __attribute__((address_space(1))) const void* pg_gptr_t;
+typedef __attribute__((address_space(3))) void* pg_lptr_t;
+typedef unsigned short pg_us2 __attribute__((ext_vector_type(2)));
+
+// Column pass of the separable blur for ONE output pixel (Y, X) of the 37x37 blurred tile, from
+// the row-pass sums hT[row pair][column] = (row 2p | row 2p+1 << 16): rows Y .. Y+6 are three
+// packed pairs and a single, shifted by 16 bits when Y is odd.  FixedPtCastEx rounding (half
+// up) and the SSE2 tie rule of the reference build (tie -> even for x < (w & ~3)).
+__device__ __forceinline__ int pg_blur_at(const uint32_t* hT, int Y, int X, const PgGauss7& G,
+                                          pg_us2 K01, pg_us2 K23, pg_us2 K45, bool tieEven)
+{
+    const uint32_t* s = hT + (Y >> 1) * 40 + X;
+    const uint32_t p0 = s[0], p1 = s[40], p2 = s[80], p3 = s[120];
+    const uint32_t sh = (uint32_t)(Y & 1) << 4;
+    const uint32_t a0 = __builtin_amdgcn_alignbit(p1, p0, sh), a1 = __builtin_amdgcn_alignbit(p2, p1, sh),
+                   a2 = __builtin_amdgcn_alignbit(p3, p2, sh), last = (p3 >> sh) & 0xFFFFu;
+    uint32_t C = __builtin_amdgcn_udot2(__builtin_bit_cast(pg_us2, a0), K01, (uint32_t)G.k0 * last, false);
+    C = __builtin_amdgcn_udot2(__builtin_bit_cast(pg_us2, a1), K23, C, false);
+    C = __builtin_amdgcn_udot2(__builtin_bit_cast(pg_us2, a2), K45, C, false);
+    int v = (int)((C + 32768u) >> 16);
+    if (tieEven && (C & 0xFFFFu) == 0x8000u) v &= ~1;
+    return min(v, 255);
+}
+
 __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 G,
                                                   pgorb_keypoint* __restrict__ kps,
                                                   uint8_t* __restrict__ desc, int cap_per_frame,
@@ -130,7 +154,6 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
 {
     __shared__ __attribute__((aligned(16))) uint8_t raw[DW_N * DW_PITCH];       // 2064 B
     __shared__ __attribute__((aligned(16))) uint32_t hbuf[22 * DH_PITCH];       // 3520 B: [row pair][column]
-    uint8_t* blur = raw;          // the blurred tile (37 x 40 B) reuses the raw window once the row pass is done
 
     const int lane = threadIdx.x;
     const int frame = blockIdx.y;
@@ -158,15 +181,18 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
 
     // ---- stage the raw 43x43 window: window column 0 lands on an LDS dword boundary --------
     const int x0 = x - DW_R, y0 = y - DW_R;
-    if (x0 >= 0 && y0 >= 0 && x0 + 52 <= w && y + DW_R < h) {   // 12 dwords + 1 stay inside the row
-        const int xa = x0 & ~3;
-        const uint32_t sh = (uint32_t)(x0 & 3);
-        const int lq = lane % 12, lr = lane / 12;               // 12 dwords x 5 rows per step
-        if (lr < 5)
-            for (int r = lr; r < DW_N; r += 5) {
-                const uint2 g = *reinterpret_cast<const uint2*>(img + (int64_t)(y0 + r) * L.pitch + xa + 4 * lq);
-                *reinterpret_cast<uint32_t*>(raw + r * DW_PITCH + 4 * lq) = __builtin_amdgcn_alignbyte(g.y, g.x, sh);
-            }
+    if (x0 >= 0 && y0 >= 0 && x0 + DW_PITCH <= w && y + DW_R < h) {   // 48 bytes stay inside the row
+        // LDS-DMA, 16 B per lane, byte-unaligned global addresses (tools/ubench/glds_unaligned.hip):
+        // 3 lanes per 48-byte row, 21 rows per instruction
+        const int lr = lane / 3, lq = lane - 3 * lr;
+        const uint8_t* g = img + (int64_t)(y0 + lr) * L.pitch + x0 + 16 * lq;
+        if (lr < 21) {
+            __builtin_amdgcn_global_load_lds((pg_gptr_t)g, (pg_lptr_t)raw, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((pg_gptr_t)(g + 21 * (int64_t)L.pitch), (pg_lptr_t)(raw + 21 * DW_PITCH), 16, 0, 0);
+            if (lr < 1)
+                __builtin_amdgcn_global_load_lds((pg_gptr_t)(g + 42 * (int64_t)L.pitch), (pg_lptr_t)(raw + 42 * DW_PITCH), 16, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0);
     } else {                                   // BORDER_REFLECT_101 (:1085)
         for (int i = lane; i < DW_N * DW_PITCH; i += 64) {
             const int r = i / DW_PITCH, c = i - r * DW_PITCH;
@@ -221,55 +247,13 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
         *reinterpret_cast<uint4*>(hT + rp * DH_PITCH + 4 * q) = st;
     }
     __syncthreads();
-    // column pass: a lane owns 2 adjacent columns and one of three row segments that start on an
-    // even row (0..13, 14..25, 26..36); per pair of output rows it slides one packed row pair in.
-    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-    const us2 K01 = __builtin_bit_cast(us2, (uint32_t)G.k0 | ((uint32_t)G.k1 << 16));
-    const us2 K23 = __builtin_bit_cast(us2, (uint32_t)G.k2 | ((uint32_t)G.k3 << 16));
-    const us2 K45 = __builtin_bit_cast(us2, (uint32_t)G.k2 | ((uint32_t)G.k1 << 16));
+    // column pass: on demand.  Only the 512 rotated tap positions of the 37x37 blurred tile are
+    // ever read, so each lane blurs its own 8 taps from the row-pass sums (4 LDS dwords, 3
+    // v_dot2_u32_u16 each) instead of the wave producing all 1369 pixels.
+    const pg_us2 K01 = __builtin_bit_cast(pg_us2, (uint32_t)G.k0 | ((uint32_t)G.k1 << 16));
+    const pg_us2 K23 = __builtin_bit_cast(pg_us2, (uint32_t)G.k2 | ((uint32_t)G.k3 << 16));
+    const pg_us2 K45 = __builtin_bit_cast(pg_us2, (uint32_t)G.k2 | ((uint32_t)G.k1 << 16));
     const int wvec = w & ~3;
-    {
-        const int cp = lane % 19, sg = lane / 19;                 // 19 column pairs x 3 segments
-        if (sg < 3) {
-            const int rbeg = sg == 0 ? 0 : (sg == 1 ? 14 : 26), rend = sg == 0 ? 14 : (sg == 1 ? 26 : DH_N);
-            const uint2* s = reinterpret_cast<const uint2*>(hT + (rbeg >> 1) * DH_PITCH) + cp;     // columns 2cp, 2cp+1
-            uint2 P0 = s[0], P1 = s[DH_PITCH / 2], P2 = s[2 * (DH_PITCH / 2)];
-            const int pmax = 21 - (rbeg >> 1);                     // last existing row pair, relative
-#pragma unroll
-            for (int j = 0; j < 7; j++) {
-                const uint2 P3 = s[min(j + 3, pmax) * (DH_PITCH / 2)];
-                const int ye = rbeg + 2 * j;
-                if (ye < rend) {
-                    uint32_t outE = 0, outO = 0;
-#pragma unroll
-                    for (int hf = 0; hf < 2; hf++) {
-                        const uint32_t p0 = hf ? P0.y : P0.x, p1 = hf ? P1.y : P1.x, p2 = hf ? P2.y : P2.x, p3 = hf ? P3.y : P3.x;
-                        const int xabs = x - 18 + 2 * cp + hf;
-                        // even output row: rows (y, y+1), (y+2, y+3), (y+4, y+5), y+6
-                        uint32_t C = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, p0), K01, (uint32_t)G.k0 * (p3 & 0xFFFFu), false);
-                        C = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, p1), K23, C, false);
-                        C = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, p2), K45, C, false);
-                        int v = (int)((C + 32768u) >> 16);                 // FixedPtCastEx: half up
-                        if (P.tieMode == 0 && (C & 0xFFFFu) == 0x8000u && xabs < wvec) v &= ~1;   // SSE2: tie -> even
-                        outE |= (uint32_t)min(v, 255) << (8 * hf);
-                        // odd output row: rows (y+1, y+2), (y+3, y+4), (y+5, y+6), y+7
-                        const uint32_t a0 = __builtin_amdgcn_alignbit(p1, p0, 16), a1 = __builtin_amdgcn_alignbit(p2, p1, 16),
-                                       a2 = __builtin_amdgcn_alignbit(p3, p2, 16);
-                        uint32_t Co = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a0), K01, (uint32_t)G.k0 * (p3 >> 16), false);
-                        Co = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a1), K23, Co, false);
-                        Co = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a2), K45, Co, false);
-                        int vo = (int)((Co + 32768u) >> 16);
-                        if (P.tieMode == 0 && (Co & 0xFFFFu) == 0x8000u && xabs < wvec) vo &= ~1;
-                        outO |= (uint32_t)min(vo, 255) << (8 * hf);
-                    }
-                    *reinterpret_cast<uint16_t*>(blur + ye * DB_PITCH + 2 * cp) = (uint16_t)outE;
-                    if (ye + 1 < rend) *reinterpret_cast<uint16_t*>(blur + (ye + 1) * DB_PITCH + 2 * cp) = (uint16_t)outO;
-                }
-                P0 = P1; P1 = P2; P2 = P3;
-            }
-        }
-    }
-    __syncthreads();
 
     // ---- rBRIEF-256 (:107-147) ------------------------------------------------------------
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
@@ -284,8 +268,8 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
         const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(px0, a), __fmul_rn(py0, b)));
         const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1, b), __fmul_rn(py1, a)));
         const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(px1, a), __fmul_rn(py1, b)));
-        const int t0 = blur[(18 + r0) * DB_PITCH + 18 + c0];
-        const int t1 = blur[(18 + r1) * DB_PITCH + 18 + c1];
+        const int t0 = pg_blur_at(hT, 18 + r0, 18 + c0, G, K01, K23, K45, P.tieMode == 0 && x + c0 < wvec);
+        const int t1 = pg_blur_at(hT, 18 + r1, 18 + c1, G, K01, K23, K45, P.tieMode == 0 && x + c1 < wvec);
         bits[r] = __ballot(t0 < t1);
     }
 

@@ -85,42 +85,61 @@ __device__ __forceinline__ int wave_prefix(unsigned long long m)
 #define FAST_LIST_CAP 768          // compacted candidates held in LDS (u16 each)
 
 // (2) necessary test + compaction of interior rows [rowBeg, rowEnd).  Each lane tests one quad
-// per step and keeps the 4 result bits of every step in a 64-bit register; ONE wave prefix sum
-// at the end turns the per-lane popcounts into list offsets (the list order is irrelevant: NMS
-// works on the score map).  Returns the list length, or -1 when the list would overflow (the
-// caller then takes the chunked slow path).
+// per step.  A pixel can only be a corner at threshold t if both opposite ring pairs (0,8) and
+// (4,12) hold a pixel darker than v-t, or both a pixel brighter than v+t.  The test runs on
+// TWO pixels per 32-bit operation with plain add/sub/and/or (the only VALU ops that issue at
+// full rate on gfx950; byte min/max via SDWA or VOP3 cost ~1.7x each): pixels are spread into
+// 16-bit fields (even / odd bytes of a dword), and for a field
+//     0x8000 + v - t - 1 - r   has bit 15 set  <=>  r < v - t        (darker)
+//     0x8000 + r - v - t - 1   has bit 15 set  <=>  r > v + t        (brighter)
+// with no borrow or carry between fields (|v - r| + t + 1 < 0x8000).
+// The 4 result bits of a step are kept in a 64-bit register (step s: bits 14-2s, 15-2s, 30-2s,
+// 31-2s of word s/8 = pixels 0,1,2,3); ONE wave prefix sum at the end turns the per-lane
+// popcounts into list offsets (list order is irrelevant: NMS works on the score map).  Returns
+// the list length, or -1 when the list would overflow (the caller then takes the chunked path).
 template <int QW>      // quads per row handled by consecutive lanes: 8 (IW <= 32) or 16 (IW <= 64)
 __device__ __forceinline__ int quick_pass(const uint8_t* tile, int TP, int IW, int rowBeg, int rowEnd,
                                           int t, uint16_t* list, int lane)
 {
     const int lq = lane & (QW - 1), lr = lane / QW;
     const int NQ = (IW + 3) >> 2;
-    unsigned long long bits = 0ull;                     // step s -> bits 4s .. 4s+3
+    const uint32_t M = 0x00FF00FFu, K15 = 0x80008000u;
+    const uint32_t Kd = (uint32_t)(0x8000 - t - 1) * 0x00010001u;
+    // columns of this quad inside the interior, in result-bit layout
+    uint32_t colMask = 0;
+    if (4 * lq + 0 < IW) colMask |= 1u << 14;
+    if (4 * lq + 1 < IW) colMask |= 1u << 15;
+    if (4 * lq + 2 < IW) colMask |= 1u << 30;
+    if (4 * lq + 3 < IW) colMask |= 1u << 31;
+    uint32_t acc[2] = {0u, 0u};
     int step = 0;
     for (int row0 = rowBeg; row0 < rowEnd; row0 += 64 / QW, step++) {
         const int iy = row0 + lr;
-        unsigned pass = 0;
+        uint32_t m = 0;
         if (iy < rowEnd && lq < NQ) {
             const uint32_t* rc = reinterpret_cast<const uint32_t*>(tile + (iy + 3) * TP) + 1 + lq;
             const uint32_t* ru = reinterpret_cast<const uint32_t*>(tile + iy * TP) + 1 + lq;
             const uint32_t* rd = reinterpret_cast<const uint32_t*>(tile + (iy + 6) * TP) + 1 + lq;
             const uint32_t C = rc[0], Lw = rc[-1], Rw = rc[1], U = ru[0], D = rd[0];
-            const uint32_t L3 = __builtin_amdgcn_alignbyte(C, Lw, 1);     // pixels x-3 .. x
-            const uint32_t R3 = __builtin_amdgcn_alignbyte(Rw, C, 3);     // pixels x+3 .. x+6
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int v = (C >> (8 * i)) & 0xFF;
-                const int r0 = (D >> (8 * i)) & 0xFF, r8 = (U >> (8 * i)) & 0xFF;
-                const int r4 = (R3 >> (8 * i)) & 0xFF, r12 = (L3 >> (8 * i)) & 0xFF;
-                // darker: both pairs hold a pixel < v-t  <=>  max(min(r0,r8), min(r4,r12)) + t < v
-                const int dk = max(min(r0, r8), min(r4, r12)) + t;
-                const int br = min(max(r0, r8), max(r4, r12)) - t;
-                if ((dk < v || br > v) && 4 * lq + i < IW) pass |= 1u << i;
-            }
+            const uint32_t Ce = C & M, Co = (C >> 8) & M;            // pixels (0,2) / (1,3)
+            const uint32_t Ue = U & M, Uo = (U >> 8) & M;            // ring 8 (3 rows up)
+            const uint32_t De = D & M, Do = (D >> 8) & M;            // ring 0 (3 rows down)
+            const uint32_t Le = Lw & M, Lo = (Lw >> 8) & M;          // pixels (-4,-2) / (-3,-1)
+            const uint32_t Re = Rw & M, Ro = (Rw >> 8) & M;          // pixels (4,6) / (5,7)
+            // ring 12 (x-3) and ring 4 (x+3) of the even and odd pixels
+            const uint32_t W12e = Lo, W4o = Re;
+            const uint32_t W12o = __builtin_amdgcn_alignbit(Ce, Le, 16);    // pixels (-2, 0)
+            const uint32_t W4e = __builtin_amdgcn_alignbit(Ro, Co, 16);     // pixels (3, 5)
+            const uint32_t Ae = Ce + Kd, Be = Kd - Ce, Ao = Co + Kd, Bo = Kd - Co;
+            const uint32_t darkE = ((Ae - De) | (Ae - Ue)) & ((Ae - W4e) | (Ae - W12e));
+            const uint32_t brightE = ((De + Be) | (Ue + Be)) & ((W4e + Be) | (W12e + Be));
+            const uint32_t darkO = ((Ao - Do) | (Ao - Uo)) & ((Ao - W4o) | (Ao - W12o));
+            const uint32_t brightO = ((Do + Bo) | (Uo + Bo)) & ((W4o + Bo) | (W12o + Bo));
+            m = ((((darkE | brightE) & K15) >> 1) | ((darkO | brightO) & K15)) & colMask;
         }
-        bits |= (unsigned long long)pass << (4 * step);
+        acc[step >> 3] |= m >> (2 * (step & 7));
     }
-    const int cnt = __popcll(bits);
+    const int cnt = __popc(acc[0]) + __popc(acc[1]);
     int incl = cnt;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -130,11 +149,16 @@ __device__ __forceinline__ int quick_pass(const uint8_t* tile, int TP, int IW, i
     const int nlist = __shfl(incl, 63);
     if (nlist > FAST_LIST_CAP) return -1;
     int off = incl - cnt;
-    while (bits) {
-        const int bpos = __ffsll((long long)bits) - 1;
-        bits &= bits - 1;
-        const int iy = rowBeg + (bpos >> 2) * (64 / QW) + lr;
-        list[off++] = (uint16_t)((iy << 8) | (4 * lq + (bpos & 3)));
+#pragma unroll
+    for (int wsel = 0; wsel < 2; wsel++) {
+        uint32_t bits = acc[wsel];
+        while (bits) {
+            const int bpos = __ffs((int)bits) - 1;
+            bits &= bits - 1;
+            const int st = wsel * 8 + 7 - ((bpos & 15) >> 1);
+            const int iy = rowBeg + st * (64 / QW) + lr;
+            list[off++] = (uint16_t)((iy << 8) | (4 * lq + ((bpos >> 4) << 1) + (bpos & 1)));
+        }
     }
     return nlist;
 }
@@ -202,8 +226,12 @@ __device__ __noinline__ int fast_pass_chunked(const uint8_t* tile, int TP, uint8
     return done;
 }
 
+typedef __attribute__((address_space(1))) const void* pg_gptr_t;
+typedef __attribute__((address_space(3))) void* pg_lptr_t;
+
 __global__ __launch_bounds__(64, 8) void k_fast_cells(const PgPlan P, int TP, int tileRows,
-                                                       int mapPitch, int mapRows, int cellsPerXcd)
+                                                       int mapPitch, int mapRows, int cellsPerXcd,
+                                                       int chunkInv)
 {
     const int lane = threadIdx.x;
     const int frame = blockIdx.y;
@@ -232,45 +260,27 @@ __global__ __launch_bounds__(64, 8) void k_fast_cells(const PgPlan P, int TP, in
     uint8_t* smap = tile + tileRows * TP;                          // [mapRows][mapPitch], 1-px zero rim
     uint16_t* list = reinterpret_cast<uint16_t*>(smap + mapRows * mapPitch);   // [FAST_LIST_CAP]
 
-    // (1) stage the window.  LDS dword j of a row holds window columns 4j-1 .. 4j+2.
-    // All global loads are issued before anything waits on them (the score map is zeroed in
-    // their shadow); lane (lr = lane>>4, lq = lane&15) owns dword lq of rows lr, lr+4, ...
+    // (1) stage the window with LDS-DMA (global_load_lds, 16 B per lane): no VGPR round trip, no
+    // alignment fix-up -- the per-lane GLOBAL address may be byte-unaligned (measured,
+    // tools/ubench/glds_unaligned.hip), the LDS side is wave base + lane * 16, i.e. TP/16 lanes
+    // per row and 64/(TP/16) rows per instruction.  LDS byte 0 of a row is global x = iniX - 1, so
+    // dword j of a row holds window columns 4j-1 .. 4j+2 and interior quads are dword aligned.
+    // Rows are read TP bytes wide: past the window that is the neighbouring cell / next row of the
+    // level, always inside the level (the window ends >= 16 rows above the level's last row).
     const uint8_t* img = L.img + (int64_t)frame * L.fstride;
-    const int gx0 = iniX - 1;                       // global x of LDS byte 0
-    const int ga = gx0 & ~3, sh = gx0 & 3;
-    const int ndw = (W + 1 + 3) >> 2;               // dwords covering bytes 0 .. W
     {
-        const int lq = lane & 15, lr = lane >> 4;       // 16 dwords x 4 rows per step
-        const uint8_t* grow = img + (int64_t)(iniY + lr) * L.pitch + ga;
-        uint8_t* trow = tile + lr * TP;
-        if (H <= 48 && ndw <= 16) {
-            uint2 pre[12];
-            const bool act = lq < ndw;
-#pragma unroll
-            for (int k = 0; k < 12; k++) {
-                const int r = lr + 4 * k;
-                pre[k] = (act && r < H) ? *reinterpret_cast<const uint2*>(grow + (int64_t)(4 * k) * L.pitch + 4 * lq)
-                                        : make_uint2(0u, 0u);
-            }
-            for (int i = lane; i < (mapRows * mapPitch) >> 2; i += 64)
-                reinterpret_cast<uint32_t*>(smap)[i] = 0;
-#pragma unroll
-            for (int k = 0; k < 12; k++) {
-                const int r = lr + 4 * k;
-                if (act && r < H)
-                    *reinterpret_cast<uint32_t*>(trow + (4 * k) * TP + 4 * lq) =
-                        __builtin_amdgcn_alignbyte(pre[k].y, pre[k].x, (uint32_t)sh);
-            }
-        } else {
-            for (int r = lr; r < H; r += 4, grow += 4 * (int64_t)L.pitch, trow += 4 * TP)
-                for (int q = lq; q < ndw; q += 16) {
-                    const uint32_t* g = reinterpret_cast<const uint32_t*>(grow) + q;
-                    const uint32_t lo = g[0], hi = g[1];
-                    *reinterpret_cast<uint32_t*>(trow + 4 * q) = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)sh);
-                }
-            for (int i = lane; i < (mapRows * mapPitch) >> 2; i += 64)
-                reinterpret_cast<uint32_t*>(smap)[i] = 0;
+        const int CH = TP >> 4, rowsPer = 64 / CH;
+        const int r0 = (lane * chunkInv) >> 16, ch = lane - r0 * CH;       // lane / CH, lane % CH
+        const uint8_t* g = img + (int64_t)(iniY + r0) * L.pitch + (iniX - 1) + ch * 16;
+        const bool laneOn = r0 < rowsPer;
+        for (int k = 0; k * rowsPer < H; k++) {
+            if (laneOn && r0 + k * rowsPer < H)
+                __builtin_amdgcn_global_load_lds((pg_gptr_t)(g + (int64_t)(k * rowsPer) * L.pitch),
+                                                 (pg_lptr_t)(tile + k * rowsPer * TP), 16, 0, 0);
         }
+        for (int i = lane; i < (mapRows * mapPitch) >> 2; i += 64)
+            reinterpret_cast<uint32_t*>(smap)[i] = 0;
+        __builtin_amdgcn_s_waitcnt(0);                     // vmcnt(0): the DMA has landed
     }
     __syncthreads();
 
@@ -354,7 +364,8 @@ void pg_launch_fast(const PgPlan& P, int nframes, hipStream_t s)
         maxW = max(maxW, P.lvl[l].wCell + 6);
         maxH = max(maxH, P.lvl[l].hCell + 6);
     }
-    const int TP = (maxW + 5 + 3) & ~3;                    // byte 0 pad + window + quick-test over-read
+    const int TP = (maxW + 6 + 15) & ~15;                  // byte 0 pad + window + quick-test over-read, 16-B chunks
+    const int chunkInv = 65536 / (TP >> 4) + 1;            // lane / (TP/16) == (lane * chunkInv) >> 16 for lane < 64
     const int tileRows = maxH;
     const int mapPitch = ((maxW - 6 + 2) + 3) & ~3;
     const int mapRows = maxH - 6 + 2;
@@ -363,5 +374,5 @@ void pg_launch_fast(const PgPlan& P, int nframes, hipStream_t s)
     if (const char* e = getenv("PGORB_FAST_EXTRA_LDS")) smem += (size_t)atoi(e);
     const int cellsPerXcd = (P.totalCells + 7) / 8;
     dim3 grid(cellsPerXcd * 8, nframes), block(64);
-    hipLaunchKernelGGL(k_fast_cells, grid, block, smem, s, P, TP, tileRows, mapPitch, mapRows, cellsPerXcd);
+    hipLaunchKernelGGL(k_fast_cells, grid, block, smem, s, P, TP, tileRows, mapPitch, mapRows, cellsPerXcd, chunkInv);
 }

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P)
     __shared__ int sh[3 * QT_W + 8];
     __shared__ int pyr[QT_PYR_CAP];                       // count pyramid, later the node map
     extern __shared__ __attribute__((aligned(16))) int qt_lds[];     // max(30 ints per node, cells + 1)
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x;
 #ifdef PGORB_QT_TIMING
     unsigned long long qt_t0 = wall_clock64();
 #endif
