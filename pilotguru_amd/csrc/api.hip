@@ -42,6 +42,7 @@ struct pgorb_ctx {
     // device memory
     Arena pyr, cand, sel, nodes, counters, tables, cellCand, cellCount, cellTab;
     Arena stageKps, stageDesc, stageN, stageA, stageB, stageOut, vocab;
+    Arena xdesc;                              // matcher scratch: train descriptors as +-1 bytes (match.hip)
     void* pinned = nullptr;                   // page-locked bounce buffer for bulk result download
     size_t pinnedBytes = 0;
     int vocabK = 0, vocabL = 0, vocabNodes = 0;
@@ -446,7 +447,7 @@ void pgorb_destroy(pgorb_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->prm.device);
     Arena* all[] = {&c->cellTab, &c->cellCand, &c->cellCount, &c->pyr, &c->cand, &c->sel, &c->nodes, &c->counters, &c->tables,
-                    &c->stageKps, &c->stageDesc, &c->stageN, &c->stageA, &c->stageB, &c->stageOut, &c->vocab};
+                    &c->stageKps, &c->stageDesc, &c->stageN, &c->stageA, &c->stageB, &c->stageOut, &c->vocab, &c->xdesc};
     for (Arena* a : all) if (a->p) (void)hipFree(a->p);
     if (c->pinned) (void)hipHostFree(c->pinned);
     for (hipEvent_t e : c->evExtract) (void)hipEventDestroy(e);
@@ -650,7 +651,8 @@ int pgorb_hamming_best2(pgorb_ctx* c, const uint8_t* a, int na, const uint8_t* b
     int32_t* d_idx = (int32_t*)c->stageOut.p;
     uint16_t* d_b1 = (uint16_t*)(d_idx + na);
     uint16_t* d_b2 = d_b1 + na;
-    pg_launch_best2((uint8_t*)c->stageA.p, na, (uint8_t*)c->stageB.p, nb, d_idx, d_b1, d_b2, 0);
+    if ((rc = ensure(c, c->xdesc, pg_match_scratch_bytes(nb, 1) + 16))) return rc;
+    pg_launch_best2((uint8_t*)c->stageA.p, na, (uint8_t*)c->stageB.p, nb, (uint8_t*)c->xdesc.p, d_idx, d_b1, d_b2, 0);
     PG_HIP(c, hipGetLastError());
     PG_HIP(c, hipMemcpy(best_idx, d_idx, (size_t)na * 4, hipMemcpyDeviceToHost));
     PG_HIP(c, hipMemcpy(best, d_b1, (size_t)na * 2, hipMemcpyDeviceToHost));
@@ -666,9 +668,13 @@ int pgorb_match_batch_device(pgorb_ctx* c, const uint8_t* d_desc, const int32_t*
     if (!d_desc || !d_n || cap < 1 || npairs < 0 || (npairs && (!d_pq || !d_pt || !d_best_idx || !d_best || !d_second)))
         return fail(c, PGORB_E_ARG, "bad argument to pgorb_match_batch_device");
     PG_HIP(c, hipSetDevice(c->prm.device));
+    if (cap >= (1 << 20)) return fail(c, PGORB_E_LIMIT, "more than 2^20 descriptors per frame");
+    int rc;
+    if ((rc = ensure(c, c->xdesc, pg_match_scratch_bytes(cap, npairs) + 16))) return rc;
     hipEvent_t* ev = (c->profMatch < c->profMax) ? &c->evMatch[2 * (size_t)c->profMatch] : nullptr;
     if (ev) PG_HIP(c, hipEventRecord(ev[0], (hipStream_t)stream));
-    pg_launch_match_batch(d_desc, d_n, cap, d_pq, d_pt, npairs, d_best_idx, d_best, d_second, (hipStream_t)stream);
+    pg_launch_match_batch(d_desc, d_n, cap, d_pq, d_pt, npairs, (uint8_t*)c->xdesc.p, d_best_idx, d_best, d_second,
+                          (hipStream_t)stream);
     if (ev) { PG_HIP(c, hipEventRecord(ev[1], (hipStream_t)stream)); c->profMatch++; }
     PG_HIP(c, hipGetLastError());
     return 0;

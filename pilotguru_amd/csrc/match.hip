@@ -50,6 +50,222 @@ __global__ __launch_bounds__(MT_T) void k_hamming_matrix(const uint8_t* __restri
     }
 }
 
+// ---- best / second-best over all train descriptors: the all-pairs scan as an i8 MFMA --------
+//
+// With bits mapped to +64 / -64 the dot product of two 256-element vectors is
+// 4096 * (256 - 2 * Hamming), so a 16 x 16 tile of distances is four v_mfma_i32_16x16x64_i8
+// (exact in int32) instead of 16 * 16 * (8 xor + 8 bcnt).  The first MFMA of a tile takes its C
+// operand from a per-lane constant, so the accumulator leaves the matrix pipe as the finished
+// sort key
+//     key = (256 - distance) << 13 | (8191 - train index)            (train index < 8192)
+// and what stays on the VALU is max + med3 per distance, which keep the two LARGEST keys
+// (k1 >= k2) of every (row, column class): larger key = smaller distance, then smaller index --
+// the reference's strict-'<' scan with bestDist / bestDist2 (ORBmatcher.cc:438-459), "first
+// minimum wins".  (dot + 256 is even, which is where the 13th index bit comes from.)
+//
+// Operand layout ("x16 block", 4 KiB per 16 descriptors): [16-bit chunk c][descriptor d][16 B],
+// byte j of an entry = bit 16c + j of descriptor d as +64 / -64.  k-step s of an MFMA operand is
+// the contiguous KiB s of a block and lane l reads its 16 bytes at l * 16: rows/columns are
+// l & 15, the K slice is chunk 4s + (l >> 4) for A and B alike (any K order works as long as
+// both sides agree).  Train frames are expanded once per pair by k_expand_trains into a scratch
+// slab and staged through LDS with LDS-DMA (double buffered); queries are expanded in registers.
+// C/D layout of the 16x16 MFMA: lane l, register r holds row 4 * (l >> 4) + r, column l & 15.
+typedef int pg_v4i __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const void* pg_gptr_t;
+typedef __attribute__((address_space(3))) void* pg_lptr_t;
+
+#define MX_BLOCK_BYTES 4096
+#define MX_TILE_BLOCKS 8          // train blocks staged per LDS tile (128 descriptors, 32 KiB)
+#define MX_WAVES 4                // 64 queries per wave, 256 per workgroup
+#define MX_IDX_BITS 13
+#define MX_IDX_MASK ((1u << MX_IDX_BITS) - 1u)
+#define MX_MAX_TRAIN (1 << MX_IDX_BITS)
+
+// 4 bits -> 4 bytes of +64 (bit set) / -64
+__device__ __forceinline__ uint32_t pg_pm64x4(uint32_t nib)
+{
+    const uint32_t x = (nib * 0x00204081u) & 0x01010101u;       // byte i = bit i
+    return (x << 7) ^ 0xC0C0C0C0u;                               // 1 -> 0x40, 0 -> 0xC0
+}
+
+__device__ __forceinline__ pg_v4i pg_pm64x16(uint32_t bits16)
+{
+    pg_v4i v;
+    v.x = (int)pg_pm64x4(bits16 & 15u); v.y = (int)pg_pm64x4((bits16 >> 4) & 15u);
+    v.z = (int)pg_pm64x4((bits16 >> 8) & 15u); v.w = (int)pg_pm64x4((bits16 >> 12) & 15u);
+    return v;
+}
+
+// grid (blocks of 16 train descriptors, pairs); 256 threads: thread t writes entry (c = t / 16, d = t % 16)
+__global__ __launch_bounds__(256) void k_expand_trains(const uint8_t* __restrict__ tdesc, const int32_t* __restrict__ n,
+                                                        int cap, const int32_t* __restrict__ pt, int nb_single,
+                                                        int blocksPerPair, uint8_t* __restrict__ xt)
+{
+    const int p = blockIdx.y, tb = blockIdx.x;
+    const int ft = pt ? pt[p] : 0;
+    const int nb = pt ? min(n[ft], cap) : nb_single;
+    if (16 * tb >= nb) return;                                   // never read
+    const int c = threadIdx.x >> 4, d = threadIdx.x & 15;
+    const int idx = 16 * tb + d;
+    pg_v4i v = {0, 0, 0, 0};
+    if (idx < nb) {
+        const uint16_t* src = reinterpret_cast<const uint16_t*>(tdesc + ((int64_t)ft * cap + idx) * 32);
+        v = pg_pm64x16(src[c]);
+    }
+    *reinterpret_cast<pg_v4i*>(xt + ((int64_t)p * blocksPerPair + tb) * MX_BLOCK_BYTES + threadIdx.x * 16) = v;
+}
+
+// The two largest keys are tracked with v_med3_f32 on the key's bit pattern: MX_KEY_BIAS puts
+// every key into [1.0, 1.5) as a float (positive, normal, never NaN), where float order is
+// integer order; 0 (= +0.0) is "none".  (A compiler-known instruction, so the hazard recogniser
+// places the wait states between the MFMA that writes a VGPR and its first VALU read.)
+#define MX_KEY_BIAS 0x3F800000u
+__device__ __forceinline__ unsigned pg_med3(unsigned a, unsigned b, unsigned c)
+{
+    return __float_as_uint(__builtin_amdgcn_fmed3f(__uint_as_float(a), __uint_as_float(b), __uint_as_float(c)));
+}
+
+// keys of this wave's 64 queries (A) against the 16 trains of one staged x16 block (B, already
+// in registers); kq = the per-lane key offset (256 << 12) + (8191 - column), in all four registers
+__device__ __forceinline__ void mx_block(const pg_v4i (&B)[4], const pg_v4i (&A)[4][4], const pg_v4i kq, pg_v4i (&acc)[4])
+{
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+            acc[a] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[a][s], B[s], s == 0 ? kq : acc[a], 0, 0, 0);
+}
+
+__device__ __forceinline__ void mx_load(const uint8_t* blockLane, pg_v4i (&B)[4])
+{
+#pragma unroll
+    for (int s = 0; s < 4; s++) B[s] = *reinterpret_cast<const pg_v4i*>(blockLane + s * 1024);
+}
+
+template <bool MASK>
+__device__ __forceinline__ void mx_update(const pg_v4i (&acc)[4], bool valid, unsigned (&k1)[4][4], unsigned (&k2)[4][4])
+{
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            unsigned key = (unsigned)acc[a][r];
+            if (MASK) key = valid ? key : 0u;
+            k2[a][r] = pg_med3(k1[a][r], k2[a][r], key);
+            k1[a][r] = pg_med3(k1[a][r], key, 0x7F800000u);          // max(k1, key): the median with +inf
+        }
+}
+
+// grid (ceil(cap / 256), pairs) or (ceil(na / 256), 1) for a single pair (pq == nullptr); nb < 8192
+__global__ __launch_bounds__(64 * MX_WAVES) void k_match_mfma(const uint8_t* __restrict__ qdesc, const uint8_t* __restrict__ xt,
+                                                              const int32_t* __restrict__ n, int cap,
+                                                              const int32_t* __restrict__ pq, const int32_t* __restrict__ pt,
+                                                              int na_single, int nb_single, int blocksPerPair,
+                                                              int32_t* best_idx, uint16_t* best, uint16_t* second)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t tile[(2 * MX_TILE_BLOCKS + 1) * MX_BLOCK_BYTES];    // + read-ahead slack
+    const int p = blockIdx.y;
+    const int fq = pq ? pq[p] : 0, ft = pt ? pt[p] : 0;
+    const int na = pq ? min(n[fq], cap) : na_single, nb = pt ? min(n[ft], cap) : nb_single;
+    if ((int)blockIdx.x * 64 * MX_WAVES >= na) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int qbase = blockIdx.x * 64 * MX_WAVES + wv * 64;
+    const bool active = qbase < na;                              // wave-uniform
+    const uint8_t* qd = qdesc + (int64_t)fq * cap * 32;
+    const int64_t o = (int64_t)p * cap;
+
+    // queries of this wave as MFMA A operands: A[a][s] = rows 16a .. 16a+15, k-step s
+    pg_v4i A[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        const int q = qbase + 16 * a + (lane & 15);
+        const uint16_t* src = reinterpret_cast<const uint16_t*>(qd + (int64_t)q * 32) + (lane >> 4);
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            A[a][s] = pg_v4i{0, 0, 0, 0};
+            if (q < na) A[a][s] = pg_pm64x16(src[4 * s]);
+        }
+    }
+    unsigned k1[4][4], k2[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) { k1[a][r] = 0u; k2[a][r] = 0u; }      // 0 = none (valid keys are > 0)
+
+    const int nblocks = (nb + 15) >> 4;
+    const uint8_t* xp = xt + (int64_t)p * blocksPerPair * MX_BLOCK_BYTES;
+    // double-buffered tiles: the LDS-DMA of tile t+1 is in flight while tile t is consumed
+    auto stage = [&](int t0, int buf) {
+        const int cnt = min(MX_TILE_BLOCKS, nblocks - t0);
+        // 16 B per lane, wave w fills KiB w, w + 4, ... of the tile
+        for (int kb = wv; kb < cnt * 4; kb += MX_WAVES)
+            __builtin_amdgcn_global_load_lds((pg_gptr_t)(xp + (int64_t)t0 * MX_BLOCK_BYTES + kb * 1024 + lane * 16),
+                                             (pg_lptr_t)(tile + buf * (MX_TILE_BLOCKS * MX_BLOCK_BYTES) + kb * 1024), 16, 0, 0);
+    };
+    if (nblocks > 0) stage(0, 0);
+    int buf = 0;
+    for (int t0 = 0; t0 < nblocks; t0 += MX_TILE_BLOCKS, buf ^= 1) {
+        const int cnt = min(MX_TILE_BLOCKS, nblocks - t0);
+        __builtin_amdgcn_s_waitcnt(0);                           // this wave's share of tile t0 has landed
+        __syncthreads();                                         // ... everybody's; and buffer buf^1 has been consumed
+        if (t0 + MX_TILE_BLOCKS < nblocks) stage(t0 + MX_TILE_BLOCKS, buf ^ 1);
+        if (!active) continue;
+        const uint8_t* bl = tile + buf * (MX_TILE_BLOCKS * MX_BLOCK_BYTES) + lane * 16;
+        int kc = (int)MX_KEY_BIAS + (256 << (MX_IDX_BITS - 1)) + (int)MX_IDX_MASK - (t0 * 16 + (lane & 15));
+        // blocks that lie entirely below nb take the unmasked update; at most one block per
+        // pair is partial (kept out of the hot loop: a select inside it costs 32 register copies)
+        const int cntFull = min(cnt, (nb >> 4) - t0);
+        // ping-pong B operands: block blk+1 is fetched from LDS while block blk is in the matrix
+        // pipe (reads past the last block of the tile stay inside the double buffer)
+        pg_v4i B0[4], B1[4], acc[4];
+        mx_load(bl, B0);
+        int blk = 0;
+        for (; blk + 2 <= cntFull; blk += 2, kc -= 32) {
+            mx_load(bl + (blk + 1) * MX_BLOCK_BYTES, B1);
+            mx_block(B0, A, pg_v4i{kc, kc, kc, kc}, acc);
+            mx_update<false>(acc, true, k1, k2);
+            mx_load(bl + (blk + 2) * MX_BLOCK_BYTES, B0);
+            mx_block(B1, A, pg_v4i{kc - 16, kc - 16, kc - 16, kc - 16}, acc);
+            mx_update<false>(acc, true, k1, k2);
+        }
+        if (blk < cntFull) {                                     // odd count: one more full block, in B0
+            mx_load(bl + (blk + 1) * MX_BLOCK_BYTES, B1);
+            mx_block(B0, A, pg_v4i{kc, kc, kc, kc}, acc);
+            mx_update<false>(acc, true, k1, k2);
+            blk++; kc -= 16;
+            if (blk < cnt) {
+                mx_block(B1, A, pg_v4i{kc, kc, kc, kc}, acc);
+                mx_update<true>(acc, (t0 + blk) * 16 + (lane & 15) < nb, k1, k2);
+            }
+        } else if (blk < cnt) {                                  // the partial block is in B0
+            mx_block(B0, A, pg_v4i{kc, kc, kc, kc}, acc);
+            mx_update<true>(acc, (t0 + blk) * 16 + (lane & 15) < nb, k1, k2);
+        }
+    }
+    if (!active) return;
+    // merge the 16 column classes of a row (lanes with equal lane >> 4)
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            unsigned m1 = k1[a][r] ? k1[a][r] - MX_KEY_BIAS : 0u, m2 = k2[a][r] ? k2[a][r] - MX_KEY_BIAS : 0u;
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) {
+                const unsigned o1 = (unsigned)__shfl_xor((int)m1, m), o2 = (unsigned)__shfl_xor((int)m2, m);
+                const unsigned hi = max(m1, o1);
+                m2 = max(min(m1, o1), max(m2, o2));
+                m1 = hi;
+            }
+            const int q = qbase + 16 * a + 4 * (lane >> 4) + r;
+            if ((lane & 15) == 0 && q < na) {
+                best_idx[o + q] = m1 ? (int32_t)(MX_IDX_MASK - (m1 & MX_IDX_MASK)) : -1;
+                best[o + q] = m1 ? (uint16_t)(256u - (m1 >> MX_IDX_BITS)) : (uint16_t)65535;
+                second[o + q] = m2 ? (uint16_t)(256u - (m2 >> MX_IDX_BITS)) : (uint16_t)65535;
+            }
+        }
+}
+
+// ---- popcount path: frames with 8192 or more descriptors (the MFMA key has 13 index bits) ----
 // best / second-best over all train descriptors (nb < 2^20) for 64 queries per workgroup.  The workgroup
 // is MT_WAVES waves: wave w scans the w-th contiguous slice of the train set for the SAME 64
 // queries (its own LDS tile), then wave 0 merges the partial results in slice order, which
@@ -145,20 +361,40 @@ void pg_launch_hamming_matrix(const uint8_t* d_a, int na, const uint8_t* d_b, in
     hipLaunchKernelGGL(k_hamming_matrix, grid, block, 0, s, d_a, na, d_b, nb, d_out);
 }
 
-void pg_launch_best2(const uint8_t* d_a, int na, const uint8_t* d_b, int nb,
+size_t pg_match_scratch_bytes(int nb_max, int npairs)
+{
+    return (size_t)npairs * (size_t)((nb_max + 15) / 16) * MX_BLOCK_BYTES;
+}
+
+// single pair: a (na descriptors) against b (nb descriptors); scratch >= pg_match_scratch_bytes(nb, 1)
+void pg_launch_best2(const uint8_t* d_a, int na, const uint8_t* d_b, int nb, uint8_t* d_scratch,
                      int32_t* d_best_idx, uint16_t* d_best, uint16_t* d_second, hipStream_t s)
 {
     if (na <= 0) return;
-    dim3 grid((na + MT_T - 1) / MT_T), block(MT_T * MT_WAVES);
-    hipLaunchKernelGGL(k_hamming_best2, grid, block, 0, s, d_a, na, d_b, nb, d_best_idx, d_best, d_second);
+    if (nb >= MX_MAX_TRAIN) {
+        hipLaunchKernelGGL(k_hamming_best2, dim3((na + MT_T - 1) / MT_T), dim3(MT_T * MT_WAVES), 0, s, d_a, na, d_b, nb,
+                           d_best_idx, d_best, d_second);
+        return;
+    }
+    const int bpp = (nb + 15) / 16;
+    if (bpp > 0)
+        hipLaunchKernelGGL(k_expand_trains, dim3(bpp, 1), dim3(256), 0, s, d_b, nullptr, nb, nullptr, nb, bpp, d_scratch);
+    hipLaunchKernelGGL(k_match_mfma, dim3((na + 64 * MX_WAVES - 1) / (64 * MX_WAVES), 1), dim3(64 * MX_WAVES), 0, s,
+                       d_a, d_scratch, nullptr, na, nullptr, nullptr, na, nb, bpp, d_best_idx, d_best, d_second);
 }
 
 void pg_launch_match_batch(const uint8_t* d_desc, const int32_t* d_n, int cap_per_frame,
-                           const int32_t* d_pq, const int32_t* d_pt, int npairs,
+                           const int32_t* d_pq, const int32_t* d_pt, int npairs, uint8_t* d_scratch,
                            int32_t* d_best_idx, uint16_t* d_best, uint16_t* d_second, hipStream_t s)
 {
     if (npairs <= 0) return;
-    dim3 grid((cap_per_frame + MT_T - 1) / MT_T, npairs), block(MT_T * MT_WAVES);
-    hipLaunchKernelGGL(k_match_batch, grid, block, 0, s, d_desc, d_n, cap_per_frame, d_pq, d_pt,
-                       d_best_idx, d_best, d_second);
+    if (cap_per_frame >= MX_MAX_TRAIN) {
+        hipLaunchKernelGGL(k_match_batch, dim3((cap_per_frame + MT_T - 1) / MT_T, npairs), dim3(MT_T * MT_WAVES), 0, s,
+                           d_desc, d_n, cap_per_frame, d_pq, d_pt, d_best_idx, d_best, d_second);
+        return;
+    }
+    const int bpp = (cap_per_frame + 15) / 16;
+    hipLaunchKernelGGL(k_expand_trains, dim3(bpp, npairs), dim3(256), 0, s, d_desc, d_n, cap_per_frame, d_pt, 0, bpp, d_scratch);
+    hipLaunchKernelGGL(k_match_mfma, dim3((cap_per_frame + 64 * MX_WAVES - 1) / (64 * MX_WAVES), npairs), dim3(64 * MX_WAVES), 0, s,
+                       d_desc, d_scratch, d_n, cap_per_frame, d_pq, d_pt, 0, 0, bpp, d_best_idx, d_best, d_second);
 }

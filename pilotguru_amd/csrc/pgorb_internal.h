@@ -93,11 +93,11 @@ void pg_launch_describe(const PgPlan& P, int nframes, pgorb_keypoint* d_kps, uin
                         int cap_per_frame, int32_t* d_n, hipStream_t s);
 void pg_launch_hamming_matrix(const uint8_t* d_a, int na, const uint8_t* d_b, int nb,
                               uint16_t* d_out, hipStream_t s);
+size_t pg_match_scratch_bytes(int nb_max, int npairs);
 void pg_launch_match_batch(const uint8_t* d_desc, const int32_t* d_n, int cap_per_frame,
-                           const int32_t* d_pq, const int32_t* d_pt, int npairs,
-                           int32_t* d_best_idx, uint16_t* d_best, uint16_t* d_second,
-                           hipStream_t s);
-void pg_launch_best2(const uint8_t* d_a, int na, const uint8_t* d_b, int nb,
+                           const int32_t* d_pq, const int32_t* d_pt, int npairs, uint8_t* d_scratch,
+                           int32_t* d_best_idx, uint16_t* d_best, uint16_t* d_second, hipStream_t s);
+void pg_launch_best2(const uint8_t* d_a, int na, const uint8_t* d_b, int nb, uint8_t* d_scratch,
                      int32_t* d_best_idx, uint16_t* d_best, uint16_t* d_second, hipStream_t s);
 
 static_assert(sizeof(PgPlan) <= 4000, "PgPlan is passed by value as a kernel argument (4 KiB limit)");

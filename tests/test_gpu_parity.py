@@ -123,6 +123,28 @@ def test_hamming_matrix_and_best2(oracle):
     assert np.all(bi == -1) and np.all(b1 == 65535)
 
 
+@pytest.mark.parametrize("na,nb", [(300, 8191), (130, 8192), (70, 9000), (1, 17), (257, 16), (64, 15)])
+def test_best2_index_field_limits(oracle, na, nb):
+    """The MFMA matcher packs the train index into 13 key bits (nb < 8192); larger train sets take
+    the popcount kernel.  Both sides of the switch, block-size multiples and tiny sets, with near
+    duplicates so that ties and the second best are exercised (ORBmatcher.cc:438-459 semantics)."""
+    rng = np.random.RandomState(na * 31 + nb)
+    a = rng.randint(0, 256, (na, 32)).astype(np.uint8)
+    b = rng.randint(0, 256, (nb, 32)).astype(np.uint8)
+    for i in range(0, na, 7):                                    # plant exact and 1-bit-off copies
+        j = (i * 97) % nb
+        b[j] = a[i]
+        k = (j * 13 + 5) % nb
+        if k != j:
+            b[k] = a[i]
+            b[k, i % 32] ^= 1 << (i % 8)
+    b[nb - 1] = a[0]
+    ext = _make(100, 320, 240)
+    bi, b1, b2 = ext.hamming_best2(a, b)
+    obi, ob1, ob2 = oracle.hamming_best2(a, b)
+    assert np.array_equal(bi, obi) and np.array_equal(b1, ob1) and np.array_equal(b2, ob2)
+
+
 def test_errors_and_edge_cases():
     import pilotguru_amd as pg
     from pilotguru_amd._lib import PGORB_E_LIMIT, PGORB_E_TOOSMALL, PgorbError
