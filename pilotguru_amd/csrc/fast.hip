@@ -229,10 +229,15 @@ __device__ __noinline__ int fast_pass_chunked(const uint8_t* tile, int TP, uint8
 typedef __attribute__((address_space(1))) const void* pg_gptr_t;
 typedef __attribute__((address_space(3))) void* pg_lptr_t;
 
-__global__ __launch_bounds__(64, 8) void k_fast_cells(const PgPlan P, int TP, int tileRows,
-                                                       int mapPitch, int mapRows, int cellsPerXcd,
+// TPC / MPC: compile-time tile and score-map pitches of the common geometry (cells up to 36 px:
+// TP = 48, map pitch 40), so that ring / neighbour offsets are instruction immediates; 0 = use the
+// run-time values (larger cells).
+template <int TPC, int MPC>
+__global__ __launch_bounds__(64, 8) void k_fast_cells(const PgPlan P, int TPr, int tileRows,
+                                                       int MPr, int mapRows, int cellsPerXcd,
                                                        int chunkInv)
 {
+    const int TP = TPC ? TPC : TPr, mapPitch = MPC ? MPC : MPr;
     const int lane = threadIdx.x;
     const int frame = blockIdx.y;
     const int cell = (blockIdx.x & 7) * cellsPerXcd + (blockIdx.x >> 3);      // XCD-contiguous
@@ -364,15 +369,20 @@ void pg_launch_fast(const PgPlan& P, int nframes, hipStream_t s)
         maxW = max(maxW, P.lvl[l].wCell + 6);
         maxH = max(maxH, P.lvl[l].hCell + 6);
     }
-    const int TP = (maxW + 6 + 15) & ~15;                  // byte 0 pad + window + quick-test over-read, 16-B chunks
-    const int chunkInv = 65536 / (TP >> 4) + 1;            // lane / (TP/16) == (lane * chunkInv) >> 16 for lane < 64
+    int TP = (maxW + 6 + 15) & ~15;                        // byte 0 pad + window + quick-test over-read, 16-B chunks
     const int tileRows = maxH;
-    const int mapPitch = ((maxW - 6 + 2) + 3) & ~3;
+    int mapPitch = ((maxW - 6 + 2) + 3) & ~3;
+    const bool common = TP <= 48 && mapPitch <= 40;        // the instantiation with immediate offsets
+    if (common) { TP = 48; mapPitch = 40; }
+    const int chunkInv = 65536 / (TP >> 4) + 1;            // lane / (TP/16) == (lane * chunkInv) >> 16 for lane < 64
     const int mapRows = maxH - 6 + 2;
     size_t smem = (size_t)tileRows * TP + (size_t)mapRows * mapPitch + FAST_LIST_CAP * 2 + 16;
     // profiling knob: extra LDS per wave lowers occupancy (occupancy sweep)
     if (const char* e = getenv("PGORB_FAST_EXTRA_LDS")) smem += (size_t)atoi(e);
     const int cellsPerXcd = (P.totalCells + 7) / 8;
     dim3 grid(cellsPerXcd * 8, nframes), block(64);
-    hipLaunchKernelGGL(k_fast_cells, grid, block, smem, s, P, TP, tileRows, mapPitch, mapRows, cellsPerXcd, chunkInv);
+    if (common)
+        hipLaunchKernelGGL((k_fast_cells<48, 40>), grid, block, smem, s, P, TP, tileRows, mapPitch, mapRows, cellsPerXcd, chunkInv);
+    else
+        hipLaunchKernelGGL((k_fast_cells<0, 0>), grid, block, smem, s, P, TP, tileRows, mapPitch, mapRows, cellsPerXcd, chunkInv);
 }
