@@ -75,6 +75,21 @@ __device__ __forceinline__ int fast_score16(const int d[16])
     return max(best_dark, -best_bright) - 1;
 }
 
+// inclusive prefix sum over the 64 lanes with DPP row shifts / broadcasts (6 cross-lane moves, no
+// LDS crossbar): Hillis-Steele inside each row of 16, then row totals carried with
+// row_bcast:15 (rows 1, 3) and row_bcast:31 (rows 2, 3)
+__device__ __forceinline__ int wave_incl_scan(int x)
+{
+    int v = x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);      // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);      // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);      // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);      // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);     // row_bcast:15
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);     // row_bcast:31
+    return v;
+}
+
 __device__ __forceinline__ int wave_prefix(unsigned long long m)
 {
     return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
@@ -140,13 +155,8 @@ __device__ __forceinline__ int quick_pass(const uint8_t* tile, int TP, int IW, i
         acc[step >> 3] |= m >> (2 * (step & 7));
     }
     const int cnt = __popc(acc[0]) + __popc(acc[1]);
-    int incl = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(incl, d);
-        if (lane >= d) incl += o;
-    }
-    const int nlist = __shfl(incl, 63);
+    const int incl = wave_incl_scan(cnt);
+    const int nlist = __builtin_amdgcn_readlane(incl, 63);
     if (nlist > FAST_LIST_CAP) return -1;
     int off = incl - cnt;
 #pragma unroll
@@ -310,55 +320,41 @@ __global__ __launch_bounds__(64, 8) void k_fast_cells(const PgPlan P, int TPr, i
         // (3) exact scores for the compacted pixels
         score_list(tile, TP, smap, mapPitch, list, nlist, t, lane);
         __syncthreads();
-        // (4) NMS (strictly greater than all 8 neighbours; outside the interior = 0)
+        // (4) NMS (strictly greater than all 8 neighbours; outside the interior = 0); survivors go
+        // straight into this cell's slots
         int total = 0;
         for (int base = 0; base < nlist; base += 64) {
             const int i = base + lane;
-            bool keep = false;
+            int sc = 0, p = 0;
             if (i < nlist) {
-                const int p = list[i];
-                keep = nms_score(smap, mapPitch, p >> 8, p & 0xFF) != 0;
-                if (keep) list[i] = (uint16_t)(p | 0x8000);          // iy < 64: bit 15 is free
+                p = list[i];
+                sc = nms_score(smap, mapPitch, p >> 8, p & 0xFF);
             }
-            total += __popcll(__ballot(keep));
-        }
-        if (total == 0) {
-            if (pass == 1) {
-                if (lane == 0) *cellCnt = 0;
-                return;
-            }
-            __syncthreads();
-            // vKeysCell.empty() -> retry at minThFAST (:812-816); clear the score map first
-            for (int base = 0; base < nlist; base += 64) {
-                const int i = base + lane;
-                if (i < nlist) {
-                    const int p = list[i] & 0x7FFF;
-                    smap[((p >> 8) + 1) * mapPitch + (p & 0xFF) + 1] = 0;
-                }
-            }
-            __syncthreads();
-            continue;
-        }
-        // emit into this cell's slots
-        if (lane == 0) *cellCnt = total;
-        int done = 0;
-        for (int base = 0; base < nlist; base += 64) {
-            const int i = base + lane;
-            const bool emit = (i < nlist) && (list[i] & 0x8000);
-            const unsigned long long m = __ballot(emit);
-            if (emit) {
-                const int pos = done + wave_prefix(m);
-                const int p = list[i] & 0x7FFF;
+            const unsigned long long m = __ballot(sc != 0);
+            if (sc) {
+                const int pos = total + wave_prefix(m);
                 const int iy = p >> 8, ix = p & 0xFF;
-                const uint32_t sc = smap[(iy + 1) * mapPitch + ix + 1];
                 if (pos < L.cellCap)
-                    out[pos] = (uint32_t)(ix + xoff) | ((uint32_t)(iy + yoff) << 12) | (sc << 24);
+                    out[pos] = (uint32_t)(ix + xoff) | ((uint32_t)(iy + yoff) << 12) | ((uint32_t)sc << 24);
                 else
                     atomicExch(P.status, PGORB_E_OVERFLOW);          // cannot happen (see header)
             }
-            done += __popcll(m);
+            total += __popcll(m);
         }
-        return;
+        if (total > 0 || pass == 1) {
+            if (lane == 0) *cellCnt = total;
+            return;
+        }
+        __syncthreads();
+        // vKeysCell.empty() -> retry at minThFAST (:812-816); clear the score map first
+        for (int base = 0; base < nlist; base += 64) {
+            const int i = base + lane;
+            if (i < nlist) {
+                const int p = list[i];
+                smap[((p >> 8) + 1) * mapPitch + (p & 0xFF) + 1] = 0;
+            }
+        }
+        __syncthreads();
     }
 }
 
