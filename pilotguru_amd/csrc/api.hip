@@ -301,14 +301,33 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
     }
     P.cellCand = (uint32_t*)c->cellCand.p; P.cellCount = (int32_t*)c->cellCount.p;
     {
-        std::vector<uint32_t> ct((size_t)cells);
-        for (int l = 0; l < L; l++)
-            for (int i = 0; i < P.lvl[l].nRows; i++)
-                for (int j = 0; j < P.lvl[l].nCols; j++)
-                    ct[(size_t)P.lvl[l].cellBase + (size_t)i * P.lvl[l].nCols + j] = (uint32_t)l | ((uint32_t)i << 4) | ((uint32_t)j << 16);
-        if ((rc = ensure(c, c->cellTab, ct.size() * 4 + 64))) return rc;
+        std::vector<uint32_t> ct((size_t)cells * 8);
+        for (int l = 0; l < L; l++) {
+            const PgLevel& V = P.lvl[l];
+            const int maxBorderX = V.w - PG_EDGE, maxBorderY = V.h - PG_EDGE;
+            for (int i = 0; i < V.nRows; i++)
+                for (int j = 0; j < V.nCols; j++) {
+                    const int cidx = i * V.nCols + j;
+                    uint32_t* r = &ct[((size_t)V.cellBase + cidx) * 8];
+                    const int iniY = PG_EDGE + i * V.hCell, iniX = PG_EDGE + j * V.wCell;      // :791-801
+                    const int W = std::min(iniX + V.wCell + 6, maxBorderX) - iniX;
+                    const int H = std::min(iniY + V.hCell + 6, maxBorderY) - iniY;
+                    // skipped cells (:794, :803) and windows cv::FAST finds nothing in (< 7 px)
+                    const bool skip = iniY >= maxBorderY - 3 || iniX >= maxBorderX - 6 || W < 7 || H < 7;
+                    const uint64_t off = (uint64_t)(pyrOff[l] * B) + (uint64_t)iniY * V.pitch + (uint64_t)(iniX - 1);
+                    r[0] = (uint32_t)l | ((uint32_t)i << 4) | ((uint32_t)j << 16);
+                    r[1] = (uint32_t)iniX | ((uint32_t)iniY << 16);
+                    r[2] = (uint32_t)(skip ? 0 : W) | ((uint32_t)(skip ? 0 : H) << 8) | ((uint32_t)skip << 16) | ((uint32_t)V.cellCap << 17);
+                    r[3] = (uint32_t)V.pitch;
+                    r[4] = (uint32_t)off; r[5] = (uint32_t)(off >> 32);
+                    r[6] = (uint32_t)V.fstride;
+                    r[7] = (uint32_t)(V.cellCandOff + (int64_t)cidx * V.cellCap);
+                }
+        }
+        if ((rc = ensure(c, c->cellTab, ct.size() * 4 + 8 * 32))) return rc;      // + 8 records of slack (fast.hip)
         PG_HIP(c, hipMemcpy(c->cellTab.p, ct.data(), ct.size() * 4, hipMemcpyHostToDevice));
         P.cellTab = (const uint32_t*)c->cellTab.p;
+        P.pyrBase = (const uint8_t*)c->pyr.p;
     }
     P.cand = (uint32_t*)c->cand.p; P.sel = (uint32_t*)c->sel.p;
     P.nodeScratch = (int32_t*)c->nodes.p;

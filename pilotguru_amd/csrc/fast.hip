@@ -112,7 +112,11 @@ __device__ __forceinline__ int wave_prefix(unsigned long long m)
 // 31-2s of word s/8 = pixels 0,1,2,3); ONE wave prefix sum at the end turns the per-lane
 // popcounts into list offsets (list order is irrelevant: NMS works on the score map).  Returns
 // the list length, or -1 when the list would overflow (the caller then takes the chunked path).
-template <int QW>      // quads per row handled by consecutive lanes: 8 (IW <= 32) or 16 (IW <= 64)
+// STRONG adds the diagonal pairs (2,10) and (6,14) to the necessary condition (a 9-long arc holds
+// one pixel of EVERY opposite pair).  It costs ~60 more operations per step and is used for the
+// minThFAST pass, where the two-pair test lets ~40 % of a textured cell through and the exact
+// scores of those pixels dominated the pass.
+template <int QW, bool STRONG>      // quads per row handled by consecutive lanes: 8 (IW <= 32) or 16 (IW <= 64)
 __device__ __forceinline__ int quick_pass(const uint8_t* tile, int TP, int IW, int rowBeg, int rowEnd,
                                           int t, uint16_t* list, int lane)
 {
@@ -146,10 +150,26 @@ __device__ __forceinline__ int quick_pass(const uint8_t* tile, int TP, int IW, i
             const uint32_t W12o = __builtin_amdgcn_alignbit(Ce, Le, 16);    // pixels (-2, 0)
             const uint32_t W4e = __builtin_amdgcn_alignbit(Ro, Co, 16);     // pixels (3, 5)
             const uint32_t Ae = Ce + Kd, Be = Kd - Ce, Ao = Co + Kd, Bo = Kd - Co;
-            const uint32_t darkE = ((Ae - De) | (Ae - Ue)) & ((Ae - W4e) | (Ae - W12e));
-            const uint32_t brightE = ((De + Be) | (Ue + Be)) & ((W4e + Be) | (W12e + Be));
-            const uint32_t darkO = ((Ao - Do) | (Ao - Uo)) & ((Ao - W4o) | (Ao - W12o));
-            const uint32_t brightO = ((Do + Bo) | (Uo + Bo)) & ((W4o + Bo) | (W12o + Bo));
+            uint32_t darkE = ((Ae - De) | (Ae - Ue)) & ((Ae - W4e) | (Ae - W12e));
+            uint32_t brightE = ((De + Be) | (Ue + Be)) & ((W4e + Be) | (W12e + Be));
+            uint32_t darkO = ((Ao - Do) | (Ao - Uo)) & ((Ao - W4o) | (Ao - W12o));
+            uint32_t brightO = ((Do + Bo) | (Uo + Bo)) & ((W4o + Bo) | (W12o + Bo));
+            if (STRONG) {
+                // rows y+2 / y-2 at x+2 / x-2: rings 2 (+2,+2), 14 (-2,+2), 6 (+2,-2), 10 (-2,-2)
+                const uint32_t* rp = reinterpret_cast<const uint32_t*>(tile + (iy + 5) * TP) + 1 + lq;
+                const uint32_t* rm = reinterpret_cast<const uint32_t*>(tile + (iy + 1) * TP) + 1 + lq;
+                const uint32_t Pc = rp[0], Pl = rp[-1], Pr = rp[1], Mc = rm[0], Ml = rm[-1], Mr = rm[1];
+                const uint32_t Pce = Pc & M, Pco = (Pc >> 8) & M, Ple = Pl & M, Plo = (Pl >> 8) & M, Pre = Pr & M, Pro = (Pr >> 8) & M;
+                const uint32_t Mce = Mc & M, Mco = (Mc >> 8) & M, Mle = Ml & M, Mlo = (Ml >> 8) & M, Mre = Mr & M, Mro = (Mr >> 8) & M;
+                const uint32_t r2e = __builtin_amdgcn_alignbit(Pre, Pce, 16), r14e = __builtin_amdgcn_alignbit(Pce, Ple, 16);
+                const uint32_t r6e = __builtin_amdgcn_alignbit(Mre, Mce, 16), r10e = __builtin_amdgcn_alignbit(Mce, Mle, 16);
+                const uint32_t r2o = __builtin_amdgcn_alignbit(Pro, Pco, 16), r14o = __builtin_amdgcn_alignbit(Pco, Plo, 16);
+                const uint32_t r6o = __builtin_amdgcn_alignbit(Mro, Mco, 16), r10o = __builtin_amdgcn_alignbit(Mco, Mlo, 16);
+                darkE &= ((Ae - r2e) | (Ae - r10e)) & ((Ae - r6e) | (Ae - r14e));
+                brightE &= ((r2e + Be) | (r10e + Be)) & ((r6e + Be) | (r14e + Be));
+                darkO &= ((Ao - r2o) | (Ao - r10o)) & ((Ao - r6o) | (Ao - r14o));
+                brightO &= ((r2o + Bo) | (r10o + Bo)) & ((r6o + Bo) | (r14o + Bo));
+            }
             m = ((((darkE | brightE) & K15) >> 1) | ((darkO | brightO) & K15)) & colMask;
         }
         acc[step >> 3] |= m >> (2 * (step & 7));
@@ -213,8 +233,8 @@ __device__ __noinline__ int fast_pass_chunked(const uint8_t* tile, int TP, uint8
     __syncthreads();
     const int rowsPer = (IW <= 32) ? 16 : 8;                 // <= 512 candidates per block
     for (int r = 0; r < IH; r += rowsPer) {
-        const int n = (IW <= 32) ? quick_pass<8>(tile, TP, IW, r, min(r + rowsPer, IH), t, list, lane)
-                                 : quick_pass<16>(tile, TP, IW, r, min(r + rowsPer, IH), t, list, lane);
+        const int n = (IW <= 32) ? quick_pass<8, true>(tile, TP, IW, r, min(r + rowsPer, IH), t, list, lane)
+                                 : quick_pass<16, true>(tile, TP, IW, r, min(r + rowsPer, IH), t, list, lane);
         __syncthreads();
         score_list(tile, TP, smap, mapPitch, list, n, t, lane);
         __syncthreads();
@@ -239,6 +259,20 @@ __device__ __noinline__ int fast_pass_chunked(const uint8_t* tile, int TP, uint8
 typedef __attribute__((address_space(1))) const void* pg_gptr_t;
 typedef __attribute__((address_space(3))) void* pg_lptr_t;
 
+#ifdef PGORB_FAST_TIMING
+// developer build only (make EXTRA=-DPGORB_FAST_TIMING): 10 ns ticks per phase of every wave (no
+// atomics: a shared counter would serialise the waves), read back by tools/experiments/fast_timing.py
+#define FT_MAXW (1 << 20)
+__device__ unsigned int pg_ft_log[FT_MAXW * 8];
+#define FT_TS(k) do { const unsigned long long t1_ = wall_clock64(); if (lane == 0 && ft_id < FT_MAXW) pg_ft_log[ft_id * 8 + (k)] = (unsigned)(t1_ - ft_t0); ft_t0 = t1_; } while (0)
+extern "C" int pgorb_debug_fast_times(unsigned int* out, int nwaves)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pg_ft_log), sizeof(unsigned) * 8 * (size_t)nwaves) == hipSuccess ? 0 : -1;
+}
+#else
+#define FT_TS(k) do {} while (0)
+#endif
+
 // TPC / MPC: compile-time tile and score-map pitches of the common geometry (cells up to 36 px:
 // TP = 48, map pitch 40), so that ring / neighbour offsets are instruction immediates; 0 = use the
 // run-time values (larger cells).
@@ -251,25 +285,39 @@ __global__ __launch_bounds__(64, 8) void k_fast_cells(const PgPlan P, int TPr, i
     const int lane = threadIdx.x;
     const int frame = blockIdx.y;
     const int cell = (blockIdx.x & 7) * cellsPerXcd + (blockIdx.x >> 3);      // XCD-contiguous
-    if (cell >= P.totalCells) return;
-    // one load instead of a dependent search through the per-level cell bases
-    const uint32_t ct = P.cellTab[cell];                 // level | cell row << 4 | cell col << 16
-    const int l = ct & 15, ci = (ct >> 4) & 0xFFF, cj = ct >> 16;
-    const PgLevel& L = P.lvl[l];
-    const int c = cell - L.cellBase;
-    const int maxBorderX = L.w - PG_EDGE, maxBorderY = L.h - PG_EDGE;
-    const int iniY = PG_EDGE + ci * L.hCell;
-    const int iniX = PG_EDGE + cj * L.wCell;
-    int32_t* cellCnt = P.cellCount + (int64_t)frame * P.totalCells + cell;
-    const int maxX = min(iniX + L.wCell + 6, maxBorderX);
-    const int maxY = min(iniY + L.hCell + 6, maxBorderY);
-    const int W = maxX - iniX, H = maxY - iniY;
-    // skipped cells (:794, :803) and windows cv::FAST finds nothing in (< 7 px)
-    if (iniY >= maxBorderY - 3 || iniX >= maxBorderX - 6 || W < 7 || H < 7) {
+#ifdef PGORB_FAST_TIMING
+    unsigned long long ft_t0 = wall_clock64();
+    const int ft_id = frame * P.totalCells + cell;
+#endif
+    // Two scalar round trips to the window address: (1) the kernel arguments, including what level
+    // 0 needs when it aliases the caller's buffer, (2) ONE s_load_dwordx8 of the cell's record
+    // (pgorb_internal.h, PgPlan::cellTab).  Left to itself the compiler spreads this over four to
+    // five dependent loads (vector loads + readfirstlane, level-0 fields fetched on demand).
+    const uint8_t* l0img = P.lvl[0].img;
+    const int l0pitch = P.lvl[0].pitch;
+    const int64_t l0fstride = P.lvl[0].fstride;
+    const uint8_t* pyrBase = P.pyrBase;
+    const uint32_t* recp = P.cellTab + 8 * (int64_t)cell;          // (the table has 8 records of slack)
+    const int totalCells = P.totalCells;
+    asm volatile("" :: "s"(l0img), "s"(l0pitch), "s"(l0fstride), "s"(pyrBase), "s"(totalCells));
+    typedef uint32_t pg_u32x8 __attribute__((ext_vector_type(8)));
+    pg_u32x8 rec;
+    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rec) : "s"(recp) : "memory");
+    if (cell >= totalCells) return;
+    const int iniX = rec[1] & 0xFFFF, iniY = rec[1] >> 16;
+    const int W = rec[2] & 0xFF, H = (rec[2] >> 8) & 0xFF, cellCap = rec[2] >> 17;
+    int32_t* cellCnt = P.cellCount + (int64_t)frame * totalCells + cell;
+    FT_TS(0);
+    if (rec[2] & 0x10000u) {                             // skipped cell
         if (lane == 0) *cellCnt = 0;
         return;
     }
     const int IW = W - 6, IH = H - 6;
+    // window start (iniY, iniX - 1) of this frame; level 0 may be the caller's buffer
+    const bool l0 = (rec[0] & 15u) == 0;
+    const int pitch = l0 ? l0pitch : (int)rec[3];
+    const uint8_t* win = l0 ? l0img + (int64_t)frame * l0fstride + (int64_t)iniY * l0pitch + (iniX - 1)
+                            : pyrBase + (((uint64_t)rec[5] << 32) | rec[4]) + (uint64_t)frame * rec[6];
 
     uint8_t* tile = pg_fast_smem;                                  // [tileRows][TP]
     uint8_t* smap = tile + tileRows * TP;                          // [mapRows][mapPitch], 1-px zero rim
@@ -282,36 +330,46 @@ __global__ __launch_bounds__(64, 8) void k_fast_cells(const PgPlan P, int TPr, i
     // dword j of a row holds window columns 4j-1 .. 4j+2 and interior quads are dword aligned.
     // Rows are read TP bytes wide: past the window that is the neighbouring cell / next row of the
     // level, always inside the level (the window ends >= 16 rows above the level's last row).
-    const uint8_t* img = L.img + (int64_t)frame * L.fstride;
     {
         const int CH = TP >> 4, rowsPer = 64 / CH;
         const int r0 = (lane * chunkInv) >> 16, ch = lane - r0 * CH;       // lane / CH, lane % CH
-        const uint8_t* g = img + (int64_t)(iniY + r0) * L.pitch + (iniX - 1) + ch * 16;
+        const uint8_t* g = win + (int64_t)r0 * pitch + ch * 16;
+#ifdef PGORB_FAST_TIMING
+        asm volatile("" :: "v"(g));
+        FT_TS(4);
+#endif
         const bool laneOn = r0 < rowsPer;
         for (int k = 0; k * rowsPer < H; k++) {
             if (laneOn && r0 + k * rowsPer < H)
-                __builtin_amdgcn_global_load_lds((pg_gptr_t)(g + (int64_t)(k * rowsPer) * L.pitch),
+                __builtin_amdgcn_global_load_lds((pg_gptr_t)(g + (int64_t)(k * rowsPer) * pitch),
                                                  (pg_lptr_t)(tile + k * rowsPer * TP), 16, 0, 0);
         }
+        FT_TS(1);
         for (int i = lane; i < (mapRows * mapPitch) >> 2; i += 64)
             reinterpret_cast<uint32_t*>(smap)[i] = 0;
         __builtin_amdgcn_s_waitcnt(0);                     // vmcnt(0): the DMA has landed
     }
     __syncthreads();
+    FT_TS(2);
 
-    uint32_t* out = P.cellCand + (int64_t)frame * P.cellCandFrame + L.cellCandOff + (int64_t)c * L.cellCap;
-    const int xoff = 3 + cj * L.wCell, yoff = 3 + ci * L.hCell;   // window-local -> region-relative (:822-823)
+    uint32_t* out = P.cellCand + (int64_t)frame * P.cellCandFrame + rec[7];
+    const int xoff = 3 + iniX - PG_EDGE, yoff = 3 + iniY - PG_EDGE;   // window-local -> region-relative (:822-823)
 
     for (int pass = 0; pass < 2; pass++) {
         const int t = pass == 0 ? P.iniTh : P.minTh;
         // (2) necessary test + compaction
-        const int nlist = (IW <= 32) ? quick_pass<8>(tile, TP, IW, 0, IH, t, list, lane)
-                                     : quick_pass<16>(tile, TP, IW, 0, IH, t, list, lane);
+        int nlist;
+        if (pass == 0)
+            nlist = (IW <= 32) ? quick_pass<8, false>(tile, TP, IW, 0, IH, t, list, lane)
+                               : quick_pass<16, false>(tile, TP, IW, 0, IH, t, list, lane);
+        else
+            nlist = (IW <= 32) ? quick_pass<8, true>(tile, TP, IW, 0, IH, t, list, lane)
+                               : quick_pass<16, true>(tile, TP, IW, 0, IH, t, list, lane);
         if (nlist < 0) {                                   // list would overflow: chunked slow path
             const int total = fast_pass_chunked(tile, TP, smap, mapPitch, mapRows, IW, IH, t, list, out,
-                                                L.cellCap, xoff, yoff, lane);
+                                                cellCap, xoff, yoff, lane);
             if (total > 0 || pass == 1) {
-                if (lane == 0) *cellCnt = min(total, L.cellCap);
+                if (lane == 0) *cellCnt = min(total, cellCap);
                 return;
             }
             continue;
@@ -334,7 +392,7 @@ __global__ __launch_bounds__(64, 8) void k_fast_cells(const PgPlan P, int TPr, i
             if (sc) {
                 const int pos = total + wave_prefix(m);
                 const int iy = p >> 8, ix = p & 0xFF;
-                if (pos < L.cellCap)
+                if (pos < cellCap)
                     out[pos] = (uint32_t)(ix + xoff) | ((uint32_t)(iy + yoff) << 12) | ((uint32_t)sc << 24);
                 else
                     atomicExch(P.status, PGORB_E_OVERFLOW);          // cannot happen (see header)
@@ -343,6 +401,7 @@ __global__ __launch_bounds__(64, 8) void k_fast_cells(const PgPlan P, int TPr, i
         }
         if (total > 0 || pass == 1) {
             if (lane == 0) *cellCnt = total;
+            FT_TS(3);
             return;
         }
         __syncthreads();
