@@ -182,42 +182,60 @@ __global__ __launch_bounds__(256) void k_pyr_resize_quads(
 typedef unsigned short pg_us2 __attribute__((ext_vector_type(2)));
 struct __attribute__((packed, aligned(1))) PgU2 { uint32_t x, y; };
 
+// (a[23:0] * b[23:0]) >> 32
+__device__ __forceinline__ uint32_t pg_mulhi_u24(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// VResizeLinear (OpenCV 2.4 imgproc/imgwarp.cpp): ((b0 * S0) >> 16) + ((b1 * S1) >> 16) + 2) >> 2
+// with S = horizontal sum >> 4.  H holds S << 4 (the horizontal sum with its low 4 bits cleared)
+// and b arrives << 12, so each product-and-shift is one v_mul_hi_u32_u24:
+// (S * 16) * (b * 4096) >> 32 == (S * b) >> 16 (S < 2^15, b <= 2^11: both factors fit 24 bits).
 template <int D, int F>
-__device__ __forceinline__ uint32_t pyr_vrow(const int (&H)[6][4], int b0, int b1)
+__device__ __forceinline__ uint32_t pyr_vrow(const uint32_t (&H)[6][4], uint32_t b0s, uint32_t b1s)
 {
     constexpr int iA = D + (F & 1), iB = iA + ((F >> 1) & 1);
     uint32_t out = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const int v = ((__mul24(b0, H[iA][j]) >> 16) + (__mul24(b1, H[iB][j]) >> 16) + 2) >> 2;   // VResizeLinear
-        out |= (uint32_t)(v & 0xFF) << (8 * j);
+        const uint32_t v = (pg_mulhi_u24(H[iA][j], b0s) + pg_mulhi_u24(H[iB][j], b1s) + 2u) >> 2;   // <= 255
+        out |= v << (8 * j);
     }
     return out;
 }
 
 template <int D>
-__device__ __forceinline__ void pyr_store_row(const int (&H)[6][4], int dy, int dh, const uint8_t* yrel,
+__device__ __forceinline__ void pyr_store_row(const uint32_t (&H)[6][4], int dy, int dh, const uint8_t* yrel,
                                               const int16_t* ybeta, uint8_t* dbase, int dpitch)
 {
     if (dy >= dh) return;
     const int f = yrel[dy];                                            // wave-uniform
-    const int b0 = ybeta[2 * dy], b1 = ybeta[2 * dy + 1];
+    const uint32_t b0s = (uint32_t)ybeta[2 * dy] << 12, b1s = (uint32_t)ybeta[2 * dy + 1] << 12;
     uint32_t out;
-    if (f == 0) out = pyr_vrow<D, 0>(H, b0, b1);
-    else if (f == 1) out = pyr_vrow<D, 1>(H, b0, b1);
-    else if (f == 2) out = pyr_vrow<D, 2>(H, b0, b1);
-    else out = pyr_vrow<D, 3>(H, b0, b1);
+    if (f == 0) out = pyr_vrow<D, 0>(H, b0s, b1s);
+    else if (f == 1) out = pyr_vrow<D, 1>(H, b0s, b1s);
+    else if (f == 2) out = pyr_vrow<D, 2>(H, b0s, b1s);
+    else out = pyr_vrow<D, 3>(H, b0s, b1s);
     *reinterpret_cast<uint32_t*>(dbase + (int64_t)dy * dpitch) = out;
 }
 
+// grid (tiles per frame rounded up to a multiple of 8, 1, frames), block (64, 4): a tile is 256
+// columns x 16 rows.  Workgroup b lands on XCD b % 8; XCD k takes the k-th eighth of the frame's
+// tiles in (row, column) order, so vertically adjacent tiles -- which share two of their six
+// source rows -- read them through the same L2.
 __global__ __launch_bounds__(256) void k_pyr_resize_rows4(
     const uint8_t* __restrict__ src, int spitch, int64_t sfstride, int sh,
     uint8_t* __restrict__ dst, int dpitch, int64_t dfstride, int dw, int dh,
     const PgQuadTab2* __restrict__ qtab, const int32_t* __restrict__ yofs,
-    const int16_t* __restrict__ ybeta, const uint8_t* __restrict__ yrel)
+    const int16_t* __restrict__ ybeta, const uint8_t* __restrict__ yrel, int nx, uint32_t nxMagic)
 {
-    const int quad = blockIdx.x * 64 + threadIdx.x;
-    const int dy0 = (blockIdx.y * 4 + threadIdx.y) * 4;
+    const int t = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int ty = (nx == 1) ? t : (int)__umulhi((uint32_t)t, nxMagic), tx = t - ty * nx;      // t / nx, t % nx
+    const int quad = tx * 64 + threadIdx.x;
+    const int dy0 = (ty * 4 + threadIdx.y) * 4;
     if (quad * 4 >= dw || dy0 >= dh) return;
     const PgQuadTab2 T = qtab[quad];
     const int sFirst = yofs[2 * dy0];                                  // wave-uniform
@@ -226,14 +244,14 @@ __global__ __launch_bounds__(256) void k_pyr_resize_rows4(
 #pragma unroll
     for (int k = 0; k < 6; k++)
         w[k] = *reinterpret_cast<const PgU2*>(sbase + (int64_t)min(sFirst + k, sh - 1) * spitch);
-    int H[6][4];
+    uint32_t H[6][4];                                                  // (horizontal sum >> 4) << 4
 #pragma unroll
     for (int k = 0; k < 6; k++)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const uint32_t taps = __builtin_amdgcn_perm(w[k].y, w[k].x, T.sel[j]);      // tap0 | tap1 << 16
-            H[k][j] = (int)(__builtin_amdgcn_udot2(__builtin_bit_cast(pg_us2, taps),
-                                                   __builtin_bit_cast(pg_us2, T.coef[j]), 0u, false) >> 4);
+            H[k][j] = __builtin_amdgcn_udot2(__builtin_bit_cast(pg_us2, taps),
+                                             __builtin_bit_cast(pg_us2, T.coef[j]), 0u, false) & ~15u;
         }
     uint8_t* dbase = dst + (int64_t)blockIdx.z * dfstride + quad * 4;
     pyr_store_row<0>(H, dy0 + 0, dh, yrel, ybeta, dbase, dpitch);
@@ -247,9 +265,12 @@ void pg_launch_pyramid_level(const PgPlan& P, int level, int nframes, hipStream_
     const PgLevel& S = P.lvl[level - 1];
     const PgLevel& D = P.lvl[level];
     if (D.qtab2 && D.yrel) {
-        dim3 block(64, 4), grid((D.w + 255) / 256, (D.h + 15) / 16, nframes);
+        const int nx = (D.w + 255) / 256, ny = (D.h + 15) / 16;
+        const int tiles = (nx * ny + 7) & ~7;
+        const uint32_t nxMagic = nx > 1 ? (uint32_t)(((1ull << 32) / (uint64_t)nx) + 1ull) : 0u;   // exact: tiles * nx < 2^32
+        dim3 block(64, 4), grid(tiles, 1, nframes);
         hipLaunchKernelGGL(k_pyr_resize_rows4, grid, block, 0, s, S.img, S.pitch, S.fstride, S.h,
-                           D.img, D.pitch, D.fstride, D.w, D.h, D.qtab2, D.yofs, D.ybeta, D.yrel);
+                           D.img, D.pitch, D.fstride, D.w, D.h, D.qtab2, D.yofs, D.ybeta, D.yrel, nx, nxMagic);
         return;
     }
     if (D.qtab) {
