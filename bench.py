@@ -209,10 +209,11 @@ def main():
         launches = 7 if rk == "pyramid" else 1
         ach = (abytes[rk] * B / launches) / (stage_ms[rk] / launches * 1e-3) / 1e9
         kname = {"pyramid": "k_pyr_resize_rows4", "fast": "k_fast_cells", "describe": "k_describe",
-                 "match": "k_match_batch"}[rk]
+                 "match": "k_match_mfma"}[rk]
         traffic = None                                  # HBM bytes per launch from the committed PMC passes
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            import glob
+            tr = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))[-1]))   # newest round
             if tr["workload"] == {"width": W, "height": H, "features": NF, "batch": B}:
                 k = tr["kernels"][kname]
                 traffic = (2.0 * k["fetch_kb"] + k["write_kb"]) * 1024.0

@@ -9,7 +9,10 @@ import sys
 
 
 def short(name):
-    return name.split("(")[0][-60:]
+    n = name.split("(")[0].strip()
+    if n.startswith("void "):
+        n = n[5:]
+    return n.split("<")[0][-60:] or "void"
 
 
 def stats(db):
