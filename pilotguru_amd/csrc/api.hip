@@ -171,7 +171,7 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
 
     // --- resize tables ---
     std::vector<uint8_t> tab;
-    struct TabOff { size_t xofs, xofs1, xalpha, yofs, ybeta, qtab, yrel, qtab2; bool hasQ, hasY, hasQ2; } toff[PG_MAXL];
+    struct TabOff { size_t xofs, xofs1, xalpha, yofs, ybeta, qtab, yrel, qtab2, rowgrp; bool hasQ, hasY, hasQ2; } toff[PG_MAXL];
     for (int l = 1; l < L; l++) {
         std::vector<int32_t> xo, xo1, yo; std::vector<int16_t> xa, yb;
         build_resize_tables(g[l - 1].w, g[l - 1].h, g[l].w, g[l].h, xo, xo1, xa, yo, yb);
@@ -237,6 +237,18 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
         }
         toff[l].hasY = oky;
         toff[l].yrel = put(yr.data(), yr.size());
+        std::vector<PgRowGrp> rg((g[l].h + 3) / 4);
+        for (size_t gi = 0; gi < rg.size(); gi++) {
+            PgRowGrp& R = rg[gi];
+            memset(&R, 0, sizeof(R));
+            R.sFirst = yo[2 * (4 * gi)];
+            for (int d = 0; d < 4; d++) {
+                const int dy = std::min((int)(4 * gi) + d, g[l].h - 1);
+                R.yrel4 |= (uint32_t)yr[dy] << (8 * d);
+                R.ybeta[2 * d] = yb[2 * dy]; R.ybeta[2 * d + 1] = yb[2 * dy + 1];
+            }
+        }
+        toff[l].rowgrp = put(rg.data(), rg.size() * sizeof(PgRowGrp));
     }
     if ((rc = ensure(c, c->tables, tab.size() + 16))) return rc;
     if (!tab.empty()) PG_HIP(c, hipMemcpy(c->tables.p, tab.data(), tab.size(), hipMemcpyHostToDevice));
@@ -296,6 +308,7 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
             V.ybeta = (const int16_t*)(t + toff[l].ybeta);
             V.qtab = toff[l].hasQ ? (const PgQuadTab*)(t + toff[l].qtab) : nullptr;
             V.yrel = toff[l].hasY ? (t + toff[l].yrel) : nullptr;
+            V.rowgrp = (const PgRowGrp*)(t + toff[l].rowgrp);
             V.qtab2 = toff[l].hasQ2 ? (const PgQuadTab2*)(t + toff[l].qtab2) : nullptr;
         }
     }

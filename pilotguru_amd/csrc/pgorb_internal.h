@@ -31,6 +31,13 @@ struct PgQuadTab2 {           // pyramid 4x4 fast path: one unaligned 8-byte win
     uint32_t coef[4];         // a0 | a1 << 16 (11-bit coefficients)
 };
 
+struct PgRowGrp {             // pyramid 4x4 fast path: everything a wave needs about its 4 destination rows
+    int32_t  sFirst;          // first source row (yofs of the group's first row)
+    uint32_t yrel4;           // the 4 row patterns, one byte each (bit 0: r0 offset, bit 1: r1 - r0)
+    int16_t  ybeta[8];        // (b0, b1) of the 4 rows, 11-bit coefficients
+    uint32_t pad[2];
+};
+
 struct PgLevel {
     // pyramid plane of this level
     uint8_t* img;             // frame 0 plane
@@ -45,6 +52,7 @@ struct PgLevel {
     const PgQuadTab* qtab;    // [ceil(w/4)] or null when a quad spans more than 3 source dwords
     const PgQuadTab2* qtab2;  // [ceil(w/4)] or null when a quad's taps do not fit one 8-byte window
     const uint8_t* yrel;      // [h] row pattern of the 4x4 fast path, or null when it does not apply
+    const PgRowGrp* rowgrp;   // [ceil(h/4)] the same, one 32-byte record per group of 4 rows (one scalar load)
     // cell grid (ORBextractor.cc:781-787)
     int32_t  nCols, nRows, wCell, hCell, cellBase;
     // quadtree (ORBextractor.cc:539-563)

@@ -208,12 +208,12 @@ __device__ __forceinline__ uint32_t pyr_vrow(const uint32_t (&H)[6][4], uint32_t
 }
 
 template <int D>
-__device__ __forceinline__ void pyr_store_row(const uint32_t (&H)[6][4], int dy, int dh, const uint8_t* yrel,
-                                              const int16_t* ybeta, uint8_t* dbase, int dpitch)
+__device__ __forceinline__ void pyr_store_row(const uint32_t (&H)[6][4], int dy, int dh, const PgRowGrp& R,
+                                              uint8_t* dbase, int dpitch)
 {
     if (dy >= dh) return;
-    const int f = yrel[dy];                                            // wave-uniform
-    const uint32_t b0s = (uint32_t)ybeta[2 * dy] << 12, b1s = (uint32_t)ybeta[2 * dy + 1] << 12;
+    const int f = (R.yrel4 >> (8 * D)) & 3;                            // wave-uniform
+    const uint32_t b0s = (uint32_t)R.ybeta[2 * D] << 12, b1s = (uint32_t)R.ybeta[2 * D + 1] << 12;
     uint32_t out;
     if (f == 0) out = pyr_vrow<D, 0>(H, b0s, b1s);
     else if (f == 1) out = pyr_vrow<D, 1>(H, b0s, b1s);
@@ -229,16 +229,32 @@ __device__ __forceinline__ void pyr_store_row(const uint32_t (&H)[6][4], int dy,
 __global__ __launch_bounds__(256) void k_pyr_resize_rows4(
     const uint8_t* __restrict__ src, int spitch, int64_t sfstride, int sh,
     uint8_t* __restrict__ dst, int dpitch, int64_t dfstride, int dw, int dh,
-    const PgQuadTab2* __restrict__ qtab, const int32_t* __restrict__ yofs,
-    const int16_t* __restrict__ ybeta, const uint8_t* __restrict__ yrel, int nx, uint32_t nxMagic)
+    const PgQuadTab2* __restrict__ qtab, const PgRowGrp* __restrict__ rowgrp, int nx, uint32_t nxMagic)
 {
+    // all kernel arguments in one scalar batch (left alone the compiler fetches them in four
+    // dependent groups around the early exits -- the wave is latency bound, not issue bound)
+    asm volatile("" :: "s"(src), "s"(spitch), "s"(sfstride), "s"(sh), "s"(dst), "s"(dpitch), "s"(dfstride),
+                 "s"(dw), "s"(dh), "s"(qtab), "s"(rowgrp), "s"(nx), "s"(nxMagic));
     const int t = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const int ty = (nx == 1) ? t : (int)__umulhi((uint32_t)t, nxMagic), tx = t - ty * nx;      // t / nx, t % nx
     const int quad = tx * 64 + threadIdx.x;
-    const int dy0 = (ty * 4 + threadIdx.y) * 4;
+    // a wave is one threadIdx.y: its 4 destination rows share ONE 32-byte record, fetched with a
+    // single s_load_dwordx8 while the quad table load is in flight (the per-row table reads used
+    // to be four more dependent round trips at the end of the wave)
+    const int grp = ty * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int dy0 = grp * 4;
+    const int ngrp = (dh + 3) >> 2;
+    const PgRowGrp* rp = rowgrp + min(grp, ngrp - 1);
+    const PgQuadTab2 T = qtab[min(quad, ((dw + 3) >> 2) - 1)];
+    typedef uint32_t pg_u32x8 __attribute__((ext_vector_type(8)));
+    pg_u32x8 rr;
+    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rr) : "s"(rp) : "memory");
     if (quad * 4 >= dw || dy0 >= dh) return;
-    const PgQuadTab2 T = qtab[quad];
-    const int sFirst = yofs[2 * dy0];                                  // wave-uniform
+    PgRowGrp R;
+    R.sFirst = (int)rr[0]; R.yrel4 = rr[1];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { R.ybeta[2 * k] = (int16_t)(rr[2 + k] & 0xFFFF); R.ybeta[2 * k + 1] = (int16_t)(rr[2 + k] >> 16); }
+    const int sFirst = R.sFirst;
     const uint8_t* sbase = src + (int64_t)blockIdx.z * sfstride + T.xb;
     PgU2 w[6];
 #pragma unroll
@@ -254,10 +270,10 @@ __global__ __launch_bounds__(256) void k_pyr_resize_rows4(
                                              __builtin_bit_cast(pg_us2, T.coef[j]), 0u, false) & ~15u;
         }
     uint8_t* dbase = dst + (int64_t)blockIdx.z * dfstride + quad * 4;
-    pyr_store_row<0>(H, dy0 + 0, dh, yrel, ybeta, dbase, dpitch);
-    pyr_store_row<1>(H, dy0 + 1, dh, yrel, ybeta, dbase, dpitch);
-    pyr_store_row<2>(H, dy0 + 2, dh, yrel, ybeta, dbase, dpitch);
-    pyr_store_row<3>(H, dy0 + 3, dh, yrel, ybeta, dbase, dpitch);
+    pyr_store_row<0>(H, dy0 + 0, dh, R, dbase, dpitch);
+    pyr_store_row<1>(H, dy0 + 1, dh, R, dbase, dpitch);
+    pyr_store_row<2>(H, dy0 + 2, dh, R, dbase, dpitch);
+    pyr_store_row<3>(H, dy0 + 3, dh, R, dbase, dpitch);
 }
 
 void pg_launch_pyramid_level(const PgPlan& P, int level, int nframes, hipStream_t s)
@@ -270,7 +286,7 @@ void pg_launch_pyramid_level(const PgPlan& P, int level, int nframes, hipStream_
         const uint32_t nxMagic = nx > 1 ? (uint32_t)(((1ull << 32) / (uint64_t)nx) + 1ull) : 0u;   // exact: tiles * nx < 2^32
         dim3 block(64, 4), grid(tiles, 1, nframes);
         hipLaunchKernelGGL(k_pyr_resize_rows4, grid, block, 0, s, S.img, S.pitch, S.fstride, S.h,
-                           D.img, D.pitch, D.fstride, D.w, D.h, D.qtab2, D.yofs, D.ybeta, D.yrel, nx, nxMagic);
+                           D.img, D.pitch, D.fstride, D.w, D.h, D.qtab2, D.rowgrp, nx, nxMagic);
         return;
     }
     if (D.qtab) {
