@@ -9,9 +9,9 @@
 //
 // The reference blurs every full pyramid level; only a 37x37 neighbourhood of each keypoint
 // is ever sampled (rotated taps reach +-18 px), so the wave stages the 43x43 RAW window in
-// LDS once (aligned 32-bit loads; reflect-101 addressing only for windows that touch the
-// image edge), takes the integer moments from it, runs the separable fixed-point blur
-// LDS->LDS and samples the 512 taps from the blurred tile.  The 256 comparisons are packed
+// LDS once (LDS-DMA; reflect-101 addressing only for windows that touch the image edge),
+// takes the integer moments from it, runs the ROW pass of the separable fixed-point blur
+// LDS->LDS and the COLUMN pass only at the 512 rotated tap positions.  The 256 comparisons are packed
 // with four 64-bit wave ballots: ballot bit j of round r is descriptor bit 64r+j, which is
 // exactly the reference's LSB-first byte packing (:127-141).
 //

@@ -14,14 +14,17 @@
 //   window interior counts as 0 (the reference's window-local score buffers).
 //
 // Structure per wave:
-//  (1) the (wCell+6)x(hCell+6) window is staged into LDS with aligned 32-bit global loads,
-//      re-aligned with v_alignbyte so that interior column 0 sits on an LDS dword boundary;
-//      (a persistent-wave variant with register prefetch of the next window measured 2x slower:
-//      the per-cell scalar set-up serialises inside one wave instead of overlapping across waves)
+//  (1) the (wCell+6)x(hCell+6) window is staged into LDS by LDS-DMA (global_load_lds, 16 B per
+//      lane, byte-unaligned source) so that interior column 0 sits on an LDS dword boundary;
+//      the wave finds its window through one 32-byte cell record (a single scalar load);
+//      (persistent waves that prefetch the next window measured slower twice -- with register
+//      prefetch 2x, with LDS-DMA double buffering 1.5x: the kernel is VALU-issue bound and
+//      needs its 8 waves per SIMD more than it needs the load latency hidden)
 //  (2) each lane tests a QUAD of 4 horizontally adjacent pixels per step from 5 aligned LDS
-//      dwords (centre, left, right, 3 rows up, 3 rows down): a pixel can only be a corner if
-//      both opposite ring pairs (0,8) and (4,12) contain a darker (or a brighter) pixel; the
-//      few percent that pass are compacted into an LDS list with ONE wave prefix sum per pass;
+//      dwords (centre, left, right, 3 rows up, 3 rows down), two pixels per 32-bit operation:
+//      a pixel can only be a corner if both opposite ring pairs (0,8) and (4,12) contain a
+//      darker (or a brighter) pixel (minThFAST pass: all four pairs incl. the diagonals); the
+//      few percent that pass are compacted into an LDS list with ONE DPP prefix sum per pass;
 //  (3) exact 16-ring scores (min3/max3 sliding arcs) for the compacted list, all lanes busy;
 //  (4) NMS on an LDS score map; survivors go to the cell's own fixed slot range of the
 //      (frame, level) candidate slab plus a per-cell count -- no atomics (a single device-scope

@@ -3,13 +3,15 @@
 // Restates ORBmatcher::DescriptorDistance (thirdparty/orb-slam2/src/ORBmatcher.cc:1651-1667,
 // identical to DBoW2 FORB::distance, thirdparty/DBoW2/DBoW2/FORB.cpp:81-101): the sum of set
 // bits of the XOR of two 32-byte descriptors.  The reference's SWAR bit-hack is the integer
-// popcount; here it is v_bcnt_u32_b32 on eight 32-bit words.  The all-pairs matrix and the
-// best/second-best scan are the superset of the reference matchers' candidate loops
-// (bestDist / bestDist2 with strict '<', ORBmatcher.cc:438-459): each lane keeps ONE query
+// popcount.  The all-pairs matrix and the best/second-best scan are the superset of the
+// reference matchers' candidate loops (bestDist / bestDist2 with strict '<',
+// ORBmatcher.cc:438-459).  Two implementations: v_bcnt_u32_b32 on eight 32-bit words (the
+// distance matrix, and best-2 for frames of 8192+ descriptors: each lane keeps ONE query
 // descriptor in 8 VGPRs and streams the train descriptors through LDS as wave-uniform
-// (broadcast, conflict-free) 128-bit reads.
+// 128-bit reads), and the i8 MFMA formulation below for the batch matcher.
 //
-// Bytes: 32 B per descriptor read once per 64-query block; popcount-bound, not HBM-bound.
+// Bytes: 32 B per descriptor read once per query block; bound by popcount issue / the matrix
+// pipe, not by HBM.
 #include "pgorb_internal.h"
 
 #define MT_T 64

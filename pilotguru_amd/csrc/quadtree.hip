@@ -20,14 +20,26 @@
 //     oracle/orb_oracle.c).  All expandable nodes alive at that point were created in the
 //     previous generation and sit in its head group in exact reverse creation order, so
 //     "later created first" == "smaller list position first".
-//   * one pass over the keys per generation: the pass that moves keys to their new node also
-//     counts them into that node's quadrants for the next generation (LDS atomics).
+//   * the generations need only COUNTS: which children of a node are non-empty / expandable.
+//     DivideNode's split points depend on the node's bounds alone, so every key's path through
+//     the first D = 5 generations (its depth-D descendant of its root) is pure geometry.  The
+//     prologue computes that index once per key and histograms it; summing groups of four gives
+//     the counts of every shallower descendant (the "count pyramid", <= 16 KiB of LDS).  While a
+//     generation splits depth <= D-1 nodes it runs on the node list and the pyramid alone -- no
+//     pass over the ~2e4 keys, and in breadth-first order ONE fused block scan places all
+//     children and all survivors.  Deeper trees (corners packed into a few depth-5 cells) leave
+//     pyramid mode: a node map turns every key's descendant index into its list position, and
+//     each further generation is one pass over the keys that moves them to their new node and
+//     counts them into its quadrants (LDS atomics).
+//   * at the end a (descendant -> list position) table gives every key its node with one LDS
+//     read; best response per node by 64-bit LDS atomicMax on (response, ~candidate order).
 //
-// The prologue compacts K2's per-cell candidate slots (one thread per cell) into
-// the dense 8-byte key records {packed candidate, node position | quadrant << 28}.
+// The prologue compacts K2's per-cell candidate slots into dense 8-byte key records, one
+// thread per RECORD (cells hold 0..100+ records; any per-cell mapping leaves one wave with the
+// long cells): the record's cell is found by binary search over the cell offsets in LDS.
 //
-// Integer/compare work on ~1e4 keys; latency-bound, not bandwidth-bound.  Throughput comes
-// from running (levels x frames) workgroups concurrently.
+// Integer/compare work on ~2e4 keys; latency-bound (the level-0 workgroup's critical path is
+// the kernel), not bandwidth-bound.  tools/experiments/qt_timing.py prints its phases.
 #include "pgorb_internal.h"
 
 #define QT_T 1024
