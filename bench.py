@@ -242,10 +242,22 @@ def main():
             out["cpu_baseline"] = cpu_baseline(W, H, NF)
             out["speedup_vs_cpu_all_cores"] = fps / out["cpu_baseline"]["value"]
             out["speedup_vs_cpu_per_core"] = fps / out["cpu_baseline"]["per_core"]
-        print(json.dumps(out))
+        line = json.dumps(out)
+    else:
+        line = None
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if line is not None:
+        # RCCL prints its version banner through C stdio, which a pipe only sees at exit: flush it
+        # first so that the JSON line is the LAST line of stdout
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
