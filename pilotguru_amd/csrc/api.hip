@@ -237,11 +237,11 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
         }
         toff[l].hasY = oky;
         toff[l].yrel = put(yr.data(), yr.size());
-        std::vector<PgRowGrp> rg((g[l].h + 3) / 4);
+        std::vector<PgRowGrp> rg((g[l].h + 3) / 4 + 1);               // + one record of slack (pairs are loaded)
         for (size_t gi = 0; gi < rg.size(); gi++) {
             PgRowGrp& R = rg[gi];
             memset(&R, 0, sizeof(R));
-            R.sFirst = yo[2 * (4 * gi)];
+            R.sFirst = yo[2 * std::min((int)(4 * gi), g[l].h - 1)];
             for (int d = 0; d < 4; d++) {
                 const int dy = std::min((int)(4 * gi) + d, g[l].h - 1);
                 R.yrel4 |= (uint32_t)yr[dy] << (8 * d);

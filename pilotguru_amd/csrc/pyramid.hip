@@ -222,44 +222,10 @@ __device__ __forceinline__ void pyr_store_row(const uint32_t (&H)[6][4], int dy,
     *reinterpret_cast<uint32_t*>(dbase + (int64_t)dy * dpitch) = out;
 }
 
-// grid (tiles per frame rounded up to a multiple of 8, 1, frames), block (64, 4): a tile is 256
-// columns x 16 rows.  Workgroup b lands on XCD b % 8; XCD k takes the k-th eighth of the frame's
-// tiles in (row, column) order, so vertically adjacent tiles -- which share two of their six
-// source rows -- read them through the same L2.
-__global__ __launch_bounds__(256) void k_pyr_resize_rows4(
-    const uint8_t* __restrict__ src, int spitch, int64_t sfstride, int sh,
-    uint8_t* __restrict__ dst, int dpitch, int64_t dfstride, int dw, int dh,
-    const PgQuadTab2* __restrict__ qtab, const PgRowGrp* __restrict__ rowgrp, int nx, uint32_t nxMagic)
+// horizontal pass of the 6 source rows of one 4-row group + the 4 destination rows
+__device__ __forceinline__ void pyr_group(const PgU2 (&w)[6], const PgQuadTab2& T, const PgRowGrp& R, int dy0, int dh,
+                                          uint8_t* dbase, int dpitch)
 {
-    // all kernel arguments in one scalar batch (left alone the compiler fetches them in four
-    // dependent groups around the early exits -- the wave is latency bound, not issue bound)
-    asm volatile("" :: "s"(src), "s"(spitch), "s"(sfstride), "s"(sh), "s"(dst), "s"(dpitch), "s"(dfstride),
-                 "s"(dw), "s"(dh), "s"(qtab), "s"(rowgrp), "s"(nx), "s"(nxMagic));
-    const int t = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const int ty = (nx == 1) ? t : (int)__umulhi((uint32_t)t, nxMagic), tx = t - ty * nx;      // t / nx, t % nx
-    const int quad = tx * 64 + threadIdx.x;
-    // a wave is one threadIdx.y: its 4 destination rows share ONE 32-byte record, fetched with a
-    // single s_load_dwordx8 while the quad table load is in flight (the per-row table reads used
-    // to be four more dependent round trips at the end of the wave)
-    const int grp = ty * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y);
-    const int dy0 = grp * 4;
-    const int ngrp = (dh + 3) >> 2;
-    const PgRowGrp* rp = rowgrp + min(grp, ngrp - 1);
-    const PgQuadTab2 T = qtab[min(quad, ((dw + 3) >> 2) - 1)];
-    typedef uint32_t pg_u32x8 __attribute__((ext_vector_type(8)));
-    pg_u32x8 rr;
-    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rr) : "s"(rp) : "memory");
-    if (quad * 4 >= dw || dy0 >= dh) return;
-    PgRowGrp R;
-    R.sFirst = (int)rr[0]; R.yrel4 = rr[1];
-#pragma unroll
-    for (int k = 0; k < 4; k++) { R.ybeta[2 * k] = (int16_t)(rr[2 + k] & 0xFFFF); R.ybeta[2 * k + 1] = (int16_t)(rr[2 + k] >> 16); }
-    const int sFirst = R.sFirst;
-    const uint8_t* sbase = src + (int64_t)blockIdx.z * sfstride + T.xb;
-    PgU2 w[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++)
-        w[k] = *reinterpret_cast<const PgU2*>(sbase + (int64_t)min(sFirst + k, sh - 1) * spitch);
     uint32_t H[6][4];                                                  // (horizontal sum >> 4) << 4
 #pragma unroll
     for (int k = 0; k < 6; k++)
@@ -269,11 +235,63 @@ __global__ __launch_bounds__(256) void k_pyr_resize_rows4(
             H[k][j] = __builtin_amdgcn_udot2(__builtin_bit_cast(pg_us2, taps),
                                              __builtin_bit_cast(pg_us2, T.coef[j]), 0u, false) & ~15u;
         }
-    uint8_t* dbase = dst + (int64_t)blockIdx.z * dfstride + quad * 4;
     pyr_store_row<0>(H, dy0 + 0, dh, R, dbase, dpitch);
     pyr_store_row<1>(H, dy0 + 1, dh, R, dbase, dpitch);
     pyr_store_row<2>(H, dy0 + 2, dh, R, dbase, dpitch);
     pyr_store_row<3>(H, dy0 + 3, dh, R, dbase, dpitch);
+}
+
+__device__ __forceinline__ PgRowGrp pyr_unpack_group(const uint32_t (&rr)[8])
+{
+    PgRowGrp R;
+    R.sFirst = (int)rr[0]; R.yrel4 = rr[1];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { R.ybeta[2 * k] = (int16_t)(rr[2 + k] & 0xFFFF); R.ybeta[2 * k + 1] = (int16_t)(rr[2 + k] >> 16); }
+    return R;
+}
+
+// grid (tiles per frame rounded up to a multiple of 8, 1, frames), block (64, 4): a tile is 256
+// columns x 32 rows, a wave (one threadIdx.y) makes two groups of 4 rows.  Workgroup b lands on
+// XCD b % 8; XCD k takes the k-th eighth of the frame's tiles in (row, column) order, so
+// vertically adjacent tiles -- which share source rows -- read them through the same L2.
+// The wave is latency bound (kernarg -> tables -> source rows -> store): all kernel arguments
+// come in one scalar batch, the two groups' 32-byte records in one s_load_dwordx16 while the
+// quad table load is in flight, and the 12 source-row loads of both groups are issued together.
+__global__ __launch_bounds__(256) void k_pyr_resize_rows4(
+    const uint8_t* __restrict__ src, int spitch, int64_t sfstride, int sh,
+    uint8_t* __restrict__ dst, int dpitch, int64_t dfstride, int dw, int dh,
+    const PgQuadTab2* __restrict__ qtab, const PgRowGrp* __restrict__ rowgrp, int nx, uint32_t nxMagic)
+{
+    asm volatile("" :: "s"(src), "s"(spitch), "s"(sfstride), "s"(sh), "s"(dst), "s"(dpitch), "s"(dfstride),
+                 "s"(dw), "s"(dh), "s"(qtab), "s"(rowgrp), "s"(nx), "s"(nxMagic));
+    const int t = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int ty = (nx == 1) ? t : (int)__umulhi((uint32_t)t, nxMagic), tx = t - ty * nx;      // t / nx, t % nx
+    const int quad = tx * 64 + threadIdx.x;
+    const int grp = (ty * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y)) * 2;      // groups grp, grp + 1
+    const int dy0 = grp * 4;
+    const int ngrp = (dh + 3) >> 2;
+    const PgRowGrp* rp = rowgrp + min(grp, ngrp - 1);                 // (the table has one record of slack)
+    const PgQuadTab2 T = qtab[min(quad, ((dw + 3) >> 2) - 1)];
+    typedef uint32_t pg_u32x16 __attribute__((ext_vector_type(16)));
+    pg_u32x16 rr;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rr) : "s"(rp) : "memory");
+    if (quad * 4 >= dw || dy0 >= dh) return;
+    const uint32_t ra[8] = {rr[0], rr[1], rr[2], rr[3], rr[4], rr[5], rr[6], rr[7]};
+    const uint32_t rb[8] = {rr[8], rr[9], rr[10], rr[11], rr[12], rr[13], rr[14], rr[15]};
+    const PgRowGrp R0 = pyr_unpack_group(ra), R1 = pyr_unpack_group(rb);
+    const bool second = dy0 + 4 < dh;                                  // wave-uniform
+    const uint8_t* sbase = src + (int64_t)blockIdx.z * sfstride + T.xb;
+    PgU2 w0[6], w1[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+        w0[k] = *reinterpret_cast<const PgU2*>(sbase + (int64_t)min(R0.sFirst + k, sh - 1) * spitch);
+    const int s1 = second ? R1.sFirst : R0.sFirst;
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+        w1[k] = *reinterpret_cast<const PgU2*>(sbase + (int64_t)min(s1 + k, sh - 1) * spitch);
+    uint8_t* dbase = dst + (int64_t)blockIdx.z * dfstride + quad * 4;
+    pyr_group(w0, T, R0, dy0, dh, dbase, dpitch);
+    if (second) pyr_group(w1, T, R1, dy0 + 4, dh, dbase, dpitch);
 }
 
 void pg_launch_pyramid_level(const PgPlan& P, int level, int nframes, hipStream_t s)
@@ -281,7 +299,7 @@ void pg_launch_pyramid_level(const PgPlan& P, int level, int nframes, hipStream_
     const PgLevel& S = P.lvl[level - 1];
     const PgLevel& D = P.lvl[level];
     if (D.qtab2 && D.yrel) {
-        const int nx = (D.w + 255) / 256, ny = (D.h + 15) / 16;
+        const int nx = (D.w + 255) / 256, ny = (D.h + 31) / 32;
         const int tiles = (nx * ny + 7) & ~7;
         const uint32_t nxMagic = nx > 1 ? (uint32_t)(((1ull << 32) / (uint64_t)nx) + 1ull) : 0u;   // exact: tiles * nx < 2^32
         dim3 block(64, 4), grid(tiles, 1, nframes);
