@@ -342,3 +342,70 @@ def test_many_roots_shallow_count_pyramid(oracle, w, h, nf):
     okp, odesc = ora.extract(img)
     kp, desc = pg.ORBextractor(nf, 1.2, 2, 20, 7, max_width=w, max_height=h)(img)
     assert len(okp) > 100 and kp.tobytes() == okp.tobytes() and np.array_equal(desc, odesc)
+
+
+def _fuzz_cases():
+    rng = np.random.RandomState(20260928)
+    cases = []
+    for i in range(14):
+        w = int(rng.randint(97, 900)); h = int(rng.randint(97, 700))
+        if not (0.45 < w / h < 6.0):
+            w, h = 320 + i, 240 + 2 * i
+        scale = float(rng.choice([1.2, 1.2, 1.2, 1.25, 1.33, 1.5, 1.7, 2.0]))
+        nlev = int(rng.randint(1, 9))
+        nf = int(rng.randint(60, 1500))
+        ini = int(rng.choice([20, 20, 12, 30, 40])); mn = int(rng.choice([7, 7, 5, 10, 3]))
+        cases.append((w, h, scale, nlev, nf, ini, min(mn, ini), i))
+    return cases
+
+
+@pytest.mark.parametrize("w,h,scale,nlev,nf,ini,mn,seed", _fuzz_cases())
+def test_randomised_configurations_bit_exact(oracle, w, h, scale, nlev, nf, ini, mn, seed):
+    """Differential test over random frame sizes / scale factors / level counts / quotas /
+    thresholds: keypoints and descriptors of the HIP path equal the oracle's, or both reject the
+    frame as too small for the cell grid."""
+    import pilotguru_amd as pg
+    img = synth_scene(100 + seed, w, h)
+    if seed % 3 == 2:                                   # low-contrast variant: most cells need the minTh pass
+        img = (96 + (img.astype(np.int32) - 128) // 6).clip(0, 255).astype(np.uint8)
+    try:
+        okp, odesc = oracle.OrbOracle(nf, scale, nlev, ini, mn).extract(img)
+    except Exception:
+        okp = None
+    ext = pg.ORBextractor(nf, scale, nlev, ini, mn, max_width=w, max_height=h)
+    if okp is None:
+        with pytest.raises(Exception):
+            ext(img)
+        return
+    kp, desc = ext(img)
+    assert len(kp) == len(okp) and kp.tobytes() == okp.tobytes() and np.array_equal(desc, odesc)
+
+
+def test_match_batch_ragged_frame_sizes(oracle):
+    """pgorb_match_batch_device on frames of very different sizes (empty, one descriptor, around
+    the 16-descriptor MFMA block and the 256-query workgroup), arbitrary pairs incl. a frame
+    against itself; near-duplicates planted so that ties and second-best values matter."""
+    import torch
+    counts = [0, 1, 15, 16, 17, 255, 256, 257, 700, 64]
+    cap = 704
+    rng = np.random.RandomState(99)
+    desc = rng.randint(0, 256, (len(counts), cap, 32)).astype(np.uint8)
+    for f in range(1, len(counts)):                       # share some descriptors between frames
+        m = min(counts[f], counts[f - 1])
+        if m:
+            desc[f, :m:3] = desc[f - 1, :m:3]
+            desc[f, 1:m:5, 7] ^= 0x10
+    pairs = [(1, 0), (0, 1), (2, 3), (3, 2), (4, 4), (8, 5), (5, 8), (6, 7), (7, 6), (9, 8), (8, 9), (1, 1), (8, 8)]
+    ext = _make(100, 320, 240)
+    d = torch.from_numpy(desc).cuda()
+    n = torch.tensor(counts, dtype=torch.int32, device="cuda")
+    pq = torch.tensor([p[0] for p in pairs], dtype=torch.int32, device="cuda")
+    pt = torch.tensor([p[1] for p in pairs], dtype=torch.int32, device="cuda")
+    bi, b1, b2 = ext.match_batch_device(d, n, pq, pt)
+    torch.cuda.synchronize()
+    for k, (q, t) in enumerate(pairs):
+        m = counts[q]
+        obi, ob1, ob2 = oracle.hamming_best2(desc[q, :m], desc[t, :counts[t]])
+        assert np.array_equal(bi[k, :m].cpu().numpy(), obi), (q, t)
+        assert np.array_equal(b1[k, :m].cpu().numpy().view(np.uint16), ob1), (q, t)
+        assert np.array_equal(b2[k, :m].cpu().numpy().view(np.uint16), ob2), (q, t)
