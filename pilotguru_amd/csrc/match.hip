@@ -52,54 +52,61 @@ __global__ __launch_bounds__(MT_T) void k_hamming_matrix(const uint8_t* __restri
     }
 }
 
-// ---- best / second-best over all train descriptors: the all-pairs scan as an i8 MFMA --------
+// ---- best / second-best over all train descriptors: the all-pairs scan on the matrix cores ----
 //
-// With bits mapped to +64 / -64 the dot product of two 256-element vectors is
-// 4096 * (256 - 2 * Hamming), so a 16 x 16 tile of distances is four v_mfma_i32_16x16x64_i8
-// (exact in int32) instead of 16 * 16 * (8 xor + 8 bcnt).  The first MFMA of a tile takes its C
-// operand from a per-lane constant, so the accumulator leaves the matrix pipe as the finished
-// sort key
-//     key = (256 - distance) << 13 | (8191 - train index)            (train index < 8192)
-// and what stays on the VALU is max + med3 per distance, which keep the two LARGEST keys
-// (k1 >= k2) of every (row, column class): larger key = smaller distance, then smaller index --
-// the reference's strict-'<' scan with bestDist / bestDist2 (ORBmatcher.cc:438-459), "first
-// minimum wins".  (dot + 256 is even, which is where the 13th index bit comes from.)
+// With bits mapped to +1 / -1 the dot product of two 256-element vectors is 256 - 2 * Hamming, so
+// a 16 x 16 tile of distances is TWO v_mfma_scale_f32_16x16x128_f8f6f4 on fp4 (e2m1) operands
+// instead of 16 * 16 * (8 xor + 8 bcnt); fp4 is the format with the highest MFMA rate on gfx950
+// and +-1 is all a bit needs.  The block scales (E8M0, 2^6 on either side) multiply the products
+// by 4096 and the first MFMA of a tile takes its C operand from a per-lane constant, so the f32
+// accumulator leaves the matrix pipe as the finished sort key
+//     key = (256 - distance) * 8192 + (8191 - train index)            (train index < 8192)
+// -- an integer below 2^22, exact in f32 -- and what stays on the VALU is two v_med3_f32 per
+// distance, which keep the two LARGEST keys (k1 >= k2) of every (row, column class): larger key =
+// smaller distance, then smaller index -- the reference's strict-'<' scan with bestDist /
+// bestDist2 (ORBmatcher.cc:438-459), "first minimum wins".  (dot + 256 is even, which is where
+// the 13th index bit comes from.)  tools/ubench/mfma_fp4_dot.hip checks the instruction's
+// semantics (D = C + 4096 * dot exactly; row 4 * (l >> 4) + r, column l & 15).
 //
-// Operand layout ("x16 block", 4 KiB per 16 descriptors): [16-bit chunk c][descriptor d][16 B],
-// byte j of an entry = bit 16c + j of descriptor d as +64 / -64.  k-step s of an MFMA operand is
-// the contiguous KiB s of a block and lane l reads its 16 bytes at l * 16: rows/columns are
-// l & 15, the K slice is chunk 4s + (l >> 4) for A and B alike (any K order works as long as
-// both sides agree).  Train frames are expanded once per pair by k_expand_trains into a scratch
-// slab and staged through LDS with LDS-DMA (double buffered); queries are expanded in registers.
-// C/D layout of the 16x16 MFMA: lane l, register r holds row 4 * (l >> 4) + r, column l & 15.
+// Operand layout ("x16 block", 2 KiB per 16 descriptors): [k-step s][lane l][16 B]; the entry of
+// lane l in k-step s holds bits 128 s + 32 (l >> 4) .. + 31 of descriptor l & 15, one fp4 per bit
+// (0x2 = +1.0, 0xA = -1.0), bit e in nibble e.  Rows/columns are l & 15 for A and B alike and both
+// sides use the same K order, which is all the dot product needs.  Train frames are expanded once
+// per pair by k_expand_trains into a scratch slab and staged through LDS with LDS-DMA (double
+// buffered); queries are expanded in registers.
 typedef int pg_v4i __attribute__((ext_vector_type(4)));
+typedef int pg_v8i __attribute__((ext_vector_type(8)));
+typedef float pg_v4f __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const void* pg_gptr_t;
 typedef __attribute__((address_space(3))) void* pg_lptr_t;
 
-#define MX_BLOCK_BYTES 4096
-#define MX_TILE_BLOCKS 8          // train blocks staged per LDS tile (128 descriptors, 32 KiB)
+#define MX_BLOCK_BYTES 2048
+#define MX_TILE_BLOCKS 8          // train blocks staged per LDS tile (128 descriptors, 16 KiB)
 #define MX_WAVES 4                // 64 queries per wave, 256 per workgroup
 #define MX_IDX_BITS 13
-#define MX_IDX_MASK ((1u << MX_IDX_BITS) - 1u)
+#define MX_IDX_MASK ((1 << MX_IDX_BITS) - 1)
 #define MX_MAX_TRAIN (1 << MX_IDX_BITS)
+#define MX_SCALE 0x85858585       // E8M0 133 = 2^6 per side: products x 4096
 
-// 4 bits -> 4 bytes of +64 (bit set) / -64
-__device__ __forceinline__ uint32_t pg_pm64x4(uint32_t nib)
+// 8 bits -> 8 fp4 values, bit e in nibble e: +1.0 (0x2) where set, -1.0 (0xA) where clear
+__device__ __forceinline__ uint32_t pg_fp4x8(uint32_t b)
 {
-    const uint32_t x = (nib * 0x00204081u) & 0x01010101u;       // byte i = bit i
-    return (x << 7) ^ 0xC0C0C0C0u;                               // 1 -> 0x40, 0 -> 0xC0
+    uint32_t x = (b | (b << 12)) & 0x000F000Fu;
+    x = (x | (x << 6)) & 0x03030303u;
+    x = (x | (x << 3)) & 0x11111111u;                            // nibble e = bit e
+    return (x << 3) ^ 0xAAAAAAAAu;
 }
 
-__device__ __forceinline__ pg_v4i pg_pm64x16(uint32_t bits16)
+__device__ __forceinline__ pg_v4i pg_fp4x32(uint32_t bits32)
 {
     pg_v4i v;
-    v.x = (int)pg_pm64x4(bits16 & 15u); v.y = (int)pg_pm64x4((bits16 >> 4) & 15u);
-    v.z = (int)pg_pm64x4((bits16 >> 8) & 15u); v.w = (int)pg_pm64x4((bits16 >> 12) & 15u);
+    v.x = (int)pg_fp4x8(bits32 & 0xFFu); v.y = (int)pg_fp4x8((bits32 >> 8) & 0xFFu);
+    v.z = (int)pg_fp4x8((bits32 >> 16) & 0xFFu); v.w = (int)pg_fp4x8(bits32 >> 24);
     return v;
 }
 
-// grid (blocks of 16 train descriptors, pairs); 256 threads: thread t writes entry (c = t / 16, d = t % 16)
-__global__ __launch_bounds__(256) void k_expand_trains(const uint8_t* __restrict__ tdesc, const int32_t* __restrict__ n,
+// grid (blocks of 16 train descriptors, pairs); 128 threads: thread t writes entry (s = t / 64, lane = t % 64)
+__global__ __launch_bounds__(128) void k_expand_trains(const uint8_t* __restrict__ tdesc, const int32_t* __restrict__ n,
                                                         int cap, const int32_t* __restrict__ pt, int nb_single,
                                                         int blocksPerPair, uint8_t* __restrict__ xt)
 {
@@ -107,54 +114,53 @@ __global__ __launch_bounds__(256) void k_expand_trains(const uint8_t* __restrict
     const int ft = pt ? pt[p] : 0;
     const int nb = pt ? min(n[ft], cap) : nb_single;
     if (16 * tb >= nb) return;                                   // never read
-    const int c = threadIdx.x >> 4, d = threadIdx.x & 15;
-    const int idx = 16 * tb + d;
-    pg_v4i v = {0, 0, 0, 0};
+    const int s = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int idx = 16 * tb + (l & 15);
+    pg_v4i v = {0, 0, 0, 0};                                     // fp4 0.0: padding columns (masked anyway)
     if (idx < nb) {
-        const uint16_t* src = reinterpret_cast<const uint16_t*>(tdesc + ((int64_t)ft * cap + idx) * 32);
-        v = pg_pm64x16(src[c]);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(tdesc + ((int64_t)ft * cap + idx) * 32);
+        v = pg_fp4x32(src[4 * s + (l >> 4)]);
     }
     *reinterpret_cast<pg_v4i*>(xt + ((int64_t)p * blocksPerPair + tb) * MX_BLOCK_BYTES + threadIdx.x * 16) = v;
 }
 
-// The two largest keys are tracked with v_med3_f32 on the key's bit pattern: MX_KEY_BIAS puts
-// every key into [1.0, 1.5) as a float (positive, normal, never NaN), where float order is
-// integer order; 0 (= +0.0) is "none".  (A compiler-known instruction, so the hazard recogniser
-// places the wait states between the MFMA that writes a VGPR and its first VALU read.)
-#define MX_KEY_BIAS 0x3F800000u
-__device__ __forceinline__ unsigned pg_med3(unsigned a, unsigned b, unsigned c)
-{
-    return __float_as_uint(__builtin_amdgcn_fmed3f(__uint_as_float(a), __uint_as_float(b), __uint_as_float(c)));
-}
+// Keys are positive integers held as f32 values; -1 is "none".  v_med3_f32 is a compiler-known
+// instruction, so the hazard recogniser places the wait states between the MFMA that writes a
+// VGPR and its first VALU read (match.hip is built with MFMA results in VGPRs, see the Makefile).
+__device__ __forceinline__ float pg_med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
 
 // keys of this wave's 64 queries (A) against the 16 trains of one staged x16 block (B, already
-// in registers); kq = the per-lane key offset (256 << 12) + (8191 - column), in all four registers
-__device__ __forceinline__ void mx_block(const pg_v4i (&B)[4], const pg_v4i (&A)[4][4], const pg_v4i kq, pg_v4i (&acc)[4])
+// in registers); kq = the per-lane key offset 256 * 4096 + (8191 - column), in all four registers
+__device__ __forceinline__ void mx_block(const pg_v4i (&B)[2], const pg_v4i (&A)[4][2], const pg_v4f kq, pg_v4f (&acc)[4])
 {
 #pragma unroll
-    for (int s = 0; s < 4; s++)
+    for (int s = 0; s < 2; s++) {
+        const pg_v8i b8 = {B[s].x, B[s].y, B[s].z, B[s].w, 0, 0, 0, 0};
 #pragma unroll
-        for (int a = 0; a < 4; a++)
-            acc[a] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[a][s], B[s], s == 0 ? kq : acc[a], 0, 0, 0);
+        for (int a = 0; a < 4; a++) {
+            const pg_v8i a8 = {A[a][s].x, A[a][s].y, A[a][s].z, A[a][s].w, 0, 0, 0, 0};
+            acc[a] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, s == 0 ? kq : acc[a], 4, 4, 0, MX_SCALE, 0, MX_SCALE);
+        }
+    }
 }
 
-__device__ __forceinline__ void mx_load(const uint8_t* blockLane, pg_v4i (&B)[4])
+__device__ __forceinline__ void mx_load(const uint8_t* blockLane, pg_v4i (&B)[2])
 {
 #pragma unroll
-    for (int s = 0; s < 4; s++) B[s] = *reinterpret_cast<const pg_v4i*>(blockLane + s * 1024);
+    for (int s = 0; s < 2; s++) B[s] = *reinterpret_cast<const pg_v4i*>(blockLane + s * 1024);
 }
 
 template <bool MASK>
-__device__ __forceinline__ void mx_update(const pg_v4i (&acc)[4], bool valid, unsigned (&k1)[4][4], unsigned (&k2)[4][4])
+__device__ __forceinline__ void mx_update(const pg_v4f (&acc)[4], bool valid, float (&k1)[4][4], float (&k2)[4][4])
 {
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            unsigned key = (unsigned)acc[a][r];
-            if (MASK) key = valid ? key : 0u;
+            float key = acc[a][r];
+            if (MASK) key = valid ? key : -1.f;
             k2[a][r] = pg_med3(k1[a][r], k2[a][r], key);
-            k1[a][r] = pg_med3(k1[a][r], key, 0x7F800000u);          // max(k1, key): the median with +inf
+            k1[a][r] = pg_med3(k1[a][r], key, __builtin_inff());     // max(k1, key): the median with +inf
         }
 }
 
@@ -177,22 +183,22 @@ __global__ __launch_bounds__(64 * MX_WAVES) void k_match_mfma(const uint8_t* __r
     const int64_t o = (int64_t)p * cap;
 
     // queries of this wave as MFMA A operands: A[a][s] = rows 16a .. 16a+15, k-step s
-    pg_v4i A[4][4];
+    pg_v4i A[4][2];
 #pragma unroll
     for (int a = 0; a < 4; a++) {
         const int q = qbase + 16 * a + (lane & 15);
-        const uint16_t* src = reinterpret_cast<const uint16_t*>(qd + (int64_t)q * 32) + (lane >> 4);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(qd + (int64_t)q * 32) + (lane >> 4);
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
+        for (int s = 0; s < 2; s++) {
             A[a][s] = pg_v4i{0, 0, 0, 0};
-            if (q < na) A[a][s] = pg_pm64x16(src[4 * s]);
+            if (q < na) A[a][s] = pg_fp4x32(src[4 * s]);
         }
     }
-    unsigned k1[4][4], k2[4][4];
+    float k1[4][4], k2[4][4];
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) { k1[a][r] = 0u; k2[a][r] = 0u; }      // 0 = none (valid keys are > 0)
+        for (int r = 0; r < 4; r++) { k1[a][r] = -1.f; k2[a][r] = -1.f; }      // -1 = none (valid keys are >= 0)
 
     const int nblocks = (nb + 15) >> 4;
     const uint8_t* xp = xt + (int64_t)p * blocksPerPair * MX_BLOCK_BYTES;
@@ -200,7 +206,7 @@ __global__ __launch_bounds__(64 * MX_WAVES) void k_match_mfma(const uint8_t* __r
     auto stage = [&](int t0, int buf) {
         const int cnt = min(MX_TILE_BLOCKS, nblocks - t0);
         // 16 B per lane, wave w fills KiB w, w + 4, ... of the tile
-        for (int kb = wv; kb < cnt * 4; kb += MX_WAVES)
+        for (int kb = wv; kb < cnt * (MX_BLOCK_BYTES / 1024); kb += MX_WAVES)
             __builtin_amdgcn_global_load_lds((pg_gptr_t)(xp + (int64_t)t0 * MX_BLOCK_BYTES + kb * 1024 + lane * 16),
                                              (pg_lptr_t)(tile + buf * (MX_TILE_BLOCKS * MX_BLOCK_BYTES) + kb * 1024), 16, 0, 0);
     };
@@ -213,34 +219,35 @@ __global__ __launch_bounds__(64 * MX_WAVES) void k_match_mfma(const uint8_t* __r
         if (t0 + MX_TILE_BLOCKS < nblocks) stage(t0 + MX_TILE_BLOCKS, buf ^ 1);
         if (!active) continue;
         const uint8_t* bl = tile + buf * (MX_TILE_BLOCKS * MX_BLOCK_BYTES) + lane * 16;
-        int kc = (int)MX_KEY_BIAS + (256 << (MX_IDX_BITS - 1)) + (int)MX_IDX_MASK - (t0 * 16 + (lane & 15));
+        float kc = (float)((256 << (MX_IDX_BITS - 1)) + MX_IDX_MASK - (t0 * 16 + (lane & 15)));
         // blocks that lie entirely below nb take the unmasked update; at most one block per
         // pair is partial (kept out of the hot loop: a select inside it costs 32 register copies)
         const int cntFull = min(cnt, (nb >> 4) - t0);
         // ping-pong B operands: block blk+1 is fetched from LDS while block blk is in the matrix
         // pipe (reads past the last block of the tile stay inside the double buffer)
-        pg_v4i B0[4], B1[4], acc[4];
+        pg_v4i B0[2], B1[2];
+        pg_v4f acc[4];
         mx_load(bl, B0);
         int blk = 0;
-        for (; blk + 2 <= cntFull; blk += 2, kc -= 32) {
+        for (; blk + 2 <= cntFull; blk += 2, kc -= 32.f) {
             mx_load(bl + (blk + 1) * MX_BLOCK_BYTES, B1);
-            mx_block(B0, A, pg_v4i{kc, kc, kc, kc}, acc);
+            mx_block(B0, A, pg_v4f{kc, kc, kc, kc}, acc);
             mx_update<false>(acc, true, k1, k2);
             mx_load(bl + (blk + 2) * MX_BLOCK_BYTES, B0);
-            mx_block(B1, A, pg_v4i{kc - 16, kc - 16, kc - 16, kc - 16}, acc);
+            mx_block(B1, A, pg_v4f{kc - 16.f, kc - 16.f, kc - 16.f, kc - 16.f}, acc);
             mx_update<false>(acc, true, k1, k2);
         }
         if (blk < cntFull) {                                     // odd count: one more full block, in B0
             mx_load(bl + (blk + 1) * MX_BLOCK_BYTES, B1);
-            mx_block(B0, A, pg_v4i{kc, kc, kc, kc}, acc);
+            mx_block(B0, A, pg_v4f{kc, kc, kc, kc}, acc);
             mx_update<false>(acc, true, k1, k2);
-            blk++; kc -= 16;
+            blk++; kc -= 16.f;
             if (blk < cnt) {
-                mx_block(B1, A, pg_v4i{kc, kc, kc, kc}, acc);
+                mx_block(B1, A, pg_v4f{kc, kc, kc, kc}, acc);
                 mx_update<true>(acc, (t0 + blk) * 16 + (lane & 15) < nb, k1, k2);
             }
         } else if (blk < cnt) {                                  // the partial block is in B0
-            mx_block(B0, A, pg_v4i{kc, kc, kc, kc}, acc);
+            mx_block(B0, A, pg_v4f{kc, kc, kc, kc}, acc);
             mx_update<true>(acc, (t0 + blk) * 16 + (lane & 15) < nb, k1, k2);
         }
     }
@@ -250,19 +257,19 @@ __global__ __launch_bounds__(64 * MX_WAVES) void k_match_mfma(const uint8_t* __r
     for (int a = 0; a < 4; a++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            unsigned m1 = k1[a][r] ? k1[a][r] - MX_KEY_BIAS : 0u, m2 = k2[a][r] ? k2[a][r] - MX_KEY_BIAS : 0u;
+            int m1 = (int)k1[a][r], m2 = (int)k2[a][r];
 #pragma unroll
             for (int m = 1; m < 16; m <<= 1) {
-                const unsigned o1 = (unsigned)__shfl_xor((int)m1, m), o2 = (unsigned)__shfl_xor((int)m2, m);
-                const unsigned hi = max(m1, o1);
+                const int o1 = __shfl_xor(m1, m), o2 = __shfl_xor(m2, m);
+                const int hi = max(m1, o1);
                 m2 = max(min(m1, o1), max(m2, o2));
                 m1 = hi;
             }
             const int q = qbase + 16 * a + 4 * (lane >> 4) + r;
             if ((lane & 15) == 0 && q < na) {
-                best_idx[o + q] = m1 ? (int32_t)(MX_IDX_MASK - (m1 & MX_IDX_MASK)) : -1;
-                best[o + q] = m1 ? (uint16_t)(256u - (m1 >> MX_IDX_BITS)) : (uint16_t)65535;
-                second[o + q] = m2 ? (uint16_t)(256u - (m2 >> MX_IDX_BITS)) : (uint16_t)65535;
+                best_idx[o + q] = m1 >= 0 ? (int32_t)(MX_IDX_MASK - (m1 & MX_IDX_MASK)) : -1;
+                best[o + q] = m1 >= 0 ? (uint16_t)(256 - (m1 >> MX_IDX_BITS)) : (uint16_t)65535;
+                second[o + q] = m2 >= 0 ? (uint16_t)(256 - (m2 >> MX_IDX_BITS)) : (uint16_t)65535;
             }
         }
 }
@@ -380,7 +387,7 @@ void pg_launch_best2(const uint8_t* d_a, int na, const uint8_t* d_b, int nb, uin
     }
     const int bpp = (nb + 15) / 16;
     if (bpp > 0)
-        hipLaunchKernelGGL(k_expand_trains, dim3(bpp, 1), dim3(256), 0, s, d_b, nullptr, nb, nullptr, nb, bpp, d_scratch);
+        hipLaunchKernelGGL(k_expand_trains, dim3(bpp, 1), dim3(128), 0, s, d_b, nullptr, nb, nullptr, nb, bpp, d_scratch);
     hipLaunchKernelGGL(k_match_mfma, dim3((na + 64 * MX_WAVES - 1) / (64 * MX_WAVES), 1), dim3(64 * MX_WAVES), 0, s,
                        d_a, d_scratch, nullptr, na, nullptr, nullptr, na, nb, bpp, d_best_idx, d_best, d_second);
 }
@@ -396,7 +403,7 @@ void pg_launch_match_batch(const uint8_t* d_desc, const int32_t* d_n, int cap_pe
         return;
     }
     const int bpp = (cap_per_frame + 15) / 16;
-    hipLaunchKernelGGL(k_expand_trains, dim3(bpp, npairs), dim3(256), 0, s, d_desc, d_n, cap_per_frame, d_pt, 0, bpp, d_scratch);
+    hipLaunchKernelGGL(k_expand_trains, dim3(bpp, npairs), dim3(128), 0, s, d_desc, d_n, cap_per_frame, d_pt, 0, bpp, d_scratch);
     hipLaunchKernelGGL(k_match_mfma, dim3((cap_per_frame + 64 * MX_WAVES - 1) / (64 * MX_WAVES), npairs), dim3(64 * MX_WAVES), 0, s,
                        d_desc, d_scratch, d_n, cap_per_frame, d_pq, d_pt, 0, 0, bpp, d_best_idx, d_best, d_second);
 }
