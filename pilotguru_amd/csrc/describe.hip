@@ -126,6 +126,12 @@ struct PgGauss7 { int k0, k1, k2, k3; };     // K[0]=K[6]=k0 ... K[3]=k3 (8-bit 
 typedef __attribute__((address_space(1))) const void* pg_gptr_t;
 typedef __attribute__((address_space(3))) void* pg_lptr_t;
 typedef unsigned short pg_us2 __attribute__((ext_vector_type(2)));
+typedef int pg_v4i __attribute__((ext_vector_type(4)));
+
+// B operand of the row-pass MFMAs: the banded Toeplitz matrix of the 7 taps as i8, [column block
+// cb][lane l][16 bytes]: byte j of an entry is T[k][n] = K[k - n] (0 <= k - n <= 6, n < 37) for
+// k = 16 (l >> 4) + j, n = 16 cb + (l & 15).  Filled once by pg_launch_describe.
+__device__ uint32_t pg_blur_btab[3 * 64 * 4];
 
 // Column pass of the separable blur for ONE output pixel (Y, X) of the 37x37 blurred tile, from
 // the row-pass sums hT[row pair][column] = (row 2p | row 2p+1 << 16): rows Y .. Y+6 are three
@@ -221,30 +227,34 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
     const float angle = pg_fast_atan2((float)m01, (float)m10);
 
     // ---- 7x7 Gaussian, fixed point, separable (OpenCV 2.4 8U path, Appendix A4) ---------
-    // row pass: a task = 4 adjacent columns of a PAIR of rows; each sum is two v_dot4_u32_u8
-    // against the packed taps (K0..K3) and (K4,K5,K6,0); the sums of the two rows are stored
-    // packed (row r | row r+1 << 16) so the column pass can use v_dot2_u32_u16.
-    const uint32_t KA = (uint32_t)G.k0 | ((uint32_t)G.k1 << 8) | ((uint32_t)G.k2 << 16) | ((uint32_t)G.k3 << 24);
-    const uint32_t KB = (uint32_t)G.k2 | ((uint32_t)G.k1 << 8) | ((uint32_t)G.k0 << 16);
+    // row pass on the matrix cores: rowsum[r][n] = sum_t K[t] * raw[r][n + t] is the product of the
+    // window (48 x 64, u8 taken as i8 by flipping bit 7, i.e. minus 128) with the banded Toeplitz
+    // matrix of the taps (64 x 48, pg_blur_btab): nine v_mfma_i32_16x16x64_i8, exact in int32,
+    // with 128 * sum(K) as the accumulator's start value.  Columns 43.. of a row operand are the
+    // next row's bytes (whatever they are: the matching Toeplitz rows are zero), rows 43.. are
+    // never stored.  The sums of two rows are stored packed (row r | row r+1 << 16) so the column
+    // pass can use v_dot2_u32_u16.  (The VALU version was 185 instructions per keypoint.)
     uint32_t* hT = hbuf;                                       // [22 row pairs][DH_PITCH columns]
-    for (int i = lane; i < 22 * 10; i += 64) {
-        const int rp = i / 10, q = i - rp * 10;
-        uint32_t o[2][4];
+    {
+        const int cinit = 128 * (2 * (G.k0 + G.k1 + G.k2) + G.k3);
+        pg_v4i Bop[3];
 #pragma unroll
-        for (int rr = 0; rr < 2; rr++) {
-            const int r = min(2 * rp + rr, DW_N - 1);          // pair 21 = (row 42, unused)
-            const uint32_t* s = reinterpret_cast<const uint32_t*>(raw + r * DW_PITCH) + q;
-            const uint32_t w0 = s[0], w1 = s[1], w2 = s[2];
-            o[rr][0] = __builtin_amdgcn_udot4(w0, KA, __builtin_amdgcn_udot4(w1, KB, 0u, false), false);
+        for (int cb = 0; cb < 3; cb++) Bop[cb] = reinterpret_cast<const pg_v4i*>(pg_blur_btab)[cb * 64 + lane];
 #pragma unroll
-            for (int k = 1; k < 4; k++)
-                o[rr][k] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, (uint32_t)k), KA,
-                               __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, (uint32_t)k), KB, 0u, false), false);
+        for (int rb = 0; rb < 3; rb++) {
+            pg_v4i Aop = *reinterpret_cast<const pg_v4i*>(raw + (16 * rb + (lane & 15)) * DW_PITCH + 16 * (lane >> 4));
+            Aop.x ^= (int)0x80808080; Aop.y ^= (int)0x80808080; Aop.z ^= (int)0x80808080; Aop.w ^= (int)0x80808080;
+            const int pair = 8 * rb + 2 * (lane >> 4);
+#pragma unroll
+            for (int cb = 0; cb < 3; cb++) {
+                const pg_v4i acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aop, Bop[cb], pg_v4i{cinit, cinit, cinit, cinit}, 0, 0, 0);
+                const int n = 16 * cb + (lane & 15);
+                if (n < DH_PITCH) {                             // each sum <= 257*255 = 65535
+                    if (pair < 22) hT[pair * DH_PITCH + n] = (uint32_t)acc.x | ((uint32_t)acc.y << 16);
+                    if (pair + 1 < 22) hT[(pair + 1) * DH_PITCH + n] = (uint32_t)acc.z | ((uint32_t)acc.w << 16);
+                }
+            }
         }
-        uint4 st;                                               // each sum <= 257*255 = 65535
-        st.x = o[0][0] | (o[1][0] << 16); st.y = o[0][1] | (o[1][1] << 16);
-        st.z = o[0][2] | (o[1][2] << 16); st.w = o[0][3] | (o[1][3] << 16);
-        *reinterpret_cast<uint4*>(hT + rp * DH_PITCH + 4 * q) = st;
     }
     __syncthreads();
     // column pass: on demand.  Only the 512 rotated tap positions of the 37x37 blurred tile are
@@ -314,6 +324,23 @@ void pg_launch_describe(const PgPlan& P, int nframes, pgorb_keypoint* d_kps, uin
                         int cap_per_frame, int32_t* d_n, hipStream_t s)
 {
     static const PgGauss7 G = pg_gauss7();
+    static bool tabReady[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !tabReady[dev]) {
+        const int K[7] = {G.k0, G.k1, G.k2, G.k3, G.k2, G.k1, G.k0};
+        uint32_t tab[3 * 64 * 4] = {};
+        for (int cb = 0; cb < 3; cb++)
+            for (int l = 0; l < 64; l++)
+                for (int j = 0; j < 16; j++) {
+                    const int k = 16 * (l >> 4) + j, n = 16 * cb + (l & 15), t = k - n;
+                    const uint32_t v = (t >= 0 && t <= 6 && n < DH_N) ? (uint32_t)K[t] : 0u;
+                    tab[(cb * 64 + l) * 4 + j / 4] |= v << (8 * (j % 4));
+                }
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(pg_blur_btab), tab, sizeof(tab), 0, hipMemcpyHostToDevice, s);
+        (void)hipStreamSynchronize(s);                           // tab is a stack array
+        tabReady[dev] = true;
+    }
     dim3 grid((P.selTotal + 7) & ~7, nframes), block(64);
     hipLaunchKernelGGL(k_describe, grid, block, 0, s, P, G, d_kps, d_desc, cap_per_frame, d_n);
 }
