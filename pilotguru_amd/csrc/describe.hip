@@ -158,8 +158,11 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
                                                   uint8_t* __restrict__ desc, int cap_per_frame,
                                                   int32_t* __restrict__ n_out)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t raw[DW_N * DW_PITCH];       // 2064 B
-    __shared__ __attribute__((aligned(16))) uint32_t hbuf[22 * DH_PITCH];       // 3520 B: [row pair][column]
+    // one 3520-byte LDS buffer per wave: first the raw window (43 rows x 48 B), then -- once the
+    // moments and the row-pass operands have been read from it -- the row sums [row pair][column]
+    // (8 waves per SIMD instead of 7: the wave is a long dependent chain, occupancy is throughput)
+    __shared__ __attribute__((aligned(16))) uint32_t hbuf[22 * DH_PITCH];
+    uint8_t* raw = reinterpret_cast<uint8_t*>(hbuf);
 
     const int lane = threadIdx.x;
     const int frame = blockIdx.y;
@@ -237,17 +240,22 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
     uint32_t* hT = hbuf;                                       // [22 row pairs][DH_PITCH columns]
     {
         const int cinit = 128 * (2 * (G.k0 + G.k1 + G.k2) + G.k3);
-        pg_v4i Bop[3];
+        pg_v4i Bop[3], Aop[3];
 #pragma unroll
         for (int cb = 0; cb < 3; cb++) Bop[cb] = reinterpret_cast<const pg_v4i*>(pg_blur_btab)[cb * 64 + lane];
+        // ALL row operands leave the raw window before the first row sum is written over it
 #pragma unroll
         for (int rb = 0; rb < 3; rb++) {
-            pg_v4i Aop = *reinterpret_cast<const pg_v4i*>(raw + (16 * rb + (lane & 15)) * DW_PITCH + 16 * (lane >> 4));
-            Aop.x ^= (int)0x80808080; Aop.y ^= (int)0x80808080; Aop.z ^= (int)0x80808080; Aop.w ^= (int)0x80808080;
+            Aop[rb] = *reinterpret_cast<const pg_v4i*>(raw + (16 * rb + (lane & 15)) * DW_PITCH + 16 * (lane >> 4));
+            Aop[rb].x ^= (int)0x80808080; Aop[rb].y ^= (int)0x80808080; Aop[rb].z ^= (int)0x80808080; Aop[rb].w ^= (int)0x80808080;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rb = 0; rb < 3; rb++) {
             const int pair = 8 * rb + 2 * (lane >> 4);
 #pragma unroll
             for (int cb = 0; cb < 3; cb++) {
-                const pg_v4i acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aop, Bop[cb], pg_v4i{cinit, cinit, cinit, cinit}, 0, 0, 0);
+                const pg_v4i acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aop[rb], Bop[cb], pg_v4i{cinit, cinit, cinit, cinit}, 0, 0, 0);
                 const int n = 16 * cb + (lane & 15);
                 if (n < DH_PITCH) {                             // each sum <= 257*255 = 65535
                     if (pair < 22) hT[pair * DH_PITCH + n] = (uint32_t)acc.x | ((uint32_t)acc.y << 16);
