@@ -123,6 +123,34 @@ __device__ __forceinline__ void pg_sincos_f(float angle, float* s_out, float* c_
 
 struct PgGauss7 { int k0, k1, k2, k3; };     // K[0]=K[6]=k0 ... K[3]=k3 (8-bit fixed point)
 
+// sum over the 64 lanes, returned wave-uniform: DPP row shifts inside each row of 16, row
+// broadcasts across rows, then lane 63 (six cross-lane moves instead of six LDS-crossbar shuffles)
+__device__ __forceinline__ int pg_wave_sum(int x)
+{
+    int v = x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);      // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);      // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);      // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);      // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);     // row_bcast:15
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);     // row_bcast:31
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+#ifdef PGORB_DESC_TIMING
+// developer build only (make EXTRA=-DPGORB_DESC_TIMING): 10 ns ticks per phase of every wave,
+// read back by tools/experiments/desc_timing.py
+#define DT_MAXW (1 << 19)
+__device__ unsigned int pg_dt_log[DT_MAXW * 8];
+#define DT_TS(k) do { const unsigned long long t1_ = wall_clock64(); if (lane == 0 && dt_id < DT_MAXW) pg_dt_log[dt_id * 8 + (k)] = (unsigned)(t1_ - dt_t0); dt_t0 = t1_; } while (0)
+extern "C" int pgorb_debug_desc_times(unsigned int* out, int nwaves)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pg_dt_log), sizeof(unsigned) * 8 * (size_t)nwaves) == hipSuccess ? 0 : -1;
+}
+#else
+#define DT_TS(k) do {} while (0)
+#endif
+
 typedef __attribute__((address_space(1))) const void* pg_gptr_t;
 typedef __attribute__((address_space(3))) void* pg_lptr_t;
 typedef unsigned short pg_us2 __attribute__((ext_vector_type(2)));
@@ -166,15 +194,39 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
 
     const int lane = threadIdx.x;
     const int frame = blockIdx.y;
+#ifdef PGORB_DESC_TIMING
+    unsigned long long dt_t0 = wall_clock64();
+    const int dt_id = frame * gridDim.x + blockIdx.x;
+#endif
     // XCD-contiguous keypoint ranges: consecutive workgroups go to consecutive XCDs, so give XCD x
     // the x-th eighth of the frame's keypoint list (neighbours in the list are neighbours in the
     // image: their 43x43 windows share L2 lines)
     int idx = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    // locate (level, index in level) from the per-level keypoint counts
+    // The wave is one long dependent chain and lives ~10 us; every load that does not depend on
+    // the keypoint is issued here, before the chain starts: the lane's entries of the moment
+    // table, the Toeplitz operands of the row pass and its four test-point pairs.
+    uint32_t mtU[5], mtM[5];
+#pragma unroll
+    for (int it = 0; it < 5; it++) {
+        const int i = min(lane + 64 * it, 31 * 9 - 1);
+        mtU[it] = pg_moment_tab.wu[i]; mtM[it] = pg_moment_tab.wm[i];
+    }
+    pg_v4i Bop[3];
+#pragma unroll
+    for (int cb = 0; cb < 3; cb++) Bop[cb] = reinterpret_cast<const pg_v4i*>(pg_blur_btab)[cb * 64 + lane];
+    uint32_t pat[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) pat[r] = *reinterpret_cast<const uint32_t*>(pg_pattern31 + 4 * (64 * r + lane));
+    // locate (level, index in level) from the per-level keypoint counts: ONE scalar load of the
+    // frame's 16 counters (a loop over kpc[q] was eight dependent round trips, 4 us of the wave)
     const int32_t* kpc = P.kpCount + frame * PG_MAXL;
+    typedef int32_t pg_i32x16 __attribute__((ext_vector_type(16)));
+    pg_i32x16 kc;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(kc) : "s"(kpc) : "memory");
     int l = 0, total = 0, before = 0, found = -1, j = 0;
-    for (int q = 0; q < P.nlevels; q++) {
-        const int c = kpc[q];
+#pragma unroll
+    for (int q = 0; q < PG_MAXL; q++) {
+        const int c = (q < P.nlevels) ? kc[q] : 0;
         if (found < 0 && idx < total + c) { found = q; before = total; }
         total += c;
     }
@@ -185,6 +237,10 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
     const uint32_t cv = P.sel[(int64_t)frame * P.selFrame + L.selOff + j];
     const int x = (int)(cv & 0xFFF) + PG_EDGE, y = (int)((cv >> 12) & 0xFFF) + PG_EDGE;   // :842-843
     const int resp = (int)(cv >> 24);
+#ifdef PGORB_DESC_TIMING
+    asm volatile("" :: "s"(cv));
+    DT_TS(0);
+#endif
     const uint8_t* img = L.img + (int64_t)frame * L.fstride;
     const int w = L.w, h = L.h;
 
@@ -210,24 +266,33 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
         }
     }
     __syncthreads();
+    DT_TS(1);
 
     // ---- IC_Angle: integer moments over the radius-15 disc (:77-104) -------------------
     // One task = one aligned dword (4 pixels) of one disc row; v_dot4_u32_u8 against the
     // precomputed per-(row, dword) weights: (u+15) inside the disc / 0 outside, and the disc mask.
     int m10 = 0, m01 = 0;
-    for (int i = lane; i < 31 * 9; i += 64) {
+#pragma unroll
+    for (int it = 0; it < 5; it++) {
+        const int i = lane + 64 * it;
+        if (i >= 31 * 9) break;
         const int r = i / 9, q = i - r * 9;                     // r = v+15, dword q+1 = columns 4q+4 ..
         const uint32_t val = *reinterpret_cast<const uint32_t*>(raw + (DW_R - 15 + r) * DW_PITCH + 4 * (q + 1));
-        const int sv = (int)__builtin_amdgcn_udot4(val, pg_moment_tab.wm[i], 0u, false);        // sum of disc pixels
-        m10 += (int)__builtin_amdgcn_udot4(val, pg_moment_tab.wu[i], 0u, false) - 15 * sv;      // sum u * I
+        const int sv = (int)__builtin_amdgcn_udot4(val, mtM[it], 0u, false);                   // sum of disc pixels
+        m10 += (int)__builtin_amdgcn_udot4(val, mtU[it], 0u, false) - 15 * sv;                 // sum u * I
         m01 += (r - 15) * sv;                                                                   // sum v * I
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        m10 += __shfl_xor(m10, d);
-        m01 += __shfl_xor(m01, d);
-    }
+    m10 = pg_wave_sum(m10);
+    m01 = pg_wave_sum(m01);
+#ifdef PGORB_DESC_TIMING
+    asm volatile("" :: "v"(m01), "v"(m10));
+    DT_TS(2);
+#endif
     const float angle = pg_fast_atan2((float)m01, (float)m10);
+#ifdef PGORB_DESC_TIMING
+    asm volatile("" :: "v"(angle));
+    DT_TS(3);
+#endif
 
     // ---- 7x7 Gaussian, fixed point, separable (OpenCV 2.4 8U path, Appendix A4) ---------
     // row pass on the matrix cores: rowsum[r][n] = sum_t K[t] * raw[r][n + t] is the product of the
@@ -240,9 +305,7 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
     uint32_t* hT = hbuf;                                       // [22 row pairs][DH_PITCH columns]
     {
         const int cinit = 128 * (2 * (G.k0 + G.k1 + G.k2) + G.k3);
-        pg_v4i Bop[3], Aop[3];
-#pragma unroll
-        for (int cb = 0; cb < 3; cb++) Bop[cb] = reinterpret_cast<const pg_v4i*>(pg_blur_btab)[cb * 64 + lane];
+        pg_v4i Aop[3];
         // ALL row operands leave the raw window before the first row sum is written over it
 #pragma unroll
         for (int rb = 0; rb < 3; rb++) {
@@ -265,6 +328,7 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
         }
     }
     __syncthreads();
+    DT_TS(4);
     // column pass: on demand.  Only the 512 rotated tap positions of the 37x37 blurred tile are
     // ever read, so each lane blurs its own 8 taps from the row-pass sums (4 LDS dwords, 3
     // v_dot2_u32_u16 each) instead of the wave producing all 1369 pixels.
@@ -277,11 +341,15 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     float a, b;
     pg_sincos_f(__fmul_rn(angle, factorPI), &b, &a);
+#ifdef PGORB_DESC_TIMING
+    asm volatile("" :: "v"(a), "v"(b));
+    DT_TS(5);
+#endif
     unsigned long long bits[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const int8_t* pt = pg_pattern31 + 4 * (64 * r + lane);
-        const float px0 = (float)pt[0], py0 = (float)pt[1], px1 = (float)pt[2], py1 = (float)pt[3];
+        const float px0 = (float)(int8_t)(pat[r] & 0xFF), py0 = (float)(int8_t)((pat[r] >> 8) & 0xFF),
+                    px1 = (float)(int8_t)((pat[r] >> 16) & 0xFF), py1 = (float)(int8_t)(pat[r] >> 24);
         const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(px0, b), __fmul_rn(py0, a)));
         const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(px0, a), __fmul_rn(py0, b)));
         const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1, b), __fmul_rn(py1, a)));
@@ -291,6 +359,10 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
         bits[r] = __ballot(t0 < t1);
     }
 
+#ifdef PGORB_DESC_TIMING
+    asm volatile("" :: "s"(bits[0]), "s"(bits[3]));
+    DT_TS(6);
+#endif
     // ---- outputs (:836-846, :1094-1102) -----------------------------------------------------
     if (idx < cap_per_frame && lane == 0) {
         const int64_t o = (int64_t)frame * cap_per_frame + idx;
