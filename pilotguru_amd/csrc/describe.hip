@@ -220,29 +220,48 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
     // locate (level, index in level) from the per-level keypoint counts: ONE scalar load of the
     // frame's 16 counters (a loop over kpc[q] was eight dependent round trips, 4 us of the wave)
     const int32_t* kpc = P.kpCount + frame * PG_MAXL;
+    // kernel arguments the chain needs, incl. every level's selection offset, in the first batch
+    const int nlevels = P.nlevels;
+    const uint32_t* selp = P.sel + (int64_t)frame * P.selFrame;
+    int selOffs[PG_MAXL];                                   // (a frame's selection slab is a few thousand entries)
+#pragma unroll
+    for (int q = 0; q < PG_MAXL; q++) selOffs[q] = (int)P.lvl[q].selOff;
+    static_assert(PG_MAXL == 16, "the pin below names 16 levels");
+    asm volatile("" :: "s"(kpc), "s"(nlevels), "s"(selp), "s"(n_out), "s"(kps), "s"(desc), "s"(cap_per_frame),
+                 "s"(selOffs[0]), "s"(selOffs[1]), "s"(selOffs[2]), "s"(selOffs[3]), "s"(selOffs[4]), "s"(selOffs[5]),
+                 "s"(selOffs[6]), "s"(selOffs[7]), "s"(selOffs[8]), "s"(selOffs[9]), "s"(selOffs[10]), "s"(selOffs[11]),
+                 "s"(selOffs[12]), "s"(selOffs[13]), "s"(selOffs[14]), "s"(selOffs[15]));
     typedef int32_t pg_i32x16 __attribute__((ext_vector_type(16)));
     pg_i32x16 kc;
     asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(kc) : "s"(kpc) : "memory");
     int l = 0, total = 0, before = 0, found = -1, j = 0;
+    int selOff = 0;
 #pragma unroll
     for (int q = 0; q < PG_MAXL; q++) {
-        const int c = (q < P.nlevels) ? kc[q] : 0;
-        if (found < 0 && idx < total + c) { found = q; before = total; }
+        const int c = (q < nlevels) ? kc[q] : 0;
+        if (found < 0 && idx < total + c) { found = q; before = total; selOff = selOffs[q]; }
         total += c;
     }
     if (blockIdx.x == 0 && lane == 0) n_out[frame] = total;      // (idx == 0 as well)
     if (found < 0) return;
     l = found; j = idx - before;
+    // the selection record and the level's fields travel together
+    const uint32_t* cvp = selp + selOff + j;
     const PgLevel& L = P.lvl[l];
-    const uint32_t cv = P.sel[(int64_t)frame * P.selFrame + L.selOff + j];
+    const uint8_t* Limg = L.img; const int64_t Lfstride = L.fstride; const int Lpitch = L.pitch, Lw = L.w, Lh = L.h;
+    const float Lscale = L.scale, LpatchSize = L.patchSize;
+    uint32_t cv;
+    asm volatile("s_load_dword %0, %1, 0x0" : "=s"(cv) : "s"(cvp) : "memory");
+    asm volatile("" :: "s"(Limg), "s"(Lfstride), "s"(Lpitch), "s"(Lw), "s"(Lh), "s"(Lscale), "s"(LpatchSize));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(cv));
     const int x = (int)(cv & 0xFFF) + PG_EDGE, y = (int)((cv >> 12) & 0xFFF) + PG_EDGE;   // :842-843
     const int resp = (int)(cv >> 24);
 #ifdef PGORB_DESC_TIMING
     asm volatile("" :: "s"(cv));
     DT_TS(0);
 #endif
-    const uint8_t* img = L.img + (int64_t)frame * L.fstride;
-    const int w = L.w, h = L.h;
+    const uint8_t* img = Limg + (int64_t)frame * Lfstride;
+    const int w = Lw, h = Lh;
 
     // ---- stage the raw 43x43 window: window column 0 lands on an LDS dword boundary --------
     const int x0 = x - DW_R, y0 = y - DW_R;
@@ -250,19 +269,19 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
         // LDS-DMA, 16 B per lane, byte-unaligned global addresses (tools/ubench/glds_unaligned.hip):
         // 3 lanes per 48-byte row, 21 rows per instruction
         const int lr = lane / 3, lq = lane - 3 * lr;
-        const uint8_t* g = img + (int64_t)(y0 + lr) * L.pitch + x0 + 16 * lq;
+        const uint8_t* g = img + (int64_t)(y0 + lr) * Lpitch + x0 + 16 * lq;
         if (lr < 21) {
             __builtin_amdgcn_global_load_lds((pg_gptr_t)g, (pg_lptr_t)raw, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((pg_gptr_t)(g + 21 * (int64_t)L.pitch), (pg_lptr_t)(raw + 21 * DW_PITCH), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((pg_gptr_t)(g + 21 * (int64_t)Lpitch), (pg_lptr_t)(raw + 21 * DW_PITCH), 16, 0, 0);
             if (lr < 1)
-                __builtin_amdgcn_global_load_lds((pg_gptr_t)(g + 42 * (int64_t)L.pitch), (pg_lptr_t)(raw + 42 * DW_PITCH), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((pg_gptr_t)(g + 42 * (int64_t)Lpitch), (pg_lptr_t)(raw + 42 * DW_PITCH), 16, 0, 0);
         }
         __builtin_amdgcn_s_waitcnt(0);
     } else {                                   // BORDER_REFLECT_101 (:1085)
         for (int i = lane; i < DW_N * DW_PITCH; i += 64) {
             const int r = i / DW_PITCH, c = i - r * DW_PITCH;
             raw[r * DW_PITCH + c] =
-                img[(int64_t)pg_reflect101(y0 + r, h) * L.pitch + pg_reflect101(x0 + c, w)];
+                img[(int64_t)pg_reflect101(y0 + r, h) * Lpitch + pg_reflect101(x0 + c, w)];
         }
     }
     __syncthreads();
@@ -369,9 +388,9 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
         unsigned long long* d = reinterpret_cast<unsigned long long*>(desc + o * 32);
         d[0] = bits[0]; d[1] = bits[1]; d[2] = bits[2]; d[3] = bits[3];
         pgorb_keypoint k;
-        k.x = (l != 0) ? __fmul_rn((float)x, L.scale) : (float)x;
-        k.y = (l != 0) ? __fmul_rn((float)y, L.scale) : (float)y;
-        k.size = L.patchSize;
+        k.x = (l != 0) ? __fmul_rn((float)x, Lscale) : (float)x;
+        k.y = (l != 0) ? __fmul_rn((float)y, Lscale) : (float)y;
+        k.size = LpatchSize;
         k.angle = angle;
         k.response = (float)resp;
         k.octave = l;
