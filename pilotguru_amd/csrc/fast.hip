@@ -102,6 +102,16 @@ __device__ __forceinline__ int wave_prefix(unsigned long long m)
 // (window column 3) is at byte 4.
 #define FAST_LIST_CAP 768          // compacted candidates held in LDS (u16 each)
 
+typedef unsigned short pg_us2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pg_pkmin(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(pg_us2f, a), __builtin_bit_cast(pg_us2f, b)));
+}
+__device__ __forceinline__ uint32_t pg_pkmax(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(pg_us2f, a), __builtin_bit_cast(pg_us2f, b)));
+}
+
 // (2) necessary test + compaction of interior rows [rowBeg, rowEnd).  Each lane tests one quad
 // per step.  A pixel can only be a corner at threshold t if both opposite ring pairs (0,8) and
 // (4,12) hold a pixel darker than v-t, or both a pixel brighter than v+t.  The test runs on
@@ -152,11 +162,11 @@ __device__ __forceinline__ int quick_pass(const uint8_t* tile, int TP, int IW, i
             const uint32_t W12e = Lo, W4o = Re;
             const uint32_t W12o = __builtin_amdgcn_alignbit(Ce, Le, 16);    // pixels (-2, 0)
             const uint32_t W4e = __builtin_amdgcn_alignbit(Ro, Co, 16);     // pixels (3, 5)
-            const uint32_t Ae = Ce + Kd, Be = Kd - Ce, Ao = Co + Kd, Bo = Kd - Co;
-            uint32_t darkE = ((Ae - De) | (Ae - Ue)) & ((Ae - W4e) | (Ae - W12e));
-            uint32_t brightE = ((De + Be) | (Ue + Be)) & ((W4e + Be) | (W12e + Be));
-            uint32_t darkO = ((Ao - Do) | (Ao - Uo)) & ((Ao - W4o) | (Ao - W12o));
-            uint32_t brightO = ((Do + Bo) | (Uo + Bo)) & ((W4o + Bo) | (W12o + Bo));
+            // per parity: dk = the larger of the pairs' minima, br = the smaller of their maxima
+            // (v_pk_min_u16 / v_pk_max_u16 on the 16-bit fields); darker-in-every-pair <=> dk < v - t,
+            // brighter-in-every-pair <=> br > v + t, each decided by bit 15 of one add / sub
+            uint32_t dkE = pg_pkmax(pg_pkmin(De, Ue), pg_pkmin(W4e, W12e)), brE = pg_pkmin(pg_pkmax(De, Ue), pg_pkmax(W4e, W12e));
+            uint32_t dkO = pg_pkmax(pg_pkmin(Do, Uo), pg_pkmin(W4o, W12o)), brO = pg_pkmin(pg_pkmax(Do, Uo), pg_pkmax(W4o, W12o));
             if (STRONG) {
                 // rows y+2 / y-2 at x+2 / x-2: rings 2 (+2,+2), 14 (-2,+2), 6 (+2,-2), 10 (-2,-2)
                 const uint32_t* rp = reinterpret_cast<const uint32_t*>(tile + (iy + 5) * TP) + 1 + lq;
@@ -168,11 +178,13 @@ __device__ __forceinline__ int quick_pass(const uint8_t* tile, int TP, int IW, i
                 const uint32_t r6e = __builtin_amdgcn_alignbit(Mre, Mce, 16), r10e = __builtin_amdgcn_alignbit(Mce, Mle, 16);
                 const uint32_t r2o = __builtin_amdgcn_alignbit(Pro, Pco, 16), r14o = __builtin_amdgcn_alignbit(Pco, Plo, 16);
                 const uint32_t r6o = __builtin_amdgcn_alignbit(Mro, Mco, 16), r10o = __builtin_amdgcn_alignbit(Mco, Mlo, 16);
-                darkE &= ((Ae - r2e) | (Ae - r10e)) & ((Ae - r6e) | (Ae - r14e));
-                brightE &= ((r2e + Be) | (r10e + Be)) & ((r6e + Be) | (r14e + Be));
-                darkO &= ((Ao - r2o) | (Ao - r10o)) & ((Ao - r6o) | (Ao - r14o));
-                brightO &= ((r2o + Bo) | (r10o + Bo)) & ((r6o + Bo) | (r14o + Bo));
+                dkE = pg_pkmax(dkE, pg_pkmax(pg_pkmin(r2e, r10e), pg_pkmin(r6e, r14e)));
+                brE = pg_pkmin(brE, pg_pkmin(pg_pkmax(r2e, r10e), pg_pkmax(r6e, r14e)));
+                dkO = pg_pkmax(dkO, pg_pkmax(pg_pkmin(r2o, r10o), pg_pkmin(r6o, r14o)));
+                brO = pg_pkmin(brO, pg_pkmin(pg_pkmax(r2o, r10o), pg_pkmax(r6o, r14o)));
             }
+            const uint32_t darkE = (Ce + Kd) - dkE, brightE = brE + (Kd - Ce);
+            const uint32_t darkO = (Co + Kd) - dkO, brightO = brO + (Kd - Co);
             m = ((((darkE | brightE) & K15) >> 1) | ((darkO | brightO) & K15)) & colMask;
         }
         acc[step >> 3] |= m >> (2 * (step & 7));
