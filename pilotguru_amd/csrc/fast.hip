@@ -135,7 +135,7 @@ __device__ __forceinline__ int quick_pass(const uint8_t* tile, int TP, int IW, i
 {
     const int lq = lane & (QW - 1), lr = lane / QW;
     const int NQ = (IW + 3) >> 2;
-    const uint32_t M = 0x00FF00FFu, K15 = 0x80008000u;
+    const uint32_t K15 = 0x80008000u;
     const uint32_t Kd = (uint32_t)(0x8000 - t - 1) * 0x00010001u;
     // columns of this quad inside the interior, in result-bit layout
     uint32_t colMask = 0;
@@ -153,15 +153,17 @@ __device__ __forceinline__ int quick_pass(const uint8_t* tile, int TP, int IW, i
             const uint32_t* ru = reinterpret_cast<const uint32_t*>(tile + iy * TP) + 1 + lq;
             const uint32_t* rd = reinterpret_cast<const uint32_t*>(tile + (iy + 6) * TP) + 1 + lq;
             const uint32_t C = rc[0], Lw = rc[-1], Rw = rc[1], U = ru[0], D = rd[0];
-            const uint32_t Ce = C & M, Co = (C >> 8) & M;            // pixels (0,2) / (1,3)
-            const uint32_t Ue = U & M, Uo = (U >> 8) & M;            // ring 8 (3 rows up)
-            const uint32_t De = D & M, Do = (D >> 8) & M;            // ring 0 (3 rows down)
-            const uint32_t Le = Lw & M, Lo = (Lw >> 8) & M;          // pixels (-4,-2) / (-3,-1)
-            const uint32_t Re = Rw & M, Ro = (Rw >> 8) & M;          // pixels (4,6) / (5,7)
+            // one v_perm_b32 per operand: bytes -> two 16-bit fields (selector 0x0c = zero byte)
+            const uint32_t EV = 0x0c020c00u, OD = 0x0c030c01u;       // (b0, b2) / (b1, b3) of one dword
+            const uint32_t X20 = 0x0c040c02u, X31 = 0x0c050c03u;     // (lo.b2, hi.b0) / (lo.b3, hi.b1) of a dword pair
+            const uint32_t Ce = __builtin_amdgcn_perm(C, C, EV), Co = __builtin_amdgcn_perm(C, C, OD);   // pixels (0,2) / (1,3)
+            const uint32_t Ue = __builtin_amdgcn_perm(U, U, EV), Uo = __builtin_amdgcn_perm(U, U, OD);   // ring 8 (3 rows up)
+            const uint32_t De = __builtin_amdgcn_perm(D, D, EV), Do = __builtin_amdgcn_perm(D, D, OD);   // ring 0 (3 rows down)
             // ring 12 (x-3) and ring 4 (x+3) of the even and odd pixels
-            const uint32_t W12e = Lo, W4o = Re;
-            const uint32_t W12o = __builtin_amdgcn_alignbit(Ce, Le, 16);    // pixels (-2, 0)
-            const uint32_t W4e = __builtin_amdgcn_alignbit(Ro, Co, 16);     // pixels (3, 5)
+            const uint32_t W12e = __builtin_amdgcn_perm(Lw, Lw, OD);   // pixels (-3, -1)
+            const uint32_t W4o = __builtin_amdgcn_perm(Rw, Rw, EV);    // pixels (4, 6)
+            const uint32_t W12o = __builtin_amdgcn_perm(C, Lw, X20);   // pixels (-2, 0)
+            const uint32_t W4e = __builtin_amdgcn_perm(Rw, C, X31);    // pixels (3, 5)
             // per parity: dk = the larger of the pairs' minima, br = the smaller of their maxima
             // (v_pk_min_u16 / v_pk_max_u16 on the 16-bit fields); darker-in-every-pair <=> dk < v - t,
             // brighter-in-every-pair <=> br > v + t, each decided by bit 15 of one add / sub
@@ -172,12 +174,10 @@ __device__ __forceinline__ int quick_pass(const uint8_t* tile, int TP, int IW, i
                 const uint32_t* rp = reinterpret_cast<const uint32_t*>(tile + (iy + 5) * TP) + 1 + lq;
                 const uint32_t* rm = reinterpret_cast<const uint32_t*>(tile + (iy + 1) * TP) + 1 + lq;
                 const uint32_t Pc = rp[0], Pl = rp[-1], Pr = rp[1], Mc = rm[0], Ml = rm[-1], Mr = rm[1];
-                const uint32_t Pce = Pc & M, Pco = (Pc >> 8) & M, Ple = Pl & M, Plo = (Pl >> 8) & M, Pre = Pr & M, Pro = (Pr >> 8) & M;
-                const uint32_t Mce = Mc & M, Mco = (Mc >> 8) & M, Mle = Ml & M, Mlo = (Ml >> 8) & M, Mre = Mr & M, Mro = (Mr >> 8) & M;
-                const uint32_t r2e = __builtin_amdgcn_alignbit(Pre, Pce, 16), r14e = __builtin_amdgcn_alignbit(Pce, Ple, 16);
-                const uint32_t r6e = __builtin_amdgcn_alignbit(Mre, Mce, 16), r10e = __builtin_amdgcn_alignbit(Mce, Mle, 16);
-                const uint32_t r2o = __builtin_amdgcn_alignbit(Pro, Pco, 16), r14o = __builtin_amdgcn_alignbit(Pco, Plo, 16);
-                const uint32_t r6o = __builtin_amdgcn_alignbit(Mro, Mco, 16), r10o = __builtin_amdgcn_alignbit(Mco, Mlo, 16);
+                const uint32_t r2e = __builtin_amdgcn_perm(Pr, Pc, X20), r14e = __builtin_amdgcn_perm(Pc, Pl, X20);   // x+2 / x-2 of pixels (0,2)
+                const uint32_t r6e = __builtin_amdgcn_perm(Mr, Mc, X20), r10e = __builtin_amdgcn_perm(Mc, Ml, X20);
+                const uint32_t r2o = __builtin_amdgcn_perm(Pr, Pc, X31), r14o = __builtin_amdgcn_perm(Pc, Pl, X31);   // ... of pixels (1,3)
+                const uint32_t r6o = __builtin_amdgcn_perm(Mr, Mc, X31), r10o = __builtin_amdgcn_perm(Mc, Ml, X31);
                 dkE = pg_pkmax(dkE, pg_pkmax(pg_pkmin(r2e, r10e), pg_pkmin(r6e, r14e)));
                 brE = pg_pkmin(brE, pg_pkmin(pg_pkmax(r2e, r10e), pg_pkmax(r6e, r14e)));
                 dkO = pg_pkmax(dkO, pg_pkmax(pg_pkmin(r2o, r10o), pg_pkmin(r6o, r14o)));
