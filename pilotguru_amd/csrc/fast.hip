@@ -187,7 +187,8 @@ __device__ __forceinline__ int quick_pass(const uint8_t* tile, int TP, int IW, i
             const uint32_t darkO = (Co + Kd) - dkO, brightO = brO + (Kd - Co);
             m = ((((darkE | brightE) & K15) >> 1) | ((darkO | brightO) & K15)) & colMask;
         }
-        acc[step >> 3] |= m >> (2 * (step & 7));
+        if (QW == 8) acc[0] |= m >> (2 * step);                 // <= 48 rows = 6 steps: one word
+        else acc[step >> 3] |= m >> (2 * (step & 7));
     }
     const int cnt = __popc(acc[0]) + __popc(acc[1]);
     const int incl = wave_incl_scan(cnt);
