@@ -430,19 +430,23 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P)
             for (int p = tid; p < n; p += QT_T) rnk[p] = (cntA[p] > 1) ? 1 : 0;
             __syncthreads();
             const int m = qt_scan_excl(rnk, n, sh);          // rnk[p] = list-order rank among expandable
+            // sort key of an expandable node: size << 11 | (2047 - list-order rank), so that "larger
+            // size first, ties: smaller list position first" (see header) is one unsigned compare
             for (int p = tid; p < n; p += QT_T) {
-                if (cntA[p] > 1) { tmp[rnk[p]] = p; ecnt[rnk[p]] = cntA[p]; }
+                if (cntA[p] > 1) { tmp[rnk[p]] = p; ecnt[rnk[p]] = (int)(((uint32_t)min(cntA[p], 0x1FFFFF) << 11) | (uint32_t)(2047 - rnk[p])); }
                 else rnk[p] = -1;
             }
             __syncthreads();
-            // descending size, ties: smaller list position first (see header)
+            // rank by counting: m <= nodeCap < 2048 keys, four per LDS read
+            const int m4 = m & ~3;
             for (int i = tid; i < m; i += QT_T) {
-                const int ci = ecnt[i];
+                const uint32_t ki = (uint32_t)ecnt[i];
                 int rank = 0;
-                for (int j = 0; j < m; j++) {
-                    const int cj = ecnt[j];
-                    rank += (cj > ci) || (cj == ci && j < i);
+                for (int j = 0; j < m4; j += 4) {
+                    const uint4 k4 = *reinterpret_cast<const uint4*>(ecnt + j);
+                    rank += (k4.x > ki) + (k4.y > ki) + (k4.z > ki) + (k4.w > ki);
                 }
+                for (int j = m4; j < m; j++) rank += (uint32_t)ecnt[j] > ki;
                 ord[rank] = tmp[i];
                 rnk[tmp[i]] = rank;
             }
