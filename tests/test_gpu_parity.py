@@ -409,3 +409,43 @@ def test_match_batch_ragged_frame_sizes(oracle):
         assert np.array_equal(bi[k, :m].cpu().numpy(), obi), (q, t)
         assert np.array_equal(b1[k, :m].cpu().numpy().view(np.uint16), ob1), (q, t)
         assert np.array_equal(b2[k, :m].cpu().numpy().view(np.uint16), ob2), (q, t)
+
+
+def test_device_entry_points_are_graph_capture_safe(oracle):
+    """After the first (allocating) call, pgorb_extract_batch_device + pgorb_match_batch_device
+    only enqueue work on the given stream: a hipGraph captured from them replays to the same
+    bytes (launch-bound callers can wrap the per-frame launch set in a graph)."""
+    import torch
+    w, h, nf = 640, 480, 800
+    ride = synth_ride(9, w, h, 2)
+    ext = _make(nf, w, h, batch=2)
+    frames = torch.from_numpy(ride).cuda()
+    cap = ext.max_keypoints(w, h)
+    kps = torch.zeros((2, cap, 7), dtype=torch.float32, device="cuda")
+    desc = torch.zeros((2, cap, 32), dtype=torch.uint8, device="cuda")
+    n = torch.zeros((2,), dtype=torch.int32, device="cuda")
+    pq = torch.tensor([1], dtype=torch.int32, device="cuda")
+    pt = torch.tensor([0], dtype=torch.int32, device="cuda")
+    mout = (torch.zeros((1, cap), dtype=torch.int32, device="cuda"), torch.zeros((1, cap), dtype=torch.int16, device="cuda"),
+            torch.zeros((1, cap), dtype=torch.int16, device="cuda"))
+    s = torch.cuda.Stream()
+
+    def step():
+        ext.extract_batch_device(frames, kps, desc, n, stream=s.cuda_stream)
+        ext.match_batch_device(desc, n, pq, pt, mout, stream=s.cuda_stream)
+
+    with torch.cuda.stream(s):
+        step()                                            # warm-up: allocations, table upload
+        s.synchronize()
+        ref = [t.clone() for t in (kps, desc, n) + mout]
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            step()
+        for t in (kps, desc, n) + mout:
+            t.zero_()
+        g.replay()
+        s.synchronize()
+    for a, b in zip(ref, (kps, desc, n) + mout):
+        assert torch.equal(a.view(torch.uint8), b.view(torch.uint8))
+    okp, odesc = oracle.OrbOracle(nf, 1.2, 8, 20, 7).extract(ride[1])
+    assert int(n[1]) == len(okp) and np.array_equal(desc[1, :len(okp)].cpu().numpy(), odesc)
