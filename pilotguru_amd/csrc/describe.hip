@@ -21,9 +21,19 @@
 // Algorithmic bytes per keypoint: 43*43 window read + 60 B written.
 #include "pgorb_internal.h"
 
-__device__ static const int8_t pg_pattern31[256 * 4] = {
+// bit_pattern_31_ (ORBextractor.cc:150-408) as floats: the test points are only ever used as
+// float factors of the rotation (:119-120), so the table holds them converted once at compile time
+struct PgPatternF { float v[256 * 4]; };
+constexpr PgPatternF pg_make_pattern_f()
+{
+    constexpr int8_t p[256 * 4] = {
 #include "orb_pattern31.inc"
-};
+    };
+    PgPatternF t = {};
+    for (int i = 0; i < 256 * 4; i++) t.v[i] = (float)p[i];
+    return t;
+}
+__device__ static const PgPatternF pg_pattern31f = pg_make_pattern_f();
 
 // (circular patch row half-widths umax, ORBextractor.cc:452-469, are baked into pg_make_moment_tab)
 
@@ -214,9 +224,9 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
     pg_v4i Bop[3];
 #pragma unroll
     for (int cb = 0; cb < 3; cb++) Bop[cb] = reinterpret_cast<const pg_v4i*>(pg_blur_btab)[cb * 64 + lane];
-    uint32_t pat[4];
+    float4 pat[4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) pat[r] = *reinterpret_cast<const uint32_t*>(pg_pattern31 + 4 * (64 * r + lane));
+    for (int r = 0; r < 4; r++) pat[r] = *reinterpret_cast<const float4*>(pg_pattern31f.v + 4 * (64 * r + lane));
     // locate (level, index in level) from the per-level keypoint counts: ONE scalar load of the
     // frame's 16 counters (a loop over kpc[q] was eight dependent round trips, 4 us of the wave)
     const int32_t* kpc = P.kpCount + frame * PG_MAXL;
@@ -367,8 +377,7 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
     unsigned long long bits[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const float px0 = (float)(int8_t)(pat[r] & 0xFF), py0 = (float)(int8_t)((pat[r] >> 8) & 0xFF),
-                    px1 = (float)(int8_t)((pat[r] >> 16) & 0xFF), py1 = (float)(int8_t)(pat[r] >> 24);
+        const float px0 = pat[r].x, py0 = pat[r].y, px1 = pat[r].z, py1 = pat[r].w;
         const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(px0, b), __fmul_rn(py0, a)));
         const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(px0, a), __fmul_rn(py0, b)));
         const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1, b), __fmul_rn(py1, a)));

@@ -361,8 +361,10 @@ __global__ __launch_bounds__(64, 8) void k_fast_cells(const PgPlan P, int TPr, i
                                                  (pg_lptr_t)(tile + k * rowsPer * TP), 16, 0, 0);
         }
         FT_TS(1);
-        for (int i = lane; i < (mapRows * mapPitch) >> 2; i += 64)
-            reinterpret_cast<uint32_t*>(smap)[i] = 0;
+        // (the score map, 16 B per lane and step, is zeroed in the shadow of the loads; the map
+        //  starts 16-byte aligned and the candidate list behind it absorbs the last partial step)
+        for (int i = lane; i < (mapRows * mapPitch + 15) >> 4; i += 64)
+            reinterpret_cast<uint4*>(smap)[i] = make_uint4(0u, 0u, 0u, 0u);
         __builtin_amdgcn_s_waitcnt(0);                     // vmcnt(0): the DMA has landed
     }
     __syncthreads();
