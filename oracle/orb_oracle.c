@@ -208,11 +208,13 @@ static int fast_corner_score(const int d[25], int threshold)
     }
     return -b0 - 1;
 }
-int orc_fast9_nms(const uint8_t* img, int w, int h, int stride, int threshold,
-                  orc_cand* out, int cap)
+/* corner scores of every pixel (0 = not a FAST-9 corner at `threshold`), before NMS; score is w*h,
+ * zeroed here.  (Also the hook for the cross-check of the corner SET against scikit-image's
+ * independent corner_fast, tests/golden/make_skimage_fast9.py.) */
+void orc_fast9_score_map(const uint8_t* img, int w, int h, int stride, int threshold, uint8_t* score)
 {
-    if (w < 7 || h < 7) return 0;
-    uint8_t* score = (uint8_t*)calloc((size_t)w * h, 1);
+    memset(score, 0, (size_t)w * h);
+    if (w < 7 || h < 7) return;
     for (int y = 3; y < h - 3; y++)
         for (int x = 3; x < w - 3; x++) {
             const uint8_t* p = img + (size_t)y * stride + x;
@@ -228,6 +230,13 @@ int orc_fast9_nms(const uint8_t* img, int w, int h, int stride, int threshold,
             if (fast_is_corner(d, threshold))
                 score[(size_t)y * w + x] = (uint8_t)fast_corner_score(d, threshold);
         }
+}
+int orc_fast9_nms(const uint8_t* img, int w, int h, int stride, int threshold,
+                  orc_cand* out, int cap)
+{
+    if (w < 7 || h < 7) return 0;
+    uint8_t* score = (uint8_t*)malloc((size_t)w * h);
+    orc_fast9_score_map(img, w, h, stride, threshold, score);
     int n = 0;
     for (int y = 3; y < h - 3; y++)
         for (int x = 3; x < w - 3; x++) {

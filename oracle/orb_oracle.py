@@ -64,6 +64,8 @@ def lib():
                                            C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.orc_fast9_nms.restype = C.c_int
         L.orc_fast9_nms.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_fast9_score_map.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_fast9_score_map.restype = None
         L.orc_distribute_octtree.restype = C.c_int
         L.orc_distribute_octtree.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                              C.c_int, C.c_int, C.c_void_p, C.c_int]
@@ -213,6 +215,15 @@ def fast9_nms(img, threshold):
     out = np.zeros(cap, CAND_DTYPE)
     n = lib().orc_fast9_nms(_p(img), img.shape[1], img.shape[0], img.shape[1], threshold, _p(out), cap)
     return out[:n].copy()
+
+
+def fast9_score_map(img, threshold):
+    """FAST-9/16 corner score of every pixel before NMS (0 = no corner at `threshold`)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    out = np.zeros((h, w), np.uint8)
+    lib().orc_fast9_score_map(_p(img), w, h, w, int(threshold), _p(out))
+    return out
 
 
 def distribute_octtree(cand, minX, maxX, minY, maxY, N):

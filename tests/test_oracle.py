@@ -363,3 +363,50 @@ def test_quota_overshoot_and_order_properties(oracle):
         y = np.rint(k["y"] / sf[l])
         assert np.all(x >= 19) and np.all(x < w - 19) and np.all(y >= 19) and np.all(y < h - 19)
     assert np.all(kp["class_id"] == -1)
+
+
+def test_fast9_corner_set_matches_scikit_image(oracle):
+    """The oracle's FAST-9/16 corner DECISION against scikit-image's corner_fast, an
+    implementation independent of OpenCV and of this repository (fixture + generator:
+    tests/golden/skimage_fast9.npz, make_skimage_fast9.py; scikit-image is not installed in the
+    test interpreter).  Pins the corner set pixel for pixel on four images x three thresholds;
+    the OpenCV score / NMS restatements stay unpinned."""
+    import os
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "skimage_fast9.npz"))
+    checked = 0
+    for i in range(4):
+        img = fx["img%d" % i]
+        h, w = img.shape
+        for t in (7, 20, 40):
+            want = np.unpackbits(fx["mask%d_t%d" % (i, t)])[: h * w].reshape(h, w).astype(bool)
+            got = oracle.fast9_score_map(img, t) > 0
+            # scikit-image leaves a 3-px border untested, like cv::FAST
+            assert not want[:3].any() and not want[-3:].any() and not want[:, :3].any() and not want[:, -3:].any()
+            assert np.array_equal(got, want), "image %d threshold %d: %d pixels differ" % (i, t, int((got != want).sum()))
+            checked += int(want.sum())
+    assert checked > 10000
+
+
+def test_ic_angle_matches_scikit_image_orientation(oracle):
+    """IC_Angle (integer moments over the radius-15 disc + cv::fastAtan2) against scikit-image's
+    corner_orientations on its ORB mask (double-precision atan2): same disc (749 pixels), same
+    axis convention, angles equal up to the 0.3 degree error of fastAtan2's polynomial."""
+    import os
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "skimage_fast9.npz"))
+    ora = oracle.OrbOracle(500, 1.2, 8, 20, 7)
+    umax = ora.umax
+    # the disc of the umax table is scikit-image's OFAST mask
+    mask = np.zeros((31, 31), np.uint8)
+    for v in range(-15, 16):
+        u = umax[abs(v)]
+        mask[v + 15, 15 - u:15 + u + 1] = 1
+    assert np.array_equal(mask, fx["ofast_mask"]) and int(mask.sum()) == 749
+    worst = 0.0
+    for i in (0, 1):
+        img = fx["img%d" % i]
+        for (r, c), rad in zip(fx["orient_pts%d" % i], fx["orient_rad%d" % i]):
+            deg = oracle.ic_angle(img, int(c), int(r), umax)
+            want = np.degrees(rad) % 360.0
+            diff = abs((deg - want + 180.0) % 360.0 - 180.0)
+            worst = max(worst, diff)
+    assert worst < 0.35, worst
