@@ -410,3 +410,21 @@ def test_ic_angle_matches_scikit_image_orientation(oracle):
             diff = abs((deg - want + 180.0) % 360.0 - 180.0)
             worst = max(worst, diff)
     assert worst < 0.35, worst
+
+
+def test_resize_geometry_matches_torch_bilinear(oracle):
+    """cv::resize(INTER_LINEAR) restatement against torch's bilinear interpolation (half-pixel
+    centres, no antialiasing: the same sampling geometry, but float arithmetic instead of OpenCV's
+    11-bit fixed point): every pixel within one grey level, most identical after rounding, bias below 0.2.
+    A library-independent check of the geometry / border convention, not of the bit-exact
+    fixed-point arithmetic (that is what the numpy restatement above covers)."""
+    import torch
+    rng = np.random.RandomState(5)
+    for (w, h, dw, dh) in [(320, 240, 267, 200), (641, 479, 534, 399), (100, 80, 50, 40), (97, 131, 81, 109)]:
+        src = (rng.randint(0, 256, (h, w)) * 0.5 + 64 + 40 * np.sin(np.arange(w) / 9.0)[None, :]).clip(0, 255).astype(np.uint8)
+        got = oracle.resize_linear(src, dw, dh).astype(np.int32)
+        t = torch.from_numpy(src.astype(np.float64))[None, None]
+        ref = torch.nn.functional.interpolate(t, size=(dh, dw), mode="bilinear", align_corners=False, antialias=False)[0, 0].numpy()
+        assert np.abs(got - ref).max() <= 1.0 + 1e-9, (w, h, np.abs(got - ref).max())
+        assert (got == np.rint(ref).astype(np.int32)).mean() > 0.8
+        assert abs((got - ref).mean()) < 0.2      # the truncating fixed-point path sits ~0.13 grey levels low
