@@ -428,3 +428,21 @@ def test_resize_geometry_matches_torch_bilinear(oracle):
         assert np.abs(got - ref).max() <= 1.0 + 1e-9, (w, h, np.abs(got - ref).max())
         assert (got == np.rint(ref).astype(np.int32)).mean() > 0.8
         assert abs((got - ref).mean()) < 0.2      # the truncating fixed-point path sits ~0.13 grey levels low
+
+
+def test_gaussian_blur_matches_scipy_float_convolution(oracle):
+    """cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) restatement (8-bit fixed-point kernel,
+    two-stage rounding) against scipy's float separable correlation with the rounded Gaussian taps and
+    mode='mirror' (the same border rule): within one grey level everywhere, borders included."""
+    from scipy import ndimage
+    rng = np.random.RandomState(11)
+    x = np.arange(-3, 4, dtype=np.float64)
+    k = np.exp(-x * x / (2.0 * 2.0 * 2.0)); k /= k.sum()
+    k = np.rint(k * 256.0) / 256.0                       # OpenCV's 8-bit taps 18 34 49 55 49 34 18 (sum 257/256)
+    assert np.array_equal(k * 256, [18, 34, 49, 55, 49, 34, 18])
+    for (w, h) in [(64, 48), (131, 97), (40, 200)]:
+        img = (rng.randint(0, 256, (h, w)) * 0.6 + 50 + 30 * np.cos(np.arange(h) / 6.0)[:, None]).clip(0, 255).astype(np.uint8)
+        got = oracle.gaussian_blur7(img).astype(np.float64)
+        ref = ndimage.correlate1d(ndimage.correlate1d(img.astype(np.float64), k, axis=1, mode="mirror"), k, axis=0, mode="mirror")
+        assert np.abs(got - ref).max() < 1.0, np.abs(got - ref).max()
+        assert abs((got - ref).mean()) < 0.1
