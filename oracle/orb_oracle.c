@@ -5,8 +5,8 @@
  * relative to /root/reference/thirdparty/orb-slam2/ unless stated; "cv2.4:"
  * marks behaviour of un-vendored OpenCV 2.4.9 restated from its published
  * algorithm -- unverifiable in this container against OpenCV itself.
- * Partial third-party evidence (tests/test_oracle.py): the FAST-9 corner set equals
- * scikit-image's corner_fast pixel for pixel, IC_Angle agrees with its corner_orientations,
+ * Partial third-party evidence (tests/test_oracle.py): the FAST-9 corner set and score equal
+ * what scikit-image's corner_fast decides pixel for pixel, IC_Angle agrees with its corner_orientations,
  * resize / blur agree with torch / scipy float implementations to one grey level.
  *
  * Build: gcc -O2 -ffp-contract=off -fno-fast-math (see oracle/Makefile).

@@ -48,6 +48,15 @@ def main():
         for t in (7, 20, 40):
             resp = corner_fast(im, n=9, threshold=(t + 0.5) / 255.0)
             out["mask%d_t%d" % (i, t)] = np.packbits(resp > 0)
+    # corner score as "the largest threshold at which the pixel is still a corner" (what OpenCV's
+    # cornerScore<16> returns), from scikit-image's DECISION alone: corners are monotone in t, so the
+    # score is (number of thresholds 0..254 at which the pixel is a corner) - 1
+    for i in (0, 3):
+        im = out["img%d" % i]
+        cnt = np.zeros(im.shape, np.int32)
+        for t in range(0, 255):
+            cnt += corner_fast(im, n=9, threshold=(t + 0.5) / 255.0) > 0
+        out["maxthr%d" % i] = (cnt - 1).astype(np.int16)        # -1 = never a corner
     # intensity-centroid orientation (Rosin) over the radius-15 disc, the same patch as ORB-SLAM2's
     # IC_Angle: scikit-image's corner_orientations with its ORB mask (749 pixels, the umax table
     # of OpenCV), angle = atan2(m01, m10) in radians, computed in double

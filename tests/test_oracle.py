@@ -446,3 +446,22 @@ def test_gaussian_blur_matches_scipy_float_convolution(oracle):
         ref = ndimage.correlate1d(ndimage.correlate1d(img.astype(np.float64), k, axis=1, mode="mirror"), k, axis=0, mode="mirror")
         assert np.abs(got - ref).max() < 1.0, np.abs(got - ref).max()
         assert abs((got - ref).mean()) < 0.1
+
+
+def test_fast9_corner_score_is_largest_corner_threshold(oracle):
+    """cv::FAST's corner score (cornerScore<16>: best arc minimum - 1) is the largest threshold at
+    which the pixel is still a FAST-9 corner.  The fixture holds that quantity computed from
+    scikit-image's corner DECISION at every threshold 0..254 -- so this pins the oracle's score
+    values, not only its corner set, against an independent implementation."""
+    import os
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "skimage_fast9.npz"))
+    n = 0
+    for i in (0, 3):
+        img, maxthr = fx["img%d" % i], fx["maxthr%d" % i].astype(np.int32)
+        for t in (7, 20, 40):
+            sc = oracle.fast9_score_map(img, t).astype(np.int32)
+            corner = maxthr >= t
+            assert np.array_equal(sc > 0, corner)
+            assert np.array_equal(sc[corner], maxthr[corner])
+            n += int(corner.sum())
+    assert n > 3000
