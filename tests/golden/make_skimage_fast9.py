@@ -68,6 +68,10 @@ def main():
         out["orient_pts%d" % i] = pts.astype(np.int32)
         out["orient_rad%d" % i] = corner_orientations(im.astype(np.float64), pts, OFAST_MASK)
     out["ofast_mask"] = OFAST_MASK.astype(np.uint8)
+    # scikit-image's copy of the learned rBRIEF pattern (feature/orb_descriptor_positions.txt)
+    import skimage
+    out["orb_positions"] = np.loadtxt(os.path.join(os.path.dirname(skimage.__file__), "feature",
+                                                   "orb_descriptor_positions.txt"), dtype=np.int64).astype(np.int8)
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "skimage_fast9.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, {k: int(np.unpackbits(v).sum()) for k, v in out.items() if k.startswith("mask")})

@@ -465,3 +465,13 @@ def test_fast9_corner_score_is_largest_corner_threshold(oracle):
             assert np.array_equal(sc[corner], maxthr[corner])
             n += int(corner.sum())
     assert n > 3000
+
+
+def test_pattern_table_equals_scikit_image_copy():
+    """The 256 x (x0, y0, x1, y1) rBRIEF test pairs equal scikit-image's copy of the learned ORB
+    pattern (feature/orb_descriptor_positions.txt in scikit-image 0.18.3), number for number."""
+    fx = np.load(os.path.join(HERE, "golden", "skimage_fast9.npz"))
+    txt = open(os.path.join(HERE, "..", "pilotguru_amd", "csrc", "orb_pattern31.inc")).read()
+    body = txt[txt.index("*/") + 2:]
+    vals = np.array([int(v) for v in body.replace("\n", " ").split(",") if v.strip()], np.int8).reshape(256, 4)
+    assert np.array_equal(vals, fx["orb_positions"])
