@@ -126,6 +126,18 @@ int  pgorb_extract_batch_color_device(pgorb_ctx* ctx, const uint8_t* d_img, int 
                                       int channels, int rgb_order,
                                       pgorb_keypoint* d_kps, uint8_t* d_desc, int cap_per_frame,
                                       int32_t* d_n, void* hip_stream);
+/* The reader's geometry as well: frames exactly as decoded, upright frames into the extractor.
+ * rotate_degrees in {0, 90, 180, 270} as the video metadata says (src/io/image_sequence_reader.cc:
+ * 186-205: 90 = cv::flip(raw.t(), 0), 180 = cv::flip(raw, -1), 270 = cv::flip(raw.t(), 1)), then
+ * the optional --vertical_flip / --horizontal_flip of the wrapper source (:53-58, :212-222;
+ * src/optical_trajectories.cc:49-52,84-85), then Tracking's grey conversion as above
+ * (channels = 1: already grey).  Extracted frames are src_h x src_w for 90 / 270. */
+int  pgorb_extract_batch_ingest_device(pgorb_ctx* ctx, const uint8_t* d_img, int nframes,
+                                       int src_w, int src_h, int stride, int64_t frame_stride,
+                                       int channels, int rgb_order, int rotate_degrees,
+                                       int vertical_flip, int horizontal_flip,
+                                       pgorb_keypoint* d_kps, uint8_t* d_desc, int cap_per_frame,
+                                       int32_t* d_n, void* hip_stream);
 
 /* Device status word of the last *_device call: 0 or PGORB_E_OVERFLOW.  Synchronises. */
 int  pgorb_check_async(pgorb_ctx* ctx, void* hip_stream);

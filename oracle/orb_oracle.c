@@ -643,6 +643,50 @@ void orc_rgb_to_gray(const uint8_t* rgb, int w, int h, int stride, uint8_t* gray
         }
 }
 
+/* ref (pilotguru): src/io/image_sequence_reader.cc:186-205 (rotation from the video metadata, as
+ * cv::transpose + cv::flip), :53-58 + :212-222 (optional flips, cv::flip axis 0 = around the x axis
+ * = rows reversed, 1 = columns reversed, -1 = both).  Restated literally as a sequence of whole-image
+ * steps; `cn` interleaved channels per pixel are carried along.  dst is dw x dh with
+ * (dw, dh) = (sh, sw) for 90 / 270.  Returns 0, or -1 for an unsupported angle (:203-207). */
+static void img_transpose(const uint8_t* a, int w, int h, int cn, uint8_t* t)        /* t is h x w -> w rows of h */
+{
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            memcpy(t + ((size_t)x * h + y) * cn, a + ((size_t)y * w + x) * cn, (size_t)cn);
+}
+static void img_flip(const uint8_t* a, int w, int h, int cn, int axis, uint8_t* f)  /* cv::flip */
+{
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const int sy = (axis == 0 || axis == -1) ? h - 1 - y : y;
+            const int sx = (axis == 1 || axis == -1) ? w - 1 - x : x;
+            memcpy(f + ((size_t)y * w + x) * cn, a + ((size_t)sy * w + sx) * cn, (size_t)cn);
+        }
+}
+int orc_ingest_geometry(const uint8_t* src, int sw, int sh, int cn, int rotate_degrees, int vertical_flip,
+                        int horizontal_flip, uint8_t* dst)
+{
+    const size_t bytes = (size_t)sw * sh * cn;
+    uint8_t* t = (uint8_t*)malloc(bytes);
+    uint8_t* r = (uint8_t*)malloc(bytes);
+    int w = sw, h = sh;
+    switch (rotate_degrees) {
+    case 0: memcpy(r, src, bytes); break;
+    case 90: img_transpose(src, sw, sh, cn, t); w = sh; h = sw; img_flip(t, w, h, cn, 0, r); break;
+    case 180: img_flip(src, sw, sh, cn, -1, r); break;
+    case 270: img_transpose(src, sw, sh, cn, t); w = sh; h = sw; img_flip(t, w, h, cn, 1, r); break;
+    default: free(t); free(r); return -1;
+    }
+    if (vertical_flip || horizontal_flip) {
+        const int axis = (vertical_flip && horizontal_flip) ? -1 : (vertical_flip ? 0 : 1);       /* MakeFlipAxis */
+        img_flip(r, w, h, cn, axis, dst);
+    } else {
+        memcpy(dst, r, bytes);
+    }
+    free(t); free(r);
+    return 0;
+}
+
 /* ------------------------------------------------------------------------ */
 /* ref: src/ORBextractor.cc:765-852 ComputeKeyPointsOctTree, cell loop part */
 static int detect_level_cells(const orc_extractor* e, const uint8_t* img, int cols, int rows,

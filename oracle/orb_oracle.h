@@ -65,6 +65,8 @@ int  orc_level_keypoints(const orc_extractor*, int level);  /* count after quadt
 /* Stand-alone stages (each cited in the .c file). */
 void orc_resize_linear_u8(const uint8_t* src, int sw, int sh, int sstride,
                           uint8_t* dst, int dw, int dh, int dstride);
+int  orc_ingest_geometry(const uint8_t* src, int sw, int sh, int cn, int rotate_degrees, int vertical_flip,
+                         int horizontal_flip, uint8_t* dst);
 void orc_fast9_score_map(const uint8_t* img, int w, int h, int stride, int threshold, uint8_t* score);
 int  orc_fast9_nms(const uint8_t* img, int w, int h, int stride, int threshold,
                    orc_cand* out, int cap);      /* cv::FAST(...,true); x,y window-local */

@@ -64,6 +64,7 @@ def lib():
                                            C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.orc_fast9_nms.restype = C.c_int
         L.orc_fast9_nms.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_ingest_geometry.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.orc_fast9_score_map.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.orc_fast9_score_map.restype = None
         L.orc_distribute_octtree.restype = C.c_int
@@ -264,6 +265,18 @@ def orb_descriptor(blurred, x, y, angle_deg):
     d = np.zeros(32, np.uint8)
     lib().orc_orb_descriptor(_p(blurred), blurred.shape[1], x, y, float(angle_deg), _p(d))
     return d
+
+
+def ingest_geometry(img, rotate_degrees=0, vertical_flip=False, horizontal_flip=False):
+    """The reader's rotation + flips (image_sequence_reader.cc:186-205, :53-58) on [H, W] or [H, W, C]."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape[:2]
+    cn = 1 if img.ndim == 2 else img.shape[2]
+    oh, ow = (w, h) if rotate_degrees in (90, 270) else (h, w)
+    out = np.zeros((oh, ow) if img.ndim == 2 else (oh, ow, cn), np.uint8)
+    if lib().orc_ingest_geometry(_p(img), w, h, cn, int(rotate_degrees), int(bool(vertical_flip)), int(bool(horizontal_flip)), _p(out)) != 0:
+        raise ValueError("unsupported rotation angle")
+    return out
 
 
 def rgb_to_gray(rgb):

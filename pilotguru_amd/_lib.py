@@ -26,6 +26,7 @@ SYMBOLS = (
     "pgorb_bow_transform_device", "pgorb_bow_vectors", "pgorb_bow_score_l1",
     "pgorb_frame_grid", "pgorb_frame_grid_batch_device", "pgorb_search_for_initialization",
     "pgorb_search_for_initialization_batch_device", "pgorb_extract_batch_color_device",
+    "pgorb_extract_batch_ingest_device",
     "pgorb_search_by_projection_points", "pgorb_search_by_projection_frame", "pgorb_search_by_bow",
     "pgorb_undistort_keypoints", "pgorb_undistort_keypoints_batch_device", "pgorb_image_bounds",
     "pgorb_host_alloc", "pgorb_host_free",
@@ -83,6 +84,8 @@ def lib():
     L.pgorb_check_async.argtypes = [vp, vp]
     L.pgorb_extract_batch_color_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int,
                                                    vp, vp, C.c_int, vp, vp]
+    L.pgorb_extract_batch_ingest_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int,
+                                                    C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp]
     L.pgorb_descriptor_distance.argtypes = [vp, vp]
     L.pgorb_hamming_matrix.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp]
     L.pgorb_hamming_best2.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp]

@@ -551,6 +551,27 @@ int pgorb_extract_batch_color_device(pgorb_ctx* c, const uint8_t* d_img, int nfr
     return run_batch(c, nullptr, true, nframes, w, h, w, 0, d_kps, d_desc, cap_per_frame, d_n, (hipStream_t)stream);
 }
 
+int pgorb_extract_batch_ingest_device(pgorb_ctx* c, const uint8_t* d_img, int nframes, int src_w, int src_h, int stride,
+                                      int64_t frame_stride, int channels, int rgb_order, int rotate_degrees,
+                                      int vertical_flip, int horizontal_flip, pgorb_keypoint* d_kps, uint8_t* d_desc,
+                                      int cap_per_frame, int32_t* d_n, void* stream)
+{
+    if (!c) return PGORB_E_ARG;
+    if (!d_img || !d_kps || !d_desc || !d_n || nframes < 1 || src_w < 1 || src_h < 1 ||
+        (channels != 1 && channels != 3 && channels != 4) || stride < src_w * channels || cap_per_frame < 1)
+        return fail(c, PGORB_E_ARG, "bad argument to pgorb_extract_batch_ingest_device");
+    if (rotate_degrees != 0 && rotate_degrees != 90 && rotate_degrees != 180 && rotate_degrees != 270)
+        return fail(c, PGORB_E_ARG, "unsupported rotation %d: only multiples of 90 degrees", rotate_degrees);   // reader :203-207
+    const bool swap = rotate_degrees == 90 || rotate_degrees == 270;
+    const int w = swap ? src_h : src_w, h = swap ? src_w : src_h;
+    PG_HIP(c, hipSetDevice(c->prm.device));
+    int rc = make_plan(c, w, h, nframes);
+    if (rc) return rc;
+    pg_launch_ingest(c->plan, d_img, stride, frame_stride, src_w, src_h, channels, rgb_order, rotate_degrees / 90,
+                     vertical_flip != 0, horizontal_flip != 0, nframes, (hipStream_t)stream);
+    return run_batch(c, nullptr, true, nframes, w, h, w, 0, d_kps, d_desc, cap_per_frame, d_n, (hipStream_t)stream);
+}
+
 int pgorb_check_async(pgorb_ctx* c, void* stream)
 {
     if (!c) return PGORB_E_ARG;

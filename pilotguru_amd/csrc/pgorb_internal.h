@@ -101,6 +101,8 @@ struct PgPlan {
 // kernel launchers (each in its own .hip file)
 void pg_launch_copy_level0(const PgPlan& P, const uint8_t* src, int stride, int64_t fstride,
                            int nframes, hipStream_t s);
+void pg_launch_ingest(const PgPlan& P, const uint8_t* src, int stride, int64_t fstride, int sw, int sh, int channels,
+                      int rgb_order, int rot, int vflip, int hflip, int nframes, hipStream_t s);
 void pg_launch_color_to_gray(const PgPlan& P, const uint8_t* src, int stride, int64_t fstride, int channels,
                              int rgb_order, int nframes, hipStream_t s);
 void pg_launch_pyramid_level(const PgPlan& P, int level, int nframes, hipStream_t s);

@@ -50,6 +50,50 @@ __global__ __launch_bounds__(256) void k_color_to_gray(const uint8_t* __restrict
     *reinterpret_cast<uint32_t*>(dst + (int64_t)blockIdx.z * dfstride + (int64_t)y * pitch + x4) = v;
 }
 
+// Ingest with the reader's geometry fused in (src/io/image_sequence_reader.cc): destination
+// pixel (r, c) of the upright frame comes from source pixel
+//   rotate   0: (r, c)          90: cv::flip(raw.t(), 0) -> (c, sw-1-r)
+//          180: (sh-1-r, sw-1-c)  270: cv::flip(raw.t(), 1) -> (sh-1-c, r)           (:186-205)
+// after the optional vertical / horizontal flip of the wrapper source (:53-58, :212-222) has been
+// undone on (r, c).  cn = 1 copies grey, 3 / 4 applies CV_RGB2GRAY / CV_BGR2GRAY (Tracking.cc:247-260).
+__global__ __launch_bounds__(256) void k_ingest(const uint8_t* __restrict__ src, int stride, int64_t sfstride,
+                                                 int sw, int sh, int cn, int rIdx, int rot, int vflip, int hflip,
+                                                 uint8_t* __restrict__ dst, int pitch, int64_t dfstride, int w, int h)
+{
+    const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x4 >= w || y >= h) return;
+    const uint8_t* s0 = src + (int64_t)blockIdx.z * sfstride;
+    const int r1 = vflip ? h - 1 - y : y;
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int c = x4 + k;
+        if (c >= w) break;
+        const int c1 = hflip ? w - 1 - c : c;
+        int sr, sc;
+        if (rot == 0) { sr = r1; sc = c1; }
+        else if (rot == 1) { sr = c1; sc = sw - 1 - r1; }
+        else if (rot == 2) { sr = sh - 1 - r1; sc = sw - 1 - c1; }
+        else { sr = sh - 1 - c1; sc = r1; }
+        const uint8_t* px = s0 + (int64_t)sr * stride + (int64_t)sc * cn;
+        int g;
+        if (cn == 1) g = px[0];
+        else { const int R = px[rIdx], G = px[1], B = px[2 - rIdx]; g = (R * 4899 + G * 9617 + B * 1868 + 8192) >> 14; }
+        v |= (uint32_t)g << (8 * k);
+    }
+    *reinterpret_cast<uint32_t*>(dst + (int64_t)blockIdx.z * dfstride + (int64_t)y * pitch + x4) = v;
+}
+
+void pg_launch_ingest(const PgPlan& P, const uint8_t* src, int stride, int64_t fstride, int sw, int sh, int channels,
+                      int rgb_order, int rot, int vflip, int hflip, int nframes, hipStream_t s)
+{
+    const PgLevel& L = P.lvl[0];
+    dim3 block(64, 4), grid((L.w + 255) / 256, (L.h + 3) / 4, nframes);
+    hipLaunchKernelGGL(k_ingest, grid, block, 0, s, src, stride, fstride, sw, sh, channels, rgb_order ? 0 : 2, rot, vflip, hflip,
+                       L.img, L.pitch, L.fstride, L.w, L.h);
+}
+
 void pg_launch_color_to_gray(const PgPlan& P, const uint8_t* src, int stride, int64_t fstride, int channels,
                              int rgb_order, int nframes, hipStream_t s)
 {

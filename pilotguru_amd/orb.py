@@ -152,6 +152,30 @@ class ORBextractor:
             C.c_void_p(n.data_ptr()), C.c_void_p(s)))
         return kps, desc, n
 
+    def extract_batch_ingest_device(self, frames, rgb_order=True, rotate_degrees=0, vertical_flip=False,
+                                    horizontal_flip=False, stream=None):
+        """`frames`: CUDA(HIP) torch uint8 tensor [B, H, W] (grey) or [B, H, W, C] (C = 3 or 4) exactly
+        as decoded; applies the reader's rotation (0/90/180/270, image_sequence_reader.cc:186-205)
+        and flips (:53-58) and Tracking's grey conversion on the device, then extracts."""
+        import torch
+        if frames.dim() == 3:
+            B, H, W = frames.shape
+            Cn = 1
+        else:
+            B, H, W, Cn = frames.shape
+        ow, oh = (H, W) if rotate_degrees in (90, 270) else (W, H)
+        cap = self.max_keypoints(ow, oh)
+        dev = frames.device
+        kps = torch.empty((B, cap, 7), dtype=torch.float32, device=dev)
+        desc = torch.empty((B, cap, 32), dtype=torch.uint8, device=dev)
+        n = torch.empty((B,), dtype=torch.int32, device=dev)
+        s = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+        self._check(self._L.pgorb_extract_batch_ingest_device(
+            self._h, C.c_void_p(frames.data_ptr()), B, W, H, frames.stride(1), frames.stride(0), Cn,
+            int(bool(rgb_order)), int(rotate_degrees), int(bool(vertical_flip)), int(bool(horizontal_flip)),
+            C.c_void_p(kps.data_ptr()), C.c_void_p(desc.data_ptr()), cap, C.c_void_p(n.data_ptr()), C.c_void_p(s)))
+        return kps, desc, n
+
     def check_async(self, stream=None):
         import torch
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream

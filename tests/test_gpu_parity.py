@@ -449,3 +449,42 @@ def test_device_entry_points_are_graph_capture_safe(oracle):
         assert torch.equal(a.view(torch.uint8), b.view(torch.uint8))
     okp, odesc = oracle.OrbOracle(nf, 1.2, 8, 20, 7).extract(ride[1])
     assert int(n[1]) == len(okp) and np.array_equal(desc[1, :len(okp)].cpu().numpy(), odesc)
+
+
+@pytest.mark.parametrize("rot", [0, 90, 180, 270])
+@pytest.mark.parametrize("cn,rgb", [(1, True), (3, True), (4, False)])
+def test_ingest_rotation_flip_colour_on_device(oracle, rot, cn, rgb):
+    """pgorb_extract_batch_ingest_device: frames as decoded (grey / RGB / BGRA) go through the
+    reader's rotation and flips and Tracking's grey conversion on the device; keypoints and
+    descriptors equal the oracle run on the oracle-ingested frame, for all four flip settings."""
+    import torch
+    import pilotguru_amd as pg
+    w, h, nf = 333, 251, 500
+    rng = np.random.RandomState(rot + cn)
+    base = synth_scene(60 + rot // 90, w, h)
+    if cn == 1:
+        frame = base
+    else:
+        frame = np.stack([base, np.roll(base, 3, axis=1), (255 - base)] + ([np.full_like(base, 255)] if cn == 4 else []), axis=2)
+        frame = np.ascontiguousarray(frame)
+    ow, oh = (h, w) if rot in (90, 270) else (w, h)
+    ext = pg.ORBextractor(nf, 1.2, 8, 20, 7, max_width=ow, max_height=oh, max_batch=2)
+    ora = oracle.OrbOracle(nf, 1.2, 8, 20, 7)
+    dev = torch.from_numpy(np.stack([frame, frame])).cuda()
+    for vf in (False, True):
+        for hf in (False, True):
+            up = oracle.ingest_geometry(frame, rot, vf, hf)
+            if cn > 1:
+                c3 = np.ascontiguousarray(up[:, :, :3] if rgb else up[:, :, 2::-1])
+                up = oracle.rgb_to_gray(c3)
+            okp, odesc = ora.extract(up)
+            kps, desc, n = ext.extract_batch_ingest_device(dev, rgb_order=rgb, rotate_degrees=rot, vertical_flip=vf, horizontal_flip=hf)
+            torch.cuda.synchronize()
+            assert np.array_equal(ext.debug_level_image(1, 0), up)
+            for f in range(2):
+                m = int(n[f])
+                assert m == len(okp) > 50
+                assert kps[f, :m].cpu().numpy().tobytes() == okp.tobytes()
+                assert np.array_equal(desc[f, :m].cpu().numpy(), odesc)
+    with pytest.raises(Exception):
+        ext.extract_batch_ingest_device(dev, rotate_degrees=45)

@@ -475,3 +475,21 @@ def test_pattern_table_equals_scikit_image_copy():
     body = txt[txt.index("*/") + 2:]
     vals = np.array([int(v) for v in body.replace("\n", " ").split(",") if v.strip()], np.int8).reshape(256, 4)
     assert np.array_equal(vals, fx["orb_positions"])
+
+
+def test_ingest_geometry_is_rot90_and_flips(oracle):
+    """The reader's rotation (cv::flip of the transpose, image_sequence_reader.cc:186-205) and
+    flips (:53-58) restated literally equal numpy's rot90 (counter-clockwise quarter turns) and
+    slicing, for grey and colour frames and all 16 combinations; other angles are rejected."""
+    rng = np.random.RandomState(3)
+    for shape in [(5, 7), (9, 4, 3), (6, 6, 4)]:
+        img = rng.randint(0, 256, shape).astype(np.uint8)
+        for rot, k in ((0, 0), (90, 1), (180, 2), (270, 3)):
+            for vf in (False, True):
+                for hf in (False, True):
+                    ref = np.rot90(img, k)
+                    if vf: ref = ref[::-1]
+                    if hf: ref = ref[:, ::-1]
+                    assert np.array_equal(oracle.ingest_geometry(img, rot, vf, hf), ref), (shape, rot, vf, hf)
+    with pytest.raises(ValueError):
+        oracle.ingest_geometry(rng.randint(0, 256, (4, 4)).astype(np.uint8), 45)
