@@ -49,10 +49,8 @@ enum {
     PGORB_E_CAP = -3,        /* output capacity too small; nothing truncated silently   */
     PGORB_E_NODEVICE = -4,   /* no HIP device / wrong architecture                      */
     PGORB_E_HIP = -5,        /* HIP runtime error (see pgorb_last_error)                */
-    PGORB_E_LIMIT = -6,      /* exceeds max_width/max_height/max_batch of the context, a level
-                              * larger than 4095 px, or a per-level keypoint quota above ~1180
-                              * (the quadtree's node list lives in LDS: nfeatures <= ~5400 with
-                              * the reference's 8 levels / 1.2; it runs 2000 and 4000)     */
+    PGORB_E_LIMIT = -6,      /* exceeds max_width/max_height/max_batch of the context, or a
+                              * level larger than 4095 px a side                          */
     PGORB_E_OVERFLOW = -7    /* internal candidate capacity exceeded                    */
 };
 

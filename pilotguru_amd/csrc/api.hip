@@ -276,12 +276,18 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
         V.cellCandOff = (int64_t)cellCandFrame;
         cellCandFrame += align_up((size_t)V.cellCap * V.nCols * V.nRows, 64);
         V.selOff = (int64_t)selFrame; selFrame += align_up(V.selCap, 16);
-        V.nodeOff = (int64_t)nodeFrame; nodeFrame += align_up((size_t)V.nCols * V.nRows, 64);   // cell offsets
+        // node arrays of the quadtree: LDS when 30 ints per node fit its 140 KB, else a global slab
+        // (quotas above ~1180 keypoints on one level: slower, but no configuration is refused)
+        V.nodeOff = -1;
+        if ((size_t)V.nodeCap * 30 * sizeof(int) > 140 * 1024) {
+            V.nodeOff = (int64_t)nodeFrame;
+            nodeFrame += align_up((size_t)V.nodeCap * 30, 64);
+        }
         V.scale = c->mvScaleFactor[l];
         V.patchSize = (float)(int)(31 * c->mvScaleFactor[l]);                     // :836
         selTotal += V.selCap;
-        if ((size_t)std::max(V.nodeCap * 30, V.nCols * V.nRows + 1) * sizeof(int) > 140 * 1024)
-            return fail(c, PGORB_E_LIMIT, "nfeatures too large for the quadtree kernel's LDS budget");
+        if ((size_t)(V.nCols * V.nRows + 1) * sizeof(int) > 140 * 1024)
+            return fail(c, PGORB_E_LIMIT, "too many cells on one level for the quadtree kernel's LDS budget");
         if (V.w > 4095 + 2 * PG_EDGE || V.h > 4095 + 2 * PG_EDGE)
             return fail(c, PGORB_E_LIMIT, "level larger than 4095 px is not supported");
     }

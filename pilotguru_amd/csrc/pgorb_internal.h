@@ -64,7 +64,8 @@ struct PgLevel {
     int32_t  candCap;
     int64_t  candOff;         // u32 offset of (frame 0, this level) inside a frame's slab
     int64_t  selOff;          // u32 offset inside a frame's selection slab
-    int64_t  nodeOff;         // int offset inside a (frame) node-scratch slab
+    int64_t  nodeOff;         // int offset of this level's node arrays inside a frame's node-scratch slab,
+                              // or -1 when they fit the quadtree workgroup's LDS (the normal case)
     int32_t  nodeCap;
     float    scale;           // mvScaleFactor[level]
     float    patchSize;       // (float)(int)(31*scale)  ORBextractor.cc:836

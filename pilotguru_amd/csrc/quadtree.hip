@@ -197,6 +197,9 @@ __device__ __forceinline__ int qt_walk(const int* map, int leaf, int nIni, int D
     return 0;                                            // unreachable: list nodes partition the keys
 }
 
+// BIG: the level's node arrays do not fit LDS (quota above ~1180) and live in a global slab;
+// the same code, just slower.  Each instantiation skips the levels of the other kind.
+template <bool BIG>
 __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P)
 {
     __shared__ int sh[3 * QT_W + 8];
@@ -213,8 +216,10 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P)
     const PgLevel& L = P.lvl[l];
     int* kpc = &P.kpCount[frame * PG_MAXL + l];
     uint2* keys = reinterpret_cast<uint2*>(P.cand) + ((int64_t)frame * P.candFrame + L.candOff);
+    if (BIG != (L.nodeOff >= 0)) return;
     const int NC = L.nodeCap;
-    int4* bndA = reinterpret_cast<int4*>(qt_lds);      // (ULx, ULy, URx, BRy) in list order
+    int* nodeBase = BIG ? P.nodeScratch + (int64_t)frame * P.nodeFrame + L.nodeOff : qt_lds;
+    int4* bndA = reinterpret_cast<int4*>(nodeBase);    // (ULx, ULy, URx, BRy) in list order
     int4* bndB = bndA + NC;
     int* cntA = reinterpret_cast<int*>(bndB + NC);
     int* cntB = cntA + NC;
@@ -430,27 +435,48 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P)
             for (int p = tid; p < n; p += QT_T) rnk[p] = (cntA[p] > 1) ? 1 : 0;
             __syncthreads();
             const int m = qt_scan_excl(rnk, n, sh);          // rnk[p] = list-order rank among expandable
-            // sort key of an expandable node: size << 11 | (2047 - list-order rank), so that "larger
-            // size first, ties: smaller list position first" (see header) is one unsigned compare
-            for (int p = tid; p < n; p += QT_T) {
-                if (cntA[p] > 1) { tmp[rnk[p]] = p; ecnt[rnk[p]] = (int)(((uint32_t)min(cntA[p], 0x1FFFFF) << 11) | (uint32_t)(2047 - rnk[p])); }
-                else rnk[p] = -1;
-            }
-            __syncthreads();
-            // rank by counting: m <= nodeCap < 2048 keys, four per LDS read
-            const int m4 = m & ~3;
-            for (int i = tid; i < m; i += QT_T) {
-                const uint32_t ki = (uint32_t)ecnt[i];
-                int rank = 0;
-                for (int j = 0; j < m4; j += 4) {
-                    const uint4 k4 = *reinterpret_cast<const uint4*>(ecnt + j);
-                    rank += (k4.x > ki) + (k4.y > ki) + (k4.z > ki) + (k4.w > ki);
+            if (BIG) {
+                // descending size, ties: smaller list position first (see header); node counts beyond
+                // the 11-bit rank field of the packed key below
+                for (int p = tid; p < n; p += QT_T) {
+                    if (cntA[p] > 1) { tmp[rnk[p]] = p; ecnt[rnk[p]] = cntA[p]; }
+                    else rnk[p] = -1;
                 }
-                for (int j = m4; j < m; j++) rank += (uint32_t)ecnt[j] > ki;
-                ord[rank] = tmp[i];
-                rnk[tmp[i]] = rank;
+                __syncthreads();
+                for (int i = tid; i < m; i += QT_T) {
+                    const int ci = ecnt[i];
+                    int rank = 0;
+                    for (int j = 0; j < m; j++) {
+                        const int cj = ecnt[j];
+                        rank += (cj > ci) || (cj == ci && j < i);
+                    }
+                    ord[rank] = tmp[i];
+                    rnk[tmp[i]] = rank;
+                }
+                __syncthreads();
+            } else {
+                // sort key of an expandable node: size << 11 | (2047 - list-order rank), so that "larger
+                // size first, ties: smaller list position first" (see header) is one unsigned compare
+                for (int p = tid; p < n; p += QT_T) {
+                    if (cntA[p] > 1) { tmp[rnk[p]] = p; ecnt[rnk[p]] = (int)(((uint32_t)min(cntA[p], 0x1FFFFF) << 11) | (uint32_t)(2047 - rnk[p])); }
+                    else rnk[p] = -1;
+                }
+                __syncthreads();
+                // rank by counting: m <= nodeCap < 2048 keys, four per LDS read
+                const int m4 = m & ~3;
+                for (int i = tid; i < m; i += QT_T) {
+                    const uint32_t ki = (uint32_t)ecnt[i];
+                    int rank = 0;
+                    for (int j = 0; j < m4; j += 4) {
+                        const uint4 k4 = *reinterpret_cast<const uint4*>(ecnt + j);
+                        rank += (k4.x > ki) + (k4.y > ki) + (k4.z > ki) + (k4.w > ki);
+                    }
+                    for (int j = m4; j < m; j++) rank += (uint32_t)ecnt[j] > ki;
+                    ord[rank] = tmp[i];
+                    rnk[tmp[i]] = rank;
+                }
+                __syncthreads();
             }
-            __syncthreads();
             // inclusive sum of non-empty child counts in processing order
             for (int r = tid; r < m; r += QT_T) {
                 const int p = ord[r];
@@ -622,16 +648,23 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P)
 
 void pg_launch_quadtree(const PgPlan& P, int nframes, hipStream_t s)
 {
-    int need = 0;
-    for (int l = 0; l < P.nlevels; l++)
-        need = max(need, max(P.lvl[l].nodeCap * 30, P.lvl[l].nCols * P.lvl[l].nRows + 1));
-    const size_t lds = (size_t)need * sizeof(int);
-    static size_t configured = 0;
-    if (lds > configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        configured = lds;
+    int need[2] = {0, 0};                                 // dynamic LDS ints: [LDS-node levels], [global-node levels]
+    for (int l = 0; l < P.nlevels; l++) {
+        const int cells = P.lvl[l].nCols * P.lvl[l].nRows + 1;
+        if (P.lvl[l].nodeOff >= 0) need[1] = max(need[1], cells);
+        else need[0] = max(need[0], max(P.lvl[l].nodeCap * 30, cells));
     }
+    static size_t configured[2] = {0, 0};
     dim3 grid(nframes, P.nlevels), block(QT_T);
-    hipLaunchKernelGGL(k_quadtree, grid, block, lds, s, P);
+    for (int big = 0; big < 2; big++) {
+        if (!need[big]) continue;
+        const size_t lds = (size_t)need[big] * sizeof(int);
+        const void* fn = big ? reinterpret_cast<const void*>(k_quadtree<true>) : reinterpret_cast<const void*>(k_quadtree<false>);
+        if (lds > configured[big]) {
+            (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            configured[big] = lds;
+        }
+        if (big) hipLaunchKernelGGL(k_quadtree<true>, grid, block, lds, s, P);
+        else hipLaunchKernelGGL(k_quadtree<false>, grid, block, lds, s, P);
+    }
 }

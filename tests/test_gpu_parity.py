@@ -488,3 +488,20 @@ def test_ingest_rotation_flip_colour_on_device(oracle, rot, cn, rgb):
                 assert np.array_equal(desc[f, :m].cpu().numpy(), odesc)
     with pytest.raises(Exception):
         ext.extract_batch_ingest_device(dev, rotate_degrees=45)
+
+
+@pytest.mark.parametrize("w,h,nf,nlev", [(969, 578, 2461, 1), (640, 480, 3000, 2), (1280, 720, 6000, 3)])
+def test_large_per_level_quota_uses_global_node_arrays(oracle, w, h, nf, nlev):
+    """Quotas above ~1180 keypoints on one level do not fit the quadtree workgroup's LDS node
+    list; those levels run the same kernel on a global slab (k_quadtree<true>).  Same keypoints,
+    same order, same descriptors as the oracle."""
+    import pilotguru_amd as pg
+    img = synth_scene(300 + nlev, w, h)
+    ora = oracle.OrbOracle(nf, 1.2, nlev, 20, 7)
+    okp, odesc = ora.extract(img)
+    ext = pg.ORBextractor(nf, 1.2, nlev, 20, 7, max_width=w, max_height=h)
+    assert max(ext.features_per_level()) > 1200
+    kp, desc = ext(img)
+    for l in range(nlev):
+        assert ext.debug_level_keypoints(0, l) == ora.level_keypoints(l), "quadtree count level %d" % l
+    assert len(okp) > 1500 and kp.tobytes() == okp.tobytes() and np.array_equal(desc, odesc)

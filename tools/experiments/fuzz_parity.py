@@ -31,8 +31,6 @@ for it in range(N):
         kp, d = ext(img)
     except Exception as e:
         kp = None; err = str(e)
-    if kp is None and "LDS budget" in err:
-        continue                                            # documented limit: per-level quota above ~1180
     if (okp is None) != (kp is None):
         print("MISMATCH (error state)", it, w, h, scale, nlev, nf, ini, mn, kind, okp is None, kp is None, err[:80]); bad += 1; continue
     if okp is None: continue
