@@ -505,3 +505,36 @@ def test_large_per_level_quota_uses_global_node_arrays(oracle, w, h, nf, nlev):
     for l in range(nlev):
         assert ext.debug_level_keypoints(0, l) == ora.level_keypoints(l), "quadtree count level %d" % l
     assert len(okp) > 1500 and kp.tobytes() == okp.tobytes() and np.array_equal(desc, odesc)
+
+
+def test_batch_with_featureless_frames(oracle):
+    """Flat (and nearly flat) frames inside a batch: zero candidates on every level for some
+    frames, normal work for the others; counts, keypoints and matches stay per frame."""
+    import torch
+    w, h, nf = 480, 360, 600
+    tex = synth_scene(21, w, h)
+    flat = np.full((h, w), 77, np.uint8)
+    dim = (100 + (tex.astype(np.int32) - 128) // 40).astype(np.uint8)        # contrast below minThFAST everywhere
+    frames = np.stack([flat, tex, dim, tex[::-1].copy(), flat])
+    ext = _make(nf, w, h, batch=len(frames))
+    kps, desc, n = ext.extract_batch_device(torch.from_numpy(frames).cuda())
+    ext.check_async()
+    ora = oracle.OrbOracle(nf, 1.2, 8, 20, 7)
+    n = n.cpu().numpy()
+    descs = []
+    for f in range(len(frames)):
+        okp, odesc = ora.extract(frames[f])
+        assert n[f] == len(okp), f
+        assert kps[f, :n[f]].cpu().numpy().tobytes() == okp.tobytes()
+        assert np.array_equal(desc[f, :n[f]].cpu().numpy(), odesc)
+        descs.append(odesc)
+    assert n[0] == 0 and n[4] == 0 and n[1] > 300
+    pq = torch.tensor([1, 0, 2, 3, 4], dtype=torch.int32, device="cuda")
+    pt = torch.tensor([0, 1, 1, 1, 0], dtype=torch.int32, device="cuda")
+    bi, b1, b2 = ext.match_batch_device(desc, torch.from_numpy(n).cuda(), pq, pt)
+    torch.cuda.synchronize()
+    for p, (q, t) in enumerate(zip(pq.tolist(), pt.tolist())):
+        obi, ob1, ob2 = oracle.hamming_best2(descs[q], descs[t])
+        m = len(descs[q])
+        assert np.array_equal(bi[p, :m].cpu().numpy(), obi)
+        assert np.array_equal(b1[p, :m].cpu().numpy().view(np.uint16), ob1)
