@@ -115,18 +115,19 @@ __device__ __forceinline__ uint32_t pg_pkmax(uint32_t a, uint32_t b)
 // (2) necessary test + compaction of interior rows [rowBeg, rowEnd).  Each lane tests one quad
 // per step.  A pixel can only be a corner at threshold t if both opposite ring pairs (0,8) and
 // (4,12) hold a pixel darker than v-t, or both a pixel brighter than v+t.  The test runs on
-// TWO pixels per 32-bit operation with plain add/sub/and/or (the only VALU ops that issue at
-// full rate on gfx950; byte min/max via SDWA or VOP3 cost ~1.7x each): pixels are spread into
-// 16-bit fields (even / odd bytes of a dword), and for a field
-//     0x8000 + v - t - 1 - r   has bit 15 set  <=>  r < v - t        (darker)
-//     0x8000 + r - v - t - 1   has bit 15 set  <=>  r > v + t        (brighter)
+// TWO pixels per 32-bit operation: v_perm_b32 spreads the bytes of a dword into 16-bit fields
+// (pixels 0,2 / 1,3, and the ring pixels x-3 / x+3 straight from the neighbouring dwords),
+// v_pk_min_u16 / v_pk_max_u16 form dk = the larger of the pairs' minima and br = the smaller of
+// their maxima, and for a field
+//     0x8000 + v - t - 1 - dk  has bit 15 set  <=>  dk < v - t       (a darker pixel in every pair)
+//     0x8000 + br - v - t - 1  has bit 15 set  <=>  br > v + t       (a brighter pixel in every pair)
 // with no borrow or carry between fields (|v - r| + t + 1 < 0x8000).
 // The 4 result bits of a step are kept in a 64-bit register (step s: bits 14-2s, 15-2s, 30-2s,
 // 31-2s of word s/8 = pixels 0,1,2,3); ONE wave prefix sum at the end turns the per-lane
 // popcounts into list offsets (list order is irrelevant: NMS works on the score map).  Returns
 // the list length, or -1 when the list would overflow (the caller then takes the chunked path).
 // STRONG adds the diagonal pairs (2,10) and (6,14) to the necessary condition (a 9-long arc holds
-// one pixel of EVERY opposite pair).  It costs ~60 more operations per step and is used for the
+// one pixel of EVERY opposite pair).  It costs ~35 more operations per step and is used for the
 // minThFAST pass, where the two-pair test lets ~40 % of a textured cell through and the exact
 // scores of those pixels dominated the pass.
 template <int QW, bool STRONG>      // quads per row handled by consecutive lanes: 8 (IW <= 32) or 16 (IW <= 64)
