@@ -109,8 +109,11 @@ int level_geometry(const pgorb_ctx* c, int w, int h, LevelGeom* g)
         g[l].hCell = (int)ceilf(height / nRows);
         const int rw = g[l].w - 2 * PG_EDGE, rh = g[l].h - 2 * PG_EDGE;
         g[l].nIni = (int)roundf((float)rw / rh);                                  // :543
-        if (g[l].nIni < 1) return PGORB_E_TOOSMALL;
-        g[l].hX = (float)rw / g[l].nIni;                                          // :545
+        // nIni == 0 (region more than twice as tall as wide): the reference divides by it and then
+        // indexes an empty vector -- but only when the level has candidates (:545-570); with none it
+        // returns an empty level.  Same here: K3 raises PGORB_E_TOOSMALL iff such a level has candidates.
+        if (g[l].nIni < 1) g[l].nIni = 0;
+        g[l].hX = g[l].nIni ? (float)rw / g[l].nIni : 0.f;                        // :545
     }
     return 0;
 }
@@ -171,7 +174,7 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
 
     // --- resize tables ---
     std::vector<uint8_t> tab;
-    struct TabOff { size_t xofs, xofs1, xalpha, yofs, ybeta, qtab, yrel, qtab2, rowgrp; bool hasQ, hasY, hasQ2; } toff[PG_MAXL];
+    struct TabOff { size_t xofs, xofs1, xalpha, yofs, ybeta, qtab, yrel, qtab2, rowgrp, tilex; int cpr, prows; bool hasQ, hasY, hasQ2; } toff[PG_MAXL];
     for (int l = 1; l < L; l++) {
         std::vector<int32_t> xo, xo1, yo; std::vector<int16_t> xa, yb;
         build_resize_tables(g[l - 1].w, g[l - 1].h, g[l].w, g[l].h, xo, xo1, xa, yo, yb);
@@ -249,6 +252,28 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
             }
         }
         toff[l].rowgrp = put(rg.data(), rg.size() * sizeof(PgRowGrp));
+        // LDS-staged variant of the 4x4 kernel: a 256 x 32 destination tile stages its source
+        // rectangle (16-byte chunks from a 16-aligned first column) through LDS
+        toff[l].cpr = 0; toff[l].prows = 0;
+        {
+            const int ntx = (g[l].w + 255) / 256, nty = (g[l].h + 31) / 32, ngrp = (g[l].h + 3) / 4;
+            std::vector<int32_t> tx0(ntx, 0);
+            int span = 0, rows = 0;
+            if (ok2 && oky) {
+                for (int tx = 0; tx < ntx; tx++) {
+                    const int qf = 64 * tx, ql = std::min(64 * tx + 63, nq - 1);
+                    tx0[tx] = q2[qf].xb & ~15;
+                    span = std::max(span, q2[ql].xb + 8 - tx0[tx]);
+                }
+                for (int ty = 0; ty < nty; ty++) {
+                    const int gf = 8 * ty, gl = std::min(8 * ty + 7, ngrp - 1);
+                    rows = std::max(rows, rg[gl].sFirst + 6 - rg[gf].sFirst);
+                }
+                const int cpr = (span + 4 + 15) / 16;
+                if (cpr <= 32 && (size_t)rows * cpr * 16 <= 20 * 1024) { toff[l].cpr = cpr; toff[l].prows = rows; }
+            }
+            toff[l].tilex = put(tx0.data(), tx0.size() * 4);
+        }
     }
     if ((rc = ensure(c, c->tables, tab.size() + 16))) return rc;
     if (!tab.empty()) PG_HIP(c, hipMemcpy(c->tables.p, tab.data(), tab.size(), hipMemcpyHostToDevice));
@@ -315,6 +340,8 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
             V.qtab = toff[l].hasQ ? (const PgQuadTab*)(t + toff[l].qtab) : nullptr;
             V.yrel = toff[l].hasY ? (t + toff[l].yrel) : nullptr;
             V.rowgrp = (const PgRowGrp*)(t + toff[l].rowgrp);
+            V.tilex = (const int32_t*)(t + toff[l].tilex);
+            V.pyrCpr = toff[l].cpr; V.pyrRows = toff[l].prows;
             V.qtab2 = toff[l].hasQ2 ? (const PgQuadTab2*)(t + toff[l].qtab2) : nullptr;
         }
     }
@@ -586,7 +613,8 @@ int pgorb_check_async(pgorb_ctx* c, void* stream)
     PG_HIP(c, hipStreamSynchronize((hipStream_t)stream));
     int32_t st = 0;
     PG_HIP(c, hipMemcpy(&st, c->plan.status, 4, hipMemcpyDeviceToHost));
-    if (st) return fail(c, st, "device status %d (internal candidate capacity exceeded)", st);
+    if (st) return fail(c, st, st == PGORB_E_TOOSMALL ? "device status %d (a pyramid level more than twice as tall as wide has candidates: the reference divides by zero there)"
+                                                     : "device status %d (internal candidate capacity exceeded)", st);
     return 0;
 }
 

@@ -53,6 +53,9 @@ struct PgLevel {
     const PgQuadTab2* qtab2;  // [ceil(w/4)] or null when a quad's taps do not fit one 8-byte window
     const uint8_t* yrel;      // [h] row pattern of the 4x4 fast path, or null when it does not apply
     const PgRowGrp* rowgrp;   // [ceil(h/4)] the same, one 32-byte record per group of 4 rows (one scalar load)
+    const int32_t* tilex;     // [ceil(w/256)] 16-aligned first source column of each 256-column tile (LDS-staged variant)
+    int32_t  pyrCpr;          // 16-byte chunks per staged source row (0: the LDS-staged variant does not apply)
+    int32_t  pyrRows;         // source rows staged per 256 x 32 tile
     // cell grid (ORBextractor.cc:781-787)
     int32_t  nCols, nRows, wCell, hCell, cellBase;
     // quadtree (ORBextractor.cc:539-563)

@@ -338,10 +338,94 @@ __global__ __launch_bounds__(256) void k_pyr_resize_rows4(
     if (second) pyr_group(w1, T, R1, dy0 + 4, dh, dbase, dpitch);
 }
 
+// LDS-staged variant: the workgroup's 256 x 32 destination tile first brings its source rectangle
+// into LDS with LDS-DMA (16-byte chunks, each source line fetched once and in full 16-byte pieces
+// instead of 64 overlapping 8-byte lane windows per row), then every lane cuts its 8-byte windows
+// out of LDS (three aligned dwords + v_alignbyte).  Same arithmetic as k_pyr_resize_rows4.
+typedef __attribute__((address_space(1))) const void* pg_gptr_t;
+typedef __attribute__((address_space(3))) void* pg_lptr_t;
+
+__global__ __launch_bounds__(256) void k_pyr_resize_rows4_lds(
+    const uint8_t* __restrict__ src, int spitch, int64_t sfstride, int sh,
+    uint8_t* __restrict__ dst, int dpitch, int64_t dfstride, int dw, int dh,
+    const PgQuadTab2* __restrict__ qtab, const PgRowGrp* __restrict__ rowgrp, int nx, uint32_t nxMagic,
+    const int32_t* __restrict__ tilex, int cpr, int cprInv, int rowsTile)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t pyr_lds[];      // [rowsTile][cpr * 16]
+    asm volatile("" :: "s"(src), "s"(spitch), "s"(sfstride), "s"(sh), "s"(dst), "s"(dpitch), "s"(dfstride),
+                 "s"(dw), "s"(dh), "s"(qtab), "s"(rowgrp), "s"(nx), "s"(nxMagic), "s"(tilex), "s"(cpr), "s"(cprInv), "s"(rowsTile));
+    const int t = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int ty = (nx == 1) ? t : (int)__umulhi((uint32_t)t, nxMagic), tx = t - ty * nx;
+    const int lane = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int quad = tx * 64 + lane;
+    const int ngrp = (dh + 3) >> 2;
+    if (ty * 8 >= ngrp) return;                                        // whole workgroup: padding tile
+    const int grp = ty * 8 + wv * 2;                                   // this wave: groups grp, grp + 1
+    const int dy0 = grp * 4;
+    const PgQuadTab2 T = qtab[min(quad, ((dw + 3) >> 2) - 1)];
+    const PgRowGrp* rp = rowgrp + min(grp, ngrp - 1);
+    typedef uint32_t pg_u32x16 __attribute__((ext_vector_type(16)));
+    pg_u32x16 rr;
+    int sTile, x0a;
+    asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dword %1, %4, 0x0\n\ts_load_dword %2, %5, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(rr), "=&s"(sTile), "=&s"(x0a) : "s"(rp), "s"(rowgrp + ty * 8), "s"(tilex + tx) : "memory");
+    // stage the tile's source rectangle: cpr lanes per row, 64 / cpr rows per instruction
+    {
+        const int pitch = cpr * 16, rowsPer = 64 / cpr;
+        const int r0 = (lane * cprInv) >> 16, ch = lane - r0 * cpr;
+        const uint8_t* sb = src + (int64_t)blockIdx.z * sfstride + x0a + ch * 16;
+        const bool laneOn = r0 < rowsPer && x0a + ch * 16 + 16 <= spitch;      // never past the row pitch
+        for (int k = wv; k * rowsPer < rowsTile; k += 4) {
+            const int r = k * rowsPer + r0;
+            if (laneOn && r < rowsTile)
+                __builtin_amdgcn_global_load_lds((pg_gptr_t)(sb + (int64_t)min(sTile + r, sh - 1) * spitch),
+                                                 (pg_lptr_t)(pyr_lds + k * rowsPer * pitch), 16, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+    }
+    __syncthreads();
+    if (quad * 4 >= dw || dy0 >= dh) return;
+    const uint32_t ra[8] = {rr[0], rr[1], rr[2], rr[3], rr[4], rr[5], rr[6], rr[7]};
+    const uint32_t rb[8] = {rr[8], rr[9], rr[10], rr[11], rr[12], rr[13], rr[14], rr[15]};
+    const PgRowGrp R0 = pyr_unpack_group(ra), R1 = pyr_unpack_group(rb);
+    const bool second = dy0 + 4 < dh;
+    const int o = T.xb - x0a;                                          // window offset in a staged row
+    const uint8_t* lb = pyr_lds + (o & ~3);
+    const uint32_t sh3 = (uint32_t)(o & 3);
+    const int pitch = cpr * 16;
+    uint8_t* dbase = dst + (int64_t)blockIdx.z * dfstride + quad * 4;
+#pragma unroll
+    for (int gi = 0; gi < 2; gi++) {
+        if (gi == 1 && !second) break;
+        const PgRowGrp& R = gi ? R1 : R0;
+        const int rel = R.sFirst - sTile;
+        PgU2 w[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const uint32_t* d = reinterpret_cast<const uint32_t*>(lb + min(rel + k, rowsTile - 1) * pitch);
+            const uint32_t d0 = d[0], d1 = d[1], d2 = d[2];
+            w[k].x = __builtin_amdgcn_alignbyte(d1, d0, sh3);
+            w[k].y = __builtin_amdgcn_alignbyte(d2, d1, sh3);
+        }
+        pyr_group(w, T, R, dy0 + 4 * gi, dh, dbase, dpitch);
+    }
+}
+
 void pg_launch_pyramid_level(const PgPlan& P, int level, int nframes, hipStream_t s)
 {
     const PgLevel& S = P.lvl[level - 1];
     const PgLevel& D = P.lvl[level];
+    static const bool noLds = getenv("PGORB_PYR_NO_LDS") != nullptr;
+    if (D.qtab2 && D.yrel && D.pyrCpr > 0 && S.pitch % 16 == 0 && !noLds) {
+        const int nx = (D.w + 255) / 256, ny = (D.h + 31) / 32;
+        const int tiles = (nx * ny + 7) & ~7;
+        const uint32_t nxMagic = nx > 1 ? (uint32_t)(((1ull << 32) / (uint64_t)nx) + 1ull) : 0u;
+        const int cprInv = 65536 / D.pyrCpr + 1;
+        dim3 block(64, 4), grid(tiles, 1, nframes);
+        hipLaunchKernelGGL(k_pyr_resize_rows4_lds, grid, block, (size_t)D.pyrRows * D.pyrCpr * 16, s, S.img, S.pitch, S.fstride, S.h,
+                           D.img, D.pitch, D.fstride, D.w, D.h, D.qtab2, D.rowgrp, nx, nxMagic, D.tilex, D.pyrCpr, cprInv, D.pyrRows);
+        return;
+    }
     if (D.qtab2 && D.yrel) {
         const int nx = (D.w + 255) / 256, ny = (D.h + 31) / 32;
         const int tiles = (nx * ny + 7) & ~7;

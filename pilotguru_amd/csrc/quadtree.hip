@@ -257,6 +257,10 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P)
         if (tid == 0) { cellOff[ncells] = ncand; P.candCount[frame * PG_MAXL + l] = ncand; }
         __syncthreads();
         if (ncand <= 0) { if (tid == 0) *kpc = 0; return; }
+        if (nIni < 1) {                                      // see api.hip level_geometry: reference UB, reported
+            if (tid == 0) { atomicExch(P.status, PGORB_E_TOOSMALL); *kpc = 0; }
+            return;
+        }
         QT_TS(8);
         // One thread per OUTPUT record (cells hold 0..cellCap records, ~10 on average but 100+ in
         // dense texture: any per-cell mapping leaves one wave with the long cells).  Record i
