@@ -7,9 +7,12 @@
 // same float/double sequence as cv::resize.  The 19-px reflect border the reference adds
 // (:1121,:1126) is never read on the monocular path, so planes are stored unpadded.
 //
-// HBM-bound u8 streaming kernel: each lane produces 4 adjacent destination pixels (one
-// 32-bit store, 256 B per wave-row) from two source rows; the source rows are read through
-// L1/L2 as bytes (a 1.2x down-scale touches 4.8 source bytes per 4 outputs per row).
+// HBM-bound u8 streaming kernels, fastest first (pg_launch_pyramid_level picks):
+//   k_pyr_resize_rows4_lds   256 x 32 destination tile per workgroup, source rectangle staged through
+//                            LDS by LDS-DMA; lane = 4 columns x 4 rows x 2 groups (scale <= ~1.4)
+//   k_pyr_resize_rows4       the same arithmetic with per-lane unaligned 8-byte global windows
+//   k_pyr_resize_quads / k_pyr_resize_bilinear_u8   generic scale factors, 4 pixels per lane from
+//                            two source rows read as bytes
 // Algorithmic bytes per launch: w_{l-1}*h_{l-1} read + w_l*h_l written, per frame.
 #include "pgorb_internal.h"
 
