@@ -208,7 +208,7 @@ def main():
         rk = max(cands, key=lambda s: stage_ms[s])
         launches = 7 if rk == "pyramid" else 1
         ach = (abytes[rk] * B / launches) / (stage_ms[rk] / launches * 1e-3) / 1e9
-        kname = {"pyramid": "k_pyr_resize_rows4", "fast": "k_fast_cells", "describe": "k_describe",
+        kname = {"pyramid": "k_pyr_resize_rows4_lds", "fast": "k_fast_cells", "describe": "k_describe",
                  "match": "k_match_mfma"}[rk]
         traffic = None                                  # HBM bytes per launch from the committed PMC passes
         try:
