@@ -309,6 +309,31 @@ int  pgorb_bow_vectors(int n, const uint32_t* word, const double* weight, const 
 double pgorb_bow_score_l1(const uint32_t* id1, const double* val1, int n1,
                           const uint32_t* id2, const double* val2, int n2);
 
+/* ---- after the path: what TrackImageSequence does to the finished trajectory ----
+ * Host functions, double precision, no context needed (the reference runs them once per segment on
+ * the CPU).  Quaternions are (w, x, y, z) like the JSON; all arrays are row-major.
+ *   pgorb_smooth_heading_directions  SmoothHeadingDirections(trajectory, sigma)  src/slam/smoothing.cc:11-47
+ *                                    (cv::getGaussianKernel(4*sigma+1, sigma), cv::sepFilter2D with
+ *                                    BORDER_REPLICATE along the trajectory, renormalisation); sigma <= 0 is the
+ *                                    reference's CHECK failure -> PGORB_E_ARG
+ *   pgorb_smooth_time_series         SmoothTimeSeries(values, timestamps, targets, sigma)  smoothing.cc:57-97
+ *   pgorb_trajectory_pca             TrajectoryToPCA  src/slam/track_image_sequence.cc:16-29: cv::PCA with
+ *                                    CV_PCA_DATA_AS_COL over the translations; eigenvectors[3][3] (rows, by
+ *                                    descending eigenvalue), eigenvalues[3], mean[3] (may be NULL).  The plane of
+ *                                    :92 is the first two rows; :83-90 drops the trajectory when
+ *                                    eigenvalues[2] > eigenvalues[1] * 1e-2.  n < 3 -> PGORB_E_LIMIT
+ *   pgorb_project_directions         ProjectDirections  src/slam/horizontal_flatten.cc:7-30 -> dirs[n][2]
+ *   pgorb_project_translations       ProjectTranslations  horizontal_flatten.cc:32-43 (in place)
+ *   pgorb_turn_angles                Projected2DDirectionsToTurnAngles  horizontal_flatten.cc:45-63 */
+int  pgorb_smooth_heading_directions(double* quat_wxyz /* [n][4] in/out */, int n, int sigma);
+int  pgorb_smooth_time_series(const double* values, const double* times, int n,
+                              const double* targets, int m, double sigma, double* out /* [m] */);
+int  pgorb_trajectory_pca(const double* translations /* [n][3] */, int n,
+                          double* eigenvectors /* [3][3] */, double* eigenvalues /* [3] */, double* mean /* [3] or NULL */);
+int  pgorb_project_directions(const double* quat_wxyz, int n, const double* plane /* [2][3] */, double* dirs /* [n][2] */);
+int  pgorb_project_translations(double* translations /* [n][3] in/out */, int n, const double* plane);
+int  pgorb_turn_angles(const double* dirs /* [n][2] */, int n, double* turn /* [n] */);
+
 /* Per-stage device timing with HIP events recorded on the launch stream around the kernel
  * groups of every *_device call: stage 0 = pyramid chain (K1, nlevels-1 launches), 1 = FAST
  * cells (K2), 2 = quadtree (K3), 3 = orientation+blur+rBRIEF (K4-6), 4 = Hamming match (K7).

@@ -21,7 +21,7 @@ CAND_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("response", "<i4")])
 def build(force=False):
     if force or not os.path.exists(_LIB) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB)
-            for f in ("orb_oracle.c", "orb_oracle.h", "orb_pattern31.inc")):
+            for f in ("orb_oracle.c", "orb_oracle.h", "orb_pattern31.inc", "post_oracle.c")):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liborb_oracle.so"],
                               stdout=subprocess.DEVNULL)
     return _LIB
@@ -484,3 +484,57 @@ def image_bounds(cols, rows, camera, dist):
     b = np.zeros(4, np.float32)
     lib().orc_image_bounds(cols, rows, _p(cam), _p(d), _p(b))
     return tuple(float(x) for x in b)
+
+
+# ---- trajectory post-processing (post_oracle.c) ----
+
+def _d(a, shape=None):
+    a = np.ascontiguousarray(a, np.float64)
+    return a if shape is None else a.reshape(shape)
+
+
+def smooth_heading_directions(quat_wxyz, sigma):
+    q = _d(quat_wxyz).reshape(-1, 4).copy()
+    rc = lib().porc_smooth_heading_directions(_p(q), len(q), int(sigma))
+    if rc:
+        raise ValueError("CHECK_GT(sigma, 0)")
+    return q
+
+
+def smooth_time_series(values, times, targets, sigma):
+    v, t, g = _d(values), _d(times), _d(targets)
+    assert len(v) == len(t)
+    out = np.zeros(len(g), np.float64)
+    f = lib().porc_smooth_time_series
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_void_p]
+    if f(_p(v), _p(t), len(v), _p(g), len(g), float(sigma), _p(out)):
+        raise ValueError("CHECK_GT(sigma, 0)")
+    return out
+
+
+def trajectory_pca(translations):
+    t = _d(translations).reshape(-1, 3)
+    vec, val, mean = np.zeros((3, 3)), np.zeros(3), np.zeros(3)
+    if lib().porc_trajectory_pca(_p(t), len(t), _p(vec), _p(val), _p(mean)):
+        raise ValueError("fewer than 3 samples")
+    return vec, val, mean
+
+
+def project_directions(quat_wxyz, plane):
+    q, pl = _d(quat_wxyz).reshape(-1, 4), _d(plane).reshape(2, 3)
+    out = np.zeros((len(q), 2))
+    lib().porc_project_directions(_p(q), len(q), _p(pl), _p(out))
+    return out
+
+
+def project_translations(translations, plane):
+    t, pl = _d(translations).reshape(-1, 3).copy(), _d(plane).reshape(2, 3)
+    lib().porc_project_translations(_p(t), len(t), _p(pl))
+    return t
+
+
+def turn_angles(dirs):
+    d = _d(dirs).reshape(-1, 2)
+    out = np.zeros(len(d))
+    lib().porc_turn_angles(_p(d), len(d), _p(out))
+    return out

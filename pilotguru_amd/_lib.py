@@ -30,6 +30,8 @@ SYMBOLS = (
     "pgorb_search_by_projection_points", "pgorb_search_by_projection_frame", "pgorb_search_by_bow",
     "pgorb_undistort_keypoints", "pgorb_undistort_keypoints_batch_device", "pgorb_image_bounds",
     "pgorb_host_alloc", "pgorb_host_free",
+    "pgorb_smooth_heading_directions", "pgorb_smooth_time_series", "pgorb_trajectory_pca",
+    "pgorb_project_directions", "pgorb_project_translations", "pgorb_turn_angles",
 )
 
 
@@ -109,6 +111,12 @@ def lib():
     L.pgorb_undistort_keypoints.argtypes = [vp, vp, C.c_int, vp, vp, vp]
     L.pgorb_undistort_keypoints_batch_device.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     L.pgorb_image_bounds.argtypes = [C.c_int, C.c_int, vp, vp, vp]
+    L.pgorb_smooth_heading_directions.argtypes = [vp, C.c_int, C.c_int]
+    L.pgorb_smooth_time_series.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_double, vp]
+    L.pgorb_trajectory_pca.argtypes = [vp, C.c_int, vp, vp, vp]
+    L.pgorb_project_directions.argtypes = [vp, C.c_int, vp, vp]
+    L.pgorb_project_translations.argtypes = [vp, C.c_int, vp]
+    L.pgorb_turn_angles.argtypes = [vp, C.c_int, vp]
     L.pgorb_host_alloc.restype = vp
     L.pgorb_host_alloc.argtypes = [C.c_int64]
     L.pgorb_host_free.restype = None

@@ -370,6 +370,14 @@ void pg_launch_hamming_matrix(const uint8_t* d_a, int na, const uint8_t* d_b, in
     hipLaunchKernelGGL(k_hamming_matrix, grid, block, 0, s, d_a, na, d_b, nb, d_out);
 }
 
+// PGORB_MATCH_POPCOUNT=1 forces the v_bcnt kernels for every size (the variant BASELINE.json's north star
+// describes), so both matchers can be timed on the same frames; results are identical.
+static bool mx_use_popcount()
+{
+    static const bool v = getenv("PGORB_MATCH_POPCOUNT") != nullptr;
+    return v;
+}
+
 size_t pg_match_scratch_bytes(int nb_max, int npairs)
 {
     return (size_t)npairs * (size_t)((nb_max + 15) / 16) * MX_BLOCK_BYTES;
@@ -380,7 +388,7 @@ void pg_launch_best2(const uint8_t* d_a, int na, const uint8_t* d_b, int nb, uin
                      int32_t* d_best_idx, uint16_t* d_best, uint16_t* d_second, hipStream_t s)
 {
     if (na <= 0) return;
-    if (nb >= MX_MAX_TRAIN) {
+    if (nb >= MX_MAX_TRAIN || mx_use_popcount()) {
         hipLaunchKernelGGL(k_hamming_best2, dim3((na + MT_T - 1) / MT_T), dim3(MT_T * MT_WAVES), 0, s, d_a, na, d_b, nb,
                            d_best_idx, d_best, d_second);
         return;
@@ -397,7 +405,7 @@ void pg_launch_match_batch(const uint8_t* d_desc, const int32_t* d_n, int cap_pe
                            int32_t* d_best_idx, uint16_t* d_best, uint16_t* d_second, hipStream_t s)
 {
     if (npairs <= 0) return;
-    if (cap_per_frame >= MX_MAX_TRAIN) {
+    if (cap_per_frame >= MX_MAX_TRAIN || mx_use_popcount()) {
         hipLaunchKernelGGL(k_match_batch, dim3((cap_per_frame + MT_T - 1) / MT_T, npairs), dim3(MT_T * MT_WAVES), 0, s,
                            d_desc, d_n, cap_per_frame, d_pq, d_pt, d_best_idx, d_best, d_second);
         return;

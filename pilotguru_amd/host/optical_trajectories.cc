@@ -9,7 +9,10 @@
 // .SearchForInitialization(previous, current, ..., 100) (Tracking.cc:596-597).  The SLAM back
 // end (Tracking/LocalMapping/LoopClosing, pose estimation) is out of scope, so instead of
 // trajectory-<k>.json (which needs poses) the run writes <out_dir>/frontend-<k>.json; the
-// trajectory JSON writer is exercised with --trajectory_in=<poses.txt> (see trajectory_json.hpp).
+// trajectory JSON writer is exercised with --trajectory_in=<poses.txt> (see trajectory_json.hpp),
+// and --poses_in=<poses.txt> runs the whole tail of TrackImageSequence on poses from any back end
+// (src/slam/track_image_sequence.cc:63-109: heading smoothing, PCA plane, eigenvalue gate,
+// projected directions, turn angles, trajectory-<segment_id>.json).
 // No libav here: --in_video takes a .y4m (Y plane), a printf pattern of PGM files
 // (frames/%06d.pgm) or a headerless .gray file sized by Camera_width/Camera_height.
 #include <algorithm>
@@ -25,14 +28,15 @@
 
 #include "orb_extractor.hpp"
 #include "trajectory_json.hpp"
+#include "trajectory_post.hpp"
 
 namespace {
 
 struct Flags {
-    std::string vocabulary_file, camera_settings, out_dir, in_video, trajectory_in, dump_features;
+    std::string vocabulary_file, camera_settings, out_dir, in_video, trajectory_in, poses_in, dump_features;
     bool visualize = true, vertical_flip = false, horizontal_flip = false, output_per_segment_videos = false;
     long long rotation_smooth_sigma = -1;
-    int device = 0, batch = 8, max_frames = -1;
+    int device = 0, batch = 8, max_frames = -1, segment_id = 0;
 };
 
 [[noreturn]] void check_failed(const char* what)
@@ -44,7 +48,7 @@ struct Flags {
 bool parse_flags(int argc, char** argv, Flags& F)
 {
     std::map<std::string, std::string*> str = {{"vocabulary_file", &F.vocabulary_file}, {"camera_settings", &F.camera_settings},
-        {"out_dir", &F.out_dir}, {"in_video", &F.in_video}, {"trajectory_in", &F.trajectory_in}, {"dump_features", &F.dump_features}};
+        {"out_dir", &F.out_dir}, {"in_video", &F.in_video}, {"trajectory_in", &F.trajectory_in}, {"poses_in", &F.poses_in}, {"dump_features", &F.dump_features}};
     std::map<std::string, bool*> bl = {{"visualize", &F.visualize}, {"vertical_flip", &F.vertical_flip},
         {"horizontal_flip", &F.horizontal_flip}, {"output_per_segment_videos", &F.output_per_segment_videos}};
     for (int i = 1; i < argc; i++) {
@@ -61,6 +65,7 @@ bool parse_flags(int argc, char** argv, Flags& F)
         else if (name == "device") F.device = atoi(val.c_str());
         else if (name == "batch") F.batch = atoi(val.c_str());
         else if (name == "max_frames") F.max_frames = atoi(val.c_str());
+        else if (name == "segment_id") F.segment_id = atoi(val.c_str());
         else { fprintf(stderr, "ERROR: unknown command line flag '%s'\n", name.c_str()); return false; }
     }
     return true;
@@ -170,6 +175,40 @@ int write_trajectory_from_text(const Flags& F)
     return EXIT_SUCCESS;
 }
 
+// The tail of TrackImageSequence (src/slam/track_image_sequence.cc:63-109) on poses read from text:
+// one "time_usec is_lost frame_id tx ty tz qw qx qy qz" line per trajectory point.
+int write_trajectory_from_poses(const Flags& F)
+{
+    std::ifstream f(F.poses_in);
+    if (!f.good()) check_failed("poses_in file is readable");
+    std::vector<pgorb::PoseWithTimestamp> trajectory;
+    for (;;) {
+        pgorb::PoseWithTimestamp p; long long t, id; int lost;
+        if (!(f >> t >> lost >> id >> p.pose.translation[0] >> p.pose.translation[1] >> p.pose.translation[2] >> p.pose.qw >>
+              p.pose.qx >> p.pose.qy >> p.pose.qz)) break;
+        p.time_usec = t; p.is_lost = lost != 0; p.frame_id = id;
+        trajectory.push_back(p);
+    }
+    if (trajectory.empty()) { fprintf(stderr, "empty trajectory, nothing written\n"); return EXIT_SUCCESS; }       // :64-66
+    if (F.rotation_smooth_sigma > 0 && !pgorb::SmoothHeadingDirections(&trajectory, (int)F.rotation_smooth_sigma))  // :68-70
+        check_failed("SmoothHeadingDirections");
+    pgorb::TrajectoryPCA pca;
+    if (!pgorb::TrajectoryToPCA(trajectory, &pca)) check_failed("trajectory has at least 3 poses (cv::PCA over 3 x N)");
+    if (pca.eigenvalues[2] > pca.eigenvalues[1] * 1e-2) {                                                           // :83-90
+        fprintf(stderr, "3rd eigenvalue was too large, dropping the trajectory. Relative magnitude wrt the 2nd eigenvalue: %g\n",
+                pca.eigenvalues[2] / pca.eigenvalues[1]);
+        return EXIT_SUCCESS;
+    }
+    const double* plane = pca.eigenvectors;                                                                          // rowRange(0, 2), :92
+    const std::vector<double> dirs = pgorb::ProjectDirections(trajectory, plane);
+    const std::vector<double> turns = pgorb::Projected2DDirectionsToTurnAngles(dirs);
+    const std::string out = F.out_dir + "/trajectory-" + std::to_string(F.segment_id) + ".json";
+    std::ofstream o(out);
+    if (!o.good()) check_failed("out_dir is writable");
+    o << pgorb::trajectory_to_json(plane, trajectory, dirs.data(), turns.data(), 0) << std::endl;
+    return EXIT_SUCCESS;
+}
+
 }  // namespace
 
 int main(int argc, char** argv)
@@ -177,6 +216,7 @@ int main(int argc, char** argv)
     Flags F;
     if (!parse_flags(argc, argv, F)) return EXIT_FAILURE;
     if (!F.trajectory_in.empty()) return write_trajectory_from_text(F);
+    if (!F.poses_in.empty()) return write_trajectory_from_poses(F);
     if (F.vocabulary_file.empty()) check_failed("!FLAGS_vocabulary_file.empty()");     // :77
     if (F.camera_settings.empty()) check_failed("!FLAGS_camera_settings.empty()");     // :78
     if (F.in_video.empty()) check_failed("!FLAGS_in_video.empty()");                   // :79
