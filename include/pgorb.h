@@ -334,6 +334,41 @@ int  pgorb_project_directions(const double* quat_wxyz, int n, const double* plan
 int  pgorb_project_translations(double* translations /* [n][3] in/out */, int n, const double* plane);
 int  pgorb_turn_angles(const double* dirs /* [n][2] */, int n, double* turn /* [n] */);
 
+/* ---- fit_motion's velocity calibration (BASELINE configs[4]), K9 calib.hip ----
+ * Inputs are the three recorder series as arrays: GPS speed [n_gps] + time, gyroscope rates
+ * [n_rot][3] (rad/s) + time, accelerations [n_acc][3] + time; times in microseconds, increasing.
+ *   pgorb_fit_num_windows        number of sliding windows = ceil(n_gps / locations_shift_step)
+ *                                (the loop of src/fit_motion.cc:173-176)
+ *   pgorb_fit_velocity_windows   for every window: AccelerometerCalibrator over the window's GPS fixes
+ *                                (src/calibration/velocity.cc:30-180) minimised from x = 0 with
+ *                                LBFGSpp::LBFGSSolver (thirdparty/LBFGS/LBFGS.h:78-181, epsilon 1e-5,
+ *                                max_iterations = optimization_iters; fit_motion.cc:163-190).  All windows
+ *                                run concurrently on the GPU, one lane each.  x[w][9] = global bias, local
+ *                                bias, initial velocity; residual[w] = loss; niter[w] = iterations, or -2 / -3
+ *                                where LBFGSpp would throw (line-search step below 1e-20 / above 1e20).
+ *   pgorb_calibrator_eval        AccelerometerCalibrator::operator() (velocity.cc:182-194) of ONE calibrator
+ *                                at n_points parameter vectors xin[n_points][9] -> fx[n_points], grad[n_points][9]
+ *   pgorb_fit_motion_velocities  ComputeAndSaveForwardVelocitiesFromImu (fit_motion.cc:151-290) up to the JSON:
+ *                                window fits on the GPU, then IntegrateTrajectory, per-sample averaging,
+ *                                SmoothTimeSeries and the forward axis on the host.  out_* need n_rot + n_acc entries. */
+int  pgorb_fit_num_windows(int n_gps, int locations_shift_step);
+int  pgorb_fit_velocity_windows(pgorb_ctx* ctx, const double* gps_velocity, const int64_t* gps_time_usec, int n_gps,
+                                const double* rotations, const int64_t* rot_time_usec, int n_rot,
+                                const double* accelerations, const int64_t* acc_time_usec, int n_acc,
+                                int locations_batch_size, int locations_shift_step, int optimization_iters,
+                                double* x /* [nw][9] */, double* residual /* [nw] */, int32_t* niter /* [nw] */);
+int  pgorb_calibrator_eval(pgorb_ctx* ctx, const double* gps_velocity, const int64_t* gps_time_usec, int n_gps,
+                           const double* rotations, const int64_t* rot_time_usec, int n_rot,
+                           const double* accelerations, const int64_t* acc_time_usec, int n_acc,
+                           const double* xin, int n_points, double* fx, double* grad);
+int  pgorb_fit_motion_velocities(pgorb_ctx* ctx, const double* gps_velocity, const int64_t* gps_time_usec, int n_gps,
+                                 const double* rotations, const int64_t* rot_time_usec, int n_rot,
+                                 const double* accelerations, const int64_t* acc_time_usec, int n_acc,
+                                 const double* vertical_axis /* [3] */, int locations_batch_size, int locations_shift_step,
+                                 int optimization_iters, double post_smoothing_sigma_sec,
+                                 double forward_axis_inference_min_velocity_m_s, double forward_axis_inference_min_rotation_rad,
+                                 int64_t* out_time_usec, double* out_velocity, int* n_out, double* forward_axis /* [3] */);
+
 /* Per-stage device timing with HIP events recorded on the launch stream around the kernel
  * groups of every *_device call: stage 0 = pyramid chain (K1, nlevels-1 launches), 1 = FAST
  * cells (K2), 2 = quadtree (K3), 3 = orientation+blur+rBRIEF (K4-6), 4 = Hamming match (K7).

@@ -21,7 +21,7 @@ CAND_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("response", "<i4")])
 def build(force=False):
     if force or not os.path.exists(_LIB) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB)
-            for f in ("orb_oracle.c", "orb_oracle.h", "orb_pattern31.inc", "post_oracle.c")):
+            for f in ("orb_oracle.c", "orb_oracle.h", "orb_pattern31.inc", "post_oracle.c", "calib_oracle.c")):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liborb_oracle.so"],
                               stdout=subprocess.DEVNULL)
     return _LIB
@@ -538,3 +538,49 @@ def turn_angles(dirs):
     out = np.zeros(len(d))
     lib().porc_turn_angles(_p(d), len(d), _p(out))
     return out
+
+
+# ---- fit_motion velocity calibration (calib_oracle.c; SURVEY §8 f4, BASELINE configs[4]) ----
+
+def _series(gps_v, gps_t, rot, rot_t, acc, acc_t):
+    a = [_d(gps_v), np.ascontiguousarray(gps_t, np.int64), _d(rot).reshape(-1, 3), np.ascontiguousarray(rot_t, np.int64),
+         _d(acc).reshape(-1, 3), np.ascontiguousarray(acc_t, np.int64)]
+    assert len(a[0]) == len(a[1]) and len(a[2]) == len(a[3]) and len(a[4]) == len(a[5])
+    return a, [_p(a[0]), _p(a[1]), len(a[0]), _p(a[2]), _p(a[3]), len(a[2]), _p(a[4]), _p(a[5]), len(a[4])]
+
+
+_SER = [C.c_void_p, C.c_void_p, C.c_int] * 3
+
+
+def calibrator_eval(gps_v, gps_t, rot, rot_t, acc, acc_t, x):
+    keep, args = _series(gps_v, gps_t, rot, rot_t, acc, acc_t)
+    x = _d(x); fx = C.c_double(0); g = np.zeros(9)
+    f = lib().porc_calibrator_eval
+    f.argtypes = _SER + [C.c_void_p, C.POINTER(C.c_double), C.c_void_p]
+    if f(*args, _p(x), C.byref(fx), _p(g)):
+        raise ValueError("calibrator cannot be built (CHECK failure in the reference)")
+    return fx.value, g
+
+
+def fit_windows(gps_v, gps_t, rot, rot_t, acc, acc_t, batch_size=40, shift_step=5, max_iters=500):
+    keep, args = _series(gps_v, gps_t, rot, rot_t, acc, acc_t)
+    nw = lib().porc_num_windows(len(keep[0]), shift_step)
+    x, res, it = np.zeros((nw, 9)), np.zeros(nw), np.zeros(nw, np.int32)
+    f = lib().porc_fit_windows
+    f.argtypes = _SER + [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    if f(*args, batch_size, shift_step, max_iters, _p(x), _p(res), _p(it)) != nw:
+        raise ValueError("calibrator cannot be built (CHECK failure in the reference)")
+    return x, res, it
+
+
+def fit_motion_velocities(gps_v, gps_t, rot, rot_t, acc, acc_t, vertical_axis, batch_size=40, shift_step=5, max_iters=500,
+                          post_smoothing_sigma_sec=0.003, min_velocity=5.0, min_rotation_rad=0.2):
+    keep, args = _series(gps_v, gps_t, rot, rot_t, acc, acc_t)
+    cap = len(keep[2]) + len(keep[4])
+    t, v, fwd, va = np.zeros(cap, np.int64), np.zeros(cap), np.zeros(3), _d(vertical_axis)
+    f = lib().porc_fit_motion_velocities
+    f.argtypes = _SER + [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+    n = f(*args, _p(va), batch_size, shift_step, max_iters, post_smoothing_sigma_sec, min_velocity, min_rotation_rad, _p(t), _p(v), _p(fwd))
+    if n < 0:
+        raise ValueError("fit_motion oracle failed: %d" % n)
+    return t[:n].copy(), v[:n].copy(), fwd

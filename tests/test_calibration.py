@@ -1,0 +1,148 @@
+"""fit_motion's velocity calibration (BASELINE configs[4]).
+
+CPU part: the oracle (oracle/calib_oracle.c) against what can be known without the reference binary --
+the merge example of align_time_series.hpp, finite-difference gradients, L-BFGS actually descending,
+a recoverable synthetic calibration.  GPU part: pilotguru_amd/csrc/calib.hip (one lane per window)
+against the oracle, bit for bit."""
+import math
+
+import numpy as np
+import pytest
+
+
+def imu_ride(seed, n_gps=30, imu_hz=50.0, noise=0.02):
+    """A drive seen by a phone: GPS speed at ~1 Hz, gyroscope and accelerometer at ~imu_hz with their own
+    clocks.  Device frame = world frame rotated by the integrated yaw; the accelerometer reads the
+    world acceleration in the device frame minus gravity plus a bias."""
+    r = np.random.default_rng(seed)
+    T = float(n_gps + 1)
+    t_rot = np.cumsum(r.uniform(0.8, 1.2, int(T * imu_hz)) / imu_hz) + 0.013
+    t_acc = np.cumsum(r.uniform(0.8, 1.2, int(T * imu_hz)) / imu_hz) + 0.007
+    t_rot, t_acc = t_rot[t_rot < T], t_acc[t_acc < T]
+    yaw_rate = lambda t: 0.25 * np.sin(0.35 * t + seed)
+    yaw = lambda t: -0.25 / 0.35 * (np.cos(0.35 * t + seed) - math.cos(seed))
+    speed = lambda t: 12.0 + 4.0 * np.sin(0.2 * t + 0.5 * seed)
+    dspeed = lambda t: 0.8 * np.cos(0.2 * t + 0.5 * seed)
+    rot = np.stack([0.01 * r.normal(0, 1, len(t_rot)), 0.01 * r.normal(0, 1, len(t_rot)), yaw_rate(t_rot)], 1)
+    rot += noise * 0.1 * r.normal(0, 1, rot.shape)
+    # world acceleration of a point moving with speed(t) along heading yaw(t)
+    h = yaw(t_acc)
+    ax = dspeed(t_acc) * np.cos(h) - speed(t_acc) * yaw_rate(t_acc) * np.sin(h)
+    ay = dspeed(t_acc) * np.sin(h) + speed(t_acc) * yaw_rate(t_acc) * np.cos(h)
+    # into the device frame (rotation by -yaw about z), gravity-like global bias and a device bias on top
+    acc = np.stack([ax * np.cos(h) + ay * np.sin(h), -ax * np.sin(h) + ay * np.cos(h), np.full(len(h), 9.81)], 1)
+    acc += np.array([0.05, -0.03, 0.02]) + noise * r.normal(0, 1, acc.shape)
+    t_gps = np.arange(1, n_gps + 1) * 1.0 + r.uniform(-0.05, 0.05, n_gps)
+    gps_v = speed(t_gps) + noise * r.normal(0, 1, n_gps)
+    us = lambda t: np.round(t * 1e6).astype(np.int64) + 1_500_000_000_000_000
+    return (gps_v, us(t_gps)), (rot, us(t_rot)), (acc, us(t_acc))
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float64).view(np.uint64)
+
+
+# ---------------------------------------------------------------- CPU: the oracle
+
+def test_oracle_gradient_matches_finite_differences(oracle):
+    gps, rot, acc = imu_ride(1, n_gps=12)
+    r = np.random.default_rng(0)
+    for _ in range(3):
+        x = r.normal(0, 0.5, 9); x[2] -= 9.8
+        f0, g = oracle.calibrator_eval(*gps, *rot, *acc, x)
+        assert np.isfinite(f0) and np.all(np.isfinite(g))
+        for k in range(9):
+            e = np.zeros(9); e[k] = 1e-6
+            fp, _ = oracle.calibrator_eval(*gps, *rot, *acc, x + e)
+            fm, _ = oracle.calibrator_eval(*gps, *rot, *acc, x - e)
+            num = (fp - fm) / 2e-6
+            # the reference's analytic gradient is approximate by design (the 1e-5 in the norm, the
+            # "TODO: not quite right" travel rule): same sign and size, not the same digits
+            assert abs(num - g[k]) <= 0.05 * max(abs(num), abs(g[k])) + 1e-4, (k, num, g[k])
+
+
+def test_oracle_lbfgs_descends_and_is_deterministic(oracle):
+    gps, rot, acc = imu_ride(2, n_gps=14)
+    f0, _ = oracle.calibrator_eval(*gps, *rot, *acc, np.zeros(9))
+    x, res, it = oracle.fit_windows(*gps, *rot, *acc, batch_size=8, shift_step=4, max_iters=60)
+    assert len(x) == 4 and np.all(it >= 1) and np.all(it <= 60)
+    assert np.all(res < f0) and np.all(np.isfinite(x))
+    # the first window's fit evaluated again gives the residual the solver reported
+    f, _ = oracle.calibrator_eval(gps[0][:8], gps[1][:8], *rot, *acc, x[0])
+    assert f == res[0]
+    x2, res2, it2 = oracle.fit_windows(*gps, *rot, *acc, batch_size=8, shift_step=4, max_iters=60)
+    assert np.array_equal(_bits(x), _bits(x2)) and np.array_equal(it, it2)
+
+
+def test_oracle_rejects_what_the_reference_checks(oracle):
+    gps, rot, acc = imu_ride(3, n_gps=6)
+    with pytest.raises(ValueError):                                   # CheckTimestampsIncreasing
+        oracle.calibrator_eval(gps[0], gps[1][::-1].copy(), *rot, *acc, np.zeros(9))
+    with pytest.raises(ValueError):                                   # disjoint series cannot be merged
+        oracle.calibrator_eval(*gps, rot[0], rot[1] + 10**9, *acc, np.zeros(9))
+
+
+def test_oracle_velocity_pipeline_recovers_the_speed(oracle):
+    gps, rot, acc = imu_ride(4, n_gps=24, noise=0.0)
+    t, v, fwd = oracle.fit_motion_velocities(*gps, *rot, *acc, [0.0, 0.0, 1.0], batch_size=10, shift_step=5, max_iters=200)
+    assert len(t) > 500 and np.all(np.diff(t) > 0)
+    ts = (t - 1_500_000_000_000_000) * 1e-6
+    truth = 12.0 + 4.0 * np.sin(0.2 * ts + 0.5 * 4)
+    assert np.median(np.abs(v - truth)) < 0.5                        # IMU-rate speed follows the GPS-rate truth
+    assert abs(np.linalg.norm(fwd) - 1.0) < 1e-3 and abs(fwd[2]) < 1e-9 and fwd[0] > 0.9    # the car drives along device +x
+
+
+# ---------------------------------------------------------------- GPU: calib.hip == oracle
+
+@pytest.fixture(scope="module")
+def ctx():
+    import pilotguru_amd as pg
+    return pg.ORBextractor(500, 1.2, 4, 20, 7, max_width=320, max_height=240, max_batch=1)
+
+
+@pytest.mark.gpu
+def test_gpu_calibrator_eval_equals_oracle(ctx, oracle):
+    from pilotguru_amd.calibration import AccelerometerCalibrator
+    gps, rot, acc = imu_ride(5, n_gps=9)
+    cal = AccelerometerCalibrator(ctx, gps, rot, acc)
+    r = np.random.default_rng(1)
+    xs = np.concatenate([np.zeros((1, 9)), r.normal(0, 1, (70, 9))])           # more points than one wave
+    fx, g = cal(xs)
+    for i in range(len(xs)):
+        f0, g0 = oracle.calibrator_eval(*gps, *rot, *acc, xs[i])
+        assert _bits(fx[i]) == _bits(f0) and np.array_equal(_bits(g[i]), _bits(g0)), i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n_gps,batch,shift,iters", [(6, 20, 8, 4, 40), (7, 33, 10, 5, 500), (8, 7, 40, 5, 25), (9, 400, 12, 3, 30)])
+def test_gpu_window_fits_equal_oracle(ctx, oracle, seed, n_gps, batch, shift, iters):
+    from pilotguru_amd.calibration import FitVelocityWindows
+    gps, rot, acc = imu_ride(seed, n_gps=n_gps, imu_hz=20.0 if n_gps > 100 else 50.0)
+    x, res, it = FitVelocityWindows(ctx, gps, rot, acc, batch, shift, iters)
+    ox, ores, oit = oracle.fit_windows(*gps, *rot, *acc, batch_size=batch, shift_step=shift, max_iters=iters)
+    assert len(x) == math.ceil(n_gps / shift)
+    assert np.array_equal(it, oit)
+    assert np.array_equal(_bits(x), _bits(ox)) and np.array_equal(_bits(res), _bits(ores))
+
+
+@pytest.mark.gpu
+def test_gpu_fit_motion_velocities_equal_oracle(ctx, oracle):
+    from pilotguru_amd.calibration import ComputeForwardVelocitiesFromImu
+    gps, rot, acc = imu_ride(10, n_gps=30)
+    axis = np.array([0.02, -0.01, 1.0]); axis /= np.linalg.norm(axis)
+    t, v, fwd = ComputeForwardVelocitiesFromImu(ctx, gps, rot, acc, axis, 10, 5, 120, 0.01, 5.0, 0.2)
+    ot, ov, ofwd = oracle.fit_motion_velocities(*gps, *rot, *acc, axis, 10, 5, 120, 0.01, 5.0, 0.2)
+    assert np.array_equal(t, ot) and np.array_equal(_bits(v), _bits(ov)) and np.array_equal(_bits(fwd), _bits(ofwd))
+
+
+@pytest.mark.gpu
+def test_gpu_calibration_argument_errors(ctx):
+    from pilotguru_amd._lib import PgorbError
+    from pilotguru_amd.calibration import FitVelocityWindows
+    gps, rot, acc = imu_ride(11, n_gps=8)
+    with pytest.raises(PgorbError):                                   # CHECK_GE(batch, shift), fit_motion.cc:304
+        FitVelocityWindows(ctx, gps, rot, acc, 4, 5, 10)
+    with pytest.raises(PgorbError):
+        FitVelocityWindows(ctx, (gps[0], gps[1][::-1].copy()), rot, acc, 8, 4, 10)
+    with pytest.raises(PgorbError):
+        FitVelocityWindows(ctx, gps, (rot[0], rot[1] + 10**9), acc, 8, 4, 10)
