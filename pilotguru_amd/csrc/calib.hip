@@ -7,32 +7,31 @@
 // one loss evaluation integrates every IMU sample of the window in time order
 // (src/geometry/geometry.cc:24-53), ~10^4 dependent steps, and the fits run one after another.
 //
-// Here: windows are independent, so ONE LANE PER WINDOW runs the whole solver, 64 windows per wave,
-// all waves concurrently.  The arithmetic inside a window stays in the reference's order (the sums
-// are sequential in time; reordering them changes the doubles and the JSON is diffed bit for bit),
-// so the parallelism is across windows only.  What does not depend on the nine parameters is
-// hoisted out of the solver and computed once per window on the host, with the same operations in
-// the same order as the reference's loop body:
+// Here: windows are independent, so ONE WAVE PER WINDOW runs the whole solver, all windows at once.
+// Every double is produced by the same operation on the same operands as in the reference (the sums
+// stay sequential in time: reordering them changes the doubles and the JSON is diffed bit for
+// bit); inside a window the lanes share out what is independent per step (see the device section).
+// What does not depend on the nine parameters is hoisted out of the solver and computed once per
+// window on the host, with the same operations in the same order as the reference's loop body:
 //   forward stream  (8 doubles / step): dt, orientation BEFORE the step (w,x,y,z), raw acceleration
 //   backward stream (11 doubles / step): total_time_sec*dt, dt, dt * total_time_weighted_rotation^T (3x3)
-//   per GPS interval: reference_distance, number of steps
+//   per GPS interval: reference_distance, first step
 // (RotationMotionToQuaternion's sin/cos therefore run in the host libm, as in the reference.)
-// Streams are interleaved by lane -- element (step, field) of the 64 windows of a group are 64
-// consecutive doubles -- so every load of the solver is one fully coalesced 512-byte request; all
-// lanes of a wave walk the same (interval, step) index, lanes whose interval is shorter idle.
-// L-BFGS history (6 x 2 x 9 doubles per lane) lives in scratch (private memory is lane-interleaved
-// by the hardware, i.e. also coalesced).  fp64 add/mul/div/sqrt are IEEE on both sides, contraction
-// is off (Makefile), so a lane reproduces the CPU run of its window bit for bit.
+// Streams are structure-of-arrays per window, so a chunk of 64 steps of one field is one coalesced
+// 512-byte request.  fp64 add/mul/div/sqrt are IEEE on both sides, contraction is off (Makefile),
+// so a wave reproduces the CPU run of its window bit for bit.
 //
 // Eigen reduction orders (the parity contract shared with oracle/calib_oracle.c, E0-E5 there):
 // 3-vectors t0 + (t1 + t2); the solver's 9-vectors in SSE2 packet order.
 #include "pgorb_internal.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <vector>
 
 int pg_ctx_fail(pgorb_ctx* c, int code, const char* msg);
@@ -40,7 +39,6 @@ int pg_ctx_device(pgorb_ctx* c);
 
 namespace {
 
-#define CB_LANES 64
 #define CB_FWD 8
 #define CB_BWD 11
 #define CB_M 6            // LBFGSParam::m (Param.h:164)
@@ -144,16 +142,59 @@ void make_window(const int64_t* ref_t, int n_ref, const Imu& M, Window& W)
 }
 
 // ---- device: AccelerometerCalibrator::eval on the prepared streams, LBFGSSolver::minimize ----
+//
+// One wave per window.  A loss evaluation walks ~10^4 steps whose sums must stay in time order, but
+// only the sums are sequential: per step the expensive part (rotate the bias-corrected acceleration
+// into the fixed frame, scale by dt; the nine gradient products) depends on the parameters and on
+// that step's data alone.  So for every chunk of 64 steps
+//   phase A  lane = step: the independent arithmetic, results to LDS (full 64-lane efficiency);
+//   phase S  lane = component: the running sums v, travel (3 lanes) / the 9 gradient sums (9 lanes)
+//            walk the chunk in order, one dependent fp64 add per step and chain.
+// The first design (one LANE per window, the whole loop body serial) spent ~1000 cycles per step and
+// was 20x slower per evaluation than one CPU core; the fit of the slowest window bounds the whole
+// run, so per-evaluation latency is what matters.  Chunks are prefetched one ahead into registers,
+// across interval and pass boundaries (the streams do not depend on the parameters).
 
-struct GroupView {
-    const double* fwd;        // [step][CB_FWD][64]
-    const double* bwd;        // [step][CB_BWD][64]
-    const double* refDist;    // [r][64]
-    const int32_t* refCnt;    // [r][64]
-    const int32_t* refOff;    // [r]   first step slot of interval r (the same for all lanes)
-    const int32_t* nRef;      // [64]
-    const double* totalSec;   // [64]
+#define CB_CHUNK 64
+
+struct WinDesc {              // one per wave (window)
+    int64_t fwd, bwd;         // element offsets of the SoA streams: fwd[CB_FWD][S], bwd[CB_BWD][S]
+    int64_t refDist;          // [nRef]
+    int64_t refOff;           // int32 [nRef + 1]: first step of each reference interval
+    int32_t S, nRef;
+    double totalSec;
 };
+
+struct Cursor {               // a position in the window's sequence of chunks
+    int r, c0;                // reference interval, first step of the chunk inside it
+};
+
+// first chunk at or after interval r (skips empty intervals); r = nRef when there is none
+__device__ inline Cursor cur_first(const int32_t* refOff, int nRef, int r)
+{
+    while (r < nRef && refOff[r + 1] == refOff[r]) r++;
+    return {r, 0};
+}
+__device__ inline Cursor cur_next(const int32_t* refOff, int nRef, Cursor c)
+{
+    if (c.c0 + CB_CHUNK < refOff[c.r + 1] - refOff[c.r]) return {c.r, c.c0 + CB_CHUNK};
+    return cur_first(refOff, nRef, c.r + 1);
+}
+
+struct FwdRegs { double dt, qw, qx, qy, qz, ax, ay, az; };
+struct BwdRegs { double c1, dt, m[9]; };
+
+__device__ inline FwdRegs load_fwd(const double* F, int S, int idx)
+{
+    return {F[idx], F[S + idx], F[2 * S + idx], F[3 * S + idx], F[4 * S + idx], F[5 * S + idx], F[6 * S + idx], F[7 * S + idx]};
+}
+__device__ inline BwdRegs load_bwd(const double* B, int S, int idx)
+{
+    BwdRegs b;
+    b.c1 = B[idx]; b.dt = B[S + idx];
+    for (int k = 0; k < 9; k++) b.m[k] = B[(2 + k) * S + idx];
+    return b;
+}
 
 __device__ inline double dot9(const double* a, const double* b)       // Eigen SSE2 redux order (contract E2)
 {
@@ -164,53 +205,80 @@ __device__ inline double dot9(const double* a, const double* b)       // Eigen S
     return (l0 + l1) + a[8] * b[8];
 }
 
-__device__ double cal_eval(const GroupView& G, int lane, const double* x, double* grad)
+struct WinView {
+    const double *F, *B, *refDist;
+    const int32_t* refOff;
+    int S, nRef;
+    double totalSec;
+    double (*sc)[CB_CHUNK];   // LDS [4][64]: c0, c1, c2, dt of the chunk
+    double (*sp)[CB_CHUNK];   // LDS [9][64]: the gradient products of the chunk
+};
+
+// velocity.cc:42-180 on the prepared streams; every lane returns the same loss and gradient.
+__device__ double cal_eval(const WinView& G, int lane, const double* x, double* grad)
 {
     const double bg[3] = {x[0], x[1], x[2]}, bl[3] = {x[3], x[4], x[5]};
-    double v[3] = {x[6], x[7], x[8]};
-    double g[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int comp = lane % 3, acc = lane % 9;
+    double vk = x[6 + comp];                          // this lane's component of integrated_velocity
+    double gj = 0;                                    // this lane's gradient accumulator (index acc)
     double result = 0;
-    const int nref = G.nRef[lane];
-    for (int r = 0; r < nref; r++) {
-        const int cnt = G.refCnt[r * CB_LANES + lane];
-        const size_t off = (size_t)G.refOff[r];
-        double travel[3] = {0, 0, 0};
-        const double* p = G.fwd + off * (CB_FWD * CB_LANES) + lane;
-        for (int i = 0; i < cnt; i++, p += CB_FWD * CB_LANES) {
-            const double dt = p[0];
-            const Quat q = {p[CB_LANES], p[2 * CB_LANES], p[3 * CB_LANES], p[4 * CB_LANES]};
-            const double lc[3] = {p[5 * CB_LANES] + bl[0], p[6 * CB_LANES] + bl[1], p[7 * CB_LANES] + bl[2]};
-            double rot[3];
-            quat_rotate(q, lc, rot);
-            for (int k = 0; k < 3; k++) {
-                const double glob = rot[k] + bg[k];
-                v[k] = v[k] + glob * dt;
-                travel[k] += dt * v[k];
+    Cursor nf = cur_first(G.refOff, G.nRef, 0), nb = nf;
+    FwdRegs fn = {}; BwdRegs bn = {};
+    if (nf.r < G.nRef) { fn = load_fwd(G.F, G.S, G.refOff[nf.r] + lane); bn = load_bwd(G.B, G.S, G.refOff[nb.r] + lane); }
+    for (int r = 0; r < G.nRef; r++) {
+        const int off = G.refOff[r], cnt = G.refOff[r + 1] - off;
+        double tk = 0;                                // this lane's component of integrated_travel
+        for (int c0 = 0; c0 < cnt; c0 += CB_CHUNK) {
+            const int n = min(CB_CHUNK, cnt - c0);
+            const FwdRegs f = fn;
+            nf = cur_next(G.refOff, G.nRef, nf);
+            if (nf.r < G.nRef) fn = load_fwd(G.F, G.S, G.refOff[nf.r] + nf.c0 + lane);
+            {   // phase A, lane = step (IntegrateMotion's parameter-dependent part, geometry.cc:34-45)
+                const Quat q = {f.qw, f.qx, f.qy, f.qz};
+                const double lc[3] = {f.ax + bl[0], f.ay + bl[1], f.az + bl[2]};
+                double rot[3];
+                quat_rotate(q, lc, rot);
+                for (int k = 0; k < 3; k++) G.sc[k][lane] = (rot[k] + bg[k]) * f.dt;
+                G.sc[3][lane] = f.dt;
             }
+            __syncthreads();
+#pragma unroll 8
+            for (int i = 0; i < n; i++) {             // phase S: v += a*dt ; travel += dt*v  (velocity.cc:99-108)
+                vk = vk + G.sc[comp][i];
+                tk += G.sc[3][i] * vk;
+            }
+            __syncthreads();
         }
+        const double travel[3] = {__shfl(tk, 0), __shfl(tk, 1), __shfl(tk, 2)};
         const double tn = sqrt(dot3(travel, travel));
-        const double diff = tn - G.refDist[r * CB_LANES + lane];
+        const double diff = tn - G.refDist[r];
         result += diff * diff;
         double d[3];
         for (int k = 0; k < 3; k++) d[k] = ((2.0 * diff) * travel[k]) / (tn + 1e-5);
-        const double* b = G.bwd + off * (CB_BWD * CB_LANES) + lane;
-        for (int i = 0; i < cnt; i++, b += CB_BWD * CB_LANES) {
-            const double c1 = b[0], dt = b[CB_LANES];
-            for (int k = 0; k < 3; k++) {
-                g[k] += c1 * d[k];
-                const double row[3] = {b[(2 + 3 * k) * CB_LANES], b[(3 + 3 * k) * CB_LANES], b[(4 + 3 * k) * CB_LANES]};
-                g[3 + k] += dot3(row, d);
-                g[6 + k] += dt * d[k];
+        for (int c0 = 0; c0 < cnt; c0 += CB_CHUNK) {
+            const int n = min(CB_CHUNK, cnt - c0);
+            const BwdRegs b = bn;
+            nb = cur_next(G.refOff, G.nRef, nb);
+            if (nb.r < G.nRef) bn = load_bwd(G.B, G.S, G.refOff[nb.r] + nb.c0 + lane);
+            for (int k = 0; k < 3; k++) {             // phase A, lane = step (velocity.cc:133-163)
+                G.sp[k][lane] = b.c1 * d[k];
+                const double row[3] = {b.m[3 * k], b.m[3 * k + 1], b.m[3 * k + 2]};
+                G.sp[3 + k][lane] = dot3(row, d);
+                G.sp[6 + k][lane] = b.dt * d[k];
             }
+            __syncthreads();
+#pragma unroll 8
+            for (int i = 0; i < n; i++) gj += G.sp[acc][i];
+            __syncthreads();
         }
     }
-    const double total = G.totalSec[lane];
-    for (int k = 0; k < 9; k++) grad[k] = g[k] / total;
-    return result / total;
+    for (int k = 0; k < 9; k++) grad[k] = __shfl(gj, k) / G.totalSec;
+    return result / G.totalSec;
 }
 
 // LBFGS.h:78-181 with Backtracking/Armijo (LineSearch.h:41-109); n = 9, m = 6, ftol 1e-4, 20 trials.
-__device__ int cal_lbfgs(const GroupView& G, int lane, double* x, double* fx_out, double epsilon, int max_iterations)
+// Wave-uniform: every lane carries the same solver state.
+__device__ int cal_lbfgs(const WinView& G, int lane, double* x, double* fx_out, double epsilon, int max_iterations)
 {
     double s[CB_M][9], y[CB_M][9], ysh[CB_M], alpha[CB_M], xp[9], grad[9], gradp[9], drt[9];
     double fx = cal_eval(G, lane, x, grad);
@@ -258,49 +326,40 @@ __device__ int cal_lbfgs(const GroupView& G, int lane, double* x, double* fx_out
     }
 }
 
-struct GroupDesc {            // one per wave: offsets (in elements) into the flat device arrays
-    int64_t fwd, bwd, refDist, refCnt, refOff;
-    int32_t lanes, pad;
-};
-
 // mode 0: L-BFGS from x = 0 (fit_motion.cc:186-190).  mode 1: one evaluation at xin (tests).
-__global__ __launch_bounds__(CB_LANES) void k_calibrate_windows(const GroupDesc* __restrict__ groups, const double* __restrict__ dbl,
-                                                              const int32_t* __restrict__ i32, const int32_t* __restrict__ nRef,
-                                                              const double* __restrict__ totalSec, int mode, const double* __restrict__ xin,
-                                                              int max_iterations, double* __restrict__ xout, double* __restrict__ fxout,
-                                                              double* __restrict__ gradout, int32_t* __restrict__ niter)
+__global__ __launch_bounds__(64) void k_calibrate_windows(const WinDesc* __restrict__ wins, const double* __restrict__ dbl,
+                                                        const int32_t* __restrict__ i32, int mode, const double* __restrict__ xin,
+                                                        int max_iterations, double* __restrict__ xout, double* __restrict__ fxout,
+                                                        double* __restrict__ gradout, int32_t* __restrict__ niter)
 {
-    const GroupDesc D = groups[blockIdx.x];
+    __shared__ double sc[4][CB_CHUNK];
+    __shared__ double sp[9][CB_CHUNK];
+    const WinDesc D = wins[blockIdx.x];
     const int lane = threadIdx.x;
-    if (lane >= D.lanes) return;
-    const size_t w = (size_t)blockIdx.x * CB_LANES + lane;
-    GroupView G;
-    G.fwd = dbl + D.fwd; G.bwd = dbl + D.bwd; G.refDist = dbl + D.refDist;
-    G.refCnt = i32 + D.refCnt; G.refOff = i32 + D.refOff;
-    G.nRef = nRef + (size_t)blockIdx.x * CB_LANES; G.totalSec = totalSec + (size_t)blockIdx.x * CB_LANES;
-    double x[9], fx;
+    const size_t w = blockIdx.x;
+    WinView G;
+    G.F = dbl + D.fwd; G.B = dbl + D.bwd; G.refDist = dbl + D.refDist; G.refOff = i32 + D.refOff;
+    G.S = D.S; G.nRef = D.nRef; G.totalSec = D.totalSec; G.sc = sc; G.sp = sp;
+    double x[9], g[9], fx;
     if (mode == 1) {
-        double grad[9];
         for (int i = 0; i < 9; i++) x[i] = xin[9 * w + i];
-        fx = cal_eval(G, lane, x, grad);
-        for (int i = 0; i < 9; i++) gradout[9 * w + i] = grad[i];
-        fxout[w] = fx;
+        fx = cal_eval(G, lane, x, g);
+        if (lane < 9) gradout[9 * w + lane] = g[lane];
+        if (lane == 0) fxout[w] = fx;
         return;
     }
     for (int i = 0; i < 9; i++) x[i] = 0.0;
     const int it = cal_lbfgs(G, lane, x, &fx, 1e-5, max_iterations);
-    for (int i = 0; i < 9; i++) xout[9 * w + i] = x[i];
-    fxout[w] = fx;
-    niter[w] = it;
+    if (lane < 9) xout[9 * w + lane] = x[lane];
+    if (lane == 0) { fxout[w] = fx; niter[w] = it; }
 }
 
 // ---- host: pack, launch ----
 
 struct Packed {
-    std::vector<GroupDesc> groups;
+    std::vector<WinDesc> wins;
     std::vector<double> dbl;
-    std::vector<int32_t> i32, nRef;
-    std::vector<double> totalSec;
+    std::vector<int32_t> i32;
 };
 
 // Streams of one window, in the order of velocity.cc:62-168 (both loops of a reference interval walk the
@@ -334,49 +393,33 @@ void window_streams(const Window& W, const Imu& M, const double* ref_v, std::vec
     *totalSec = (double)total_usec * 1e-6;
 }
 
+
+// One window's streams as structure-of-arrays (a chunk of 64 consecutive steps of one field = 512 contiguous bytes).
+void pack_window(const Window& W, const Imu& M, const double* ref_v, Packed& P)
+{
+    std::vector<double> fwd, bwd, rd;
+    WinDesc D;
+    window_streams(W, M, ref_v, fwd, bwd, rd, &D.totalSec);
+    const size_t n = W.steps.size();
+    D.S = (int32_t)((n + CB_CHUNK - 1) / CB_CHUNK * CB_CHUNK + CB_CHUNK);   // a chunk load may start at the last step
+    D.nRef = (int32_t)W.refCnt.size();
+    D.fwd = (int64_t)P.dbl.size();     P.dbl.resize(P.dbl.size() + (size_t)D.S * CB_FWD, 0.0);
+    D.bwd = (int64_t)P.dbl.size();     P.dbl.resize(P.dbl.size() + (size_t)D.S * CB_BWD, 0.0);
+    D.refDist = (int64_t)P.dbl.size(); P.dbl.insert(P.dbl.end(), rd.begin(), rd.end());
+    D.refOff = (int64_t)P.i32.size();
+    int32_t off = 0;
+    for (int32_t c : W.refCnt) { P.i32.push_back(off); off += c; }
+    P.i32.push_back(off);
+    for (size_t i = 0; i < n; i++) {
+        for (int f = 0; f < CB_FWD; f++) P.dbl[D.fwd + (size_t)f * D.S + i] = fwd[i * CB_FWD + f];
+        for (int f = 0; f < CB_BWD; f++) P.dbl[D.bwd + (size_t)f * D.S + i] = bwd[i * CB_BWD + f];
+    }
+    P.wins.push_back(D);
+}
+
 void pack_windows(const std::vector<Window>& wins, const Imu& M, const std::vector<const double*>& ref_v, Packed& P)
 {
-    const int nw = (int)wins.size(), ng = (nw + CB_LANES - 1) / CB_LANES;
-    P.groups.resize(ng);
-    P.nRef.assign((size_t)ng * CB_LANES, 0);
-    P.totalSec.assign((size_t)ng * CB_LANES, 1.0);
-    std::vector<double> fwd, bwd, rd;
-    for (int g = 0; g < ng; g++) {
-        const int w0 = g * CB_LANES, lanes = std::min(CB_LANES, nw - w0);
-        int maxRef = 0;
-        for (int l = 0; l < lanes; l++) maxRef = std::max(maxRef, (int)wins[w0 + l].refCnt.size());
-        std::vector<int32_t> refOff(maxRef + 1, 0);
-        for (int r = 0; r < maxRef; r++) {
-            int mx = 0;
-            for (int l = 0; l < lanes; l++) if (r < (int)wins[w0 + l].refCnt.size()) mx = std::max(mx, wins[w0 + l].refCnt[r]);
-            refOff[r + 1] = refOff[r] + mx;
-        }
-        const size_t slots = (size_t)refOff[maxRef];
-        GroupDesc& D = P.groups[g];
-        D.lanes = lanes; D.pad = 0;
-        D.fwd = (int64_t)P.dbl.size();     P.dbl.resize(P.dbl.size() + slots * CB_FWD * CB_LANES, 0.0);
-        D.bwd = (int64_t)P.dbl.size();     P.dbl.resize(P.dbl.size() + slots * CB_BWD * CB_LANES, 0.0);
-        D.refDist = (int64_t)P.dbl.size(); P.dbl.resize(P.dbl.size() + (size_t)maxRef * CB_LANES, 0.0);
-        D.refCnt = (int64_t)P.i32.size();  P.i32.resize(P.i32.size() + (size_t)maxRef * CB_LANES, 0);
-        D.refOff = (int64_t)P.i32.size();  P.i32.insert(P.i32.end(), refOff.begin(), refOff.end());
-        for (int l = 0; l < lanes; l++) {
-            const Window& W = wins[w0 + l];
-            double total;
-            window_streams(W, M, ref_v[w0 + l], fwd, bwd, rd, &total);
-            P.nRef[(size_t)g * CB_LANES + l] = (int32_t)W.refCnt.size();
-            P.totalSec[(size_t)g * CB_LANES + l] = total;
-            size_t si = 0;
-            for (size_t r = 0; r < W.refCnt.size(); r++) {
-                P.i32[D.refCnt + r * CB_LANES + l] = W.refCnt[r];
-                P.dbl[D.refDist + r * CB_LANES + l] = rd[r];
-                for (int i = 0; i < W.refCnt[r]; i++, si++) {
-                    const size_t slot = (size_t)refOff[r] + i;
-                    for (int f = 0; f < CB_FWD; f++) P.dbl[D.fwd + (slot * CB_FWD + f) * CB_LANES + l] = fwd[si * CB_FWD + f];
-                    for (int f = 0; f < CB_BWD; f++) P.dbl[D.bwd + (slot * CB_BWD + f) * CB_LANES + l] = bwd[si * CB_BWD + f];
-                }
-            }
-        }
-    }
+    for (size_t w = 0; w < wins.size(); w++) pack_window(wins[w], M, ref_v[w], P);
 }
 
 struct DevBuf {
@@ -386,25 +429,28 @@ struct DevBuf {
     bool make(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8) == hipSuccess; }
 };
 
-int run_windows(pgorb_ctx* c, const Packed& P, int nw, int mode, const double* xin, int max_iters, double* x, double* fx, double* grad, int32_t* niter)
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+bool timing_on() { static const bool v = getenv("PGORB_CALIB_TIMING") != nullptr; return v; }
+
+int run_windows(pgorb_ctx* c, const Packed& P, int mode, const double* xin, int max_iters, double* x, double* fx, double* grad, int32_t* niter)
 {
+    const double t0 = now_s();
     if (hipSetDevice(pg_ctx_device(c)) != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "hipSetDevice failed");
-    const size_t slots = P.groups.size() * CB_LANES;
-    DevBuf dG, dD, dI, dN, dT, dXin, dX, dF, dGr, dNi;
-    std::vector<double> xpad(slots * 9, 0.0);
-    if (xin) memcpy(xpad.data(), xin, sizeof(double) * 9 * (size_t)nw);
-    if (!dG.put(P.groups.data(), P.groups.size() * sizeof(GroupDesc)) || !dD.put(P.dbl.data(), P.dbl.size() * 8) ||
-        !dI.put(P.i32.data(), P.i32.size() * 4) || !dN.put(P.nRef.data(), P.nRef.size() * 4) || !dT.put(P.totalSec.data(), P.totalSec.size() * 8) ||
-        !dXin.put(xpad.data(), xpad.size() * 8) || !dX.make(slots * 72) || !dF.make(slots * 8) || !dGr.make(slots * 72) || !dNi.make(slots * 4))
+    const size_t nw = P.wins.size();
+    DevBuf dW, dD, dI, dXin, dX, dF, dGr, dNi;
+    if (!dW.put(P.wins.data(), nw * sizeof(WinDesc)) || !dD.put(P.dbl.data(), P.dbl.size() * 8) || !dI.put(P.i32.data(), P.i32.size() * 4) ||
+        !dXin.put(xin, xin ? nw * 72 : 0) || !dX.make(nw * 72) || !dF.make(nw * 8) || !dGr.make(nw * 72) || !dNi.make(nw * 4))
         return pg_ctx_fail(c, PGORB_E_HIP, "device allocation / upload for the calibration windows failed");
-    hipLaunchKernelGGL(k_calibrate_windows, dim3((unsigned)P.groups.size()), dim3(CB_LANES), 0, 0, (const GroupDesc*)dG.p, (const double*)dD.p,
-                       (const int32_t*)dI.p, (const int32_t*)dN.p, (const double*)dT.p, mode, (const double*)dXin.p, max_iters,
-                       (double*)dX.p, (double*)dF.p, (double*)dGr.p, (int32_t*)dNi.p);
+    const double t1 = now_s();
+    hipLaunchKernelGGL(k_calibrate_windows, dim3((unsigned)nw), dim3(64), 0, 0, (const WinDesc*)dW.p, (const double*)dD.p, (const int32_t*)dI.p,
+                       mode, (const double*)dXin.p, max_iters, (double*)dX.p, (double*)dF.p, (double*)dGr.p, (int32_t*)dNi.p);
     if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "k_calibrate_windows failed");
-    bool ok = hipMemcpy(fx, dF.p, sizeof(double) * (size_t)nw, hipMemcpyDeviceToHost) == hipSuccess;
-    if (mode == 1) ok = ok && hipMemcpy(grad, dGr.p, sizeof(double) * 9 * (size_t)nw, hipMemcpyDeviceToHost) == hipSuccess;
-    else ok = ok && hipMemcpy(x, dX.p, sizeof(double) * 9 * (size_t)nw, hipMemcpyDeviceToHost) == hipSuccess &&
-              hipMemcpy(niter, dNi.p, sizeof(int32_t) * (size_t)nw, hipMemcpyDeviceToHost) == hipSuccess;
+    if (timing_on())
+        fprintf(stderr, "[calib] %zu windows, %.1f MB of streams: upload %.3f s, solver kernel %.3f s\n", nw, P.dbl.size() * 8e-6, t1 - t0, now_s() - t1);
+    bool ok = hipMemcpy(fx, dF.p, sizeof(double) * nw, hipMemcpyDeviceToHost) == hipSuccess;
+    if (mode == 1) ok = ok && hipMemcpy(grad, dGr.p, sizeof(double) * 9 * nw, hipMemcpyDeviceToHost) == hipSuccess;
+    else ok = ok && hipMemcpy(x, dX.p, sizeof(double) * 9 * nw, hipMemcpyDeviceToHost) == hipSuccess &&
+              hipMemcpy(niter, dNi.p, sizeof(int32_t) * nw, hipMemcpyDeviceToHost) == hipSuccess;
     return ok ? PGORB_OK : pg_ctx_fail(c, PGORB_E_HIP, "download of the calibration results failed");
 }
 
@@ -450,8 +496,10 @@ int pgorb_fit_velocity_windows(pgorb_ctx* c, const double* gps_velocity, const i
     std::vector<const double*> refv;
     for (int s : starts) refv.push_back(gps_velocity + s);
     Packed P;
+    const double t0 = now_s();
     pack_windows(wins, M, refv, P);
-    return run_windows(c, P, (int)wins.size(), 0, nullptr, optimization_iters, x, residual, nullptr, niter);
+    if (timing_on()) fprintf(stderr, "[calib] host preparation of the streams %.3f s\n", now_s() - t0);
+    return run_windows(c, P, 0, nullptr, optimization_iters, x, residual, nullptr, niter);
 }
 
 int pgorb_calibrator_eval(pgorb_ctx* c, const double* gps_velocity, const int64_t* gps_time_usec, int n_gps,
@@ -469,11 +517,10 @@ int pgorb_calibrator_eval(pgorb_ctx* c, const double* gps_velocity, const int64_
     for (int i = 0; i + 1 < n_gps; i++) if (!(gps_time_usec[i] < gps_time_usec[i + 1])) return pg_ctx_fail(c, PGORB_E_ARG, "GPS timestamps must increase");
     std::vector<Window> wins(1);
     make_window(gps_time_usec, n_gps, M, wins[0]);
-    wins.resize(n_points, wins[0]);                          // the same calibrator evaluated at n_points parameter vectors
-    std::vector<const double*> refv(n_points, gps_velocity);
     Packed P;
-    pack_windows(wins, M, refv, P);
-    return run_windows(c, P, n_points, 1, xin, 0, nullptr, fx, grad, nullptr);
+    pack_window(wins[0], M, gps_velocity, P);
+    P.wins.resize(n_points, P.wins[0]);                      // the same calibrator (shared streams) at n_points parameter vectors
+    return run_windows(c, P, 1, xin, 0, nullptr, fx, grad, nullptr);
 }
 
 int pgorb_fit_motion_velocities(pgorb_ctx* c, const double* gps_velocity, const int64_t* gps_time_usec, int n_gps,

@@ -39,7 +39,11 @@ def imu_ride(seed, n_gps=30, imu_hz=50.0, noise=0.02):
 
 
 def _bits(a):
-    return np.ascontiguousarray(a, np.float64).view(np.uint64)
+    """Bit patterns, all NaNs made one (a window without IMU samples is 0/0 in the reference; which NaN
+    comes out depends on the instruction set, and the JSON prints none of them)."""
+    a = np.ascontiguousarray(a, np.float64).copy()
+    a[np.isnan(a)] = np.nan
+    return a.view(np.uint64)
 
 
 # ---------------------------------------------------------------- CPU: the oracle
