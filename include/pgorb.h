@@ -351,6 +351,16 @@ int  pgorb_turn_angles(const double* dirs /* [n][2] */, int n, double* turn /* [
  *   pgorb_fit_motion_velocities  ComputeAndSaveForwardVelocitiesFromImu (fit_motion.cc:151-290) up to the JSON:
  *                                window fits on the GPU, then IntegrateTrajectory, per-sample averaging,
  *                                SmoothTimeSeries and the forward axis on the host.  out_* need n_rot + n_acc entries. */
+/*   pgorb_principal_rotation_axes         GetPrincipalRotationAxes (src/calibration/rotation.cc:16-57): gyroscope
+ *                                         rates integrated over intervals of integration_interval_usec, cv::PCA over
+ *                                         the quaternion vector parts; eigenvectors[3][3] rows by descending
+ *                                         eigenvalue, row 0 = the vehicle's vertical axis (fit_motion.cc:322-329).
+ *                                         Fewer than 3 integrated intervals -> PGORB_E_LIMIT.  Host.
+ *   pgorb_angular_velocities_around_axis  GetAngularVelocitiesAroundAxisDirect (rotation.cc:111-129) = the steering
+ *                                         output of fit_motion (fit_motion.cc:130-148); axis must have norm 1 +- 1e-2. Host. */
+int  pgorb_principal_rotation_axes(const double* rotations /* [n][3] */, const int64_t* rot_time_usec, int n,
+                                   int64_t integration_interval_usec, double* eigenvectors /* [3][3] */);
+int  pgorb_angular_velocities_around_axis(const double* rotations, int n, const double* axis /* [3] */, double* out /* [n] */);
 int  pgorb_fit_num_windows(int n_gps, int locations_shift_step);
 int  pgorb_fit_velocity_windows(pgorb_ctx* ctx, const double* gps_velocity, const int64_t* gps_time_usec, int n_gps,
                                 const double* rotations, const int64_t* rot_time_usec, int n_rot,

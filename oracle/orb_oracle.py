@@ -584,3 +584,22 @@ def fit_motion_velocities(gps_v, gps_t, rot, rot_t, acc, acc_t, vertical_axis, b
     if n < 0:
         raise ValueError("fit_motion oracle failed: %d" % n)
     return t[:n].copy(), v[:n].copy(), fwd
+
+
+def principal_rotation_axes(rot, rot_t, integration_interval_usec=500000):
+    r, t = _d(rot).reshape(-1, 3), np.ascontiguousarray(rot_t, np.int64)
+    vec = np.zeros((3, 3))
+    f = lib().porc_principal_rotation_axes
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p]
+    rc = f(_p(r), _p(t), len(r), int(integration_interval_usec), _p(vec))
+    if rc:
+        raise ValueError("CHECK failure in GetPrincipalRotationAxes (%d)" % rc)
+    return vec
+
+
+def angular_velocities_around_axis(rot, axis):
+    r, a = _d(rot).reshape(-1, 3), _d(axis)
+    out = np.zeros(len(r))
+    if lib().porc_angular_velocities_around_axis(_p(r), len(r), _p(a), _p(out)):
+        raise ValueError("axis not normalised")
+    return out

@@ -316,3 +316,80 @@ void porc_turn_angles(const double* dirs, int n, double* turn_angles)
         turn_angles[point_idx] = acos(rotation_cos) * (cross_z > 0 ? 1.0 : -1.0);
     }
 }
+
+/* ---- src/calibration/rotation.cc ---- */
+
+/* cv::PCA(data m x 3, noArray(), CV_PCA_DATA_AS_ROW): reduce(dim 0, AVG), mulTransposed(aTa, delta = mean row), eigen */
+static void cv_pca_rows3(const double* data, int m, double* eigenvalues, double* eigenvectors)
+{
+    double buf[3], mean[3], covar[9];
+    double* col_buf = (double*)malloc(sizeof(double) * (size_t)m);
+    int i, j, k;
+    for (i = 0; i < 3; i++) buf[i] = data[i];                      /* reduceR_: first row, then row after row */
+    for (k = 1; k < m; k++) for (i = 0; i < 3; i++) buf[i] = buf[i] + data[3 * (size_t)k + i];
+    for (i = 0; i < 3; i++) mean[i] = buf[i] * (1. / m) + 0.0;
+    for (i = 0; i < 3; i++) {                                      /* MulTransposedR, width 3: only the scalar tail */
+        for (k = 0; k < m; k++) col_buf[k] = data[3 * (size_t)k + i] - mean[i];
+        for (j = i; j < 3; j++) {
+            double s0 = 0;
+            for (k = 0; k < m; k++) s0 += col_buf[k] * (data[3 * (size_t)k + j] - mean[j]);
+            covar[3 * i + j] = s0 * (1. / m);
+        }
+    }
+    for (i = 0; i < 3; i++) for (j = 0; j < i; j++) covar[3 * i + j] = covar[3 * j + i];
+    cv_jacobi(covar, 3, eigenvalues, eigenvectors);
+    free(col_buf);
+}
+
+/* rotation.cc:16-57.  Returns 0, -1 for the CHECK_GT on the interval, -2 for fewer than 3 integrated rotations. */
+int porc_principal_rotation_axes(const double* rot, const long long* time_usec, int n, long long integration_interval_usec, double* eigenvectors)
+{
+    double* interval_rotations;
+    double q[4] = {1, 0, 0, 0}, eigenvalues[3];                    /* w x y z */
+    long long current_interval_usec = 0;
+    int rotation_idx, m = 0;
+    if (integration_interval_usec <= 0) return -1;
+    interval_rotations = (double*)malloc(sizeof(double) * 3 * (size_t)(n > 0 ? n : 1));
+    for (rotation_idx = 1; rotation_idx < n; ++rotation_idx) {
+        const double* r = rot + 3 * (size_t)rotation_idx;
+        const long long rotation_duration_usec = time_usec[rotation_idx] - time_usec[rotation_idx - 1];
+        const double duration_sec = (double)rotation_duration_usec * 1e-6;
+        /* RotationMotionToQuaternion, geometry.cc:6-22 */
+        const double rate = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+        const double half_theta = rate * duration_sec * 0.5;
+        const double sn = sin(half_theta) / (rate + 1e-30);
+        const double b[4] = {cos(half_theta), r[0] * sn, r[1] * sn, r[2] * sn};
+        double c[4];
+        current_interval_usec += rotation_duration_usec;
+        c[0] = q[0] * b[0] - q[1] * b[1] - q[2] * b[2] - q[3] * b[3];      /* Eigen quaternion product, generic form */
+        c[1] = q[0] * b[1] + q[1] * b[0] + q[2] * b[3] - q[3] * b[2];
+        c[2] = q[0] * b[2] + q[2] * b[0] + q[3] * b[1] - q[1] * b[3];
+        c[3] = q[0] * b[3] + q[3] * b[0] + q[1] * b[2] - q[2] * b[1];
+        memcpy(q, c, sizeof(q));
+        if (current_interval_usec >= integration_interval_usec) {
+            interval_rotations[3 * m] = q[1]; interval_rotations[3 * m + 1] = q[2]; interval_rotations[3 * m + 2] = q[3]; m++;
+            q[0] = 1; q[1] = q[2] = q[3] = 0;
+            current_interval_usec = 0;
+        }
+    }
+    if (m < 3) { free(interval_rotations); return -2; }
+    cv_pca_rows3(interval_rotations, m, eigenvalues, eigenvectors);
+    free(interval_rotations);
+    return 0;
+}
+
+/* rotation.cc:111-129 */
+int porc_angular_velocities_around_axis(const double* rot, int n, const double* axis, double* result)
+{
+    double s = 0, axis_norm;
+    int i, k;
+    for (k = 0; k < 3; k++) s += axis[k] * axis[k];
+    axis_norm = sqrt(s);
+    if (!(axis_norm > 1.0 - 1e-2) || !(axis_norm < 1.0 + 1e-2)) return -1;
+    for (i = 0; i < n; i++) {
+        double dot = 0;
+        for (k = 0; k < 3; k++) dot += rot[3 * (size_t)i + k] * axis[k];
+        result[i] = dot / axis_norm;
+    }
+    return 0;
+}

@@ -73,3 +73,23 @@ def ComputeForwardVelocitiesFromImu(ctx, gps, rotations, accelerations, vertical
                                                        post_smoothing_sigma_sec, forward_axis_inference_min_velocity_m_s,
                                                        forward_axis_inference_min_rotation_rad, _p(t), _p(v), C.byref(n), _p(fwd)))
     return t[:n.value].copy(), v[:n.value].copy(), fwd
+
+
+def GetPrincipalRotationAxes(raw_rotations, integration_interval_usec=500000):
+    """rotation.cc:16-57 -> eigenvectors[3][3] (rows); row 0 is taken as the vertical axis (fit_motion.cc:322-329)."""
+    rot, t = _d(raw_rotations[0]).reshape(-1, 3), np.ascontiguousarray(raw_rotations[1], np.int64)
+    vec = np.zeros((3, 3))
+    rc = _lib.lib().pgorb_principal_rotation_axes(_p(rot), _p(t), len(rot), int(integration_interval_usec), _p(vec))
+    if rc != _lib.PGORB_OK:
+        raise _lib.PgorbError(rc, "GetPrincipalRotationAxes: interval must be > 0 and give at least 3 integrated rotations")
+    return vec
+
+
+def GetAngularVelocitiesAroundAxisDirect(raw_rotations, axis):
+    """rotation.cc:111-129: the steering series of fit_motion."""
+    rot, a = _d(raw_rotations[0]).reshape(-1, 3), _d(axis)
+    out = np.zeros(len(rot))
+    rc = _lib.lib().pgorb_angular_velocities_around_axis(_p(rot), len(rot), _p(a), _p(out))
+    if rc != _lib.PGORB_OK:
+        raise _lib.PgorbError(rc, "GetAngularVelocitiesAroundAxisDirect: the axis must be normalised")
+    return out

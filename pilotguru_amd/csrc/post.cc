@@ -14,6 +14,9 @@
 //   TrajectoryToPCA                    src/slam/track_image_sequence.cc:16-29
 //     cv::PCA(DATA_AS_COL)             OpenCV 2.4 matmul.cpp: reduce(AVG) with two alternating partial sums,
 //                                      MulTransposedL (groups of four products), scale 1/n, cv::eigen = JacobiImpl_
+//   GetPrincipalRotationAxes, GetAngularVelocitiesAroundAxisDirect   src/calibration/rotation.cc:16-57,111-129
+//     cv::PCA(DATA_AS_ROW)             reduce over rows = one running sum per column, MulTransposedR = one running
+//                                      sum per matrix element (3 columns: the 4-wide unrolled path is not taken)
 //   ProjectDirections / ProjectTranslations / Projected2DDirectionsToTurnAngles
 //                                      src/slam/horizontal_flatten.cc:7-63 (Eigen's _transformVector,
 //                                      cv::gemm's k-ordered dot products, cv::Vec dot / cross / norm)
@@ -251,6 +254,71 @@ int pgorb_turn_angles(const double* dirs, int n, double* turn)
         const double rotation_cos = dot / std::sqrt(np) / std::sqrt(nc);
         const double cross_z = prev[0] * curr[1] - prev[1] * curr[0];
         turn[i] = std::acos(rotation_cos) * (cross_z > 0 ? 1.0 : -1.0);
+    }
+    return PGORB_OK;
+}
+
+int pgorb_principal_rotation_axes(const double* rot, const int64_t* time_usec, int n, int64_t integration_interval_usec,
+                                  double* eigenvectors)
+{
+    if (!rot || !time_usec || !eigenvectors || n < 0) return PGORB_E_ARG;
+    if (integration_interval_usec <= 0) return PGORB_E_ARG;                 // CHECK_GT, rotation.cc:19
+    std::vector<double> rows;                                               // interval_rotations, x y z per row
+    double cw = 1, cx = 0, cy = 0, cz = 0;
+    int64_t cur_usec = 0;
+    for (int i = 1; i < n; i++) {
+        const int64_t dur = time_usec[i] - time_usec[i - 1];
+        cur_usec += dur;
+        const double rx = rot[3 * (size_t)i], ry = rot[3 * (size_t)i + 1], rz = rot[3 * (size_t)i + 2];
+        const double duration_sec = static_cast<double>(dur) * 1e-6;
+        const double rate = std::sqrt(rx * rx + ry * ry + rz * rz);            // RotationMotionToQuaternion, geometry.cc:6-22
+        const double half_theta = rate * duration_sec * 0.5;
+        const double sn = std::sin(half_theta) / (rate + 1e-30);
+        const double bw = std::cos(half_theta), bx = rx * sn, by = ry * sn, bz = rz * sn;
+        const double nw = cw * bw - cx * bx - cy * by - cz * bz, nx = cw * bx + cx * bw + cy * bz - cz * by;
+        const double ny = cw * by + cy * bw + cz * bx - cx * bz, nz = cw * bz + cz * bw + cx * by - cy * bx;
+        cw = nw; cx = nx; cy = ny; cz = nz;
+        if (cur_usec >= integration_interval_usec) {
+            rows.push_back(cx); rows.push_back(cy); rows.push_back(cz);
+            cw = 1; cx = cy = cz = 0;
+            cur_usec = 0;
+        }
+    }
+    const int m = (int)(rows.size() / 3);
+    if (m < 3) return PGORB_E_LIMIT;                                        // CHECK_GE(interval_rotations.size(), 3), :47
+    double mu[3];
+    for (int j = 0; j < 3; j++) {                                           // reduce(dim 0, AVG)
+        double b = rows[j];
+        for (int k = 1; k < m; k++) b = b + rows[3 * (size_t)k + j];
+        mu[j] = b * (1. / m) + 0.0;
+    }
+    std::vector<double> cov(9), col(m);
+    for (int i = 0; i < 3; i++) {                                           // MulTransposedR, delta = the mean row
+        for (int k = 0; k < m; k++) col[k] = rows[3 * (size_t)k + i] - mu[i];
+        for (int j = i; j < 3; j++) {
+            double s0 = 0;
+            for (int k = 0; k < m; k++) s0 += col[k] * (rows[3 * (size_t)k + j] - mu[j]);
+            cov[3 * i + j] = s0 * (1. / m);
+        }
+    }
+    for (int i = 0; i < 3; i++) for (int j = 0; j < i; j++) cov[3 * i + j] = cov[3 * j + i];
+    std::vector<double> W, V;
+    Jacobi3::run(cov, 3, W, V);
+    for (int i = 0; i < 9; i++) eigenvectors[i] = V[i];
+    return PGORB_OK;
+}
+
+int pgorb_angular_velocities_around_axis(const double* rot, int n, const double* axis, double* out)
+{
+    if (n < 0 || (n && (!rot || !out)) || !axis) return PGORB_E_ARG;
+    double s = 0;
+    for (int k = 0; k < 3; k++) s += axis[k] * axis[k];
+    const double axis_norm = std::sqrt(s);
+    if (!(axis_norm > 1.0 - 1e-2) || !(axis_norm < 1.0 + 1e-2)) return PGORB_E_ARG;    // the two CHECKs, rotation.cc:114-116
+    for (int i = 0; i < n; i++) {
+        double d = 0;
+        for (int k = 0; k < 3; k++) d += rot[3 * (size_t)i + k] * axis[k];
+        out[i] = d / axis_norm;
     }
     return PGORB_OK;
 }

@@ -150,3 +150,111 @@ def test_gpu_calibration_argument_errors(ctx):
         FitVelocityWindows(ctx, (gps[0], gps[1][::-1].copy()), rot, acc, 8, 4, 10)
     with pytest.raises(PgorbError):
         FitVelocityWindows(ctx, gps, (rot[0], rot[1] + 10**9), acc, 8, 4, 10)
+
+
+# ---------------------------------------------------------------- rotation.cc (host) and the fit_motion CLI
+
+@pytest.mark.parametrize("seed,n_gps,interval", [(12, 12, 500000), (13, 40, 250000), (14, 6, 1000000)])
+def test_principal_rotation_axes_and_steering_equal_oracle(oracle, seed, n_gps, interval):
+    from pilotguru_amd.calibration import GetAngularVelocitiesAroundAxisDirect, GetPrincipalRotationAxes
+    _, rot, _ = imu_ride(seed, n_gps=n_gps)
+    vec = GetPrincipalRotationAxes(rot, interval)
+    assert np.array_equal(_bits(vec), _bits(oracle.principal_rotation_axes(*rot, interval)))
+    assert np.allclose(vec @ vec.T, np.eye(3), atol=1e-13)
+    assert abs(abs(vec[0, 2]) - 1.0) < 0.05                          # the synthetic car only yaws: vertical = device z
+    st = GetAngularVelocitiesAroundAxisDirect(rot, vec[0])
+    assert np.array_equal(_bits(st), _bits(oracle.angular_velocities_around_axis(rot[0], vec[0])))
+    assert np.allclose(st, rot[0] @ vec[0], atol=1e-14)
+
+
+def test_principal_rotation_axes_against_numpy_and_errors():
+    from pilotguru_amd._lib import PgorbError
+    from pilotguru_amd.calibration import GetAngularVelocitiesAroundAxisDirect, GetPrincipalRotationAxes
+    _, rot, _ = imu_ride(15, n_gps=30)
+    r, t = rot
+    # the integrated interval rotations, straight from the definition
+    rows, q, acc_us = [], np.array([1.0, 0, 0, 0]), 0
+    for i in range(1, len(r)):
+        dt = (t[i] - t[i - 1]) * 1e-6
+        rate = np.linalg.norm(r[i]); h = rate * dt * 0.5
+        b = np.concatenate([[math.cos(h)], r[i] * (math.sin(h) / (rate + 1e-30))])
+        q = np.array([q[0] * b[0] - q[1:] @ b[1:], *(q[0] * b[1:] + b[0] * q[1:] + np.cross(q[1:], b[1:]))])
+        acc_us += t[i] - t[i - 1]
+        if acc_us >= 500000:
+            rows.append(q[1:].copy()); q = np.array([1.0, 0, 0, 0]); acc_us = 0
+    w, v = np.linalg.eigh(np.cov(np.array(rows).T, bias=True))
+    vec = GetPrincipalRotationAxes(rot)
+    for k in range(3):
+        assert min(np.abs(vec[k] - v[:, 2 - k]).max(), np.abs(vec[k] + v[:, 2 - k]).max()) < 1e-6
+    with pytest.raises(PgorbError):                                   # CHECK_GT(integration_interval_usec, 0)
+        GetPrincipalRotationAxes(rot, 0)
+    with pytest.raises(PgorbError):                                   # CHECK_GE(interval_rotations.size(), 3)
+        GetPrincipalRotationAxes((r[:20], t[:20]), 10**9)
+    with pytest.raises(PgorbError):                                   # axis not normalised
+        GetAngularVelocitiesAroundAxisDirect(rot, [0, 0, 2.0])
+
+
+def _write_recorder_json(d, gps, rot, acc):
+    import json
+    import os
+    def dump(name, root, rows):
+        with open(os.path.join(d, name), "w") as f:
+            json.dump({root: rows}, f)
+    dump("locations.json", "locations", [{"speed_m_s": float(v), "time_usec": int(t), "lat": 1.0, "lon": 2.0} for v, t in zip(*gps)])
+    dump("rotations.json", "rotations", [{"x": float(a[0]), "y": float(a[1]), "z": float(a[2]), "time_usec": int(t)} for a, t in zip(*rot)])
+    dump("accelerations.json", "accelerations", [{"x": float(a[0]), "y": float(a[1]), "z": float(a[2]), "time_usec": int(t)} for a, t in zip(*acc)])
+
+
+def test_fit_motion_cli_checks_flags(tmp_path):
+    import os
+    import subprocess
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pilotguru_amd", "host", "fit_motion")
+    assert os.path.exists(cli), "build it: make -C pilotguru_amd/csrc"
+    run = lambda *a: subprocess.run([cli] + list(a), stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+    r = run()
+    assert r.returncode != 0 and "!FLAGS_rotations_json.empty()" in r.stderr
+    r = run("--rotations_json=a", "--accelerations_json=b", "--locations_json=c", "--locations_batch_size=3", "--locations_shift_step=5")
+    assert r.returncode != 0 and "FLAGS_locations_batch_size >= FLAGS_locations_shift_step" in r.stderr
+    r = run("--rotations_json=a", "--accelerations_json=b", "--locations_json=c", "--post_smoothing_sigma_sec=0")
+    assert r.returncode != 0 and "FLAGS_post_smoothing_sigma_sec > 0" in r.stderr
+    # the steering output needs no GPU: host arithmetic only
+    gps, rot, acc = imu_ride(16, n_gps=10)
+    _write_recorder_json(str(tmp_path), gps, rot, acc)
+    d = str(tmp_path)
+    r = run("--rotations_json=%s/rotations.json" % d, "--accelerations_json=%s/accelerations.json" % d, "--locations_json=%s/locations.json" % d,
+            "--steering_out_json=%s/steering.json" % d)
+    assert r.returncode == 0, r.stderr
+    import json
+    from pilotguru_amd.calibration import GetAngularVelocitiesAroundAxisDirect, GetPrincipalRotationAxes
+    st = json.load(open(d + "/steering.json"))["steering"]
+    want = GetAngularVelocitiesAroundAxisDirect(rot, GetPrincipalRotationAxes(rot)[0])
+    assert [e["time_usec"] for e in st] == [int(t) for t in rot[1]]
+    assert [e["angular_velocity"] for e in st] == [float("%.15g" % v) for v in want]
+    txt = open(d + "/steering.json").read()
+    assert txt.startswith('{\n  "steering": [\n    {\n      "angular_velocity": ') and txt.endswith("\n  ]\n}\n")
+
+
+@pytest.mark.gpu
+def test_gpu_fit_motion_cli_writes_the_oracles_numbers(tmp_path, oracle):
+    import json
+    import os
+    import subprocess
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pilotguru_amd", "host", "fit_motion")
+    gps, rot, acc = imu_ride(17, n_gps=26)
+    d = str(tmp_path)
+    _write_recorder_json(d, gps, rot, acc)
+    r = subprocess.run([cli, "--rotations_json=%s/rotations.json" % d, "--accelerations_json=%s/accelerations.json" % d,
+                        "--locations_json=%s/locations.json" % d, "--velocities_out_json=%s/v.json" % d, "--forward_axis_out_json=%s/f.json" % d,
+                        "--steering_out_json=%s/s.json" % d, "--locations_batch_size=10", "--optimization_iters=80",
+                        "--post_smoothing_sigma_sec=0.01"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+    assert r.returncode == 0, r.stderr
+    axis = oracle.principal_rotation_axes(*rot)[0]
+    ot, ov, ofwd = oracle.fit_motion_velocities(*gps, *rot, *acc, axis, 10, 5, 80, 0.01, 5.0, 0.2)
+    r15 = lambda x: float("%.15g" % x)
+    v = json.load(open(d + "/v.json"))["velocities"]
+    assert [e["time_usec"] for e in v] == [int(t) for t in ot]
+    assert [e["speed_m_s"] for e in v] == [r15(x) for x in ov]
+    f = json.load(open(d + "/f.json"))["forward_axis"]
+    assert [f["x"], f["y"], f["z"]] == [r15(x) for x in ofwd]
+    s = json.load(open(d + "/s.json"))["steering"]
+    assert [e["angular_velocity"] for e in s] == [r15(x) for x in oracle.angular_velocities_around_axis(rot[0], axis)]
