@@ -157,29 +157,26 @@ void make_window(const int64_t* ref_t, int n_ref, const Imu& M, Window& W)
 
 #define CB_CHUNK 64
 
+// developer build: make EXTRA=-DPGORB_CALIB_PROF -- shader-clock cycles per phase of cal_eval, summed by lane 0 of block 0
+#ifdef PGORB_CALIB_PROF
+__device__ unsigned long long cb_prof[8];
+#define CP_DECL unsigned long long cp_t = __builtin_readcyclecounter(), cp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define CP_TICK(k) do { const unsigned long long cp_n = __builtin_readcyclecounter(); cp_acc[k] += cp_n - cp_t; cp_t = cp_n; } while (0)
+#define CP_FLUSH do { if (lane == 0 && blockIdx.x == 0) for (int cp_i = 0; cp_i < 8; cp_i++) atomicAdd(&cb_prof[cp_i], cp_acc[cp_i]); } while (0)
+#else
+#define CP_DECL
+#define CP_TICK(k)
+#define CP_FLUSH
+#endif
+
 struct WinDesc {              // one per wave (window)
     int64_t fwd, bwd;         // element offsets of the SoA streams: fwd[CB_FWD][S], bwd[CB_BWD][S]
     int64_t refDist;          // [nRef]
     int64_t refOff;           // int32 [nRef + 1]: first step of each reference interval
+    int64_t chunks;           // int32 [nChunks + 2]: first step of every chunk of <= 64 steps, in order (+ 2 repeats of the last)
     int32_t S, nRef;
     double totalSec;
 };
-
-struct Cursor {               // a position in the window's sequence of chunks
-    int r, c0;                // reference interval, first step of the chunk inside it
-};
-
-// first chunk at or after interval r (skips empty intervals); r = nRef when there is none
-__device__ inline Cursor cur_first(const int32_t* refOff, int nRef, int r)
-{
-    while (r < nRef && refOff[r + 1] == refOff[r]) r++;
-    return {r, 0};
-}
-__device__ inline Cursor cur_next(const int32_t* refOff, int nRef, Cursor c)
-{
-    if (c.c0 + CB_CHUNK < refOff[c.r + 1] - refOff[c.r]) return {c.r, c.c0 + CB_CHUNK};
-    return cur_first(refOff, nRef, c.r + 1);
-}
 
 struct FwdRegs { double dt, qw, qx, qy, qz, ax, ay, az; };
 struct BwdRegs { double c1, dt, m[9]; };
@@ -207,12 +204,119 @@ __device__ inline double dot9(const double* a, const double* b)       // Eigen S
 
 struct WinView {
     const double *F, *B, *refDist;
-    const int32_t* refOff;
+    const int32_t *refOff, *chunks;
     int S, nRef;
     double totalSec;
-    double (*sc)[CB_CHUNK];   // LDS [4][64]: c0, c1, c2, dt of the chunk
-    double (*sp)[CB_CHUNK];   // LDS [9][64]: the gradient products of the chunk
+    // LDS, step-major so that the few lanes of phase S read neighbouring words (a field-major layout put
+    // the 9 rows one bank apart: 9-way conflicts, 23 cycles per dependent add instead of 8)
+    double (*sc)[4];          // [64][4]: c0, c1, c2, dt of each step of the chunk
+    double (*sp)[9];          // [64][9]: the gradient products of each step
 };
+
+// ---- phase S: the running sums of one chunk ----
+// A dependent fp64 operation issues ~17 cycles after its producer and an LDS read takes ~100, and the
+// compiler keeps LDS reads next to their use.  So (i) the operands of 16 steps are read into registers
+// one batch ahead (the empty asm keeps the reads above the arithmetic of the previous batch), and
+// (ii) the forward chains are skewed so that no operation of a slot waits for another one of the same
+// slot.  travel + (+0.0) is exact (travel starts at +0.0 and a sum is -0.0 only if both terms are),
+// which lets every slot have the same shape; the pending products are flushed, oldest first, at the
+// end of the chunk.
+#define CB_BATCH 16
+
+struct FwdBatch { double c[CB_BATCH], dt[CB_BATCH]; };
+
+__device__ inline void fwd_read(double (*sc)[4], int comp, int i0, FwdBatch& b)
+{
+#pragma unroll
+    for (int j = 0; j < CB_BATCH; j++) { b.c[j] = sc[i0 + j][comp]; b.dt[j] = sc[i0 + j][3]; }
+}
+
+// One slot = { travel += m2 ; m1' = dt[i-1] * v ; v += c[i] }: the product is consumed two slots after it was
+// issued (fp64 multiplies take about twice as long as adds here), so a slot only waits for the v chain.
+// The scheduling barrier keeps the compiler from folding the slots back into product-then-add order.
+template <bool FIRST>
+__device__ inline void fwd_steps(const FwdBatch& b, double& v, double& m1, double& m2, double& dtp, double& t)
+{
+#pragma unroll
+    for (int j = 0; j < CB_BATCH; j++) {
+        if (!(FIRST && j == 0)) { t += m2; m2 = m1; m1 = dtp * v; }
+        v = v + b.c[j];
+        dtp = b.dt[j];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__device__ inline void fwd_chain(double (*sc)[4], int comp, int n, double& vk, double& tk)
+{
+    double v = vk, t = tk, m1 = 0.0, m2 = 0.0, dtp = 0.0;
+    int i = 0;
+    if (n >= CB_BATCH) {                       // whole batches, operands one batch ahead (rows past the chunk are padding)
+        FwdBatch A, B;
+        fwd_read(sc, comp, 0, A);
+        fwd_read(sc, comp, CB_BATCH, B);
+        asm volatile("" ::: "memory");
+        fwd_steps<true>(A, v, m1, m2, dtp, t);
+        i = CB_BATCH;
+        while (i + CB_BATCH <= n) {
+            fwd_read(sc, comp, i + CB_BATCH, A);
+            asm volatile("" ::: "memory");
+            fwd_steps<false>(B, v, m1, m2, dtp, t);
+            i += CB_BATCH;
+            if (i + CB_BATCH > n) break;
+            fwd_read(sc, comp, i + CB_BATCH, B);
+            asm volatile("" ::: "memory");
+            fwd_steps<false>(A, v, m1, m2, dtp, t);
+            i += CB_BATCH;
+        }
+    }
+    for (; i < n; i++) {                       // the odd steps of a short chunk
+        if (i > 0) { t += m2; m2 = m1; m1 = dtp * v; }
+        v = v + sc[i][comp];
+        dtp = sc[i][3];
+    }
+    t += m2;                                   // flush, oldest product first
+    t += m1;
+    t += dtp * v;
+    vk = v; tk = t;
+}
+
+struct BwdBatch { double p[CB_BATCH]; };
+
+__device__ inline void bwd_read(double (*sp)[9], int acc, int i0, BwdBatch& b)
+{
+#pragma unroll
+    for (int j = 0; j < CB_BATCH; j++) b.p[j] = sp[i0 + j][acc];
+}
+
+__device__ inline void bwd_chain(double (*sp)[9], int acc, int n, double& gj)
+{
+    double g = gj;
+    int i = 0;
+    if (n >= CB_BATCH) {
+        BwdBatch A, B;
+        bwd_read(sp, acc, 0, A);
+        bwd_read(sp, acc, CB_BATCH, B);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < CB_BATCH; j++) g += A.p[j];
+        i = CB_BATCH;
+        while (i + CB_BATCH <= n) {
+            bwd_read(sp, acc, i + CB_BATCH, A);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < CB_BATCH; j++) g += B.p[j];
+            i += CB_BATCH;
+            if (i + CB_BATCH > n) break;
+            bwd_read(sp, acc, i + CB_BATCH, B);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < CB_BATCH; j++) g += A.p[j];
+            i += CB_BATCH;
+        }
+    }
+    for (; i < n; i++) g += sp[i][acc];
+    gj = g;
+}
 
 // velocity.cc:42-180 on the prepared streams; every lane returns the same loss and gradient.
 __device__ double cal_eval(const WinView& G, int lane, const double* x, double* grad)
@@ -222,32 +326,37 @@ __device__ double cal_eval(const WinView& G, int lane, const double* x, double* 
     double vk = x[6 + comp];                          // this lane's component of integrated_velocity
     double gj = 0;                                    // this lane's gradient accumulator (index acc)
     double result = 0;
-    Cursor nf = cur_first(G.refOff, G.nRef, 0), nb = nf;
-    FwdRegs fn = {}; BwdRegs bn = {};
-    if (nf.r < G.nRef) { fn = load_fwd(G.F, G.S, G.refOff[nf.r] + lane); bn = load_bwd(G.B, G.S, G.refOff[nb.r] + lane); }
+    CP_DECL;
+    // chunk t+1 of each stream is loaded while chunk t is worked on; the chunk starts come from a flat list
+    // (two entries ahead in SGPRs), so no address depends on a load of the same trip
+    int fi = 0, bi = 0;
+    FwdRegs fn = load_fwd(G.F, G.S, G.chunks[0] + lane);
+    BwdRegs bn = load_bwd(G.B, G.S, G.chunks[0] + lane);
+    int fnext = G.chunks[1], bnext = fnext;
     for (int r = 0; r < G.nRef; r++) {
         const int off = G.refOff[r], cnt = G.refOff[r + 1] - off;
         double tk = 0;                                // this lane's component of integrated_travel
         for (int c0 = 0; c0 < cnt; c0 += CB_CHUNK) {
             const int n = min(CB_CHUNK, cnt - c0);
+            CP_TICK(0);
             const FwdRegs f = fn;
-            nf = cur_next(G.refOff, G.nRef, nf);
-            if (nf.r < G.nRef) fn = load_fwd(G.F, G.S, G.refOff[nf.r] + nf.c0 + lane);
+            fn = load_fwd(G.F, G.S, fnext + lane);
+            fnext = G.chunks[++fi + 1];
+            CP_TICK(1);
             {   // phase A, lane = step (IntegrateMotion's parameter-dependent part, geometry.cc:34-45)
                 const Quat q = {f.qw, f.qx, f.qy, f.qz};
                 const double lc[3] = {f.ax + bl[0], f.ay + bl[1], f.az + bl[2]};
                 double rot[3];
                 quat_rotate(q, lc, rot);
-                for (int k = 0; k < 3; k++) G.sc[k][lane] = (rot[k] + bg[k]) * f.dt;
-                G.sc[3][lane] = f.dt;
+                for (int k = 0; k < 3; k++) G.sc[lane][k] = (rot[k] + bg[k]) * f.dt;
+                G.sc[lane][3] = f.dt;
             }
             __syncthreads();
-#pragma unroll 8
-            for (int i = 0; i < n; i++) {             // phase S: v += a*dt ; travel += dt*v  (velocity.cc:99-108)
-                vk = vk + G.sc[comp][i];
-                tk += G.sc[3][i] * vk;
-            }
+            CP_TICK(2);
+            // phase S: v += a*dt ; travel += dt*v  (velocity.cc:99-108)
+            fwd_chain(G.sc, comp, n, vk, tk);
             __syncthreads();
+            CP_TICK(3);
         }
         const double travel[3] = {__shfl(tk, 0), __shfl(tk, 1), __shfl(tk, 2)};
         const double tn = sqrt(dot3(travel, travel));
@@ -257,21 +366,25 @@ __device__ double cal_eval(const WinView& G, int lane, const double* x, double* 
         for (int k = 0; k < 3; k++) d[k] = ((2.0 * diff) * travel[k]) / (tn + 1e-5);
         for (int c0 = 0; c0 < cnt; c0 += CB_CHUNK) {
             const int n = min(CB_CHUNK, cnt - c0);
+            CP_TICK(4);
             const BwdRegs b = bn;
-            nb = cur_next(G.refOff, G.nRef, nb);
-            if (nb.r < G.nRef) bn = load_bwd(G.B, G.S, G.refOff[nb.r] + nb.c0 + lane);
+            bn = load_bwd(G.B, G.S, bnext + lane);
+            bnext = G.chunks[++bi + 1];
+            CP_TICK(5);
             for (int k = 0; k < 3; k++) {             // phase A, lane = step (velocity.cc:133-163)
-                G.sp[k][lane] = b.c1 * d[k];
+                G.sp[lane][k] = b.c1 * d[k];
                 const double row[3] = {b.m[3 * k], b.m[3 * k + 1], b.m[3 * k + 2]};
-                G.sp[3 + k][lane] = dot3(row, d);
-                G.sp[6 + k][lane] = b.dt * d[k];
+                G.sp[lane][3 + k] = dot3(row, d);
+                G.sp[lane][6 + k] = b.dt * d[k];
             }
             __syncthreads();
-#pragma unroll 8
-            for (int i = 0; i < n; i++) gj += G.sp[acc][i];
+            CP_TICK(6);
+            bwd_chain(G.sp, acc, n, gj);
             __syncthreads();
+            CP_TICK(7);
         }
     }
+    CP_FLUSH;
     for (int k = 0; k < 9; k++) grad[k] = __shfl(gj, k) / G.totalSec;
     return result / G.totalSec;
 }
@@ -332,13 +445,13 @@ __global__ __launch_bounds__(64) void k_calibrate_windows(const WinDesc* __restr
                                                         int max_iterations, double* __restrict__ xout, double* __restrict__ fxout,
                                                         double* __restrict__ gradout, int32_t* __restrict__ niter)
 {
-    __shared__ double sc[4][CB_CHUNK];
-    __shared__ double sp[9][CB_CHUNK];
+    __shared__ double sc[CB_CHUNK + 2 * CB_BATCH][4];      // + rows the one-batch-ahead reads may touch
+    __shared__ double sp[CB_CHUNK + 2 * CB_BATCH][9];
     const WinDesc D = wins[blockIdx.x];
     const int lane = threadIdx.x;
     const size_t w = blockIdx.x;
     WinView G;
-    G.F = dbl + D.fwd; G.B = dbl + D.bwd; G.refDist = dbl + D.refDist; G.refOff = i32 + D.refOff;
+    G.F = dbl + D.fwd; G.B = dbl + D.bwd; G.refDist = dbl + D.refDist; G.refOff = i32 + D.refOff; G.chunks = i32 + D.chunks;
     G.S = D.S; G.nRef = D.nRef; G.totalSec = D.totalSec; G.sc = sc; G.sp = sp;
     double x[9], g[9], fx;
     if (mode == 1) {
@@ -410,6 +523,14 @@ void pack_window(const Window& W, const Imu& M, const double* ref_v, Packed& P)
     int32_t off = 0;
     for (int32_t c : W.refCnt) { P.i32.push_back(off); off += c; }
     P.i32.push_back(off);
+    D.chunks = (int64_t)P.i32.size();
+    off = 0;
+    int32_t last = 0;
+    for (int32_t c : W.refCnt) {
+        for (int32_t c0 = 0; c0 < c; c0 += CB_CHUNK) { last = off + c0; P.i32.push_back(last); }
+        off += c;
+    }
+    P.i32.push_back(last); P.i32.push_back(last); P.i32.push_back(last);     // the prefetcher reads up to two chunks past the end
     for (size_t i = 0; i < n; i++) {
         for (int f = 0; f < CB_FWD; f++) P.dbl[D.fwd + (size_t)f * D.S + i] = fwd[i * CB_FWD + f];
         for (int f = 0; f < CB_BWD; f++) P.dbl[D.bwd + (size_t)f * D.S + i] = bwd[i * CB_BWD + f];
@@ -445,8 +566,17 @@ int run_windows(pgorb_ctx* c, const Packed& P, int mode, const double* xin, int 
     hipLaunchKernelGGL(k_calibrate_windows, dim3((unsigned)nw), dim3(64), 0, 0, (const WinDesc*)dW.p, (const double*)dD.p, (const int32_t*)dI.p,
                        mode, (const double*)dXin.p, max_iters, (double*)dX.p, (double*)dF.p, (double*)dGr.p, (int32_t*)dNi.p);
     if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "k_calibrate_windows failed");
+#ifdef PGORB_CALIB_PROF
+    {
+        unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(cb_prof), sizeof(h));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(cb_prof), z, sizeof(z));
+        fprintf(stderr, "[calib prof] cycles: rest/interval-end %llu | F: cursor+issue %llu, phase A %llu, phase S %llu | B: wait+d %llu, cursor+issue %llu, phase A %llu, phase S %llu\n",
+                h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+    }
+#endif
     if (timing_on())
-        fprintf(stderr, "[calib] %zu windows, %.1f MB of streams: upload %.3f s, solver kernel %.3f s\n", nw, P.dbl.size() * 8e-6, t1 - t0, now_s() - t1);
+        fprintf(stderr, "[calib] %zu windows, %.1f MB of streams: upload %.3f s, solver kernel %.1f us\n", nw, P.dbl.size() * 8e-6, t1 - t0, (now_s() - t1) * 1e6);
     bool ok = hipMemcpy(fx, dF.p, sizeof(double) * nw, hipMemcpyDeviceToHost) == hipSuccess;
     if (mode == 1) ok = ok && hipMemcpy(grad, dGr.p, sizeof(double) * 9 * nw, hipMemcpyDeviceToHost) == hipSuccess;
     else ok = ok && hipMemcpy(x, dX.p, sizeof(double) * 9 * nw, hipMemcpyDeviceToHost) == hipSuccess &&
