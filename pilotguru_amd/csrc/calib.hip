@@ -143,38 +143,40 @@ void make_window(const int64_t* ref_t, int n_ref, const Imu& M, Window& W)
 
 // ---- device: AccelerometerCalibrator::eval on the prepared streams, LBFGSSolver::minimize ----
 //
-// One wave per window.  A loss evaluation walks ~10^4 steps whose sums must stay in time order, but
-// only the sums are sequential: per step the expensive part (rotate the bias-corrected acceleration
-// into the fixed frame, scale by dt; the nine gradient products) depends on the parameters and on
-// that step's data alone.  So for every chunk of 64 steps
-//   phase A  lane = step: the independent arithmetic, results to LDS (full 64-lane efficiency);
-//   phase S  lane = component: the running sums v, travel (3 lanes) / the 9 gradient sums (9 lanes)
-//            walk the chunk in order, one dependent fp64 add per step and chain.
-// The first design (one LANE per window, the whole loop body serial) spent ~1000 cycles per step and
-// was 20x slower per evaluation than one CPU core; the fit of the slowest window bounds the whole
-// run, so per-evaluation latency is what matters.  Chunks are prefetched one ahead into registers,
-// across interval and pass boundaries (the streams do not depend on the parameters).
+// One workgroup of FIVE waves per window.  A loss evaluation walks ~10^4 steps whose sums must stay in
+// time order, but only the sums are sequential: per step the expensive part (rotate the bias-corrected
+// acceleration into the fixed frame, scale by dt; dt*v; the nine gradient products) is a function of
+// the parameters and that step's data, and the gradient sums of a GPS interval need nothing from the
+// forward sums but that interval's d_loss_d_travel.  So the window's chunks of <= 64 steps flow through
+// a pipeline, one workgroup barrier per chunk ("tick"); every stage is either a lane = step map (P*)
+// or ONE running fp64 sum per lane:
+//   PF  (lane = step)  tick t:   a*dt of chunk t            -> LDS;   dt*v of chunk t-2  -> LDS
+//   V   (lanes x,y,z)  tick t:   v += a*dt over chunk t-1, every v_i -> LDS
+//   T   (lanes x,y,z)  tick t:   travel += dt*v over chunk t-3; at the end of a GPS interval hands travel over
+//   B   (9 lanes)      tick t:   the interval ends F delivered one tick earlier: loss term, d_loss_d_travel
+//                                (one divide per lane);  the 9 gradient sums over chunk t-lag
+//   PB  (lane = step)  tick t:   the 9 gradient products of chunk t-lag+1 -> LDS
+// lag = (most chunks in one interval) + 5 ticks, odd, make every hand-over visible in time.  The streams
+// are read two chunks ahead into registers.  A tick costs what the slowest stage costs -- a running sum
+// of 64 steps at ~13 cycles each (one dependent fp64 add plus its operand's LDS read: an LDS instruction
+// costs the wave ~5 issue cycles whatever the number of active lanes, tools/ubench/fp64_chain.hip) --
+// instead of the sum of all stages.
+// History: one LANE per window with the whole loop body serial needed 68 s for a one-hour ride (every
+// step waited for HBM); one WAVE per window doing the stages one after the other 2.5 s; three waves
+// (producer, forward sums, backward sums) 1.5 s.  The fit of the slowest window bounds the run, so the
+// latency of ONE evaluation is what counts; the machine is otherwise nearly idle (0.1 s of its time).
 
 #define CB_CHUNK 64
+#define CB_BATCH 16
+#define CB_ROWS (CB_CHUNK + 2 * CB_BATCH)      // LDS rows per chunk buffer: the one-batch-ahead reads may run past the chunk
+#define CB_WAVES 5
+#define CB_LAG_EXTRA 5
 
-// developer build: make EXTRA=-DPGORB_CALIB_PROF -- shader-clock cycles per phase of cal_eval, summed by lane 0 of block 0
-#ifdef PGORB_CALIB_PROF
-__device__ unsigned long long cb_prof[8];
-#define CP_DECL unsigned long long cp_t = __builtin_readcyclecounter(), cp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define CP_TICK(k) do { const unsigned long long cp_n = __builtin_readcyclecounter(); cp_acc[k] += cp_n - cp_t; cp_t = cp_n; } while (0)
-#define CP_FLUSH do { if (lane == 0 && blockIdx.x == 0) for (int cp_i = 0; cp_i < 8; cp_i++) atomicAdd(&cb_prof[cp_i], cp_acc[cp_i]); } while (0)
-#else
-#define CP_DECL
-#define CP_TICK(k)
-#define CP_FLUSH
-#endif
-
-struct WinDesc {              // one per wave (window)
+struct WinDesc {              // one per workgroup (window)
     int64_t fwd, bwd;         // element offsets of the SoA streams: fwd[CB_FWD][S], bwd[CB_BWD][S]
     int64_t refDist;          // [nRef]
-    int64_t refOff;           // int32 [nRef + 1]: first step of each reference interval
-    int64_t chunks;           // int32 [nChunks + 2]: first step of every chunk of <= 64 steps, in order (+ 2 repeats of the last)
-    int32_t S, nRef;
+    int64_t meta;             // int32 [2 * (nChunks + lag + 4)]: per chunk {first step, n | interval << 8 | last-of-interval << 31}
+    int32_t S, nRef, nChunks, lag;
     double totalSec;
 };
 
@@ -204,197 +206,243 @@ __device__ inline double dot9(const double* a, const double* b)       // Eigen S
 
 struct WinView {
     const double *F, *B, *refDist;
-    const int32_t *refOff, *chunks;
-    int S, nRef;
+    const int32_t* lmeta;         // LDS copy of the chunk list
+    int S, nRef, nChunks, lag;
     double totalSec;
-    // LDS, step-major so that the few lanes of phase S read neighbouring words (a field-major layout put
-    // the 9 rows one bank apart: 9-way conflicts, 23 cycles per dependent add instead of 8)
-    double (*sc)[4];          // [64][4]: c0, c1, c2, dt of each step of the chunk
-    double (*sp)[9];          // [64][9]: the gradient products of each step
+    // LDS; chunk buffers step-major so that the few lanes of a sum read neighbouring words (a field-major
+    // layout put the 9 gradient rows one bank apart: 9-way conflicts)
+    double (*sc)[CB_ROWS][5];     // [4][rows][5]: a*dt (x, y, z), dt of each step, pad (odd row pitch: a pitch of 4 doubles
+                                  //                puts every 4th lane of a store on the same banks)     PF -> V, PF
+    double (*sv)[CB_ROWS][3];     // [2][rows][3]: v after each step                        V -> PF
+    double (*sm)[CB_ROWS][3];     // [2][rows][3]: dt*v of each step                        PF -> T
+    double (*sp)[CB_ROWS][9];     // [2][rows][9]: the gradient products of each step       PB -> B
+    double (*travel)[3];          // [nRef]: integrated_travel of each interval             T -> B
+    double (*dvec)[3];            // [nRef]: d_loss_d_travel of each interval               B -> PB
+    double* xch;                  // [10]: loss and gradient                                B -> everybody
 };
 
-// ---- phase S: the running sums of one chunk ----
-// A dependent fp64 operation issues ~17 cycles after its producer and an LDS read takes ~100, and the
-// compiler keeps LDS reads next to their use.  So (i) the operands of 16 steps are read into registers
-// one batch ahead (the empty asm keeps the reads above the arithmetic of the previous batch), and
-// (ii) the forward chains are skewed so that no operation of a slot waits for another one of the same
-// slot.  travel + (+0.0) is exact (travel starts at +0.0 and a sum is -0.0 only if both terms are),
-// which lets every slot have the same shape; the pending products are flushed, oldest first, at the
-// end of the chunk.
-#define CB_BATCH 16
+// ---- the running sums of one chunk ----
+// An LDS read takes ~100 cycles and the compiler keeps LDS reads next to their use, so the operands of
+// a batch of steps are read into registers one batch ahead (the empty asm keeps the reads above the
+// arithmetic of the previous batch).  The batch is sized so that a wave never has more than 15 LDS
+// operations in flight: lgkmcnt is a 4-bit counter and the 16th operation stalls the wave until the
+// first one has come back -- with 16-step batches of two-operand or read + write chains that stall,
+// not the arithmetic, set the pace (34 cycles per step instead of 11).
+template <int BATCH> struct Batch { double p[BATCH]; };
 
-struct FwdBatch { double c[CB_BATCH], dt[CB_BATCH]; };
-
-__device__ inline void fwd_read(double (*sc)[4], int comp, int i0, FwdBatch& b)
+template <int STRIDE, int BATCH>
+__device__ inline void batch_read(const double* src, int i0, Batch<BATCH>& b)
 {
 #pragma unroll
-    for (int j = 0; j < CB_BATCH; j++) { b.c[j] = sc[i0 + j][comp]; b.dt[j] = sc[i0 + j][3]; }
+    for (int j = 0; j < BATCH; j++) b.p[j] = src[(i0 + j) * STRIDE];
 }
 
-// One slot = { travel += m2 ; m1' = dt[i-1] * v ; v += c[i] }: the product is consumed two slots after it was
-// issued (fp64 multiplies take about twice as long as adds here), so a slot only waits for the v chain.
-// The scheduling barrier keeps the compiler from folding the slots back into product-then-add order.
-template <bool FIRST>
-__device__ inline void fwd_steps(const FwdBatch& b, double& v, double& m1, double& m2, double& dtp, double& t)
+// acc += src[i * STRIDE] for i = 0 .. n-1, in order; with OUT also out[i * 3] = acc after every step
+template <int STRIDE, bool OUT, int BATCH>
+__device__ inline void sum_chain(const double* src, int n, double& acc, double* out)
 {
-#pragma unroll
-    for (int j = 0; j < CB_BATCH; j++) {
-        if (!(FIRST && j == 0)) { t += m2; m2 = m1; m1 = dtp * v; }
-        v = v + b.c[j];
-        dtp = b.dt[j];
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-__device__ inline void fwd_chain(double (*sc)[4], int comp, int n, double& vk, double& tk)
-{
-    double v = vk, t = tk, m1 = 0.0, m2 = 0.0, dtp = 0.0;
+    double a = acc;
     int i = 0;
-    if (n >= CB_BATCH) {                       // whole batches, operands one batch ahead (rows past the chunk are padding)
-        FwdBatch A, B;
-        fwd_read(sc, comp, 0, A);
-        fwd_read(sc, comp, CB_BATCH, B);
+    auto steps = [&](const Batch<BATCH>& b, int i0) {
+#pragma unroll
+        for (int j = 0; j < BATCH; j++) {
+            a = a + b.p[j];
+            if (OUT) out[(i0 + j) * 3] = a;
+        }
+    };
+    if (n >= BATCH) {                          // whole batches (rows past the chunk are padding)
+        Batch<BATCH> A, B;
+        batch_read<STRIDE, BATCH>(src, 0, A);
+        batch_read<STRIDE, BATCH>(src, BATCH, B);
         asm volatile("" ::: "memory");
-        fwd_steps<true>(A, v, m1, m2, dtp, t);
-        i = CB_BATCH;
-        while (i + CB_BATCH <= n) {
-            fwd_read(sc, comp, i + CB_BATCH, A);
+        steps(A, 0);
+        i = BATCH;
+        while (i + BATCH <= n) {
+            batch_read<STRIDE, BATCH>(src, i + BATCH, A);
             asm volatile("" ::: "memory");
-            fwd_steps<false>(B, v, m1, m2, dtp, t);
-            i += CB_BATCH;
-            if (i + CB_BATCH > n) break;
-            fwd_read(sc, comp, i + CB_BATCH, B);
+            steps(B, i);
+            i += BATCH;
+            if (i + BATCH > n) break;
+            batch_read<STRIDE, BATCH>(src, i + BATCH, B);
             asm volatile("" ::: "memory");
-            fwd_steps<false>(A, v, m1, m2, dtp, t);
-            i += CB_BATCH;
+            steps(A, i);
+            i += BATCH;
         }
     }
     for (; i < n; i++) {                       // the odd steps of a short chunk
-        if (i > 0) { t += m2; m2 = m1; m1 = dtp * v; }
-        v = v + sc[i][comp];
-        dtp = sc[i][3];
+        a = a + src[i * STRIDE];
+        if (OUT) out[i * 3] = a;
     }
-    t += m2;                                   // flush, oldest product first
-    t += m1;
-    t += dtp * v;
-    vk = v; tk = t;
+    acc = a;
 }
 
-struct BwdBatch { double p[CB_BATCH]; };
-
-__device__ inline void bwd_read(double (*sp)[9], int acc, int i0, BwdBatch& b)
+// The tick barrier.  __syncthreads() would do, but the compiler puts "wait for ALL memory operations" in front
+// of every s_barrier it knows about -- including the producer's stream loads for the next chunks, i.e. one trip
+// to HBM per tick (that, not arithmetic, set the pace of the first versions: 1.1 us per chunk).  Only LDS traffic
+// has to be ordered here: the streams are read-only.
+#ifdef PGORB_CALIB_PROF      // developer build (make EXTRA=-DPGORB_CALIB_PROF): cycles of work per role, block 0
+__device__ unsigned long long cb_prof[8];
+#endif
+__device__ inline void cb_tick_barrier()
 {
-#pragma unroll
-    for (int j = 0; j < CB_BATCH; j++) b.p[j] = sp[i0 + j][acc];
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+#ifdef PGORB_CALIB_PROF
+#define CP_BEGIN unsigned long long cp_w = 0, cp_t0 = __builtin_readcyclecounter(), cp_all = cp_t0
+#define CP_WORK_DONE do { cp_w += __builtin_readcyclecounter() - cp_t0; } while (0)
+#define CP_AFTER_BARRIER do { cp_t0 = __builtin_readcyclecounter(); } while (0)
+#define CP_END(role) do { if (lane == 0 && blockIdx.x == 0) { atomicAdd(&cb_prof[role], cp_w); if (role == 0) atomicAdd(&cb_prof[5], __builtin_readcyclecounter() - cp_all); } } while (0)
+#else
+#define CP_BEGIN
+#define CP_WORK_DONE
+#define CP_AFTER_BARRIER
+#define CP_END(role)
+#endif
 
-__device__ inline void bwd_chain(double (*sp)[9], int acc, int n, double& gj)
+// velocity.cc:42-180 on the prepared streams.  Every wave returns the same loss and gradient.
+// All waves run the same tick loop with the same trip count; the barrier is outside the roles.
+// Chunk metadata sits in LDS (copied once per kernel): scalar loads would share a counter with the LDS
+// reads of the sums and, returning out of order, turn each of their waits into "wait for everything".
+__device__ double cal_eval(const WinView& G, int wave, int lane, const double* x, double* grad)
 {
-    double g = gj;
-    int i = 0;
-    if (n >= CB_BATCH) {
-        BwdBatch A, B;
-        bwd_read(sp, acc, 0, A);
-        bwd_read(sp, acc, CB_BATCH, B);
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int j = 0; j < CB_BATCH; j++) g += A.p[j];
-        i = CB_BATCH;
-        while (i + CB_BATCH <= n) {
-            bwd_read(sp, acc, i + CB_BATCH, A);
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int j = 0; j < CB_BATCH; j++) g += B.p[j];
-            i += CB_BATCH;
-            if (i + CB_BATCH > n) break;
-            bwd_read(sp, acc, i + CB_BATCH, B);
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int j = 0; j < CB_BATCH; j++) g += A.p[j];
-            i += CB_BATCH;
-        }
-    }
-    for (; i < n; i++) g += sp[i][acc];
-    gj = g;
-}
-
-// velocity.cc:42-180 on the prepared streams; every lane returns the same loss and gradient.
-__device__ double cal_eval(const WinView& G, int lane, const double* x, double* grad)
-{
-    const double bg[3] = {x[0], x[1], x[2]}, bl[3] = {x[3], x[4], x[5]};
-    const int comp = lane % 3, acc = lane % 9;
-    double vk = x[6 + comp];                          // this lane's component of integrated_velocity
-    double gj = 0;                                    // this lane's gradient accumulator (index acc)
-    double result = 0;
-    CP_DECL;
-    // chunk t+1 of each stream is loaded while chunk t is worked on; the chunk starts come from a flat list
-    // (two entries ahead in SGPRs), so no address depends on a load of the same trip
-    int fi = 0, bi = 0;
-    FwdRegs fn = load_fwd(G.F, G.S, G.chunks[0] + lane);
-    BwdRegs bn = load_bwd(G.B, G.S, G.chunks[0] + lane);
-    int fnext = G.chunks[1], bnext = fnext;
-    for (int r = 0; r < G.nRef; r++) {
-        const int off = G.refOff[r], cnt = G.refOff[r + 1] - off;
-        double tk = 0;                                // this lane's component of integrated_travel
-        for (int c0 = 0; c0 < cnt; c0 += CB_CHUNK) {
-            const int n = min(CB_CHUNK, cnt - c0);
-            CP_TICK(0);
-            const FwdRegs f = fn;
-            fn = load_fwd(G.F, G.S, fnext + lane);
-            fnext = G.chunks[++fi + 1];
-            CP_TICK(1);
-            {   // phase A, lane = step (IntegrateMotion's parameter-dependent part, geometry.cc:34-45)
+    const int T = G.nChunks + G.lag;
+    auto start_of = [&](int j) { return __builtin_amdgcn_readfirstlane(G.lmeta[2 * (j < 0 ? 0 : j)]); };
+    auto word_of = [&](int j) { return __builtin_amdgcn_readfirstlane(G.lmeta[2 * (j < 0 ? 0 : j) + 1]); };
+    auto in_range = [&](int j) { return j >= 0 && j < G.nChunks; };
+    if (wave == 3) {                                      // ---- PF: a*dt of chunk t, dt*v of chunk t-2 ----
+        const double bg[3] = {x[0], x[1], x[2]}, bl[3] = {x[3], x[4], x[5]};
+        // The stream is read TWO chunks ahead (a tick is shorter than a trip to HBM): two register sets, the
+        // tick loop unrolled by two so that each set keeps its registers.
+        FwdRegs fA = load_fwd(G.F, G.S, start_of(0) + lane), fB = load_fwd(G.F, G.S, start_of(1) + lane);
+        CP_BEGIN;
+        auto tick = [&](int t, FwdRegs& fr) {
+            const int startF = start_of(t + 2);
+            // the load is unconditional (past the end it re-reads the last chunk): a load under an `if` makes the
+            // register set a phi, and the copies at the join wait for the loads just issued
+            const FwdRegs f = fr;
+            fr = load_fwd(G.F, G.S, startF + lane);
+            if (in_range(t)) {                            // IntegrateMotion's parameter-dependent part (geometry.cc:34-45)
                 const Quat q = {f.qw, f.qx, f.qy, f.qz};
                 const double lc[3] = {f.ax + bl[0], f.ay + bl[1], f.az + bl[2]};
                 double rot[3];
                 quat_rotate(q, lc, rot);
-                for (int k = 0; k < 3; k++) G.sc[lane][k] = (rot[k] + bg[k]) * f.dt;
-                G.sc[lane][3] = f.dt;
+                double (*o)[5] = G.sc[t & 3];
+                for (int k = 0; k < 3; k++) o[lane][k] = (rot[k] + bg[k]) * f.dt;
+                o[lane][3] = f.dt;
             }
-            __syncthreads();
-            CP_TICK(2);
-            // phase S: v += a*dt ; travel += dt*v  (velocity.cc:99-108)
-            fwd_chain(G.sc, comp, n, vk, tk);
-            __syncthreads();
-            CP_TICK(3);
-        }
-        const double travel[3] = {__shfl(tk, 0), __shfl(tk, 1), __shfl(tk, 2)};
-        const double tn = sqrt(dot3(travel, travel));
-        const double diff = tn - G.refDist[r];
-        result += diff * diff;
-        double d[3];
-        for (int k = 0; k < 3; k++) d[k] = ((2.0 * diff) * travel[k]) / (tn + 1e-5);
-        for (int c0 = 0; c0 < cnt; c0 += CB_CHUNK) {
-            const int n = min(CB_CHUNK, cnt - c0);
-            CP_TICK(4);
-            const BwdRegs b = bn;
-            bn = load_bwd(G.B, G.S, bnext + lane);
-            bnext = G.chunks[++bi + 1];
-            CP_TICK(5);
-            for (int k = 0; k < 3; k++) {             // phase A, lane = step (velocity.cc:133-163)
-                G.sp[lane][k] = b.c1 * d[k];
-                const double row[3] = {b.m[3 * k], b.m[3 * k + 1], b.m[3 * k + 2]};
-                G.sp[lane][3 + k] = dot3(row, d);
-                G.sp[lane][6 + k] = b.dt * d[k];
+            const int jm = t - 2;
+            if (in_range(jm)) {                           // the product of `travel += dt * v` (velocity.cc:105-106)
+                const double dt = G.sc[jm & 3][lane][3];
+                for (int k = 0; k < 3; k++) G.sm[jm & 1][lane][k] = dt * G.sv[jm & 1][lane][k];
             }
-            __syncthreads();
-            CP_TICK(6);
-            bwd_chain(G.sp, acc, n, gj);
-            __syncthreads();
-            CP_TICK(7);
+            CP_WORK_DONE;
+            cb_tick_barrier();
+            CP_AFTER_BARRIER;
+        };
+        for (int t = 0; t < T; t += 2) {
+            tick(t, fA);
+            if (t + 1 < T) tick(t + 1, fB);
         }
+        CP_END(3);
+    } else if (wave == 4) {                               // ---- PB: gradient products of chunk t-lag+1 (velocity.cc:133-163) ----
+        // lag is odd, so backward chunk jb = t - lag + 1 has the parity of t: the same two-set scheme
+        BwdRegs bA = load_bwd(G.B, G.S, start_of(0) + lane), bB = load_bwd(G.B, G.S, start_of(1) + lane);
+        CP_BEGIN;
+        auto tick = [&](int t, BwdRegs& br) {
+            const int jb = t - G.lag + 1;
+            const int startB = start_of(jb + 2), wordB = word_of(jb);
+            const BwdRegs b = br;
+            br = load_bwd(G.B, G.S, startB + lane);
+            if (in_range(jb)) {
+                const int r = (wordB >> 8) & 0x7fffff;
+                const double d[3] = {G.dvec[r][0], G.dvec[r][1], G.dvec[r][2]};
+                double (*o)[9] = G.sp[jb & 1];
+                for (int k = 0; k < 3; k++) {
+                    o[lane][k] = b.c1 * d[k];
+                    const double row[3] = {b.m[3 * k], b.m[3 * k + 1], b.m[3 * k + 2]};
+                    o[lane][3 + k] = dot3(row, d);
+                    o[lane][6 + k] = b.dt * d[k];
+                }
+            }
+            CP_WORK_DONE;
+            cb_tick_barrier();
+            CP_AFTER_BARRIER;
+        };
+        for (int t = 0; t < T; t += 2) {
+            tick(t, bA);
+            if (t + 1 < T) tick(t + 1, bB);
+        }
+        CP_END(4);
+    } else if (wave == 0) {                               // ---- V: v += a*dt (velocity.cc:99-101), every v_i kept ----
+        const int comp = lane % 3;
+        double vk = x[6 + comp];
+        CP_BEGIN;
+        for (int t = 0; t < T; t++) {
+            const int j = t - 1;
+            // three lanes only: 64 lanes storing to three words would be serialised by the LDS as 21-way conflicts
+            if (in_range(j) && lane < 3) sum_chain<5, true, 8>(&G.sc[j & 3][0][comp], word_of(j) & 0xff, vk, &G.sv[j & 1][0][comp]);
+            CP_WORK_DONE;
+            cb_tick_barrier();
+            CP_AFTER_BARRIER;
+        }
+        CP_END(0);
+    } else if (wave == 1) {                               // ---- T: travel += dt*v (velocity.cc:105-108) ----
+        const int comp = lane % 3;
+        double tk = 0;
+        CP_BEGIN;
+        for (int t = 0; t < T; t++) {
+            const int j = t - 3;
+            if (in_range(j)) {
+                const int m = word_of(j);
+                if (lane < 3) sum_chain<3, false, 16>(&G.sm[j & 1][0][comp], m & 0xff, tk, nullptr);
+                if (m < 0) {                              // last chunk of its interval
+                    if (lane < 3) G.travel[(m >> 8) & 0x7fffff][lane] = tk;
+                    tk = 0;
+                }
+            }
+            CP_WORK_DONE;
+            cb_tick_barrier();
+            CP_AFTER_BARRIER;
+        }
+        CP_END(1);
+    } else {                                              // ---- B: interval ends and the gradient sums ----
+        const int acc = lane % 9, comp = lane % 3;
+        double gj = 0, result = 0;
+        CP_BEGIN;
+        for (int t = 0; t < T; t++) {
+            const int je = t - 4, j = t - G.lag;
+            const int we = word_of(je), wj = word_of(j);
+            if (in_range(je) && we < 0) {                 // T finished an interval during the previous tick (velocity.cc:118-127)
+                const int r = (we >> 8) & 0x7fffff;
+                const double travel[3] = {G.travel[r][0], G.travel[r][1], G.travel[r][2]};
+                const double tn = sqrt(dot3(travel, travel));
+                const double diff = tn - G.refDist[r];
+                result += diff * diff;
+                if (lane < 3) G.dvec[r][lane] = ((2.0 * diff) * travel[comp]) / (tn + 1e-5);
+            }
+            if (in_range(j) && lane < 9) sum_chain<9, false, 16>(&G.sp[j & 1][0][acc], wj & 0xff, gj, nullptr);
+            CP_WORK_DONE;
+            cb_tick_barrier();
+            CP_AFTER_BARRIER;
+        }
+        CP_END(2);
+        if (lane < 9) G.xch[1 + lane] = gj;
+        if (lane == 0) G.xch[0] = result;
     }
-    CP_FLUSH;
-    for (int k = 0; k < 9; k++) grad[k] = __shfl(gj, k) / G.totalSec;
-    return result / G.totalSec;
+    __syncthreads();
+    const double fx = G.xch[0] / G.totalSec;
+    for (int k = 0; k < 9; k++) grad[k] = G.xch[1 + k] / G.totalSec;
+    __syncthreads();                                      // xch is rewritten only at the end of the next evaluation, but keep the waves together
+    return fx;
 }
 
 // LBFGS.h:78-181 with Backtracking/Armijo (LineSearch.h:41-109); n = 9, m = 6, ftol 1e-4, 20 trials.
-// Wave-uniform: every lane carries the same solver state.
-__device__ int cal_lbfgs(const WinView& G, int lane, double* x, double* fx_out, double epsilon, int max_iterations)
+// Every lane of every wave carries the same solver state (the evaluations return identical doubles to all),
+// so all three waves take the same branches and meet at the same barriers.
+__device__ int cal_lbfgs(const WinView& G, int wave, int lane, double* x, double* fx_out, double epsilon, int max_iterations)
 {
     double s[CB_M][9], y[CB_M][9], ysh[CB_M], alpha[CB_M], xp[9], grad[9], gradp[9], drt[9];
-    double fx = cal_eval(G, lane, x, grad);
+    double fx = cal_eval(G, wave, lane, x, grad);
     double xnorm = sqrt(dot9(x, x)), gnorm = sqrt(dot9(grad, grad));
     if (gnorm <= epsilon * fmax(xnorm, 1.0)) { *fx_out = fx; return 1; }
     for (int i = 0; i < 9; i++) drt[i] = -grad[i];
@@ -405,7 +453,7 @@ __device__ int cal_lbfgs(const WinView& G, int lane, double* x, double* fx_out, 
         const double fx_init = fx, dg_init = dot9(grad, drt), dg_test = 1e-4 * dg_init;
         for (int iter = 0; iter < 20; iter++) {
             for (int i = 0; i < 9; i++) x[i] = xp[i] + step * drt[i];
-            fx = cal_eval(G, lane, x, grad);
+            fx = cal_eval(G, wave, lane, x, grad);
             if (!(fx > fx_init + step * dg_test)) break;
             if (step < 1e-20) { *fx_out = fx; return -2; }        // the reference throws here
             if (step > 1e+20) { *fx_out = fx; return -3; }
@@ -440,31 +488,62 @@ __device__ int cal_lbfgs(const WinView& G, int lane, double* x, double* fx_out, 
 }
 
 // mode 0: L-BFGS from x = 0 (fit_motion.cc:186-190).  mode 1: one evaluation at xin (tests).
-__global__ __launch_bounds__(64) void k_calibrate_windows(const WinDesc* __restrict__ wins, const double* __restrict__ dbl,
-                                                        const int32_t* __restrict__ i32, int mode, const double* __restrict__ xin,
-                                                        int max_iterations, double* __restrict__ xout, double* __restrict__ fxout,
-                                                        double* __restrict__ gradout, int32_t* __restrict__ niter)
+__global__ __launch_bounds__(64 * CB_WAVES) void k_calibrate_windows(const WinDesc* __restrict__ wins, const double* __restrict__ dbl,
+                                                                   const int32_t* __restrict__ i32, int mode, const double* __restrict__ xin,
+                                                                   int max_iterations, double* __restrict__ xout, double* __restrict__ fxout,
+                                                                   double* __restrict__ gradout, int32_t* __restrict__ niter)
 {
-    __shared__ double sc[CB_CHUNK + 2 * CB_BATCH][4];      // + rows the one-batch-ahead reads may touch
-    __shared__ double sp[CB_CHUNK + 2 * CB_BATCH][9];
+    extern __shared__ __attribute__((aligned(16))) double cb_lds[];
     const WinDesc D = wins[blockIdx.x];
-    const int lane = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / 64), lane = threadIdx.x % 64;
     const size_t w = blockIdx.x;
     WinView G;
-    G.F = dbl + D.fwd; G.B = dbl + D.bwd; G.refDist = dbl + D.refDist; G.refOff = i32 + D.refOff; G.chunks = i32 + D.chunks;
-    G.S = D.S; G.nRef = D.nRef; G.totalSec = D.totalSec; G.sc = sc; G.sp = sp;
+    G.F = dbl + D.fwd; G.B = dbl + D.bwd; G.refDist = dbl + D.refDist;
+    G.S = D.S; G.nRef = D.nRef; G.nChunks = D.nChunks; G.lag = D.lag; G.totalSec = D.totalSec;
+    double* l = cb_lds;
+    G.sc = (double (*)[CB_ROWS][5])l;      l += 4 * CB_ROWS * 5;
+    G.sv = (double (*)[CB_ROWS][3])l;      l += 2 * CB_ROWS * 3;
+    G.sm = (double (*)[CB_ROWS][3])l;      l += 2 * CB_ROWS * 3;
+    G.sp = (double (*)[CB_ROWS][9])l;      l += 2 * CB_ROWS * 9;
+    G.xch = l;                             l += 16;
+    G.travel = (double (*)[3])l;           l += 3 * (size_t)D.nRef;
+    G.dvec = (double (*)[3])l;             l += 3 * (size_t)D.nRef;
+    int32_t* lm = (int32_t*)l;
+    for (int i = threadIdx.x; i < 2 * (D.nChunks + D.lag + 4); i += 64 * CB_WAVES) lm[i] = i32[D.meta + i];
+    G.lmeta = lm;
+    // Roles by placement: five waves on four SIMDs means one SIMD carries two.  The two running sums that wait
+    // most (T, B: one dependent add per step) share it; V, which sets the pace, and the two producers get a SIMD
+    // each.  HW_ID[5:4] is the SIMD the wave landed on.
+    int32_t* simdOf = lm + 2 * (D.nChunks + D.lag + 4);
+    if (lane == 0) simdOf[wave] = __builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11));
+    __syncthreads();
+    int role;
+    {
+        int cnt[4] = {0, 0, 0, 0}, shared = 0;
+        for (int i = 0; i < CB_WAVES; i++) cnt[simdOf[i] & 3]++;
+        while (shared < 3 && cnt[shared] < 2) shared++;
+        int pair = 0, single = 0;
+        role = 0;
+        for (int i = 0; i < CB_WAVES; i++) {
+            const bool inPair = (simdOf[i] & 3) == shared && pair < 2;
+            const int r = inPair ? 1 + pair : (single == 0 ? 0 : 2 + single);      // pair -> T (1), B (2); singles -> V (0), PF (3), PB (4)
+            if (inPair) pair++; else single++;
+            if (i == wave) role = r;
+        }
+        role = __builtin_amdgcn_readfirstlane(role);
+    }
     double x[9], g[9], fx;
     if (mode == 1) {
         for (int i = 0; i < 9; i++) x[i] = xin[9 * w + i];
-        fx = cal_eval(G, lane, x, g);
-        if (lane < 9) gradout[9 * w + lane] = g[lane];
-        if (lane == 0) fxout[w] = fx;
+        fx = cal_eval(G, role, lane, x, g);
+        if (wave == 0 && lane < 9) gradout[9 * w + lane] = g[lane];
+        if (wave == 0 && lane == 0) fxout[w] = fx;
         return;
     }
     for (int i = 0; i < 9; i++) x[i] = 0.0;
-    const int it = cal_lbfgs(G, lane, x, &fx, 1e-5, max_iterations);
-    if (lane < 9) xout[9 * w + lane] = x[lane];
-    if (lane == 0) { fxout[w] = fx; niter[w] = it; }
+    const int it = cal_lbfgs(G, role, lane, x, &fx, 1e-5, max_iterations);
+    if (wave == 0 && lane < 9) xout[9 * w + lane] = x[lane];
+    if (wave == 0 && lane == 0) { fxout[w] = fx; niter[w] = it; }
 }
 
 // ---- host: pack, launch ----
@@ -519,18 +598,25 @@ void pack_window(const Window& W, const Imu& M, const double* ref_v, Packed& P)
     D.fwd = (int64_t)P.dbl.size();     P.dbl.resize(P.dbl.size() + (size_t)D.S * CB_FWD, 0.0);
     D.bwd = (int64_t)P.dbl.size();     P.dbl.resize(P.dbl.size() + (size_t)D.S * CB_BWD, 0.0);
     D.refDist = (int64_t)P.dbl.size(); P.dbl.insert(P.dbl.end(), rd.begin(), rd.end());
-    D.refOff = (int64_t)P.i32.size();
-    int32_t off = 0;
-    for (int32_t c : W.refCnt) { P.i32.push_back(off); off += c; }
-    P.i32.push_back(off);
-    D.chunks = (int64_t)P.i32.size();
-    off = 0;
-    int32_t last = 0;
-    for (int32_t c : W.refCnt) {
-        for (int32_t c0 = 0; c0 < c; c0 += CB_CHUNK) { last = off + c0; P.i32.push_back(last); }
+    // chunk list: {first step, n | interval << 8 | last-of-interval << 31}; intervals without steps have no chunk
+    // (their loss term and gradient contribution are exactly +0: travel = 0, reference_distance = 0)
+    D.meta = (int64_t)P.i32.size();
+    int32_t off = 0, last = 0, nchunks = 0, maxPer = 0;
+    for (size_t r = 0; r < W.refCnt.size(); r++) {
+        const int32_t c = W.refCnt[r];
+        int32_t per = 0;
+        for (int32_t c0 = 0; c0 < c; c0 += CB_CHUNK, per++, nchunks++) {
+            const int32_t nn = std::min(CB_CHUNK, c - c0);
+            last = off + c0;
+            P.i32.push_back(last);
+            P.i32.push_back(nn | ((int32_t)r << 8) | (c0 + CB_CHUNK >= c ? (int32_t)0x80000000 : 0));
+        }
+        maxPer = std::max(maxPer, per);
         off += c;
     }
-    P.i32.push_back(last); P.i32.push_back(last); P.i32.push_back(last);     // the prefetcher reads up to two chunks past the end
+    D.nChunks = nchunks;
+    D.lag = (maxPer + CB_LAG_EXTRA) | 1;                                                     // odd: see the producers
+    for (int i = 0; i < D.lag + 4; i++) { P.i32.push_back(last); P.i32.push_back(0); }      // what the prefetcher reads past the end
     for (size_t i = 0; i < n; i++) {
         for (int f = 0; f < CB_FWD; f++) P.dbl[D.fwd + (size_t)f * D.S + i] = fwd[i * CB_FWD + f];
         for (int f = 0; f < CB_BWD; f++) P.dbl[D.bwd + (size_t)f * D.S + i] = bwd[i * CB_BWD + f];
@@ -563,7 +649,12 @@ int run_windows(pgorb_ctx* c, const Packed& P, int mode, const double* xin, int 
         !dXin.put(xin, xin ? nw * 72 : 0) || !dX.make(nw * 72) || !dF.make(nw * 8) || !dGr.make(nw * 72) || !dNi.make(nw * 4))
         return pg_ctx_fail(c, PGORB_E_HIP, "device allocation / upload for the calibration windows failed");
     const double t1 = now_s();
-    hipLaunchKernelGGL(k_calibrate_windows, dim3((unsigned)nw), dim3(64), 0, 0, (const WinDesc*)dW.p, (const double*)dD.p, (const int32_t*)dI.p,
+    size_t maxRef = 1, maxMeta = 1;
+    for (const WinDesc& D : P.wins) { maxRef = std::max(maxRef, (size_t)D.nRef); maxMeta = std::max(maxMeta, (size_t)(D.nChunks + D.lag + 4)); }
+    const size_t lds = (CB_ROWS * (4 * 5 + 2 * 3 + 2 * 3 + 2 * 9) + 16 + 6 * maxRef + maxMeta + 4) * sizeof(double);
+    if (lds > 160 * 1024) return pg_ctx_fail(c, PGORB_E_LIMIT, "locations_batch_size too large for the calibration workgroup's LDS");
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_calibrate_windows), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_calibrate_windows, dim3((unsigned)nw), dim3(64 * CB_WAVES), lds, 0, (const WinDesc*)dW.p, (const double*)dD.p, (const int32_t*)dI.p,
                        mode, (const double*)dXin.p, max_iters, (double*)dX.p, (double*)dF.p, (double*)dGr.p, (int32_t*)dNi.p);
     if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "k_calibrate_windows failed");
 #ifdef PGORB_CALIB_PROF
@@ -571,8 +662,7 @@ int run_windows(pgorb_ctx* c, const Packed& P, int mode, const double* xin, int 
         unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(cb_prof), sizeof(h));
         (void)hipMemcpyToSymbol(HIP_SYMBOL(cb_prof), z, sizeof(z));
-        fprintf(stderr, "[calib prof] cycles: rest/interval-end %llu | F: cursor+issue %llu, phase A %llu, phase S %llu | B: wait+d %llu, cursor+issue %llu, phase A %llu, phase S %llu\n",
-                h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+        fprintf(stderr, "[calib prof] work cycles per role: V %llu, T %llu, B %llu, PF %llu, PB %llu; loop %llu\n", h[0], h[1], h[2], h[3], h[4], h[5]);
     }
 #endif
     if (timing_on())
