@@ -7,10 +7,10 @@
 // one loss evaluation integrates every IMU sample of the window in time order
 // (src/geometry/geometry.cc:24-53), ~10^4 dependent steps, and the fits run one after another.
 //
-// Here: windows are independent, so ONE WAVE PER WINDOW runs the whole solver, all windows at once.
+// Here: windows are independent, so ONE WORKGROUP PER WINDOW runs the whole solver, all windows at once.
 // Every double is produced by the same operation on the same operands as in the reference (the sums
 // stay sequential in time: reordering them changes the doubles and the JSON is diffed bit for
-// bit); inside a window the lanes share out what is independent per step (see the device section).
+// bit); inside a window five waves form a pipeline over chunks of 64 steps (see the device section).
 // What does not depend on the nine parameters is hoisted out of the solver and computed once per
 // window on the host, with the same operations in the same order as the reference's loop body:
 //   forward stream  (8 doubles / step): dt, orientation BEFORE the step (w,x,y,z), raw acceleration
@@ -19,7 +19,7 @@
 // (RotationMotionToQuaternion's sin/cos therefore run in the host libm, as in the reference.)
 // Streams are structure-of-arrays per window, so a chunk of 64 steps of one field is one coalesced
 // 512-byte request.  fp64 add/mul/div/sqrt are IEEE on both sides, contraction is off (Makefile),
-// so a wave reproduces the CPU run of its window bit for bit.
+// so a workgroup reproduces the CPU run of its window bit for bit.
 //
 // Eigen reduction orders (the parity contract shared with oracle/calib_oracle.c, E0-E5 there):
 // 3-vectors t0 + (t1 + t2); the solver's 9-vectors in SSE2 packet order.
