@@ -31,7 +31,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <memory>
+#include <thread>
 #include <vector>
 
 int pg_ctx_fail(pgorb_ctx* c, int code, const char* msg);
@@ -550,54 +553,22 @@ __global__ __launch_bounds__(64 * CB_WAVES) void k_calibrate_windows(const WinDe
 
 struct Packed {
     std::vector<WinDesc> wins;
-    std::vector<double> dbl;
+    std::unique_ptr<double[]> dbl;       // not value-initialised: every element is written by fill_window (864 MB for a one-hour ride)
+    size_t dblCount = 0;
     std::vector<int32_t> i32;
 };
 
-// Streams of one window, in the order of velocity.cc:62-168 (both loops of a reference interval walk the
-// same steps; the quantities below depend on the data only).
-void window_streams(const Window& W, const Imu& M, const double* ref_v, std::vector<double>& fwd, std::vector<double>& bwd,
-                    std::vector<double>& refDist, double* totalSec)
+// Sizes and the chunk list of one window (cheap, serial); the streams are filled in by fill_window.
+void layout_window(const Window& W, Packed& P)
 {
-    Quat q = {1.0, 0.0, 0.0, 0.0};
-    double twr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    int64_t total_usec = 0;
-    fwd.resize(W.steps.size() * CB_FWD); bwd.resize(W.steps.size() * CB_BWD);
-    refDist.assign(W.refCnt.size(), 0.0);
-    for (size_t i = 0; i < W.steps.size(); i++) {
-        const Step& S = W.steps[i];
-        const double* rr = M.rot + 3 * (size_t)M.evRot[S.event];
-        const double* aa = M.acc + 3 * (size_t)M.evAcc[S.event];
-        const double dt = (double)S.usec * 1e-6;
-        double* f = &fwd[i * CB_FWD];
-        f[0] = dt; f[1] = q.w; f[2] = q.x; f[3] = q.y; f[4] = q.z; f[5] = aa[0]; f[6] = aa[1]; f[7] = aa[2];
-        refDist[W.refIdx[i]] += dt * ref_v[W.refIdx[i]];
-        q = quat_mul(q, rotation_motion_to_quaternion(rr[0], rr[1], rr[2], dt));
-        total_usec += S.usec;
-        const double total_sec = (double)total_usec * 1e-6;
-        double R[9];
-        quat_matrix(q, R);
-        for (int k = 0; k < 9; k++) twr[k] += R[k] * dt;
-        double* b = &bwd[i * CB_BWD];
-        b[0] = total_sec * dt; b[1] = dt;
-        for (int k = 0; k < 3; k++) { b[2 + 3 * k] = dt * twr[k]; b[3 + 3 * k] = dt * twr[3 + k]; b[4 + 3 * k] = dt * twr[6 + k]; }
-    }
-    *totalSec = (double)total_usec * 1e-6;
-}
-
-
-// One window's streams as structure-of-arrays (a chunk of 64 consecutive steps of one field = 512 contiguous bytes).
-void pack_window(const Window& W, const Imu& M, const double* ref_v, Packed& P)
-{
-    std::vector<double> fwd, bwd, rd;
     WinDesc D;
-    window_streams(W, M, ref_v, fwd, bwd, rd, &D.totalSec);
     const size_t n = W.steps.size();
     D.S = (int32_t)((n + CB_CHUNK - 1) / CB_CHUNK * CB_CHUNK + CB_CHUNK);   // a chunk load may start at the last step
     D.nRef = (int32_t)W.refCnt.size();
-    D.fwd = (int64_t)P.dbl.size();     P.dbl.resize(P.dbl.size() + (size_t)D.S * CB_FWD, 0.0);
-    D.bwd = (int64_t)P.dbl.size();     P.dbl.resize(P.dbl.size() + (size_t)D.S * CB_BWD, 0.0);
-    D.refDist = (int64_t)P.dbl.size(); P.dbl.insert(P.dbl.end(), rd.begin(), rd.end());
+    D.totalSec = 0;
+    D.fwd = (int64_t)P.dblCount;     P.dblCount += (size_t)D.S * CB_FWD;
+    D.bwd = (int64_t)P.dblCount;     P.dblCount += (size_t)D.S * CB_BWD;
+    D.refDist = (int64_t)P.dblCount; P.dblCount += (size_t)D.nRef;
     // chunk list: {first step, n | interval << 8 | last-of-interval << 31}; intervals without steps have no chunk
     // (their loss term and gradient contribution are exactly +0: travel = 0, reference_distance = 0)
     D.meta = (int64_t)P.i32.size();
@@ -617,16 +588,61 @@ void pack_window(const Window& W, const Imu& M, const double* ref_v, Packed& P)
     D.nChunks = nchunks;
     D.lag = (maxPer + CB_LAG_EXTRA) | 1;                                                     // odd: see the producers
     for (int i = 0; i < D.lag + 4; i++) { P.i32.push_back(last); P.i32.push_back(0); }      // what the prefetcher reads past the end
-    for (size_t i = 0; i < n; i++) {
-        for (int f = 0; f < CB_FWD; f++) P.dbl[D.fwd + (size_t)f * D.S + i] = fwd[i * CB_FWD + f];
-        for (int f = 0; f < CB_BWD; f++) P.dbl[D.bwd + (size_t)f * D.S + i] = bwd[i * CB_BWD + f];
-    }
     P.wins.push_back(D);
+}
+
+// Streams of one window as structure-of-arrays (a chunk of 64 consecutive steps of one field = 512 contiguous
+// bytes), in the order of velocity.cc:62-168: both loops of a reference interval walk the same steps, and the
+// quantities below depend on the data only.
+void fill_window(const Window& W, const Imu& M, const double* ref_v, WinDesc& D, double* dbl)
+{
+    double* F = dbl + D.fwd; double* B = dbl + D.bwd; double* refDist = dbl + D.refDist;
+    const size_t S = (size_t)D.S, n = W.steps.size();
+    for (int r = 0; r < D.nRef; r++) refDist[r] = 0.0;
+    for (size_t i = n; i < S; i++) {                       // padding rows the prefetcher may read
+        for (int f = 0; f < CB_FWD; f++) F[f * S + i] = 0.0;
+        for (int f = 0; f < CB_BWD; f++) B[f * S + i] = 0.0;
+    }
+    Quat q = {1.0, 0.0, 0.0, 0.0};
+    double twr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t total_usec = 0;
+    for (size_t i = 0; i < n; i++) {
+        const Step& St = W.steps[i];
+        const double* rr = M.rot + 3 * (size_t)M.evRot[St.event];
+        const double* aa = M.acc + 3 * (size_t)M.evAcc[St.event];
+        const double dt = (double)St.usec * 1e-6;
+        F[i] = dt; F[S + i] = q.w; F[2 * S + i] = q.x; F[3 * S + i] = q.y; F[4 * S + i] = q.z;
+        F[5 * S + i] = aa[0]; F[6 * S + i] = aa[1]; F[7 * S + i] = aa[2];
+        refDist[W.refIdx[i]] += dt * ref_v[W.refIdx[i]];
+        q = quat_mul(q, rotation_motion_to_quaternion(rr[0], rr[1], rr[2], dt));
+        total_usec += St.usec;
+        const double total_sec = (double)total_usec * 1e-6;
+        double R[9];
+        quat_matrix(q, R);
+        for (int k = 0; k < 9; k++) twr[k] += R[k] * dt;
+        B[i] = total_sec * dt; B[S + i] = dt;
+        for (int k = 0; k < 3; k++) {
+            B[(2 + 3 * k) * S + i] = dt * twr[k]; B[(3 + 3 * k) * S + i] = dt * twr[3 + k]; B[(4 + 3 * k) * S + i] = dt * twr[6 + k];
+        }
+    }
+    D.totalSec = (double)total_usec * 1e-6;
 }
 
 void pack_windows(const std::vector<Window>& wins, const Imu& M, const std::vector<const double*>& ref_v, Packed& P)
 {
-    for (size_t w = 0; w < wins.size(); w++) pack_window(wins[w], M, ref_v[w], P);
+    for (const Window& W : wins) layout_window(W, P);
+    P.dbl.reset(new double[P.dblCount ? P.dblCount : 1]);
+    // the windows are independent: one host thread per core, windows handed out by an atomic counter
+    std::atomic<size_t> next(0);
+    auto work = [&]() {
+        for (size_t w = next++; w < wins.size(); w = next++) fill_window(wins[w], M, ref_v[w], P.wins[w], P.dbl.get());
+    };
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t nthreads = std::min<size_t>(wins.size(), std::max(1u, std::min(hw ? hw : 1u, 32u)));
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < nthreads; t++) pool.emplace_back(work);
+    work();
+    for (std::thread& t : pool) t.join();
 }
 
 struct DevBuf {
@@ -645,7 +661,7 @@ int run_windows(pgorb_ctx* c, const Packed& P, int mode, const double* xin, int 
     if (hipSetDevice(pg_ctx_device(c)) != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "hipSetDevice failed");
     const size_t nw = P.wins.size();
     DevBuf dW, dD, dI, dXin, dX, dF, dGr, dNi;
-    if (!dW.put(P.wins.data(), nw * sizeof(WinDesc)) || !dD.put(P.dbl.data(), P.dbl.size() * 8) || !dI.put(P.i32.data(), P.i32.size() * 4) ||
+    if (!dW.put(P.wins.data(), nw * sizeof(WinDesc)) || !dD.put(P.dbl.get(), P.dblCount * 8) || !dI.put(P.i32.data(), P.i32.size() * 4) ||
         !dXin.put(xin, xin ? nw * 72 : 0) || !dX.make(nw * 72) || !dF.make(nw * 8) || !dGr.make(nw * 72) || !dNi.make(nw * 4))
         return pg_ctx_fail(c, PGORB_E_HIP, "device allocation / upload for the calibration windows failed");
     const double t1 = now_s();
@@ -666,7 +682,7 @@ int run_windows(pgorb_ctx* c, const Packed& P, int mode, const double* xin, int 
     }
 #endif
     if (timing_on())
-        fprintf(stderr, "[calib] %zu windows, %.1f MB of streams: upload %.3f s, solver kernel %.1f us\n", nw, P.dbl.size() * 8e-6, t1 - t0, (now_s() - t1) * 1e6);
+        fprintf(stderr, "[calib] %zu windows, %.1f MB of streams: upload %.3f s, solver kernel %.1f us\n", nw, P.dblCount * 8e-6, t1 - t0, (now_s() - t1) * 1e6);
     bool ok = hipMemcpy(fx, dF.p, sizeof(double) * nw, hipMemcpyDeviceToHost) == hipSuccess;
     if (mode == 1) ok = ok && hipMemcpy(grad, dGr.p, sizeof(double) * 9 * nw, hipMemcpyDeviceToHost) == hipSuccess;
     else ok = ok && hipMemcpy(x, dX.p, sizeof(double) * 9 * nw, hipMemcpyDeviceToHost) == hipSuccess &&
@@ -738,7 +754,7 @@ int pgorb_calibrator_eval(pgorb_ctx* c, const double* gps_velocity, const int64_
     std::vector<Window> wins(1);
     make_window(gps_time_usec, n_gps, M, wins[0]);
     Packed P;
-    pack_window(wins[0], M, gps_velocity, P);
+    pack_windows(wins, M, std::vector<const double*>(1, gps_velocity), P);
     P.wins.resize(n_points, P.wins[0]);                      // the same calibrator (shared streams) at n_points parameter vectors
     return run_windows(c, P, 1, xin, 0, nullptr, fx, grad, nullptr);
 }
