@@ -175,6 +175,8 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
     // --- resize tables ---
     std::vector<uint8_t> tab;
     struct TabOff { size_t xofs, xofs1, xalpha, yofs, ybeta, qtab, yrel, qtab2, rowgrp, tilex; int cpr, prows; bool hasQ, hasY, hasQ2; } toff[PG_MAXL];
+    int pyrGpw = 2;                                                   // 4-row groups per wave of the LDS-staged resize
+    if (const char* e = getenv("PGORB_PYR_TILE_ROWS")) { const int r = atoi(e); if (r == 16 || r == 32 || r == 64) pyrGpw = r / 16; }
     for (int l = 1; l < L; l++) {
         std::vector<int32_t> xo, xo1, yo; std::vector<int16_t> xa, yb;
         build_resize_tables(g[l - 1].w, g[l - 1].h, g[l].w, g[l].h, xo, xo1, xa, yo, yb);
@@ -240,7 +242,7 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
         }
         toff[l].hasY = oky;
         toff[l].yrel = put(yr.data(), yr.size());
-        std::vector<PgRowGrp> rg((g[l].h + 3) / 4 + 1);               // + one record of slack (pairs are loaded)
+        std::vector<PgRowGrp> rg((g[l].h + 3) / 4 + 4);               // + records of slack (a wave loads its 1, 2 or 4 records at once)
         for (size_t gi = 0; gi < rg.size(); gi++) {
             PgRowGrp& R = rg[gi];
             memset(&R, 0, sizeof(R));
@@ -256,7 +258,8 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
         // rectangle (16-byte chunks from a 16-aligned first column) through LDS
         toff[l].cpr = 0; toff[l].prows = 0;
         {
-            const int ntx = (g[l].w + 255) / 256, nty = (g[l].h + 31) / 32, ngrp = (g[l].h + 3) / 4;
+            const int tileRows = 16 * pyrGpw, gpt = 4 * pyrGpw;         // rows / 4-row groups per tile
+            const int ntx = (g[l].w + 255) / 256, nty = (g[l].h + tileRows - 1) / tileRows, ngrp = (g[l].h + 3) / 4;
             std::vector<int32_t> tx0(ntx, 0);
             int span = 0, rows = 0;
             if (ok2 && oky) {
@@ -266,11 +269,11 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
                     span = std::max(span, q2[ql].xb + 8 - tx0[tx]);
                 }
                 for (int ty = 0; ty < nty; ty++) {
-                    const int gf = 8 * ty, gl = std::min(8 * ty + 7, ngrp - 1);
+                    const int gf = gpt * ty, gl = std::min(gpt * ty + gpt - 1, ngrp - 1);
                     rows = std::max(rows, rg[gl].sFirst + 6 - rg[gf].sFirst);
                 }
                 const int cpr = (span + 4 + 15) / 16;
-                if (cpr <= 32 && (size_t)rows * cpr * 16 <= 20 * 1024) { toff[l].cpr = cpr; toff[l].prows = rows; }
+                if (cpr <= 32 && (size_t)rows * cpr * 16 <= (size_t)10 * 1024 * pyrGpw) { toff[l].cpr = cpr; toff[l].prows = rows; }
             }
             toff[l].tilex = put(tx0.data(), tx0.size() * 4);
         }
@@ -341,7 +344,7 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
             V.yrel = toff[l].hasY ? (t + toff[l].yrel) : nullptr;
             V.rowgrp = (const PgRowGrp*)(t + toff[l].rowgrp);
             V.tilex = (const int32_t*)(t + toff[l].tilex);
-            V.pyrCpr = toff[l].cpr; V.pyrRows = toff[l].prows;
+            V.pyrCpr = toff[l].cpr; V.pyrRows = toff[l].prows; V.pyrGpw = pyrGpw;
             V.qtab2 = toff[l].hasQ2 ? (const PgQuadTab2*)(t + toff[l].qtab2) : nullptr;
         }
     }

@@ -55,7 +55,9 @@ struct PgLevel {
     const PgRowGrp* rowgrp;   // [ceil(h/4)] the same, one 32-byte record per group of 4 rows (one scalar load)
     const int32_t* tilex;     // [ceil(w/256)] 16-aligned first source column of each 256-column tile (LDS-staged variant)
     int32_t  pyrCpr;          // 16-byte chunks per staged source row (0: the LDS-staged variant does not apply)
-    int32_t  pyrRows;         // source rows staged per 256 x 32 tile
+    int32_t  pyrRows;         // source rows staged per tile
+    int32_t  pyrGpw;          // 4-row groups per wave: the tile is 256 columns x 16 * pyrGpw rows (2 = the 256 x 32 default;
+                              // PGORB_PYR_TILE_ROWS = 16 | 32 | 64 at plan time, for the tile-size sweep in DESIGN.md)
     // cell grid (ORBextractor.cc:781-787)
     int32_t  nCols, nRows, wCell, hCell, cellBase;
     // quadtree (ORBextractor.cc:539-563)

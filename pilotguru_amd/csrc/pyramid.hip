@@ -348,6 +348,10 @@ __global__ __launch_bounds__(256) void k_pyr_resize_rows4(
 typedef __attribute__((address_space(1))) const void* pg_gptr_t;
 typedef __attribute__((address_space(3))) void* pg_lptr_t;
 
+// GPW = 4-row groups per wave: the tile is 256 columns x 16 * GPW rows.  GPW = 2 is the shipped shape; 1 and 4
+// exist for the tile-size sweep (PGORB_PYR_TILE_ROWS) and load their row-group records with plain
+// scalar loads.
+template <int GPW>
 __global__ __launch_bounds__(256) void k_pyr_resize_rows4_lds(
     const uint8_t* __restrict__ src, int spitch, int64_t sfstride, int sh,
     uint8_t* __restrict__ dst, int dpitch, int64_t dfstride, int dw, int dh,
@@ -362,16 +366,21 @@ __global__ __launch_bounds__(256) void k_pyr_resize_rows4_lds(
     const int lane = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
     const int quad = tx * 64 + lane;
     const int ngrp = (dh + 3) >> 2;
-    if (ty * 8 >= ngrp) return;                                        // whole workgroup: padding tile
-    const int grp = ty * 8 + wv * 2;                                   // this wave: groups grp, grp + 1
+    if (ty * (4 * GPW) >= ngrp) return;                                // whole workgroup: padding tile
+    const int grp = ty * (4 * GPW) + wv * GPW;                         // this wave: groups grp .. grp + GPW - 1
     const int dy0 = grp * 4;
     const PgQuadTab2 T = qtab[min(quad, ((dw + 3) >> 2) - 1)];
     const PgRowGrp* rp = rowgrp + min(grp, ngrp - 1);
     typedef uint32_t pg_u32x16 __attribute__((ext_vector_type(16)));
     pg_u32x16 rr;
     int sTile, x0a;
-    asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dword %1, %4, 0x0\n\ts_load_dword %2, %5, 0x0\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(rr), "=&s"(sTile), "=&s"(x0a) : "s"(rp), "s"(rowgrp + ty * 8), "s"(tilex + tx) : "memory");
+    if (GPW == 2)
+        asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dword %1, %4, 0x0\n\ts_load_dword %2, %5, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(rr), "=&s"(sTile), "=&s"(x0a) : "s"(rp), "s"(rowgrp + ty * 8), "s"(tilex + tx) : "memory");
+    else {
+        sTile = rowgrp[ty * (4 * GPW)].sFirst;
+        x0a = tilex[tx];
+    }
     // stage the tile's source rectangle: cpr lanes per row, 64 / cpr rows per instruction
     {
         const int pitch = cpr * 16, rowsPer = 64 / cpr;
@@ -388,19 +397,28 @@ __global__ __launch_bounds__(256) void k_pyr_resize_rows4_lds(
     }
     __syncthreads();
     if (quad * 4 >= dw || dy0 >= dh) return;
-    const uint32_t ra[8] = {rr[0], rr[1], rr[2], rr[3], rr[4], rr[5], rr[6], rr[7]};
-    const uint32_t rb[8] = {rr[8], rr[9], rr[10], rr[11], rr[12], rr[13], rr[14], rr[15]};
-    const PgRowGrp R0 = pyr_unpack_group(ra), R1 = pyr_unpack_group(rb);
-    const bool second = dy0 + 4 < dh;
+    PgRowGrp RG[GPW];
+    if (GPW == 2) {
+        const uint32_t ra[8] = {rr[0], rr[1], rr[2], rr[3], rr[4], rr[5], rr[6], rr[7]};
+        const uint32_t rb[8] = {rr[8], rr[9], rr[10], rr[11], rr[12], rr[13], rr[14], rr[15]};
+        RG[0] = pyr_unpack_group(ra); RG[GPW - 1] = pyr_unpack_group(rb);
+    } else {
+#pragma unroll
+        for (int gi = 0; gi < GPW; gi++) {
+            const uint32_t* rw = reinterpret_cast<const uint32_t*>(rp + gi);
+            const uint32_t ra[8] = {rw[0], rw[1], rw[2], rw[3], rw[4], rw[5], rw[6], rw[7]};
+            RG[gi] = pyr_unpack_group(ra);
+        }
+    }
     const int o = T.xb - x0a;                                          // window offset in a staged row
     const uint8_t* lb = pyr_lds + (o & ~3);
     const uint32_t sh3 = (uint32_t)(o & 3);
     const int pitch = cpr * 16;
     uint8_t* dbase = dst + (int64_t)blockIdx.z * dfstride + quad * 4;
 #pragma unroll
-    for (int gi = 0; gi < 2; gi++) {
-        if (gi == 1 && !second) break;
-        const PgRowGrp& R = gi ? R1 : R0;
+    for (int gi = 0; gi < GPW; gi++) {
+        if (gi > 0 && dy0 + 4 * gi >= dh) break;
+        const PgRowGrp& R = RG[gi];
         const int rel = R.sFirst - sTile;
         PgU2 w[6];
 #pragma unroll
@@ -420,13 +438,17 @@ void pg_launch_pyramid_level(const PgPlan& P, int level, int nframes, hipStream_
     const PgLevel& D = P.lvl[level];
     static const bool noLds = getenv("PGORB_PYR_NO_LDS") != nullptr;
     if (D.qtab2 && D.yrel && D.pyrCpr > 0 && S.pitch % 16 == 0 && !noLds) {
-        const int nx = (D.w + 255) / 256, ny = (D.h + 31) / 32;
+        const int tileRows = 16 * D.pyrGpw;
+        const int nx = (D.w + 255) / 256, ny = (D.h + tileRows - 1) / tileRows;
         const int tiles = (nx * ny + 7) & ~7;
         const uint32_t nxMagic = nx > 1 ? (uint32_t)(((1ull << 32) / (uint64_t)nx) + 1ull) : 0u;
         const int cprInv = 65536 / D.pyrCpr + 1;
+        const size_t lds = (size_t)D.pyrRows * D.pyrCpr * 16;
         dim3 block(64, 4), grid(tiles, 1, nframes);
-        hipLaunchKernelGGL(k_pyr_resize_rows4_lds, grid, block, (size_t)D.pyrRows * D.pyrCpr * 16, s, S.img, S.pitch, S.fstride, S.h,
-                           D.img, D.pitch, D.fstride, D.w, D.h, D.qtab2, D.rowgrp, nx, nxMagic, D.tilex, D.pyrCpr, cprInv, D.pyrRows);
+#define PG_PYR_LDS(G) hipLaunchKernelGGL(k_pyr_resize_rows4_lds<G>, grid, block, lds, s, S.img, S.pitch, S.fstride, S.h, D.img, D.pitch, D.fstride, \
+                                         D.w, D.h, D.qtab2, D.rowgrp, nx, nxMagic, D.tilex, D.pyrCpr, cprInv, D.pyrRows)
+        if (D.pyrGpw == 1) PG_PYR_LDS(1); else if (D.pyrGpw == 4) PG_PYR_LDS(4); else PG_PYR_LDS(2);
+#undef PG_PYR_LDS
         return;
     }
     if (D.qtab2 && D.yrel) {
