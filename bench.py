@@ -213,10 +213,12 @@ def main():
         traffic = None                                  # HBM bytes per launch from the committed PMC passes
         try:
             import glob
-            tr = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))[-1]))   # newest round
-            if tr["workload"] == {"width": W, "height": H, "features": NF, "batch": B}:
-                k = tr["kernels"][kname]
-                traffic = (2.0 * k["fetch_kb"] + k["write_kb"]) * 1024.0
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):   # newest round first
+                tr = json.load(open(path))
+                if tr["workload"] == {"width": W, "height": H, "features": NF, "batch": B} and kname in tr["kernels"]:
+                    k = tr["kernels"][kname]
+                    traffic = (2.0 * k["fetch_kb"] + k["write_kb"]) * 1024.0
+                    break
         except (OSError, KeyError, ValueError):
             pass
         out = {
