@@ -777,57 +777,83 @@ int pgorb_fit_motion_velocities(pgorb_ctx* c, const double* gps_velocity, const 
                                         n_acc, locations_batch_size, locations_shift_step, optimization_iters, x.data(), res.data(), it.data());
     if (rc) return rc;
     for (int w = 0; w < nw; w++) if (it[w] < 0) return pg_ctx_fail(c, PGORB_E_LIMIT, "the line search step left [1e-20, 1e20] (LBFGSpp throws here)");
-    // fit_motion.cc:196-246 with the fitted parameters: IntegrateTrajectory (velocity.cc:200-253) per window
+    // fit_motion.cc:196-246 with the fitted parameters: IntegrateTrajectory (velocity.cc:200-253) per window.  The
+    // windows are integrated on all host cores; what the reference accumulates across windows (the per-sample lists
+    // it later sums front to back, the Kahan sum of local-frame velocities) is then merged in window order.
     Imu M;
     merge_imu(rotations, rot_time_usec, n_rot, accelerations, acc_time_usec, n_acc, M);
     const int nev = (int)M.time.size();
-    std::vector<std::vector<double>> lists(nev);                           // integrated_velocities (std::map keyed by event)
-    double ksum[3] = {0, 0, 0}, krem[3] = {0, 0, 0};
-    std::vector<Quat> ori(nev); std::vector<double> vel((size_t)nev * 3); std::vector<uint8_t> has(nev);
-    for (int w = 0, start = 0; start < n_gps; start += locations_shift_step, w++) {
-        const int end = std::min(start + locations_batch_size, n_gps);
-        Window W;
-        make_window(gps_time_usec + start, end - start, M, W);
-        const double* p = &x[(size_t)w * 9];
-        Quat q = {1.0, 0.0, 0.0, 0.0};
-        double v[3] = {p[6], p[7], p[8]};
-        std::fill(has.begin(), has.end(), 0);
-        for (const Step& S : W.steps) {
-            const double* rr = rotations + 3 * (size_t)M.evRot[S.event];
-            const double* aa = accelerations + 3 * (size_t)M.evAcc[S.event];
-            const double dt = (double)S.usec * 1e-6;
-            const double lc[3] = {aa[0] + p[3], aa[1] + p[4], aa[2] + p[5]};
-            double rot[3];
-            quat_rotate(q, lc, rot);
-            for (int k = 0; k < 3; k++) v[k] = v[k] + (rot[k] + p[k]) * dt;
-            q = quat_mul(q, rotation_motion_to_quaternion(rr[0], rr[1], rr[2], dt));
-            ori[S.event] = q; has[S.event] = 1;
-            for (int k = 0; k < 3; k++) vel[3 * (size_t)S.event + k] = v[k];
-        }
-        double min_rotation_cos = 1.0;
-        for (int e = 0; e < nev; e++) if (has[e]) {
-            lists[e].push_back(sqrt(dot3(&vel[3 * (size_t)e], &vel[3 * (size_t)e])));
-            min_rotation_cos = std::min(min_rotation_cos, std::abs(ori[e].w));
-        }
-        if (acos(min_rotation_cos) >= forward_axis_inference_min_rotation_rad)
-            for (int e = 0; e < nev; e++) if (has[e] && sqrt(dot3(&vel[3 * (size_t)e], &vel[3 * (size_t)e])) >= forward_axis_inference_min_velocity_m_s) {
-                const Quat inv = {ori[e].w, -ori[e].x, -ori[e].y, -ori[e].z};
-                double vl[3];
-                quat_rotate(inv, &vel[3 * (size_t)e], vl);
-                for (int k = 0; k < 3; k++) {                              // KahanSum::add (math.hpp:13-19)
-                    const double proposed = vl[k] + krem[k], updated = ksum[k] + proposed, actual = updated - ksum[k];
-                    krem[k] = proposed - actual; ksum[k] = updated;
+    struct WinOut {
+        std::vector<int32_t> ev;            // the merged events the window reaches, ascending (the keys of the std::map)
+        std::vector<double> nrm;            // velocity.norm() per event
+        std::vector<double> vl;             // local-frame velocity (3 per entry) of the events that count for the forward axis
+    };
+    std::vector<WinOut> outs((size_t)nw);
+    {
+        std::atomic<int> next(0);
+        auto work = [&]() {
+            std::vector<Quat> ori; std::vector<double> vel;
+            for (int w = next++; w < nw; w = next++) {
+                const int start = w * locations_shift_step, end = std::min(start + locations_batch_size, n_gps);
+                Window W;
+                make_window(gps_time_usec + start, end - start, M, W);
+                WinOut& O = outs[w];
+                ori.clear(); vel.clear();
+                const double* p = &x[(size_t)w * 9];
+                Quat q = {1.0, 0.0, 0.0, 0.0};
+                double v[3] = {p[6], p[7], p[8]};
+                for (const Step& S : W.steps) {
+                    const double* rr = rotations + 3 * (size_t)M.evRot[S.event];
+                    const double* aa = accelerations + 3 * (size_t)M.evAcc[S.event];
+                    const double dt = (double)S.usec * 1e-6;
+                    const double lc[3] = {aa[0] + p[3], aa[1] + p[4], aa[2] + p[5]};
+                    double rot[3];
+                    quat_rotate(q, lc, rot);
+                    for (int k = 0; k < 3; k++) v[k] = v[k] + (rot[k] + p[k]) * dt;
+                    q = quat_mul(q, rotation_motion_to_quaternion(rr[0], rr[1], rr[2], dt));
+                    if (O.ev.empty() || O.ev.back() != S.event) { O.ev.push_back(S.event); ori.push_back(q); vel.insert(vel.end(), v, v + 3); }
+                    else { ori.back() = q; std::copy(v, v + 3, vel.end() - 3); }   // an interval split at a GPS fix: the later part wins (:244-248)
                 }
+                double min_rotation_cos = 1.0;
+                O.nrm.resize(O.ev.size());
+                for (size_t i = 0; i < O.ev.size(); i++) {
+                    O.nrm[i] = sqrt(dot3(&vel[3 * i], &vel[3 * i]));
+                    min_rotation_cos = std::min(min_rotation_cos, std::abs(ori[i].w));
+                }
+                if (acos(min_rotation_cos) >= forward_axis_inference_min_rotation_rad)
+                    for (size_t i = 0; i < O.ev.size(); i++) if (O.nrm[i] >= forward_axis_inference_min_velocity_m_s) {
+                        const Quat inv = {ori[i].w, -ori[i].x, -ori[i].y, -ori[i].z};
+                        double vl[3];
+                        quat_rotate(inv, &vel[3 * i], vl);
+                        O.vl.insert(O.vl.end(), vl, vl + 3);
+                    }
+            }
+        };
+        const unsigned hw = std::thread::hardware_concurrency();
+        const int nthreads = std::max(1, std::min<int>(nw, std::min(hw ? hw : 1u, 32u)));
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nthreads; t++) pool.emplace_back(work);
+        work();
+        for (std::thread& t : pool) t.join();
+    }
+    std::vector<double> vsum(nev, 0.0);                                     // std::accumulate(list, 0.0) = the running sum in push order
+    std::vector<int32_t> vcnt(nev, 0);
+    double ksum[3] = {0, 0, 0}, krem[3] = {0, 0, 0};
+    for (int w = 0; w < nw; w++) {
+        const WinOut& O = outs[w];
+        for (size_t i = 0; i < O.ev.size(); i++) { vsum[O.ev[i]] += O.nrm[i]; vcnt[O.ev[i]]++; }
+        for (size_t i = 0; i + 2 < O.vl.size(); i += 3)
+            for (int k = 0; k < 3; k++) {                                  // KahanSum::add (math.hpp:13-19)
+                const double proposed = O.vl[i + k] + krem[k], updated = ksum[k] + proposed, actual = updated - ksum[k];
+                krem[k] = proposed - actual; ksum[k] = updated;
             }
     }
     std::vector<double> avg, tsec;
     int n = 0;
-    for (int e = 0; e < nev; e++) if (!lists[e].empty()) {
+    for (int e = 0; e < nev; e++) if (vcnt[e]) {
         out_time_usec[n] = M.time[e];
         tsec.push_back((double)(out_time_usec[n] - out_time_usec[0]) * 1e-6);
-        double sum = 0.0;
-        for (double vv : lists[e]) sum += vv;
-        avg.push_back(sum / lists[e].size());
+        avg.push_back(vsum[e] / vcnt[e]);
         n++;
     }
     if (n && pgorb_smooth_time_series(avg.data(), tsec.data(), n, tsec.data(), n, post_smoothing_sigma_sec, out_velocity) != PGORB_OK)
