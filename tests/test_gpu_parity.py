@@ -538,3 +538,44 @@ def test_batch_with_featureless_frames(oracle):
         m = len(descs[q])
         assert np.array_equal(bi[p, :m].cpu().numpy(), obi)
         assert np.array_equal(b1[p, :m].cpu().numpy().view(np.uint16), ob1)
+
+
+@pytest.mark.parametrize("rows", [16, 64])
+def test_pyramid_tile_height_variants_bit_exact(oracle, rows, monkeypatch):
+    """PGORB_PYR_TILE_ROWS (read when a plan is built) selects the 256 x 16 / 256 x 64 shapes of the LDS-staged
+    resize used for the tile-size sweep in DESIGN.md: every level and the final output must not change."""
+    import pilotguru_amd as pg
+    monkeypatch.setenv("PGORB_PYR_TILE_ROWS", str(rows))
+    w, h, nf = 1000, 701, 1200
+    img = synth_scene(77, w, h)
+    ext = pg.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    kp, desc = ext(img)
+    orc = oracle.OrbOracle(nf, 1.2, 8, 20, 7)
+    okp, odesc = orc.extract(img)
+    for lvl in range(1, 8):
+        assert np.array_equal(ext.debug_level_image(0, lvl), orc.level_image(lvl)), (rows, lvl)
+    assert kp.tobytes() == okp.tobytes() and np.array_equal(desc, odesc)
+
+
+def test_popcount_matcher_switch_gives_the_same_matches(tmp_path):
+    """PGORB_MATCH_POPCOUNT=1 routes every size through the v_bcnt kernels (the matcher BASELINE.json's north star
+    describes); the flag is read once per process, so the comparison runs in two child processes."""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import pilotguru_amd as pg;"
+            "r = np.random.RandomState(5); a = r.randint(0, 256, (1500, 32)).astype(np.uint8); b = r.randint(0, 256, (1777, 32)).astype(np.uint8);"
+            "b[:200] = a[:200]; ext = pg.ORBextractor(500, 1.2, 4, 20, 7, max_width=320, max_height=240);"
+            "i, d1, d2 = ext.hamming_best2(a, b); np.savez(sys.argv[1], i=i, d1=d1, d2=d2)") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in (None, "1"):
+        env = dict(os.environ)
+        env.pop("PGORB_MATCH_POPCOUNT", None)
+        if flag:
+            env["PGORB_MATCH_POPCOUNT"] = flag
+        out = os.path.join(str(tmp_path), "m%s.npz" % (flag or "0"))
+        subprocess.run([sys.executable, "-c", code, out], check=True, env=env)
+        outs.append(np.load(out))
+    for k in ("i", "d1", "d2"):
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+    assert np.all(outs[0]["d1"][:200] == 0)
