@@ -10,7 +10,7 @@
 // Here: windows are independent, so ONE WORKGROUP PER WINDOW runs the whole solver, all windows at once.
 // Every double is produced by the same operation on the same operands as in the reference (the sums
 // stay sequential in time: reordering them changes the doubles and the JSON is diffed bit for
-// bit); inside a window five waves form a pipeline over chunks of 64 steps (see the device section).
+// bit); inside a window five waves form a pipeline over chunks of 128 steps (see the device section).
 // What does not depend on the nine parameters is hoisted out of the solver and computed once per
 // window on the host, with the same operations in the same order as the reference's loop body:
 //   forward stream  (8 doubles / step): dt, orientation BEFORE the step (w,x,y,z), raw acceleration
@@ -150,7 +150,7 @@ void make_window(const int64_t* ref_t, int n_ref, const Imu& M, Window& W)
 // time order, but only the sums are sequential: per step the expensive part (rotate the bias-corrected
 // acceleration into the fixed frame, scale by dt; dt*v; the nine gradient products) is a function of
 // the parameters and that step's data, and the gradient sums of a GPS interval need nothing from the
-// forward sums but that interval's d_loss_d_travel.  So the window's chunks of <= 64 steps flow through
+// forward sums but that interval's d_loss_d_travel.  So the window's chunks of <= 128 steps flow through
 // a pipeline, one workgroup barrier per chunk ("tick"); every stage is either a lane = step map (P*)
 // or ONE running fp64 sum per lane:
 //   PF  (lane = step)  tick t:   a*dt of chunk t            -> LDS;   dt*v of chunk t-2  -> LDS
@@ -169,7 +169,11 @@ void make_window(const int64_t* ref_t, int n_ref, const Imu& M, Window& W)
 // (producer, forward sums, backward sums) 1.5 s.  The fit of the slowest window bounds the run, so the
 // latency of ONE evaluation is what counts; the machine is otherwise nearly idle (0.1 s of its time).
 
-#define CB_CHUNK 64
+#define CB_CHUNK 128                           // steps per tick: two 64-lane halves for the lane = step stages
+#define CB_HALVES (CB_CHUNK / 64)
+#define CB_NBITS 10                            // chunk metadata word: steps | interval << CB_NBITS | last-of-interval << 31
+#define CB_NMASK ((1 << CB_NBITS) - 1)
+#define CB_RMASK ((1 << (31 - CB_NBITS)) - 1)
 #define CB_BATCH 16
 #define CB_ROWS (CB_CHUNK + 2 * CB_BATCH)      // LDS rows per chunk buffer: the one-batch-ahead reads may run past the chunk
 #define CB_WAVES 5
@@ -178,7 +182,7 @@ void make_window(const int64_t* ref_t, int n_ref, const Imu& M, Window& W)
 struct WinDesc {              // one per workgroup (window)
     int64_t fwd, bwd;         // element offsets of the SoA streams: fwd[CB_FWD][S], bwd[CB_BWD][S]
     int64_t refDist;          // [nRef]
-    int64_t meta;             // int32 [2 * (nChunks + lag + 4)]: per chunk {first step, n | interval << 8 | last-of-interval << 31}
+    int64_t meta;             // int32 [2 * (nChunks + lag + 4)]: per chunk {first step, n | interval << CB_NBITS | last-of-interval << 31}
     int32_t S, nRef, nChunks, lag;
     double totalSec;
 };
@@ -316,27 +320,34 @@ __device__ double cal_eval(const WinView& G, int wave, int lane, const double* x
         const double bg[3] = {x[0], x[1], x[2]}, bl[3] = {x[3], x[4], x[5]};
         // The stream is read TWO chunks ahead (a tick is shorter than a trip to HBM): two register sets, the
         // tick loop unrolled by two so that each set keeps its registers.
-        FwdRegs fA = load_fwd(G.F, G.S, start_of(0) + lane), fB = load_fwd(G.F, G.S, start_of(1) + lane);
+        FwdRegs fA[CB_HALVES], fB[CB_HALVES];
+        for (int h = 0; h < CB_HALVES; h++) { fA[h] = load_fwd(G.F, G.S, start_of(0) + 64 * h + lane); fB[h] = load_fwd(G.F, G.S, start_of(1) + 64 * h + lane); }
         CP_BEGIN;
-        auto tick = [&](int t, FwdRegs& fr) {
+        auto tick = [&](int t, FwdRegs (&fr)[CB_HALVES]) {
             const int startF = start_of(t + 2);
-            // the load is unconditional (past the end it re-reads the last chunk): a load under an `if` makes the
-            // register set a phi, and the copies at the join wait for the loads just issued
-            const FwdRegs f = fr;
-            fr = load_fwd(G.F, G.S, startF + lane);
-            if (in_range(t)) {                            // IntegrateMotion's parameter-dependent part (geometry.cc:34-45)
-                const Quat q = {f.qw, f.qx, f.qy, f.qz};
-                const double lc[3] = {f.ax + bl[0], f.ay + bl[1], f.az + bl[2]};
-                double rot[3];
-                quat_rotate(q, lc, rot);
-                double (*o)[5] = G.sc[t & 3];
-                for (int k = 0; k < 3; k++) o[lane][k] = (rot[k] + bg[k]) * f.dt;
-                o[lane][3] = f.dt;
-            }
+            const bool on = in_range(t);
             const int jm = t - 2;
-            if (in_range(jm)) {                           // the product of `travel += dt * v` (velocity.cc:105-106)
-                const double dt = G.sc[jm & 3][lane][3];
-                for (int k = 0; k < 3; k++) G.sm[jm & 1][lane][k] = dt * G.sv[jm & 1][lane][k];
+            const bool onM = in_range(jm);
+#pragma unroll
+            for (int h = 0; h < CB_HALVES; h++) {
+                const int row = 64 * h + lane;
+                // the load is unconditional (past the end it re-reads the last chunk): a load under an `if` makes the
+                // register set a phi, and the copies at the join wait for the loads just issued
+                const FwdRegs f = fr[h];
+                fr[h] = load_fwd(G.F, G.S, startF + row);
+                if (on) {                                 // IntegrateMotion's parameter-dependent part (geometry.cc:34-45)
+                    const Quat q = {f.qw, f.qx, f.qy, f.qz};
+                    const double lc[3] = {f.ax + bl[0], f.ay + bl[1], f.az + bl[2]};
+                    double rot[3];
+                    quat_rotate(q, lc, rot);
+                    double (*o)[5] = G.sc[t & 3];
+                    for (int k = 0; k < 3; k++) o[row][k] = (rot[k] + bg[k]) * f.dt;
+                    o[row][3] = f.dt;
+                }
+                if (onM) {                                // the product of `travel += dt * v` (velocity.cc:105-106)
+                    const double dt = G.sc[jm & 3][row][3];
+                    for (int k = 0; k < 3; k++) G.sm[jm & 1][row][k] = dt * G.sv[jm & 1][row][k];
+                }
             }
             CP_WORK_DONE;
             cb_tick_barrier();
@@ -349,22 +360,29 @@ __device__ double cal_eval(const WinView& G, int wave, int lane, const double* x
         CP_END(3);
     } else if (wave == 4) {                               // ---- PB: gradient products of chunk t-lag+1 (velocity.cc:133-163) ----
         // lag is odd, so backward chunk jb = t - lag + 1 has the parity of t: the same two-set scheme
-        BwdRegs bA = load_bwd(G.B, G.S, start_of(0) + lane), bB = load_bwd(G.B, G.S, start_of(1) + lane);
+        BwdRegs bA[CB_HALVES], bB[CB_HALVES];
+        for (int h = 0; h < CB_HALVES; h++) { bA[h] = load_bwd(G.B, G.S, start_of(0) + 64 * h + lane); bB[h] = load_bwd(G.B, G.S, start_of(1) + 64 * h + lane); }
         CP_BEGIN;
-        auto tick = [&](int t, BwdRegs& br) {
+        auto tick = [&](int t, BwdRegs (&br)[CB_HALVES]) {
             const int jb = t - G.lag + 1;
             const int startB = start_of(jb + 2), wordB = word_of(jb);
-            const BwdRegs b = br;
-            br = load_bwd(G.B, G.S, startB + lane);
-            if (in_range(jb)) {
-                const int r = (wordB >> 8) & 0x7fffff;
-                const double d[3] = {G.dvec[r][0], G.dvec[r][1], G.dvec[r][2]};
-                double (*o)[9] = G.sp[jb & 1];
-                for (int k = 0; k < 3; k++) {
-                    o[lane][k] = b.c1 * d[k];
-                    const double row[3] = {b.m[3 * k], b.m[3 * k + 1], b.m[3 * k + 2]};
-                    o[lane][3 + k] = dot3(row, d);
-                    o[lane][6 + k] = b.dt * d[k];
+            const bool on = in_range(jb);
+            const int r = (wordB >> CB_NBITS) & CB_RMASK;
+            double d[3] = {0, 0, 0};
+            if (on) { d[0] = G.dvec[r][0]; d[1] = G.dvec[r][1]; d[2] = G.dvec[r][2]; }
+#pragma unroll
+            for (int h = 0; h < CB_HALVES; h++) {
+                const int row = 64 * h + lane;
+                const BwdRegs b = br[h];
+                br[h] = load_bwd(G.B, G.S, startB + row);
+                if (on) {
+                    double (*o)[9] = G.sp[jb & 1];
+                    for (int k = 0; k < 3; k++) {
+                        o[row][k] = b.c1 * d[k];
+                        const double rw[3] = {b.m[3 * k], b.m[3 * k + 1], b.m[3 * k + 2]};
+                        o[row][3 + k] = dot3(rw, d);
+                        o[row][6 + k] = b.dt * d[k];
+                    }
                 }
             }
             CP_WORK_DONE;
@@ -383,7 +401,7 @@ __device__ double cal_eval(const WinView& G, int wave, int lane, const double* x
         for (int t = 0; t < T; t++) {
             const int j = t - 1;
             // three lanes only: 64 lanes storing to three words would be serialised by the LDS as 21-way conflicts
-            if (in_range(j) && lane < 3) sum_chain<5, true, 8>(&G.sc[j & 3][0][comp], word_of(j) & 0xff, vk, &G.sv[j & 1][0][comp]);
+            if (in_range(j) && lane < 3) sum_chain<5, true, 8>(&G.sc[j & 3][0][comp], word_of(j) & CB_NMASK, vk, &G.sv[j & 1][0][comp]);
             CP_WORK_DONE;
             cb_tick_barrier();
             CP_AFTER_BARRIER;
@@ -397,9 +415,9 @@ __device__ double cal_eval(const WinView& G, int wave, int lane, const double* x
             const int j = t - 3;
             if (in_range(j)) {
                 const int m = word_of(j);
-                if (lane < 3) sum_chain<3, false, 16>(&G.sm[j & 1][0][comp], m & 0xff, tk, nullptr);
+                if (lane < 3) sum_chain<3, false, 16>(&G.sm[j & 1][0][comp], m & CB_NMASK, tk, nullptr);
                 if (m < 0) {                              // last chunk of its interval
-                    if (lane < 3) G.travel[(m >> 8) & 0x7fffff][lane] = tk;
+                    if (lane < 3) G.travel[(m >> CB_NBITS) & CB_RMASK][lane] = tk;
                     tk = 0;
                 }
             }
@@ -416,14 +434,14 @@ __device__ double cal_eval(const WinView& G, int wave, int lane, const double* x
             const int je = t - 4, j = t - G.lag;
             const int we = word_of(je), wj = word_of(j);
             if (in_range(je) && we < 0) {                 // T finished an interval during the previous tick (velocity.cc:118-127)
-                const int r = (we >> 8) & 0x7fffff;
+                const int r = (we >> CB_NBITS) & CB_RMASK;
                 const double travel[3] = {G.travel[r][0], G.travel[r][1], G.travel[r][2]};
                 const double tn = sqrt(dot3(travel, travel));
                 const double diff = tn - G.refDist[r];
                 result += diff * diff;
                 if (lane < 3) G.dvec[r][lane] = ((2.0 * diff) * travel[comp]) / (tn + 1e-5);
             }
-            if (in_range(j) && lane < 9) sum_chain<9, false, 16>(&G.sp[j & 1][0][acc], wj & 0xff, gj, nullptr);
+            if (in_range(j) && lane < 9) sum_chain<9, false, 16>(&G.sp[j & 1][0][acc], wj & CB_NMASK, gj, nullptr);
             CP_WORK_DONE;
             cb_tick_barrier();
             CP_AFTER_BARRIER;
@@ -569,7 +587,7 @@ void layout_window(const Window& W, Packed& P)
     D.fwd = (int64_t)P.dblCount;     P.dblCount += (size_t)D.S * CB_FWD;
     D.bwd = (int64_t)P.dblCount;     P.dblCount += (size_t)D.S * CB_BWD;
     D.refDist = (int64_t)P.dblCount; P.dblCount += (size_t)D.nRef;
-    // chunk list: {first step, n | interval << 8 | last-of-interval << 31}; intervals without steps have no chunk
+    // chunk list: {first step, n | interval << CB_NBITS | last-of-interval << 31}; intervals without steps have no chunk
     // (their loss term and gradient contribution are exactly +0: travel = 0, reference_distance = 0)
     D.meta = (int64_t)P.i32.size();
     int32_t off = 0, last = 0, nchunks = 0, maxPer = 0;
@@ -580,7 +598,7 @@ void layout_window(const Window& W, Packed& P)
             const int32_t nn = std::min(CB_CHUNK, c - c0);
             last = off + c0;
             P.i32.push_back(last);
-            P.i32.push_back(nn | ((int32_t)r << 8) | (c0 + CB_CHUNK >= c ? (int32_t)0x80000000 : 0));
+            P.i32.push_back(nn | ((int32_t)r << CB_NBITS) | (c0 + CB_CHUNK >= c ? (int32_t)0x80000000 : 0));
         }
         maxPer = std::max(maxPer, per);
         off += c;
