@@ -38,6 +38,27 @@ def imu_ride(seed, n_gps=30, imu_hz=50.0, noise=0.02):
     return (gps_v, us(t_gps)), (rot, us(t_rot)), (acc, us(t_acc))
 
 
+def irregular_series(r):
+    """Recorder series with everything irregular: 2-60 fixes at any rate, IMU clocks from 3 to 400 Hz with jitter,
+    offsets against the GPS clock, gaps in the recording."""
+    n_gps = int(r.integers(2, 60))
+    gps_dt = r.uniform(0.2, 2.5)
+    t_gps = np.cumsum(r.uniform(0.5, 1.5, n_gps) * gps_dt) + r.uniform(0, 3)
+    T = t_gps[-1] + r.uniform(-1.0, 2.0)
+
+    def imu(hz):
+        n = max(3, int(T * hz))
+        t = np.cumsum(r.uniform(0.3, 1.7, n) / hz) + r.uniform(-1.0, 1.5)
+        if r.random() < 0.3:
+            k = int(r.integers(1, n)); t[k:] += r.uniform(0.5, 3.0)
+        return t
+    t_rot, t_acc = imu(r.uniform(3, 400)), imu(r.uniform(3, 400))
+    rot = r.normal(0, 0.3, (len(t_rot), 3)); acc = r.normal(0, 2.0, (len(t_acc), 3)) + [0, 0, 9.8]
+    us = lambda t: np.unique(np.round(t * 1e6).astype(np.int64) + 10**15)
+    tg, tr, ta = us(t_gps), us(t_rot), us(t_acc)
+    return (np.abs(r.normal(10, 5, len(tg))), tg), (rot[:len(tr)], tr), (acc[:len(ta)], ta)
+
+
 def _bits(a):
     """Bit patterns, all NaNs made one (a window without IMU samples is 0/0 in the reference; which NaN
     comes out depends on the instruction set, and the JSON prints none of them)."""
@@ -127,6 +148,25 @@ def test_gpu_window_fits_equal_oracle(ctx, oracle, seed, n_gps, batch, shift, it
     assert len(x) == math.ceil(n_gps / shift)
     assert np.array_equal(it, oit)
     assert np.array_equal(_bits(x), _bits(ox)) and np.array_equal(_bits(res), _bits(ores))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(12))
+def test_gpu_irregular_series_equal_oracle(ctx, oracle, seed):
+    """The committed slice of tools/experiments/fuzz_calib.py (750 cases there): short and long windows, single-fix
+    windows, intervals without IMU samples, partial chunks of every length."""
+    from pilotguru_amd.calibration import ComputeForwardVelocitiesFromImu, FitVelocityWindows
+    r = np.random.default_rng(100 + seed)
+    gps, rot, acc = irregular_series(r)
+    batch = int(r.integers(1, 45)); shift = int(r.integers(1, batch + 1)); iters = int(r.integers(1, 60))
+    ox, ores, oit = oracle.fit_windows(*gps, *rot, *acc, batch, shift, iters)
+    x, res, it = FitVelocityWindows(ctx, gps, rot, acc, batch, shift, iters)
+    assert np.array_equal(it, oit) and np.array_equal(_bits(x), _bits(ox)) and np.array_equal(_bits(res), _bits(ores))
+    if np.all(oit >= 0):
+        axis = np.array([0.1, -0.2, 1.0]); axis /= np.linalg.norm(axis)
+        t, v, f = ComputeForwardVelocitiesFromImu(ctx, gps, rot, acc, axis, batch, shift, iters, 0.01, 3.0, 0.1)
+        ot, ov, of = oracle.fit_motion_velocities(*gps, *rot, *acc, axis, batch, shift, iters, 0.01, 3.0, 0.1)
+        assert np.array_equal(t, ot) and np.array_equal(_bits(v), _bits(ov)) and np.array_equal(_bits(f), _bits(of))
 
 
 @pytest.mark.gpu

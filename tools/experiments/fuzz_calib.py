@@ -19,23 +19,8 @@ def bits(a):
     return a.view(np.uint64)
 
 
-def series(r):
-    n_gps = int(r.integers(2, 60))
-    gps_dt = r.uniform(0.2, 2.5)
-    t_gps = np.cumsum(r.uniform(0.5, 1.5, n_gps) * gps_dt) + r.uniform(0, 3)
-    T = t_gps[-1] + r.uniform(-1.0, 2.0)
-    def imu(hz):
-        n = max(3, int(T * hz))
-        t = np.cumsum(r.uniform(0.3, 1.7, n) / hz) + r.uniform(-1.0, 1.5)
-        if r.random() < 0.3:                       # a gap in the recording
-            k = int(r.integers(1, n)); t[k:] += r.uniform(0.5, 3.0)
-        return t
-    t_rot, t_acc = imu(r.uniform(3, 400)), imu(r.uniform(3, 400))
-    rot = r.normal(0, 0.3, (len(t_rot), 3)); acc = r.normal(0, 2.0, (len(t_acc), 3)) + [0, 0, 9.8]
-    us = lambda t: np.unique(np.round(t * 1e6).astype(np.int64) + 10**15)
-    tg, tr, ta = us(t_gps), us(t_rot), us(t_acc)
-    return (np.abs(r.normal(10, 5, len(tg))), tg), (rot[:len(tr)], tr), (acc[:len(ta)], ta)
-
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from test_calibration import irregular_series as series  # noqa: E402
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 r = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
