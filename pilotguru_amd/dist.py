@@ -45,3 +45,51 @@ def max_over_ranks(seconds, device):
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def frame_chunk_for_rank(nframes, rank, world):
+    """One ride over several GPUs: contiguous chunks of frames with a one-frame overlap.
+
+    Returns (first_extracted, first_owned, stop): the rank extracts frames [first_extracted, stop) and owns frame f
+    -- its keypoints and its match against frame f-1 -- for f in [first_owned, stop).  first_extracted is
+    first_owned - 1 except for the first chunk: the border frame is extracted twice, nothing is exchanged."""
+    per, extra = divmod(nframes, world)
+    first = rank * per + min(rank, extra)
+    stop = first + per + (1 if rank < extra else 0)
+    return (max(first - 1, 0) if stop > first else first), first, stop
+
+
+def window_range_for_rank(nwindows, rank, world):
+    """fit_motion's sliding windows are independent fits: contiguous, balanced ranges, no exchange but the gather."""
+    per, extra = divmod(nwindows, world)
+    first = rank * per + min(rank, extra)
+    return first, first + per + (1 if rank < extra else 0)
+
+
+def fit_velocity_windows_sharded(ctx, gps, rotations, accelerations, locations_batch_size=40, locations_shift_step=5,
+                                 optimization_iters=500, fit=None):
+    """pilotguru_amd.calibration.FitVelocityWindows with the windows split over the ranks of the default group.
+
+    Window w only looks at GPS fixes [w * step, w * step + batch) (src/fit_motion.cc:173-183), so a rank fits the
+    windows of its range on the slice of the GPS series they touch and every rank ends up with all results
+    (one all_gather of a few KB).  `fit` defaults to the GPU path; tests pass a CPU checker."""
+    import numpy as np
+    import torch.distributed as dist
+    if fit is None:
+        from .calibration import FitVelocityWindows as fit
+    v, t = np.asarray(gps[0]), np.asarray(gps[1])
+    n, s, b = len(v), int(locations_shift_step), int(locations_batch_size)
+    nw = (n + s - 1) // s if n > 0 else 0
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+    a, e = window_range_for_rank(nw, rank, world)
+    if e > a:
+        lo, hi = a * s, min(n, (e - 1) * s + b)
+        x, res, it = fit(ctx, (v[lo:hi], t[lo:hi]), rotations, accelerations, b, s, optimization_iters)
+        mine = (np.asarray(x)[:e - a], np.asarray(res)[:e - a], np.asarray(it)[:e - a])
+    else:
+        mine = (np.zeros((0, 9)), np.zeros(0), np.zeros(0, np.int32))
+    parts = [mine]
+    if world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, mine)
+    return tuple(np.concatenate([p[k] for p in parts]) for k in range(3))

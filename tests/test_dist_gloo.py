@@ -29,6 +29,17 @@ def _worker(rank, world, port, out):
     u = unpack_vocabulary(got.numpy())
     t = pgd.max_over_ranks(1.0 + rank, dev)
     rides = pgd.ride_for_rank(rank, world, nrides=5)
+    # fit_motion's windows split over the ranks; the CPU oracle stands in for the GPU fit
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_calibration import imu_ride
+    from oracle import orb_oracle
+    gps, rot, acc = imu_ride(8, n_gps=23)
+    cpu_fit = lambda ctx, g, r, a, b, s, it: orb_oracle.fit_windows(*g, *r, *a, b, s, it)
+    sx, sres, sit = pgd.fit_velocity_windows_sharded(None, gps, rot, acc, 8, 3, 25, fit=cpu_fit)
+    ox, ores, oit = orb_oracle.fit_windows(*gps, *rot, *acc, 8, 3, 25)
+    assert np.array_equal(sx.view(np.uint64), ox.view(np.uint64)) and np.array_equal(sres.view(np.uint64), ores.view(np.uint64))
+    assert np.array_equal(sit, oit) and len(sit) == 8
     out.put((rank, int(got.numel()), int(np.frombuffer(got.numpy().tobytes(), np.uint8).astype(np.uint64).sum()),
              u["nnodes"], t, rides))
     dist.barrier()
@@ -50,3 +61,18 @@ def test_two_rank_vocab_broadcast_and_sharding():
     assert (n0, s0, nodes0) == (n1, s1, nodes1) and nodes0 == 1 + 3 + 9 + 27
     assert t0 == t1 == 2.0                                   # MAX over ranks
     assert rides0 == [0, 2, 4] and rides1 == [1, 3]          # every ride owned exactly once
+
+
+def test_frame_chunks_and_window_ranges_cover_everything_once():
+    from pilotguru_amd import dist as pgd
+    for world in (1, 2, 3, 8):
+        for n in (0, 1, 2, 7, 8, 9, 100, 1001):
+            owned, prev_stop = [], 0
+            for r in range(world):
+                fe, fo, stop = pgd.frame_chunk_for_rank(n, r, world)
+                assert fo == prev_stop and fe == (max(fo - 1, 0) if stop > fo else fo)      # contiguous, one frame of overlap
+                owned += list(range(fo, stop)); prev_stop = stop
+            assert owned == list(range(n))                                               # every frame (and pair f-1, f) exactly once
+            w = [pgd.window_range_for_rank(n, r, world) for r in range(world)]
+            assert w[0][0] == 0 and w[-1][1] == n and all(w[i][1] == w[i + 1][0] for i in range(world - 1))
+            assert max(b - a for a, b in w) - min(b - a for a, b in w) <= 1
