@@ -384,6 +384,10 @@ __global__ __launch_bounds__(64, 8) void k_fast_cells(const PgPlan P, int TPr, i
         else
             nlist = (IW <= 32) ? quick_pass<8, true>(tile, TP, IW, 0, IH, t, list, lane)
                                : quick_pass<16, true>(tile, TP, IW, 0, IH, t, list, lane);
+#if defined(PGORB_FAST_SKIP) && PGORB_FAST_SKIP == 1       // timing experiment: staging + the iniTh quick test only
+        if (lane == 0) *cellCnt = 0;
+        return;
+#endif
         if (nlist < 0) {                                   // list would overflow: chunked slow path
             const int total = fast_pass_chunked(tile, TP, smap, mapPitch, mapRows, IW, IH, t, list, out,
                                                 cellCap, xoff, yoff, lane);
@@ -418,6 +422,10 @@ __global__ __launch_bounds__(64, 8) void k_fast_cells(const PgPlan P, int TPr, i
             }
             total += __popcll(m);
         }
+#if defined(PGORB_FAST_SKIP) && PGORB_FAST_SKIP == 2       // timing experiment: no minTh retry
+        if (lane == 0) *cellCnt = total;
+        return;
+#endif
         if (total > 0 || pass == 1) {
             if (lane == 0) *cellCnt = total;
             FT_TS(3);
