@@ -361,6 +361,9 @@ int  pgorb_turn_angles(const double* dirs /* [n][2] */, int n, double* turn /* [
 int  pgorb_principal_rotation_axes(const double* rotations /* [n][3] */, const int64_t* rot_time_usec, int n,
                                    int64_t integration_interval_usec, double* eigenvectors /* [3][3] */);
 int  pgorb_angular_velocities_around_axis(const double* rotations, int n, const double* axis /* [3] */, double* out /* [n] */);
+/*   pgorb_kahan_sum                       KahanSum<T>::add over n vectors of dim components (include/math/math.hpp:8-25),
+ *                                         the accumulator of fit_motion's forward-axis estimate.  Host. */
+int  pgorb_kahan_sum(const double* values /* [n][dim] */, int n, int dim, double* sum /* [dim] */);
 int  pgorb_fit_num_windows(int n_gps, int locations_shift_step);
 int  pgorb_fit_velocity_windows(pgorb_ctx* ctx, const double* gps_velocity, const int64_t* gps_time_usec, int n_gps,
                                 const double* rotations, const int64_t* rot_time_usec, int n_rot,

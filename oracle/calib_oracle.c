@@ -469,3 +469,18 @@ int porc_fit_motion_velocities(const double* ref_v, const int64_t* ref_t, int n_
     calibrator_free(&all);
     return npts;
 }
+
+/* include/math/math.hpp:8-25, n vectors of dim components (the form used inside porc_fit_motion_velocities) */
+int porc_kahan_sum(const double* values, int n, int dim, double* sum)
+{
+    int i, k;
+    for (k = 0; k < dim; k++) {
+        double s = 0.0, rem = 0.0;
+        for (i = 0; i < n; i++) {
+            const double proposed = values[(size_t)i * dim + k] + rem, updated = s + proposed, actual = updated - s;
+            rem = proposed - actual; s = updated;
+        }
+        sum[k] = s;
+    }
+    return 0;
+}

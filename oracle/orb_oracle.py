@@ -603,3 +603,26 @@ def angular_velocities_around_axis(rot, axis):
     if lib().porc_angular_velocities_around_axis(_p(r), len(r), _p(a), _p(out)):
         raise ValueError("axis not normalised")
     return out
+
+
+def kahan_sum(values):
+    v = _d(values); v = v.reshape(len(v), -1)
+    out = np.zeros(v.shape[1])
+    lib().porc_kahan_sum(_p(v), v.shape[0], v.shape[1], _p(out))
+    return out
+
+
+_MATH_REF = os.path.join(_HERE, "_ref", "libmath_ref.so")
+
+
+def ref_kahan_sum(values):
+    """The REFERENCE's own KahanSum (oracle/_ref/libmath_ref.so, built from include/math/math.hpp by Makefile.ref)."""
+    if not os.path.exists(_MATH_REF):
+        if os.path.isdir("/root/reference"):
+            subprocess.check_call(["make", "-C", _HERE, "-f", "Makefile.ref"], stdout=subprocess.DEVNULL)
+        else:
+            return None
+    v = _d(values); v = v.reshape(len(v), -1)
+    out = np.zeros(v.shape[1])
+    C.CDLL(_MATH_REF).ref_kahan_sum(_p(v), v.shape[0], v.shape[1], _p(out))
+    return out

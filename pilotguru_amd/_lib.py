@@ -33,7 +33,7 @@ SYMBOLS = (
     "pgorb_smooth_heading_directions", "pgorb_smooth_time_series", "pgorb_trajectory_pca",
     "pgorb_project_directions", "pgorb_project_translations", "pgorb_turn_angles",
     "pgorb_principal_rotation_axes", "pgorb_angular_velocities_around_axis",
-    "pgorb_fit_num_windows", "pgorb_fit_velocity_windows", "pgorb_calibrator_eval", "pgorb_fit_motion_velocities",
+    "pgorb_kahan_sum", "pgorb_fit_num_windows", "pgorb_fit_velocity_windows", "pgorb_calibrator_eval", "pgorb_fit_motion_velocities",
 )
 
 
@@ -122,6 +122,7 @@ def lib():
     series = [vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int]
     L.pgorb_principal_rotation_axes.argtypes = [vp, vp, C.c_int, C.c_int64, vp]
     L.pgorb_angular_velocities_around_axis.argtypes = [vp, C.c_int, vp, vp]
+    L.pgorb_kahan_sum.argtypes = [vp, C.c_int, C.c_int, vp]
     L.pgorb_fit_num_windows.argtypes = [C.c_int, C.c_int]
     L.pgorb_fit_velocity_windows.argtypes = [vp] + series + [C.c_int, C.c_int, C.c_int, vp, vp, vp]
     L.pgorb_calibrator_eval.argtypes = [vp] + series + [vp, C.c_int, vp, vp]

@@ -93,3 +93,15 @@ def GetAngularVelocitiesAroundAxisDirect(raw_rotations, axis):
     if rc != _lib.PGORB_OK:
         raise _lib.PgorbError(rc, "GetAngularVelocitiesAroundAxisDirect: the axis must be normalised")
     return out
+
+
+def KahanSum(values):
+    """include/math/math.hpp:8-25: compensated sum of the rows of `values` ([n][dim]), as fit_motion accumulates the
+    local-frame velocities."""
+    v = _d(values)
+    v = v.reshape(len(v), v.shape[-1] if v.ndim > 1 else 1)
+    out = np.zeros(v.shape[1])
+    rc = _lib.lib().pgorb_kahan_sum(_p(v), v.shape[0], v.shape[1], _p(out))
+    if rc != _lib.PGORB_OK:
+        raise _lib.PgorbError(rc, "KahanSum")
+    return out

@@ -323,4 +323,21 @@ int pgorb_angular_velocities_around_axis(const double* rot, int n, const double*
     return PGORB_OK;
 }
 
+int pgorb_kahan_sum(const double* values, int n, int dim, double* sum)
+{
+    if (n < 0 || dim <= 0 || !sum || (n && !values)) return PGORB_E_ARG;
+    for (int k = 0; k < dim; k++) {
+        double s = 0.0, rem = 0.0;
+        for (int i = 0; i < n; i++) {                          // KahanSum::add, include/math/math.hpp:13-19
+            const double proposed = values[(size_t)i * dim + k] + rem;
+            const double updated = s + proposed;
+            const double actual = updated - s;
+            rem = proposed - actual;
+            s = updated;
+        }
+        sum[k] = s;
+    }
+    return PGORB_OK;
+}
+
 }  // extern "C"

@@ -298,3 +298,22 @@ def test_gpu_fit_motion_cli_writes_the_oracles_numbers(tmp_path, oracle):
     assert [f["x"], f["y"], f["z"]] == [r15(x) for x in ofwd]
     s = json.load(open(d + "/s.json"))["steering"]
     assert [e["angular_velocity"] for e in s] == [r15(x) for x in oracle.angular_velocities_around_axis(rot[0], axis)]
+
+
+def test_kahan_sum_equals_the_reference_header(oracle):
+    """include/math/math.hpp is the one file of the fit_motion path that builds with this image's toolchain:
+    oracle/_ref/libmath_ref.so is the reference's own KahanSum; the oracle's and the product's must agree with it
+    bit for bit (and differ from the naive sum on an ill-conditioned series, or the test tests nothing)."""
+    from pilotguru_amd.calibration import KahanSum
+    r = np.random.default_rng(6)
+    v = r.normal(0, 1, (5000, 3)) * 10.0 ** r.integers(-8, 9, (5000, 1))
+    ref = oracle.ref_kahan_sum(v)
+    if ref is None:
+        pytest.skip("oracle/_ref/libmath_ref.so not built and /root/reference absent")
+    assert np.array_equal(_bits(oracle.kahan_sum(v)), _bits(ref))
+    assert np.array_equal(_bits(KahanSum(v)), _bits(ref))
+    naive = np.zeros(3)
+    for row in v:
+        naive = naive + row
+    assert not np.array_equal(_bits(naive), _bits(ref))
+    assert np.array_equal(_bits(KahanSum(np.zeros((0, 3)))), _bits(np.zeros(3)))
