@@ -146,11 +146,13 @@ int orc_bow_transform(const orc_vocab* v, const uint8_t* desc, int n, int levels
             f_node[nacc] = nid; f_idx[nacc] = (uint32_t)i; nacc++;
         }
     }
-    const int must = (v->scoring == 0 || v->scoring == 1);
+    /* mustNormalize, ScoringObject.h:74-89: every scoring type but DOT_PRODUCT(5); the norm is L2 for
+     * L2_NORM(1) and L1 for L1_NORM(0), CHI_SQUARE(2), KL(3), BHATTACHARYYA(4) */
+    const int must = (v->scoring != 5), l2 = (v->scoring == 1);
     if (tf && nb > 0 && !must) { const double nd = nb; for (int i = 0; i < nb; i++) bow_val[i] /= nd; }
     if (must) {                                                                    /* BowVector::normalize */
         double norm = 0.0;
-        if (v->scoring == 0) for (int i = 0; i < nb; i++) norm += fabs(bow_val[i]);
+        if (!l2) for (int i = 0; i < nb; i++) norm += fabs(bow_val[i]);
         else { for (int i = 0; i < nb; i++) norm += bow_val[i] * bow_val[i]; norm = sqrt(norm); }
         if (norm > 0.0) for (int i = 0; i < nb; i++) bow_val[i] /= norm;
     }

@@ -372,10 +372,11 @@ def ref_dbow2():
             return None
     R = C.CDLL(_REF)
     R.ref_bow_vectors.argtypes = [C.c_int] + [C.c_void_p] * 10
+    R.ref_bow_vectors2.argtypes = [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_int] + [C.c_void_p] * 7
     return R
 
 
-def ref_bow_vectors(word, weight, node):
+def ref_bow_vectors(word, weight, node, scoring=None, weighting=None):
     R = ref_dbow2()
     n = len(word)
     word = np.ascontiguousarray(word, np.uint32)
@@ -384,8 +385,14 @@ def ref_bow_vectors(word, weight, node):
     bid, bval = np.zeros(n + 1, np.uint32), np.zeros(n + 1, np.float64)
     fnode, fstart, ffeat = np.zeros(n + 1, np.uint32), np.zeros(n + 2, np.int32), np.zeros(n + 1, np.uint32)
     nb, nf = C.c_int32(), C.c_int32()
-    R.ref_bow_vectors(n, _p(word), _p(weight), _p(node), _p(bid), _p(bval), C.cast(C.byref(nb), C.c_void_p),
-                      _p(fnode), _p(fstart), _p(ffeat), C.cast(C.byref(nf), C.c_void_p))
+    if scoring is None:
+        R.ref_bow_vectors(n, _p(word), _p(weight), _p(node), _p(bid), _p(bval), C.cast(C.byref(nb), C.c_void_p),
+                          _p(fnode), _p(fstart), _p(ffeat), C.cast(C.byref(nf), C.c_void_p))
+    else:
+        rc = R.ref_bow_vectors2(n, _p(word), _p(weight), _p(node), int(scoring), int(weighting), _p(bid), _p(bval),
+                                C.cast(C.byref(nb), C.c_void_p), _p(fnode), _p(fstart), _p(ffeat),
+                                C.cast(C.byref(nf), C.c_void_p))
+        assert rc == 0
     nb, nf = nb.value, nf.value
     return (bid[:nb].copy(), bval[:nb].copy()), (fnode[:nf].copy(), fstart[:nf + 1].copy(), ffeat[:fstart[nf]].copy())
 

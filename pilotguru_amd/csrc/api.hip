@@ -167,6 +167,9 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
     int rc = level_geometry(c, w, h, g);
     if (rc) return fail(c, rc, "frame %dx%d too small: every pyramid level needs >= 62 px per side "
                                "and aspect >= 0.5", w, h);
+    // the old plan dies here: a failure below (allocation, copy, limit) must not leave planValid set for
+    // arenas that were already resized or a plan that is half written
+    c->planValid = false;
     PgPlan& P = c->plan;
     memset(&P, 0, sizeof(P));
     P.nlevels = L; P.iniTh = c->prm.ini_th_fast; P.minTh = c->prm.min_th_fast;
@@ -442,8 +445,20 @@ int pg_ctx_vocab_store(pgorb_ctx* c, const void* src, size_t nbytes, bool src_on
         PG_HIP(c, hipMemcpyAsync(hdr, src, 64, hipMemcpyDeviceToHost, s));
         PG_HIP(c, hipStreamSynchronize(s));
     } else memcpy(hdr, src, 64);
-    if (hdr[0] != 0x43564750 || hdr[1] != 1 || hdr[4] < 1)
+    if (hdr[0] != 0x43564750 || hdr[1] != 1 || hdr[4] < 2)
         return fail(c, PGORB_E_ARG, "not a pgorb vocabulary blob");
+    {
+        // the sections the header implies must fit (bow.hip, blob layout); the structure itself is checked
+        // by pgorb_vocab_from_blob / the loader, and the kernel stops at a node without children
+        const size_t n = (size_t)hdr[4];
+        auto pad = [](size_t v) { return (v + 63) / 64 * 64; };
+        size_t need = 64;
+        need = pad(need + n * 32); need = pad(need + n * 8);
+        for (int k = 0; k < 4; k++) need = pad(need + n * 4);
+        need = pad(need + (n - 1) * 4);
+        if (nbytes < need)
+            return fail(c, PGORB_E_ARG, "vocabulary blob truncated: %zu bytes, header implies %zu", nbytes, need);
+    }
     int rc = ensure(c, c->vocab, nbytes);
     if (rc) return rc;
     if (src_on_device) PG_HIP(c, hipMemcpyAsync(c->vocab.p, src, nbytes, hipMemcpyDeviceToDevice, s));

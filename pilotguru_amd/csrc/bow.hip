@@ -64,7 +64,18 @@ bool view_blob(const uint8_t* b, size_t nbytes, BlobView& v)
     v.word = reinterpret_cast<const int32_t*>(b + off); off = pad64(off + n * 4);
     v.children = reinterpret_cast<const int32_t*>(b + off); off = pad64(off + (n - 1) * 4);
     v.total = off;
-    return nbytes >= off;
+    if (nbytes < off) return false;
+    // structure: a root with children, every child id in [1, n), child ranges inside children[]
+    // (a truncated or corrupt blob -- they arrive from files and broadcasts -- is an error code, not a GPU fault)
+    if (n < 2 || v.nchild[0] < 1) return false;
+    for (size_t i = 0; i < n; i++) {
+        const int64_t c0 = v.child0[i], nc = v.nchild[i];
+        if (c0 < 0 || nc < 0 || c0 + nc > (int64_t)n - 1) return false;
+        if (i && (v.parent[i] < 0 || (size_t)v.parent[i] >= n)) return false;
+    }
+    for (size_t i = 0; i + 1 < n; i++)
+        if (v.children[i] < 1 || (size_t)v.children[i] >= n) return false;
+    return true;
 }
 
 std::vector<uint8_t> pack_blob(int k, int L, int scoring, int weighting, const std::vector<uint8_t>& desc,
@@ -128,6 +139,7 @@ __global__ __launch_bounds__(64) void k_bow_transform(const uint8_t* __restrict_
     do {                                                    // :1231-1254
         ++level;
         const int c0 = child0[cur], nc = nchild[cur];
+        if (nc <= 0) break;                                 // (only a malformed blob: the loaders refuse a childless root)
         int best = -1, bestd = 0x7fffffff;
         for (int j = 0; j < nc; j++) {
             const int id = children[c0 + j];
@@ -178,6 +190,7 @@ int pgorb_vocab_load_text(const char* path, pgorb_vocab** out)
         sn >> w;
         weight.push_back(w);
     }
+    if (parent.size() < 2) return PGORB_E_ARG;             // header only: no vocabulary (the reference's transform would return an empty vector)
     pgorb_vocab* v = new pgorb_vocab();
     v->k = k; v->L = L; v->scoring = n1; v->weighting = n2; v->nnodes = (int)parent.size();
     v->blob = pack_blob(k, L, n1, n2, desc, weight, parent, leaf, &v->nwords);
@@ -284,15 +297,17 @@ int pgorb_bow_vectors(int n, const uint32_t* word, const double* weight, const u
             fv[node[i]].push_back((uint32_t)i);            // FeatureVector::addFeature
         }
     }
-    // mustNormalize: L1_NORM(0) -> L1, L2_NORM(1) -> L2, others false (ScoringObject.h)
-    const bool must = (scoring == 0 || scoring == 1);
+    // mustNormalize (ScoringObject.h:74-89): L1_NORM(0), CHI_SQUARE(2), KL(3), BHATTACHARYYA(4) -> true with the
+    // L1 norm; L2_NORM(1) -> true with the L2 norm; DOT_PRODUCT(5) -> false
+    const bool must = (scoring != 5);
+    const bool l2 = (scoring == 1);
     if (tf && !v.empty() && !must) {                       // :1164-1170
         const double nd = (double)v.size();
         for (auto& kv : v) kv.second /= nd;
     }
     if (must) {                                            // BowVector::normalize (:62-84)
         double norm = 0.0;
-        if (scoring == 0) for (auto& kv : v) norm += fabs(kv.second);
+        if (!l2) for (auto& kv : v) norm += fabs(kv.second);
         else { for (auto& kv : v) norm += kv.second * kv.second; norm = sqrt(norm); }
         if (norm > 0.0) for (auto& kv : v) kv.second /= norm;
     }

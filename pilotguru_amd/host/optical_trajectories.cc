@@ -93,10 +93,36 @@ std::map<std::string, double> read_settings(const std::string& path)
 struct FrameSource {                  // ImageSequenceSource (include/io/image_sequence_reader.hpp:23-28), grey only
     std::string path; int w = 0, h = 0; double fps = 30; long frame = 0;
     FILE* fp = nullptr; bool y4m = false, pattern = false; size_t y4mFrameBytes = 0;
+    std::string patHead, patTail; int patWidth = 0; bool patZero = false;      // "<head>%0Nd<tail>", parsed once
+    // The user's path is never handed to printf as a format: exactly one %d / %Nd / %0Nd conversion is
+    // accepted ("%%" is a literal per cent sign) and the frame name is assembled by hand.
+    bool parse_pattern(const std::string& p)
+    {
+        bool seen = false;
+        std::string* cur = &patHead;
+        for (size_t i = 0; i < p.size(); i++) {
+            if (p[i] != '%') { *cur += p[i]; continue; }
+            if (i + 1 < p.size() && p[i + 1] == '%') { *cur += '%'; i++; continue; }
+            if (seen) return false;
+            size_t j = i + 1;
+            if (j < p.size() && p[j] == '0') { patZero = true; j++; }
+            int wd = 0;
+            while (j < p.size() && p[j] >= '0' && p[j] <= '9' && wd < 100) wd = wd * 10 + (p[j++] - '0');
+            if (j >= p.size() || p[j] != 'd' || wd > 32) return false;
+            patWidth = wd; seen = true; cur = &patTail; i = j;
+        }
+        return seen;
+    }
+    std::string frame_name(long k) const
+    {
+        std::string num = std::to_string(k);
+        if ((int)num.size() < patWidth) num.insert(0, (size_t)patWidth - num.size(), patZero ? '0' : ' ');
+        return patHead + num + patTail;
+    }
     bool open(const std::string& p, int sw, int sh, double f)
     {
         path = p; fps = f;
-        if (p.find('%') != std::string::npos) { pattern = true; return true; }
+        if (p.find('%') != std::string::npos) { pattern = true; return parse_pattern(p); }
         fp = fopen(p.c_str(), "rb");
         if (!fp) return false;
         if (p.size() > 4 && p.substr(p.size() - 4) == ".y4m") {
@@ -119,11 +145,17 @@ struct FrameSource {                  // ImageSequenceSource (include/io/image_s
     bool next(std::vector<uint8_t>& gray, long long* time_usec, long long* frame_id)
     {
         if (pattern) {
-            char name[1024]; snprintf(name, sizeof(name), path.c_str(), (int)frame);
-            FILE* f = fopen(name, "rb");
+            FILE* f = fopen(frame_name(frame).c_str(), "rb");
             if (!f) return false;
-            char magic[3] = {0}; int maxv = 0;
-            if (fscanf(f, "%2s %d %d %d", magic, &w, &h, &maxv) != 4 || strcmp(magic, "P5") || maxv != 255) { fclose(f); return false; }
+            char magic[3] = {0}; int maxv = 0, fw = 0, fh = 0;
+            if (fscanf(f, "%2s %d %d %d", magic, &fw, &fh, &maxv) != 4 || strcmp(magic, "P5") || maxv != 255) { fclose(f); return false; }
+            // every frame of a sequence has the first frame's size (the context and the buffers are sized once)
+            if (fw <= 0 || fh <= 0 || (frame > 0 && (fw != w || fh != h))) {
+                fclose(f);
+                fprintf(stderr, "ERROR: frame %ld is %dx%d, the sequence started with %dx%d\n", frame, fw, fh, w, h);
+                return false;
+            }
+            w = fw; h = fh;
             fgetc(f);
             gray.resize((size_t)w * h);
             const bool ok = fread(gray.data(), 1, gray.size(), f) == gray.size();
@@ -158,13 +190,15 @@ int write_trajectory_from_text(const Flags& F)
     // time_usec is_lost frame_id tx ty tz qw qx qy qz dir_x dir_y turn_angle
     std::ifstream f(F.trajectory_in);
     if (!f.good()) check_failed("trajectory_in file is readable");
+    // numbers go through strtod so that "nan" / "inf" can be fed to the writer (operator>> refuses them)
+    auto num = [&](double* v) { std::string tok; if (!(f >> tok)) return false; char* e = nullptr; *v = strtod(tok.c_str(), &e); return e != tok.c_str(); };
     double plane[6];
-    for (double& v : plane) f >> v;
+    for (double& v : plane) num(&v);
     std::vector<pgorb::PoseWithTimestamp> traj; std::vector<double> dirs, turns;
     for (;;) {
         pgorb::PoseWithTimestamp p; long long t, id; int lost; double dx, dy, turn;
-        if (!(f >> t >> lost >> id >> p.pose.translation[0] >> p.pose.translation[1] >> p.pose.translation[2] >> p.pose.qw >>
-              p.pose.qx >> p.pose.qy >> p.pose.qz >> dx >> dy >> turn)) break;
+        if (!(f >> t >> lost >> id) || !num(&p.pose.translation[0]) || !num(&p.pose.translation[1]) || !num(&p.pose.translation[2]) ||
+            !num(&p.pose.qw) || !num(&p.pose.qx) || !num(&p.pose.qy) || !num(&p.pose.qz) || !num(&dx) || !num(&dy) || !num(&turn)) break;
         p.time_usec = t; p.is_lost = lost != 0; p.frame_id = id;
         traj.push_back(p); dirs.push_back(dx); dirs.push_back(dy); turns.push_back(turn);
     }

@@ -12,6 +12,7 @@
 #pragma once
 #include <cstdint>
 #include <cstdio>
+#include <cmath>
 #include <string>
 #include <vector>
 
@@ -22,12 +23,13 @@ struct PoseWithTimestamp { Pose pose; int64_t time_usec; bool is_lost; int64_t f
 
 inline std::string json_double(double x)
 {
+    // nlohmann 2.x turns a non-finite float into JSON null when the value is constructed, so the reference's
+    // files stay parseable after a diverged fit or a 0/0 angular velocity
+    if (!std::isfinite(x)) return "null";
     char buf[64];
     snprintf(buf, sizeof(buf), "%.15g", x);
     std::string s(buf);
-    if (s.find_first_of(".eE") == std::string::npos && s.find_first_of("0123456789") != std::string::npos &&
-        s != "nan" && s != "inf" && s != "-inf")
-        s += ".0";
+    if (s.find_first_of(".eE") == std::string::npos) s += ".0";
     return s;
 }
 

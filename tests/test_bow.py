@@ -53,6 +53,40 @@ def test_bow_vectors_match_real_reference_code(oracle):
             assert abs(got[0][1].sum() - 1.0) < 1e-12           # L1 normalised
 
 
+@pytest.mark.parametrize("scoring", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("weighting", [0, 1, 2, 3])
+def test_bow_vectors_every_scoring_and_weighting_type(oracle, tmp_path, scoring, weighting):
+    """ScoringObject.h:74-89: L1 norm for L1_NORM / CHI_SQUARE / KL / BHATTACHARYYA, L2 for L2_NORM, none
+    for DOT_PRODUCT (then tf / |v| for TF weightings, TemplatedVocabulary.h:1164-1170).  Product ==
+    reference BowVector code == oracle, bit for bit."""
+    if oracle.ref_dbow2() is None:
+        pytest.skip("oracle/_ref/libdbow2_ref.so not built and /root/reference absent")
+    rng = np.random.RandomState(40 + scoring * 4 + weighting)
+    n = 700
+    word = rng.randint(0, 120, n).astype(np.uint32)
+    wtab = np.round(rng.uniform(0.0, 9.0, 120), 5)
+    wtab[rng.randint(0, 120, 9)] = 0.0
+    weight, node = wtab[word], (word // 5).astype(np.uint32)
+    got = V.bow_vectors(word, weight, node, scoring=scoring, weighting=weighting)
+    ref = oracle.ref_bow_vectors(word, weight, node, scoring, weighting)
+    for g, r in zip(got[0] + got[1], ref[0] + ref[1]):
+        assert g.dtype == r.dtype and g.tobytes() == r.tobytes()
+    val = got[0][1]
+    if scoring == 1:
+        assert abs(np.sqrt((val * val).sum()) - 1.0) < 1e-12
+    elif scoring != 5:
+        assert abs(np.abs(val).sum() - 1.0) < 1e-12
+    # the oracle's whole transform() with this header agrees as well
+    desc, wgt, parent = V.synth_vocabulary(4, 3, 1)
+    path = os.path.join(str(tmp_path), "voc_%d_%d.txt" % (scoring, weighting))
+    V.write_vocabulary_text(path, 4, 3, desc, wgt, parent, scoring=scoring, weighting=weighting)
+    ora = oracle.VocabOracle(path)
+    feats = rng.randint(0, 256, (200, 32)).astype(np.uint8)
+    (bid, bval), ofv = ora.transform(feats, levelsup=2)
+    got2 = V.bow_vectors(*ora.transform_features(feats, 2), scoring, weighting)
+    assert np.array_equal(got2[0][0], bid) and got2[0][1].tobytes() == bval.tobytes()
+
+
 def test_oracle_transform_vs_product_host_accumulation(tmp_path, oracle):
     path, desc, weight, parent = _vocab_file(tmp_path)
     ora = oracle.VocabOracle(path)

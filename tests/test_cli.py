@@ -49,6 +49,34 @@ def test_trajectory_json_writer_matches_fixture(tmp_path):
     assert abs(p["angular_velocity"] - 0.01 / (0.033333 + 1e-10)) < 1e-12
 
 
+def test_trajectory_json_non_finite_numbers_become_null(tmp_path):
+    """nlohmann 2.1.1 stores a non-finite float as null, so the reference's files stay valid JSON."""
+    src = open(os.path.join(HERE, "golden", "trajectory_in.txt")).read().split("\n")
+    idx = [i for i, l in enumerate(src) if l.startswith("33333 ")][0]
+    f = src[idx].split()
+    f[3], f[12] = "nan", "inf"                                       # tx of point 1, its turn angle
+    src[idx] = " ".join(f)
+    path = os.path.join(str(tmp_path), "traj_nan.txt")
+    open(path, "w").write("\n".join(src))
+    r = _cli("--trajectory_in=" + path, "--out_dir=" + str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    got = open(os.path.join(str(tmp_path), "trajectory-0.json")).read()
+    d = json.loads(got)                                               # parses: no bare nan / inf tokens
+    assert d["trajectory"][1]["pose"]["translation"][0] is None
+    assert d["trajectory"][1]["angular_velocity"] is None
+    assert "nan" not in got and "inf" not in got
+
+
+def test_cli_rejects_hostile_frame_patterns(tmp_path):
+    """--in_video is never used as a printf format: one %d / %0Nd conversion or nothing."""
+    settings = os.path.join(str(tmp_path), "cam.yml")
+    open(settings, "w").write("%YAML:1.0\nCamera_width: 64\nCamera_height: 64\n")
+    for bad in ("f_%s.pgm", "f_%d_%d.pgm", "f_%n.pgm", "f_%5000d.pgm", "f_%", "f_%x.pgm"):
+        r = _cli("--vocabulary_file=v.txt", "--camera_settings=" + settings, "--in_video=" + os.path.join(str(tmp_path), bad),
+                 "--out_dir=" + str(tmp_path), "--novisualize")
+        assert r.returncode != 0 and "input video opens" in r.stderr, (bad, r.stderr)
+
+
 @pytest.mark.gpu
 def test_cli_front_end_run_matches_python_path(tmp_path, oracle):
     import pilotguru_amd as pg
