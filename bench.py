@@ -50,47 +50,123 @@ import sys, time
 sys.path.insert(0, sys.argv[1])
 import numpy as np
 from oracle import orb_oracle
-from pilotguru_amd.synth import synth_ride
-w, h, nf, budget, seed = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5]), int(sys.argv[6])
-ride = synth_ride(1000 + seed, w, h, 4)
+from pilotguru_amd.synth import synth_ride, synth_ride_road
+w, h, nf, warm, reps, rep_s, seed, scene = (int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]),
+                                            int(sys.argv[6]), float(sys.argv[7]), int(sys.argv[8]), sys.argv[9])
+ride = (synth_ride_road if scene == "road" else synth_ride)(1000 + seed, w, h, 4)
 ora = orb_oracle.OrbOracle(nf, 1.2, 8, 20, 7)
-kp, prev = ora.extract(ride[0])                       # warm-up, also the first "previous frame"
+kp, prev = ora.extract(ride[0])
 sys.stdout.write("ready\n"); sys.stdout.flush()
 sys.stdin.readline()                                   # start gate
-t0 = time.perf_counter(); done = 0
-while time.perf_counter() - t0 < budget:
+done = 0
+def one():
+    global prev, done
     kp, desc = ora.extract(ride[(done + 1) % 4])
     orb_oracle.hamming_best2(desc, prev)
     prev = desc; done += 1
-print(done, time.perf_counter() - t0)
+for _ in range(warm):
+    one()
+out = []
+for r in range(reps):
+    t0 = time.perf_counter(); k = 0
+    while time.perf_counter() - t0 < rep_s:
+        one(); k += 1
+    out.append("%d:%.6f" % (k, time.perf_counter() - t0))
+print(" ".join(out))
 """
 
 
-def cpu_baseline(w, h, nfeatures, budget_s=12.0):
-    """The CPU oracle (oracle/: a port of the reference path, the reference binary itself cannot
-    be built here) timed on this host: one extractor per core like running one ride per core
-    (the reference runs extraction on one thread, Frame.cc:254), on a bounded sample of the same
-    workload: extract + best-2 match against the previous frame, ~12 s per worker."""
+def _cpu_leg(nproc, w, h, nfeatures, warm, reps, rep_s, scene, lib_path):
+    """`nproc` oracle workers (one extractor each); per repetition r the rate is the frames all workers
+    finished in their r-th window / the longest such window.  Returns the per-repetition rates."""
     import subprocess
-    cores = min(os.cpu_count() or 1, 64)
-    procs = [subprocess.Popen([sys.executable, "-c", _CPU_WORKER, ROOT, str(w), str(h), str(nfeatures), str(budget_s), str(i)],
-                              stdin=subprocess.PIPE, stdout=subprocess.PIPE, universal_newlines=True)
-             for i in range(cores)]
+    env = dict(os.environ)
+    if lib_path:
+        env["PGORB_ORACLE_LIB"] = lib_path
+    procs = [subprocess.Popen([sys.executable, "-c", _CPU_WORKER, ROOT, str(w), str(h), str(nfeatures), str(warm), str(reps),
+                               str(rep_s), str(i), scene],
+                              stdin=subprocess.PIPE, stdout=subprocess.PIPE, universal_newlines=True, env=env)
+             for i in range(nproc)]
     for p in procs:
-        p.stdout.readline()                            # all workers generated their frames
+        p.stdout.readline()                            # every worker has generated its frames
     for p in procs:
         p.stdin.write("go\n"); p.stdin.flush()
-    frames, tmax, single = 0, 0.0, 0.0
-    for i, p in enumerate(procs):
-        out = p.stdout.readline().split()
+    frames = [0] * reps
+    tmax = [0.0] * reps
+    for p in procs:
+        toks = p.stdout.readline().split()
         p.wait()
-        d, t = int(out[0]), float(out[1])
-        frames += d; tmax = max(tmax, t)
-    return {"value": frames / tmax, "unit": "frames/s", "cores": cores, "kind": "port",
-            "per_core": frames / tmax / cores,
-            "sample": "%d synthetic %dx%d frames over %d worker processes (one oracle extractor per core), "
-                      "%d features, extract + best-2 match vs previous frame, %.0f s budget"
-                      % (frames, w, h, cores, nfeatures, budget_s)}
+        for r, tok in enumerate(toks):
+            k, t = tok.split(":")
+            frames[r] += int(k); tmax[r] = max(tmax[r], float(t))
+    return [f / t for f, t in zip(frames, tmax)], sum(frames)
+
+
+def cpu_baseline(w, h, nfeatures, scene="textured"):
+    """The CPU oracle (oracle/: a scalar plain-C port of the reference path; the reference binary itself
+    needs OpenCV 2.4 and cannot be built or shipped) timed on this host per BASELINE.md section 2: same
+    workload (extract + best-2 match against the previous frame), built -O3 -march=native
+    -ffp-contract=off on this box when it has a compiler (generic x86-64 build otherwise), (i) ONE
+    thread -- how the reference runs extraction (Frame.cc:254) -- after a 20-frame warm-up, (ii) one
+    extractor per host core, frames sharded; median of 5 repetitions each."""
+    import statistics
+    import subprocess
+    cores = os.cpu_count() or 1
+    lib_path, flags = None, "-O3 -ffp-contract=off (generic x86-64, prebuilt)"
+    try:
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "native"], stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL)
+        lib_path = os.path.join(ROOT, "oracle", "_native", "liborb_oracle.so")
+        flags = "-O3 -march=native -ffp-contract=off (built on this host)"
+    except (OSError, subprocess.CalledProcessError):
+        pass
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    one, n1 = _cpu_leg(1, w, h, nfeatures, 20, 5, 1.5, scene, lib_path)
+    allc, na = _cpu_leg(cores, w, h, nfeatures, 3, 5, 2.0, scene, lib_path)
+    v1, va = statistics.median(one), statistics.median(allc)
+    return {"value": va, "unit": "frames/s", "cores": cores, "kind": "port",
+            "per_core": va / cores,
+            "one_thread": {"value": v1, "ms_per_frame": 1e3 / v1, "cores": 1, "repetitions": one},
+            "all_cores_repetitions": allc, "flags": flags, "cpu_model": model,
+            "sample": "%d + %d synthetic %dx%d frames (%s scene), %d features, extract + best-2 match vs previous "
+                      "frame: 1 thread (20-frame warm-up, median of 5 x 1.5 s) and %d worker processes, one oracle "
+                      "extractor per core (3-frame warm-up, median of 5 x 2 s)"
+                      % (n1, na, w, h, scene, nfeatures, cores)}
+
+
+def verify_against_oracle(ride, kps, desc, n, mout, nfeatures):
+    """After the timed region: the first and the last frame of the batch the timed steps processed and
+    the last frame's best-2 match against its predecessor, byte for byte against the CPU oracle.  A
+    mismatch ends the run without a JSON line."""
+    import numpy as np
+    from oracle import orb_oracle
+    B = ride.shape[0]
+    nh = n.cpu().numpy()
+    odesc = {}
+    for f in sorted({0, B - 2, B - 1}):
+        if f < 0:
+            continue
+        okp, od = orb_oracle.OrbOracle(nfeatures, 1.2, 8, 20, 7).extract(ride[f])
+        if f in (0, B - 1):
+            if nh[f] != len(okp) or kps[f, :nh[f]].cpu().numpy().tobytes() != okp.tobytes() or \
+                    not np.array_equal(desc[f, :nh[f]].cpu().numpy(), od):
+                raise SystemExit("bench verification FAILED: frame %d differs from the oracle" % f)
+        odesc[f] = od
+    if B >= 2:
+        obi, ob1, ob2 = orb_oracle.hamming_best2(odesc[B - 1], odesc[B - 2])
+        m = nh[B - 1]
+        if not (np.array_equal(mout[0][B - 2, :m].cpu().numpy(), obi) and
+                np.array_equal(mout[1][B - 2, :m].cpu().numpy().view(np.uint16), ob1) and
+                np.array_equal(mout[2][B - 2, :m].cpu().numpy().view(np.uint16), ob2)):
+            raise SystemExit("bench verification FAILED: best-2 match of the last pair differs from the oracle")
+    return True
 
 
 def main():
@@ -102,13 +178,19 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--features", type=int, default=2000)
+    ap.add_argument("--scene", choices=("textured", "road"), default="textured",
+                    help="textured = SURVEY.md 8d's scene (the headline workload); road = sky / asphalt / texture band")
+    ap.add_argument("--sustain-seconds", type=float, default=3.0,
+                    help="after the timed steps, keep stepping for this long and report sustained_fps (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-upload-leg", action="store_true")
     args = ap.parse_args()
 
     import numpy as np
     import torch
     import pilotguru_amd as pg
-    from pilotguru_amd.synth import synth_ride
+    from pilotguru_amd.synth import synth_ride, synth_ride_road
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -127,7 +209,8 @@ def main():
 
     # one ride per rank (ride id = rank): B consecutive frames, resident in HBM
     from pilotguru_amd import dist as pgd0
-    ride = synth_ride(pgd0.ride_for_rank(rank, world)[0], W, H, B)
+    make_ride = synth_ride_road if args.scene == "road" else synth_ride
+    ride = make_ride(pgd0.ride_for_rank(rank, world)[0], W, H, B)
     frames = torch.from_numpy(ride).to(dev)
     cap = ext.max_keypoints(W, H)
     kps = torch.empty((B, cap, 7), dtype=torch.float32, device=dev)
@@ -135,9 +218,9 @@ def main():
     n = torch.empty((B,), dtype=torch.int32, device=dev)
     pq = torch.arange(1, B, dtype=torch.int32, device=dev)      # frame f (query) vs f-1 (train)
     pt = torch.arange(0, B - 1, dtype=torch.int32, device=dev)
-    mout = (torch.empty((B - 1, cap), dtype=torch.int32, device=dev),
-            torch.empty((B - 1, cap), dtype=torch.int16, device=dev),
-            torch.empty((B - 1, cap), dtype=torch.int16, device=dev))
+    mout = (torch.empty((max(B - 1, 1), cap), dtype=torch.int32, device=dev),
+            torch.empty((max(B - 1, 1), cap), dtype=torch.int16, device=dev),
+            torch.empty((max(B - 1, 1), cap), dtype=torch.int16, device=dev))
 
     # the one collective of this path: broadcast the (synthetic) ORB vocabulary root -> peers
     vocab_bytes = 0
@@ -169,7 +252,8 @@ def main():
 
     def step():
         ext.extract_batch_device(frames, kps, desc, n)
-        ext.match_batch_device(desc, n, pq, pt, mout)
+        if B > 1:
+            ext.match_batch_device(desc, n, pq, pt, mout)
 
     for _ in range(args.warmup):
         step()
@@ -195,6 +279,48 @@ def main():
     ncalls, stage_ms = ext.profile_read()
     ext.check_async()
 
+    # ---- everything below is outside the timed region ------------------------------------------
+    verified = None
+    if not args.no_verify and rank == 0:
+        verified = verify_against_oracle(ride, kps, desc, n, mout, NF)
+
+    # sustained rate: the same step for >= --sustain-seconds (clocks and power settle; the 20-step region
+    # above is only tens of milliseconds)
+    sustained = None
+    if args.sustain_seconds > 0 and dist is None:
+        k_chunk = max(10, int(0.25 / max(elapsed / args.steps, 1e-6)))
+        torch.cuda.synchronize()
+        ts = time.perf_counter(); ksteps = 0
+        while time.perf_counter() - ts < args.sustain_seconds:
+            for _ in range(k_chunk):
+                step()
+            torch.cuda.synchronize()
+            ksteps += k_chunk
+        te = time.perf_counter()
+        ext.check_async()
+        sustained = {"fps": ksteps * B / (te - ts), "seconds": te - ts, "steps": ksteps}
+
+    # the matcher the north star describes (ballot / popcount), timed on the same descriptors
+    matcher = ext.matcher_name(cap)
+    popcount_ms = None
+    if dist is None and B > 1:
+        ext.set_option("matcher", 1)
+        for _ in range(2):
+            ext.match_batch_device(desc, n, pq, pt, mout)
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        for _ in range(5):
+            ext.match_batch_device(desc, n, pq, pt, mout)
+        torch.cuda.synchronize()
+        popcount_ms = (time.perf_counter() - tp) / 5 * 1e3
+        ext.set_option("matcher", 0)
+
+    # frames that start in HOST memory: the streamed path (pinned double buffers, copies overlapped with
+    # the kernels of the neighbouring batches) -- PCIe-inclusive, reported next to `value`, never as it
+    uploaded = None
+    if not args.no_upload_leg and dist is None and hasattr(ext, "upload_leg"):
+        uploaded = ext.upload_leg(ride, seconds=2.0)
+
     if rank == 0:
         frames_total = world * B * args.steps
         fps = frames_total / elapsed
@@ -208,16 +334,18 @@ def main():
         rk = max(cands, key=lambda s: stage_ms[s])
         launches = 7 if rk == "pyramid" else 1
         ach = (abytes[rk] * B / launches) / (stage_ms[rk] / launches * 1e-3) / 1e9
-        kname = {"pyramid": "k_pyr_resize_rows4_lds", "fast": "k_fast_cells", "describe": "k_describe",
+        kname = {"pyramid": "k_pyr_resize_rows4_lds", "fast": ext.fast_kernel_name(), "describe": "k_describe",
                  "match": "k_match_mfma"}[rk]
-        traffic = None                                  # HBM bytes per launch from the committed PMC passes
+        traffic, traffic_src = None, None               # HBM bytes per launch from the committed PMC passes
         try:
             import glob
             for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):   # newest round first
                 tr = json.load(open(path))
-                if tr["workload"] == {"width": W, "height": H, "features": NF, "batch": B} and kname in tr["kernels"]:
+                if tr["workload"] == {"width": W, "height": H, "features": NF, "batch": B} and kname in tr["kernels"] \
+                        and tr.get("scene", "textured") == args.scene:
                     k = tr["kernels"][kname]
                     traffic = (2.0 * k["fetch_kb"] + k["write_kb"]) * 1024.0
+                    traffic_src = "profiles/" + os.path.basename(path)
                     break
         except (OSError, KeyError, ValueError):
             pass
@@ -230,20 +358,30 @@ def main():
             "config": {"workload": "%dx%d grayscale, %d kp/frame, 8-level pyramid, batch %d frames/GPU "
                                    "resident in HBM, extract + best-2 Hamming match vs previous frame"
                                    % (W, H, NF, B),
+                       "scene": args.scene,
                        "batch": B, "keypoints_per_frame": nkp, "parallelism": "frames-sharded x%d" % world,
-                       "vocab_broadcast_bytes": vocab_bytes},
+                       "vocab_broadcast_bytes": vocab_bytes,
+                       "matcher": matcher, "matcher_popcount_ms_per_step": popcount_ms},
             "roofline": {"bound": "hbm", "kernel": kname,
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": (traffic_src + " (rocprofv3 PMC passes of this command on an earlier run; "
+                                            "not re-measured by this process)") if traffic_src else None,
                          "algorithmic_bytes_per_launch": abytes[rk] * B / launches,
                          "launch_ms": stage_ms[rk] / launches},
             "stage_ms_per_step": stage_ms, "dominant_stage": dom,
             "whole_path_algorithmic_GBps": sum(abytes.values()) * fps / world / 1e9,
+            "verified": verified,
         }
+        if sustained is not None:
+            out["sustained_fps"] = sustained["fps"]
+            out["sustained"] = sustained
+        if uploaded is not None:
+            out["frames_uploaded"] = uploaded
         if not args.no_cpu_baseline and world == 1:            # rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(W, H, NF)
+            out["cpu_baseline"] = cpu_baseline(W, H, NF, args.scene)
             out["speedup_vs_cpu_all_cores"] = fps / out["cpu_baseline"]["value"]
-            out["speedup_vs_cpu_per_core"] = fps / out["cpu_baseline"]["per_core"]
+            out["speedup_vs_cpu_one_thread"] = fps / out["cpu_baseline"]["one_thread"]["value"]
         line = json.dumps(out)
     else:
         line = None

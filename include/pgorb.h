@@ -392,6 +392,14 @@ int  pgorb_fit_motion_velocities(pgorb_ctx* ctx, const double* gps_velocity, con
 int  pgorb_profile_begin(pgorb_ctx* ctx, int max_calls);
 int  pgorb_profile_read(pgorb_ctx* ctx, double* ms);
 
+/* Measurement switches (no counterpart in the reference; results never depend on them -- the parity suite
+ * runs under each).  key "matcher": 0 = the default (fp4 block-scaled MFMA for < 8192 descriptors per
+ * frame), 1 = the ballot / popcount kernels BASELINE.json's north star describes, for every size.
+ * Process-wide.  Returns PGORB_E_ARG for an unknown key. */
+int  pgorb_set_option(pgorb_ctx* ctx, const char* key, int value);
+/* 1 when a match of `cap_per_frame` descriptors per frame takes the popcount kernels, else 0 */
+int  pgorb_matcher_is_popcount(const pgorb_ctx* ctx, int cap_per_frame);
+
 /* Stage taps for parity tests (host buffers, synchronous; operate on the LAST batch). */
 int  pgorb_debug_level_size(const pgorb_ctx* ctx, int level, int* w, int* h);
 int  pgorb_debug_level_image(pgorb_ctx* ctx, int frame, int level, uint8_t* out /* w*h */);

@@ -11,7 +11,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "liborb_oracle.so")
+# PGORB_ORACLE_LIB: another build of the same sources (bench.py's cpu_baseline leg times a -march=native one)
+_LIB = os.environ.get("PGORB_ORACLE_LIB") or os.path.join(_HERE, "liborb_oracle.so")
 
 KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                            ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])

@@ -799,6 +799,15 @@ int pgorb_profile_begin(pgorb_ctx* c, int max_calls)
     return 0;
 }
 
+int pgorb_set_option(pgorb_ctx* c, const char* key, int value)
+{
+    if (!key) return PGORB_E_ARG;
+    if (!strcmp(key, "matcher")) { pg_match_set_popcount(value); return 0; }
+    return c ? fail(c, PGORB_E_ARG, "unknown option '%s'", key) : PGORB_E_ARG;
+}
+
+int pgorb_matcher_is_popcount(const pgorb_ctx*, int cap_per_frame) { return pg_match_uses_popcount(cap_per_frame) ? 1 : 0; }
+
 int pgorb_profile_read(pgorb_ctx* c, double* ms)
 {
     if (!c || !ms) return PGORB_E_ARG;

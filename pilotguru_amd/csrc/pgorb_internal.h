@@ -125,4 +125,7 @@ void pg_launch_match_batch(const uint8_t* d_desc, const int32_t* d_n, int cap_pe
 void pg_launch_best2(const uint8_t* d_a, int na, const uint8_t* d_b, int nb, uint8_t* d_scratch,
                      int32_t* d_best_idx, uint16_t* d_best, uint16_t* d_second, hipStream_t s);
 
+void pg_match_set_popcount(int on);
+bool pg_match_uses_popcount(int cap_per_frame);
+
 static_assert(sizeof(PgPlan) <= 4000, "PgPlan is passed by value as a kernel argument (4 KiB limit)");

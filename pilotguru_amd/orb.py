@@ -199,6 +199,17 @@ class ORBextractor:
             C.c_void_p(out[2].data_ptr()), C.c_void_p(s)))
         return out
 
+    def set_option(self, key, value):
+        """Measurement switches of the library (include/pgorb.h: pgorb_set_option)."""
+        self._check(self._L.pgorb_set_option(self._h, key.encode(), int(value)))
+
+    def matcher_name(self, cap_per_frame):
+        return "popcount" if self._L.pgorb_matcher_is_popcount(self._h, int(cap_per_frame)) else "mfma_fp4"
+
+    def fast_kernel_name(self):
+        """Name of the K2 kernel the common cell geometry takes (for bench.py's roofline object)."""
+        return "k_fast_cells"
+
     STAGES = ("pyramid", "fast", "quadtree", "describe", "match")
 
     def profile_begin(self, max_calls):

@@ -74,3 +74,41 @@ def synth_ride(seed, w, h, nframes, dx=2, dy=1):
     for k in range(nframes):
         out[k] = scene[k * dy:k * dy + h, k * dx:k * dx + w]
     return out
+
+
+def synth_scene_road(seed, w, h):
+    """A driving-like scene: the top 42 % is "sky" (smooth vertical gradient, +-2 noise, a few faint
+    clouds whose contrast of 14 grey levels lies between minThFAST = 7 and iniThFAST = 20), the bottom
+    30 % is "asphalt" (flat grey, +-3 noise, a few bright lane markings), the band in between is the
+    textured scene.  More than half of the 30-px cells hold no corner at iniThFAST, so the detector's
+    per-cell retry at minThFAST (ORBextractor.cc:812-816) runs on most of the image."""
+    img = synth_scene(seed, w, h).astype(np.int64)
+    X, Y = np.meshgrid(np.arange(w, dtype=np.uint64), np.arange(h, dtype=np.uint64))
+    ys = np.arange(h, dtype=np.int64)[:, None]
+    sky_end, road_beg = (42 * h) // 100, (70 * h) // 100
+    sky = 205 - (ys * 40) // max(h, 1) + ((_hash2(seed, 21, X, Y) % np.uint64(5)).astype(np.int64) - 2)
+    road = 90 + ((_hash2(seed, 22, X, Y) % np.uint64(7)).astype(np.int64) - 3)
+    img[:sky_end] = np.broadcast_to(sky, (h, w))[:sky_end]
+    img[road_beg:] = np.broadcast_to(road, (h, w))[road_beg:]
+    nobj = max(6, (60 * w * h) // (1920 * 1080))
+    r = _mix(np.arange(nobj * 4, dtype=np.uint64) + (np.uint64(seed) << np.uint64(32)) + np.uint64(991)).reshape(nobj, 4)
+    for i in range(nobj):
+        rw, rh = 10 + int(r[i, 0] % np.uint64(50)), 6 + int(r[i, 1] % np.uint64(20))
+        x0 = int(r[i, 2] % np.uint64(max(1, w - rw)))
+        if i % 2 == 0 and sky_end > rh + 2:                                   # cloud: +14 on the sky
+            y0 = int(r[i, 3] % np.uint64(max(1, sky_end - rh - 1)))
+            img[y0:y0 + rh, x0:x0 + rw] += 14
+        elif h - road_beg > rh + 2:                                           # lane marking: bright on the asphalt
+            y0 = road_beg + 1 + int(r[i, 3] % np.uint64(max(1, h - road_beg - rh - 1)))
+            img[y0:y0 + rh, x0:x0 + rw] = 215
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def synth_ride_road(seed, w, h, nframes, dx=2, dy=0):
+    """nframes x h x w uint8 of the driving-like scene; the camera pans horizontally (dy = 0 keeps the
+    horizon where it is)."""
+    scene = synth_scene_road(seed, w + dx * (nframes - 1), h + dy * (nframes - 1))
+    out = np.empty((nframes, h, w), np.uint8)
+    for k in range(nframes):
+        out[k] = scene[k * dy:k * dy + h, k * dx:k * dx + w]
+    return out

@@ -1,0 +1,141 @@
+"""Parity at the shapes bench.py measures, and the N > 1 code on one GPU.
+
+ * every frame of a ride at BASELINE.json configs[1] (1920x1080 / 2000, 32 frames) and configs[2]
+   (3840x2160 / 4000, 8 frames): keypoints (28-byte records as bytes), descriptors AND the best-2
+   Hamming match of every frame against its predecessor, against the oracle (fanned over a process
+   pool) -- SURVEY.md section 7's config-2 criterion "bit-exact on every frame of the ride";
+ * the same for the driving-like scene class (sky / asphalt: the minThFAST retry is live);
+ * configs[3]'s code path (RCCL process group, vocabulary broadcast, device-side blob upload, the
+   cross-rank BoW signature) as a one-rank torchrun of bench.py on the one GPU a test box has;
+ * one ride split over two contexts with dist.frame_chunk_for_rank reproduces the unsplit ride.
+
+Reference semantics: ORBextractor.cc:1042-1104 (operator()), ORBmatcher.cc:1651-1667
+(DescriptorDistance), src/optical_trajectories.cc:87-94 (one vocabulary for every System)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from pilotguru_amd.synth import synth_ride, synth_ride_road
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+
+pytestmark = pytest.mark.gpu
+
+
+def _ride_vs_oracle(ride, nf, batch):
+    import torch
+    import pilotguru_amd as pg
+    from _oracle_pool import oracle_ride
+    B, h, w = ride.shape
+    ext = pg.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=batch)
+    cap = ext.max_keypoints(w, h)
+    oext, omatch = oracle_ride(list(ride), (nf, 1.2, 8, 20, 7))
+    kall, dall, nall = [], [], []
+    for b0 in range(0, B, batch):                                   # the bench's call, batch by batch
+        fr = torch.from_numpy(ride[b0:b0 + batch]).cuda()
+        kps, desc, n = ext.extract_batch_device(fr)
+        ext.check_async()
+        kall.append(kps.clone()); dall.append(desc.clone()); nall.append(n.clone())
+    kps, desc, n = torch.cat(kall), torch.cat(dall), torch.cat(nall)
+    nh = n.cpu().numpy()
+    for f in range(B):
+        okp, odesc = oext[f]
+        assert nh[f] * 28 == len(okp), "frame %d: %d keypoints, oracle %d" % (f, nh[f], len(okp) // 28)
+        assert kps[f, :nh[f]].cpu().numpy().tobytes() == okp, "keypoints of frame %d" % f
+        assert desc[f, :nh[f]].cpu().numpy().tobytes() == odesc, "descriptors of frame %d" % f
+    pq = torch.arange(1, B, dtype=torch.int32, device="cuda")
+    pt = torch.arange(0, B - 1, dtype=torch.int32, device="cuda")
+    bi, b1, b2 = ext.match_batch_device(desc, n, pq, pt)
+    ext.check_async()
+    torch.cuda.synchronize()
+    bi, b1, b2 = bi.cpu().numpy(), b1.cpu().numpy().view(np.uint16), b2.cpu().numpy().view(np.uint16)
+    for f in range(1, B):
+        obi, ob1, ob2 = omatch[f - 1]
+        assert bi[f - 1, :nh[f]].tobytes() == obi and b1[f - 1, :nh[f]].tobytes() == ob1 and \
+            b2[f - 1, :nh[f]].tobytes() == ob2, "best-2 match of frame %d vs %d" % (f, f - 1)
+    return nh
+
+
+@pytest.mark.parametrize("w,h,nf,B,batch", [(1920, 1080, 2000, 32, 16), (3840, 2160, 4000, 8, 4)])
+def test_every_frame_of_a_ride_at_bench_shapes(w, h, nf, B, batch):
+    nh = _ride_vs_oracle(synth_ride(0, w, h, B), nf, batch)
+    assert nh.min() >= nf - 1                      # acceptance of the scene: every level fills its quota
+
+
+@pytest.mark.parametrize("w,h,nf,B", [(1920, 1080, 2000, 12), (640, 480, 1000, 6)])
+def test_driving_scene_with_flat_regions(w, h, nf, B, oracle):
+    """>= 40 % of the cells are sky / asphalt: no corner at iniThFAST, the per-cell minThFAST retry
+    (ORBextractor.cc:812-816) decides what those cells contribute."""
+    ride = synth_ride_road(3, w, h, B)
+    ora = oracle.OrbOracle(nf, 1.2, 8, 20, 7)
+    ora.extract(ride[0])
+    resp = ora.level_candidates(0)["response"]
+    assert (resp < 20).mean() > 0.4                # the retry produced a large share of level 0's candidates
+    _ride_vs_oracle(ride, nf, B)
+
+
+def test_single_ride_split_over_two_contexts():
+    """SURVEY.md section 8(e), single ride over several GPUs: contiguous chunks with a one-frame overlap,
+    nothing exchanged.  Two contexts (standing in for two ranks) each take their chunk; owned frames
+    and owned (f, f-1) matches together equal the unsplit run."""
+    import torch
+    import pilotguru_amd as pg
+    from pilotguru_amd import dist as pgd
+    w, h, nf, B = 640, 480, 1000, 9
+    ride = synth_ride(11, w, h, B)
+
+    def run(frames):
+        ext = pg.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=len(frames))
+        kps, desc, n = ext.extract_batch_device(torch.from_numpy(frames).cuda())
+        m = len(frames) - 1
+        pq = torch.arange(1, m + 1, dtype=torch.int32, device="cuda")
+        pt = torch.arange(0, m, dtype=torch.int32, device="cuda")
+        bi, b1, b2 = ext.match_batch_device(desc, n, pq, pt) if m else (None, None, None)
+        ext.check_async()
+        torch.cuda.synchronize()
+        nh = n.cpu().numpy()
+        out = []
+        for f in range(len(frames)):
+            rec = [kps[f, :nh[f]].cpu().numpy().tobytes(), desc[f, :nh[f]].cpu().numpy().tobytes(), None]
+            if f >= 1:
+                rec[2] = (bi[f - 1, :nh[f]].cpu().numpy().tobytes(), b1[f - 1, :nh[f]].cpu().numpy().tobytes(),
+                          b2[f - 1, :nh[f]].cpu().numpy().tobytes())
+            out.append(rec)
+        return out
+
+    whole = run(ride)
+    for world in (2, 3):
+        owned = {}
+        for rank in range(world):
+            fe, fo, stop = pgd.frame_chunk_for_rank(B, rank, world)
+            part = run(ride[fe:stop])
+            for f in range(fo, stop):
+                owned[f] = part[f - fe]
+        assert sorted(owned) == list(range(B))
+        for f in range(B):
+            assert owned[f][0] == whole[f][0] and owned[f][1] == whole[f][1]
+            if f >= 1:
+                assert owned[f][2] == whole[f][2], "match of frame %d lost at a chunk border" % f
+
+
+def test_multi_gpu_code_path_on_one_gpu():
+    """bench.py's N > 1 branch as a one-rank job under torch.distributed.run: init_process_group("nccl")
+    (RCCL), broadcast_vocabulary, pgorb_vocab_upload_device, the BoW transform on every rank and the
+    all_gather of its signature, the barriers and the max-over-ranks timing."""
+    env = dict(os.environ, PGORB_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", "29631", os.path.join(ROOT, "bench.py"),
+           "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "8", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["config"]["vocab_broadcast_bytes"] > 1 << 20          # the k=10, L=5 blob went through RCCL
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["verified"] is True
