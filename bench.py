@@ -102,6 +102,27 @@ def _cpu_leg(nproc, w, h, nfeatures, warm, reps, rep_s, scene, lib_path):
     return [f / t for f, t in zip(frames, tmax)], sum(frames)
 
 
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (the GPU
+    box shows 256 logical CPUs but grants 16 CPUs of time; 256 workers on 16 CPUs only measure the scheduler)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            tok = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if tok[0] != "max":
+                    n = min(n, max(1, int(float(tok[0]) / float(tok[1]) + 0.999)))
+            else:
+                q = int(tok[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, (q + per - 1) // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(w, h, nfeatures, scene="textured"):
     """The CPU oracle (oracle/: a scalar plain-C port of the reference path; the reference binary itself
     needs OpenCV 2.4 and cannot be built or shipped) timed on this host per BASELINE.md section 2: same
@@ -111,7 +132,7 @@ def cpu_baseline(w, h, nfeatures, scene="textured"):
     extractor per host core, frames sharded; median of 5 repetitions each."""
     import statistics
     import subprocess
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     lib_path, flags = None, "-O3 -ffp-contract=off (generic x86-64, prebuilt)"
     try:
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "native"], stdout=subprocess.DEVNULL,
@@ -131,7 +152,7 @@ def cpu_baseline(w, h, nfeatures, scene="textured"):
     one, n1 = _cpu_leg(1, w, h, nfeatures, 20, 5, 1.5, scene, lib_path)
     allc, na = _cpu_leg(cores, w, h, nfeatures, 3, 5, 2.0, scene, lib_path)
     v1, va = statistics.median(one), statistics.median(allc)
-    return {"value": va, "unit": "frames/s", "cores": cores, "kind": "port",
+    return {"value": va, "unit": "frames/s", "cores": cores, "logical_cpus_visible": os.cpu_count(), "kind": "port",
             "per_core": va / cores,
             "one_thread": {"value": v1, "ms_per_frame": 1e3 / v1, "cores": 1, "repetitions": one},
             "all_cores_repetitions": allc, "flags": flags, "cpu_model": model,

@@ -29,7 +29,7 @@ SYMBOLS = (
     "pgorb_extract_batch_ingest_device",
     "pgorb_search_by_projection_points", "pgorb_search_by_projection_frame", "pgorb_search_by_bow",
     "pgorb_undistort_keypoints", "pgorb_undistort_keypoints_batch_device", "pgorb_image_bounds",
-    "pgorb_host_alloc", "pgorb_host_free", "pgorb_set_option", "pgorb_matcher_is_popcount",
+    "pgorb_host_alloc", "pgorb_host_free", "pgorb_set_option", "pgorb_get_option", "pgorb_matcher_is_popcount",
     "pgorb_smooth_heading_directions", "pgorb_smooth_time_series", "pgorb_trajectory_pca",
     "pgorb_project_directions", "pgorb_project_translations", "pgorb_turn_angles",
     "pgorb_principal_rotation_axes", "pgorb_angular_velocities_around_axis",
@@ -99,6 +99,7 @@ def lib():
     L.pgorb_debug_level_candidates.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int]
     L.pgorb_debug_level_keypoints.argtypes = [vp, C.c_int, C.c_int]
     L.pgorb_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+    L.pgorb_get_option.argtypes = [vp, C.c_char_p]
     L.pgorb_matcher_is_popcount.argtypes = [vp, C.c_int]
     L.pgorb_profile_begin.argtypes = [vp, C.c_int]
     L.pgorb_profile_read.argtypes = [vp, C.POINTER(C.c_double)]

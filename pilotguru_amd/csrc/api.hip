@@ -40,7 +40,8 @@ struct pgorb_ctx {
     int planW = 0, planH = 0, planBatch = 0;
     bool planValid = false;
     // device memory
-    Arena pyr, cand, sel, nodes, counters, tables, cellCand, cellCount, cellTab;
+    Arena pyr, cand, sel, nodes, counters, tables, cellCand, cellCount, cellTab, blockTab;
+    int fastBlockCX = 4, fastBlockCY = 2;     // K2 block shape in cells (pgorb_set_option "fast_block_cx" / "_cy")
     Arena stageKps, stageDesc, stageN, stageA, stageB, stageOut, vocab;
     Arena xdesc;                              // matcher scratch: train descriptors as +-1 bytes (match.hip)
     void* pinned = nullptr;                   // page-locked bounce buffer for bulk result download
@@ -381,6 +382,48 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
         P.cellTab = (const uint32_t*)c->cellTab.p;
         P.pyrBase = (const uint8_t*)c->pyr.p;
     }
+    {
+        // K2 block records (fast.hip, k_fast_blocks): blocks of blkCX x blkCY cells, row-major per level.
+        // A block's interior must fit 128 x 128 px (32 quads per tile row, 16 steps of 8 rows).
+        std::vector<uint32_t> bt;
+        bool ok = true;
+        for (int l = 0; l < L && ok; l++) {
+            PgLevel& V = P.lvl[l];
+            V.blkCX = std::max(1, std::min(std::min(c->fastBlockCX, 4), 128 / V.wCell));
+            V.blkCY = std::max(1, std::min(std::min(c->fastBlockCY, 4), 128 / V.hCell));
+            if (V.wCell > 128 || V.hCell > 128 || V.nCols > 65535 || V.cellCap > 65535) { ok = false; break; }
+            const int maxBorderX = V.w - PG_EDGE, maxBorderY = V.h - PG_EDGE;
+            for (int bi = 0; bi < V.nRows; bi += V.blkCY)
+                for (int bj = 0; bj < V.nCols; bj += V.blkCX) {
+                    const int ncx = std::min(V.blkCX, V.nCols - bj), ncy = std::min(V.blkCY, V.nRows - bi);
+                    const int iniY = PG_EDGE + bi * V.hCell, iniX = PG_EDGE + bj * V.wCell;
+                    // interior = [iniX + 3, min(iniX + ncx * wCell + 6, maxBorderX) - 3): the cells tile it
+                    const int BW = std::max(0, std::min(iniX + ncx * V.wCell + 6, maxBorderX) - 6 - iniX);
+                    const int BH = std::max(0, std::min(iniY + ncy * V.hCell + 6, maxBorderY) - 6 - iniY);
+                    const uint64_t off = (uint64_t)(pyrOff[l] * B) + (uint64_t)iniY * V.pitch + (uint64_t)(iniX - 1);
+                    const int cidx = bi * V.nCols + bj;
+                    uint32_t r[16] = {0};
+                    r[0] = (uint32_t)l | ((uint32_t)ncx << 4) | ((uint32_t)ncy << 8);
+                    r[1] = (uint32_t)iniX | ((uint32_t)iniY << 16);
+                    r[2] = (uint32_t)BW | ((uint32_t)BH << 8) | ((uint32_t)V.wCell << 16) | ((uint32_t)V.hCell << 24);
+                    r[3] = (uint32_t)V.pitch;
+                    r[4] = (uint32_t)off; r[5] = (uint32_t)(off >> 32);
+                    r[6] = (uint32_t)V.fstride;
+                    r[7] = (uint32_t)(V.cellCandOff + (int64_t)cidx * V.cellCap);
+                    r[8] = (uint32_t)V.nCols | ((uint32_t)V.cellCap << 16);
+                    r[9] = (uint32_t)(V.cellBase + cidx);
+                    r[10] = (uint32_t)(65535 / V.wCell + 1) | ((uint32_t)(65535 / V.hCell + 1) << 16);
+                    bt.insert(bt.end(), r, r + 16);
+                }
+        }
+        P.blockTab = nullptr; P.totalBlocks = 0;
+        if (ok && (uint64_t)pyrFrame * B < ((uint64_t)1 << 40)) {
+            if ((rc = ensure(c, c->blockTab, bt.size() * 4 + 8 * 64))) return rc;      // + 8 records of slack
+            PG_HIP(c, hipMemcpy(c->blockTab.p, bt.data(), bt.size() * 4, hipMemcpyHostToDevice));
+            P.blockTab = (const uint32_t*)c->blockTab.p;
+            P.totalBlocks = (int)(bt.size() / 16);
+        }
+    }
     P.cand = (uint32_t*)c->cand.p; P.sel = (uint32_t*)c->sel.p;
     P.nodeScratch = (int32_t*)c->nodes.p;
     P.candCount = (int32_t*)c->counters.p;
@@ -529,7 +572,7 @@ void pgorb_destroy(pgorb_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->prm.device);
-    Arena* all[] = {&c->cellTab, &c->cellCand, &c->cellCount, &c->pyr, &c->cand, &c->sel, &c->nodes, &c->counters, &c->tables,
+    Arena* all[] = {&c->blockTab, &c->cellTab, &c->cellCand, &c->cellCount, &c->pyr, &c->cand, &c->sel, &c->nodes, &c->counters, &c->tables,
                     &c->stageKps, &c->stageDesc, &c->stageN, &c->stageA, &c->stageB, &c->stageOut, &c->vocab, &c->xdesc};
     for (Arena* a : all) if (a->p) (void)hipFree(a->p);
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -803,7 +846,23 @@ int pgorb_set_option(pgorb_ctx* c, const char* key, int value)
 {
     if (!key) return PGORB_E_ARG;
     if (!strcmp(key, "matcher")) { pg_match_set_popcount(value); return 0; }
+    if (!strcmp(key, "fast_kernel")) { pg_fast_set_kernel(value); return 0; }
+    if (c && (!strcmp(key, "fast_block_cx") || !strcmp(key, "fast_block_cy"))) {
+        if (value < 1 || value > 4) return fail(c, PGORB_E_ARG, "%s must be 1..4", key);
+        (key[12] == 'x' ? c->fastBlockCX : c->fastBlockCY) = value;
+        c->planValid = false;                              // the block table is part of the plan
+        return 0;
+    }
     return c ? fail(c, PGORB_E_ARG, "unknown option '%s'", key) : PGORB_E_ARG;
+}
+
+int pgorb_get_option(const pgorb_ctx* c, const char* key)
+{
+    if (!key) return PGORB_E_ARG;
+    if (!strcmp(key, "fast_kernel")) return pg_fast_get_kernel();
+    if (c && !strcmp(key, "fast_block_cx")) return c->fastBlockCX;
+    if (c && !strcmp(key, "fast_block_cy")) return c->fastBlockCY;
+    return PGORB_E_ARG;
 }
 
 int pgorb_matcher_is_popcount(const pgorb_ctx*, int cap_per_frame) { return pg_match_uses_popcount(cap_per_frame) ? 1 : 0; }

@@ -60,6 +60,7 @@ struct PgLevel {
                               // PGORB_PYR_TILE_ROWS = 16 | 32 | 64 at plan time, for the tile-size sweep in DESIGN.md)
     // cell grid (ORBextractor.cc:781-787)
     int32_t  nCols, nRows, wCell, hCell, cellBase;
+    int32_t  blkCX, blkCY;    // cells per K2 block in x / y (fast.hip, block form)
     // quadtree (ORBextractor.cc:539-563)
     int32_t  quota, nIni, selCap;
     float    hX;
@@ -95,6 +96,9 @@ struct PgPlan {
     //   w6 level frame stride                           w7 slot offset of the cell in the frame's slab
     // Level 0 may alias the caller's buffer: its base / pitch / frame stride come from lvl[0].
     const uint32_t* cellTab;
+    // [totalBlocks] 64-byte record per K2 block of blkCX x blkCY cells (fast.hip: k_fast_blocks), or null
+    const uint32_t* blockTab;
+    int32_t  totalBlocks;
     const uint8_t*  pyrBase;  // pyramid arena
     uint32_t* cand;           // K3: dense uint2 key records (2 u32 per key)
     uint32_t* sel;
@@ -126,6 +130,8 @@ void pg_launch_best2(const uint8_t* d_a, int na, const uint8_t* d_b, int nb, uin
                      int32_t* d_best_idx, uint16_t* d_best, uint16_t* d_second, hipStream_t s);
 
 void pg_match_set_popcount(int on);
+void pg_fast_set_kernel(int k);
+int  pg_fast_get_kernel();
 bool pg_match_uses_popcount(int cap_per_frame);
 
 static_assert(sizeof(PgPlan) <= 4000, "PgPlan is passed by value as a kernel argument (4 KiB limit)");

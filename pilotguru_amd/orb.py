@@ -208,7 +208,7 @@ class ORBextractor:
 
     def fast_kernel_name(self):
         """Name of the K2 kernel the common cell geometry takes (for bench.py's roofline object)."""
-        return "k_fast_cells"
+        return "k_fast_blocks" if self._L.pgorb_get_option(self._h, b"fast_kernel") == 1 else "k_fast_cells"
 
     STAGES = ("pyramid", "fast", "quadtree", "describe", "match")
 
