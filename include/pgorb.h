@@ -392,6 +392,29 @@ int  pgorb_fit_motion_velocities(pgorb_ctx* ctx, const double* gps_velocity, con
 int  pgorb_profile_begin(pgorb_ctx* ctx, int max_calls);
 int  pgorb_profile_read(pgorb_ctx* ctx, double* ms);
 
+/* ---- Streamed ingest: frames that start in HOST memory --------------------------------------------------
+ * Replaces the reference's frame loop around the extractor -- ImageSequenceSource::next() handing one decoded
+ * frame at a time to System::TrackMonocular (src/io/image_sequence_reader.cc:138-208,
+ * src/slam/track_image_sequence.cc:43-47) -- for callers whose frames are not already on the GPU.  A stream owns
+ * `depth` (2..8) slots; a slot is one batch of up to `batch` w x h grey frames in PAGE-LOCKED host memory that
+ * the decoder fills directly (pgorb_stream_input).  pgorb_stream_submit queues, without blocking: the upload of
+ * the slot, K1..K6 on it, K7 of every frame against its predecessor (frame 0 against the last frame of the
+ * previously submitted batch; after pgorb_stream_reset, or at the start, it has none and its best_idx are -1),
+ * and the download of all results -- on three HIP streams, so the upload of batch i+1 and the download of
+ * batch i-1 overlap the kernels of batch i.  pgorb_stream_wait blocks until the slot's results are in host
+ * memory and returns the number of frames of the batch (< 0: error); the pointers stay valid until the slot is
+ * submitted again: n[f] keypoints of frame f, kps[f * cap + i], desc[(f * cap + i) * 32], and for query
+ * keypoint i of frame f best_idx / best / second [f * cap + i] exactly as pgorb_match_batch_device returns them.
+ * One stream per context at a time; the context's other calls must not run between submit and wait. */
+typedef struct pgorb_stream pgorb_stream;
+int      pgorb_stream_create(pgorb_ctx* ctx, int w, int h, int batch, int depth, pgorb_stream** out);
+void     pgorb_stream_destroy(pgorb_stream* s);
+uint8_t* pgorb_stream_input(pgorb_stream* s, int slot);          /* batch * h * w bytes, row pitch w */
+int      pgorb_stream_reset(pgorb_stream* s);                    /* the next batch starts a new ride */
+int      pgorb_stream_submit(pgorb_stream* s, int slot, int nframes);
+int      pgorb_stream_wait(pgorb_stream* s, int slot, const int32_t** n, const pgorb_keypoint** kps, const uint8_t** desc,
+                           const int32_t** best_idx, const uint16_t** best, const uint16_t** second, int* cap);
+
 /* Measurement switches (no counterpart in the reference; results never depend on them -- the parity suite
  * runs under each).  key "matcher": 0 = the default (fp4 block-scaled MFMA for < 8192 descriptors per
  * frame), 1 = the ballot / popcount kernels BASELINE.json's north star describes, for every size.

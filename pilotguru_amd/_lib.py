@@ -29,7 +29,8 @@ SYMBOLS = (
     "pgorb_extract_batch_ingest_device",
     "pgorb_search_by_projection_points", "pgorb_search_by_projection_frame", "pgorb_search_by_bow",
     "pgorb_undistort_keypoints", "pgorb_undistort_keypoints_batch_device", "pgorb_image_bounds",
-    "pgorb_host_alloc", "pgorb_host_free", "pgorb_set_option", "pgorb_get_option", "pgorb_matcher_is_popcount",
+    "pgorb_host_alloc", "pgorb_host_free", "pgorb_stream_create", "pgorb_stream_destroy", "pgorb_stream_input", "pgorb_stream_reset", "pgorb_stream_submit",
+    "pgorb_stream_wait", "pgorb_set_option", "pgorb_get_option", "pgorb_matcher_is_popcount",
     "pgorb_smooth_heading_directions", "pgorb_smooth_time_series", "pgorb_trajectory_pca",
     "pgorb_project_directions", "pgorb_project_translations", "pgorb_turn_angles",
     "pgorb_principal_rotation_axes", "pgorb_angular_velocities_around_axis",
@@ -98,6 +99,14 @@ def lib():
     L.pgorb_debug_level_image.argtypes = [vp, C.c_int, C.c_int, vp]
     L.pgorb_debug_level_candidates.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int]
     L.pgorb_debug_level_keypoints.argtypes = [vp, C.c_int, C.c_int]
+    L.pgorb_stream_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.pgorb_stream_destroy.restype = None
+    L.pgorb_stream_destroy.argtypes = [vp]
+    L.pgorb_stream_input.restype = vp
+    L.pgorb_stream_input.argtypes = [vp, C.c_int]
+    L.pgorb_stream_reset.argtypes = [vp]
+    L.pgorb_stream_submit.argtypes = [vp, C.c_int, C.c_int]
+    L.pgorb_stream_wait.argtypes = [vp, C.c_int] + [C.POINTER(vp)] * 6 + [i32p]
     L.pgorb_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     L.pgorb_get_option.argtypes = [vp, C.c_char_p]
     L.pgorb_matcher_is_popcount.argtypes = [vp, C.c_int]
@@ -150,7 +159,7 @@ def lib():
     L.pgorb_bow_score_l1.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int]
     for name in SYMBOLS:
         if name not in ("pgorb_destroy", "pgorb_last_error", "pgorb_vocab_free", "pgorb_bow_score_l1",
-                        "pgorb_host_alloc", "pgorb_host_free"):
+                        "pgorb_host_alloc", "pgorb_host_free", "pgorb_stream_destroy", "pgorb_stream_input"):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L

@@ -945,3 +945,185 @@ int pgorb_debug_level_keypoints(pgorb_ctx* c, int frame, int level)
 }
 
 }  // extern "C"
+
+// ---- streamed ingest: frames that start in HOST memory ----------------------------------------------
+// The reference's frames come from the decoder one at a time (src/io/image_sequence_reader.cc:138-208) and are
+// consumed by the tracking loop (src/slam/track_image_sequence.cc:43-47).  Here the decoder writes grey frames
+// straight into page-locked input slots; a slot (one batch) then flows through three HIP streams --
+//   copy-in:  H2D of the slot's frames                        (PCIe, ~2.07 MB per 1080p frame)
+//   compute:  K1..K6 on the slot's device frames (level 0 aliases them) + K7 of every frame against its
+//             predecessor, including the last frame of the previous batch
+//   copy-out: D2H of counts, keypoints, descriptors, matches into the slot's page-locked result block
+// so that the upload of batch i+1 and the download of batch i-1 overlap the kernels of batch i.  Events order
+// the three streams per slot; nothing blocks the host until pgorb_stream_wait.
+struct pgorb_stream {
+    pgorb_ctx* c = nullptr;
+    int w = 0, h = 0, B = 0, depth = 0, cap = 0;
+    hipStream_t sIn = nullptr, sRun = nullptr, sOut = nullptr;
+    struct Slot {
+        uint8_t* hIn = nullptr;            // pinned [B][h][w]
+        uint8_t* dIn = nullptr;            // device  [B][h][w]
+        uint8_t* dOut = nullptr;           // device result block (layout below)
+        uint8_t* hOut = nullptr;           // pinned copy of it
+        hipEvent_t evIn = nullptr, evRun = nullptr, evOut = nullptr;
+        int frames = 0; bool busy = false;
+    };
+    std::vector<Slot> slot;
+    // result block: n[B+1] (index 0 = the previous batch's last frame) | kps[B][cap] | desc[B+1][cap][32] |
+    // best_idx[B][cap] | best[B][cap] | second[B][cap]
+    size_t offN = 0, offK = 0, offD = 0, offI = 0, offB1 = 0, offB2 = 0, outBytes = 0;
+    int32_t *dPq = nullptr, *dPt = nullptr;                // pairs (f, f-1), f = 1..B, in desc[] indexing
+    uint8_t* dPrevDesc = nullptr; int32_t* dPrevN = nullptr;
+    bool havePrev = false;
+};
+
+extern "C" {
+
+int pgorb_stream_create(pgorb_ctx* c, int w, int h, int batch, int depth, pgorb_stream** out)
+{
+    if (!c || !out) return PGORB_E_ARG;
+    *out = nullptr;
+    if (batch < 1 || batch > c->prm.max_batch || depth < 2 || depth > 8 || w < 1 || h < 1)
+        return fail(c, PGORB_E_ARG, "pgorb_stream_create: batch 1..max_batch, depth 2..8");
+    PG_HIP(c, hipSetDevice(c->prm.device));
+    int rc = make_plan(c, w, h, batch);
+    if (rc) return rc;
+    pgorb_stream* s = new pgorb_stream();
+    s->c = c; s->w = w; s->h = h; s->B = batch; s->depth = depth; s->cap = c->plan.selTotal;
+    const size_t cap = (size_t)s->cap, B = (size_t)batch;
+    auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+    s->offN = 0; s->offK = al((B + 1) * 4); s->offD = s->offK + al(B * cap * sizeof(pgorb_keypoint));
+    s->offI = s->offD + al((B + 1) * cap * 32); s->offB1 = s->offI + al(B * cap * 4);
+    s->offB2 = s->offB1 + al(B * cap * 2); s->outBytes = s->offB2 + al(B * cap * 2);      // (+ the status word behind it)
+    bool ok = hipStreamCreateWithFlags(&s->sIn, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&s->sRun, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&s->sOut, hipStreamNonBlocking) == hipSuccess;
+    s->slot.resize(depth);
+    for (auto& sl : s->slot) {
+        ok = ok && hipHostMalloc((void**)&sl.hIn, B * w * h, hipHostMallocDefault) == hipSuccess;
+        ok = ok && hipMalloc((void**)&sl.dIn, B * w * h + 256) == hipSuccess;
+        ok = ok && hipMalloc((void**)&sl.dOut, s->outBytes + 256) == hipSuccess;
+        ok = ok && hipHostMalloc((void**)&sl.hOut, s->outBytes + 256, hipHostMallocDefault) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&sl.evIn, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&sl.evRun, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&sl.evOut, hipEventDisableTiming) == hipSuccess;
+    }
+    std::vector<int32_t> pq(batch), pt(batch);
+    for (int f = 0; f < batch; f++) { pq[f] = f + 1; pt[f] = f; }
+    ok = ok && hipMalloc((void**)&s->dPq, B * 4) == hipSuccess && hipMalloc((void**)&s->dPt, B * 4) == hipSuccess;
+    ok = ok && hipMalloc((void**)&s->dPrevDesc, cap * 32) == hipSuccess && hipMalloc((void**)&s->dPrevN, 4) == hipSuccess;
+    ok = ok && hipMemcpy(s->dPq, pq.data(), B * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(s->dPt, pt.data(), B * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && ensure(c, c->xdesc, pg_match_scratch_bytes(s->cap, batch) + 16) == 0;
+    if (!ok) { pgorb_stream_destroy(s); return fail(c, PGORB_E_HIP, "pgorb_stream_create: allocation failed"); }
+    *out = s;
+    return 0;
+}
+
+void pgorb_stream_destroy(pgorb_stream* s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->c->prm.device);
+    if (s->sIn) (void)hipStreamSynchronize(s->sIn);
+    if (s->sRun) (void)hipStreamSynchronize(s->sRun);
+    if (s->sOut) (void)hipStreamSynchronize(s->sOut);
+    for (auto& sl : s->slot) {
+        if (sl.hIn) (void)hipHostFree(sl.hIn);
+        if (sl.dIn) (void)hipFree(sl.dIn);
+        if (sl.dOut) (void)hipFree(sl.dOut);
+        if (sl.hOut) (void)hipHostFree(sl.hOut);
+        if (sl.evIn) (void)hipEventDestroy(sl.evIn);
+        if (sl.evRun) (void)hipEventDestroy(sl.evRun);
+        if (sl.evOut) (void)hipEventDestroy(sl.evOut);
+    }
+    if (s->dPq) (void)hipFree(s->dPq);
+    if (s->dPt) (void)hipFree(s->dPt);
+    if (s->dPrevDesc) (void)hipFree(s->dPrevDesc);
+    if (s->dPrevN) (void)hipFree(s->dPrevN);
+    if (s->sIn) (void)hipStreamDestroy(s->sIn);
+    if (s->sRun) (void)hipStreamDestroy(s->sRun);
+    if (s->sOut) (void)hipStreamDestroy(s->sOut);
+    delete s;
+}
+
+uint8_t* pgorb_stream_input(pgorb_stream* s, int slot)
+{
+    return (s && slot >= 0 && slot < s->depth) ? s->slot[slot].hIn : nullptr;
+}
+
+int pgorb_stream_reset(pgorb_stream* s)                  // a new ride: the next batch has no predecessor frame
+{
+    if (!s) return PGORB_E_ARG;
+    s->havePrev = false;
+    return 0;
+}
+
+int pgorb_stream_submit(pgorb_stream* s, int slot, int nframes)
+{
+    if (!s || slot < 0 || slot >= s->depth) return PGORB_E_ARG;
+    pgorb_ctx* c = s->c;
+    if (nframes < 1 || nframes > s->B) return fail(c, PGORB_E_ARG, "pgorb_stream_submit: 1..batch frames");
+    pgorb_stream::Slot& sl = s->slot[slot];
+    if (sl.busy) return fail(c, PGORB_E_ARG, "pgorb_stream_submit: slot %d not collected with pgorb_stream_wait", slot);
+    PG_HIP(c, hipSetDevice(c->prm.device));
+    int rc = make_plan(c, s->w, s->h, nframes);
+    if (rc) return rc;
+    const size_t fbytes = (size_t)s->w * s->h, cap = (size_t)s->cap;
+    // copy-in: after the kernels of this slot's previous batch have read its device frames
+    PG_HIP(c, hipStreamWaitEvent(s->sIn, sl.evRun, 0));
+    PG_HIP(c, hipMemcpyAsync(sl.dIn, sl.hIn, fbytes * nframes, hipMemcpyHostToDevice, s->sIn));
+    PG_HIP(c, hipEventRecord(sl.evIn, s->sIn));
+    // compute: after the upload, and after the previous download of this slot's result block
+    PG_HIP(c, hipStreamWaitEvent(s->sRun, sl.evIn, 0));
+    PG_HIP(c, hipStreamWaitEvent(s->sRun, sl.evOut, 0));
+    int32_t* dN = (int32_t*)(sl.dOut + s->offN);
+    pgorb_keypoint* dK = (pgorb_keypoint*)(sl.dOut + s->offK);
+    uint8_t* dD = sl.dOut + s->offD;
+    if (s->havePrev) {
+        PG_HIP(c, hipMemcpyAsync(dD, s->dPrevDesc, cap * 32, hipMemcpyDeviceToDevice, s->sRun));
+        PG_HIP(c, hipMemcpyAsync(dN, s->dPrevN, 4, hipMemcpyDeviceToDevice, s->sRun));
+    } else {
+        PG_HIP(c, hipMemsetAsync(dN, 0, 4, s->sRun));
+    }
+    rc = run_batch(c, sl.dIn, false, nframes, s->w, s->h, s->w, (int64_t)fbytes, dK, dD + cap * 32, s->cap, dN + 1, s->sRun);
+    if (rc) return rc;
+    pg_launch_match_batch(dD, dN, s->cap, s->dPq, s->dPt, nframes, (uint8_t*)c->xdesc.p, (int32_t*)(sl.dOut + s->offI),
+                          (uint16_t*)(sl.dOut + s->offB1), (uint16_t*)(sl.dOut + s->offB2), s->sRun);
+    PG_HIP(c, hipMemcpyAsync(s->dPrevDesc, dD + (size_t)nframes * cap * 32, cap * 32, hipMemcpyDeviceToDevice, s->sRun));
+    PG_HIP(c, hipMemcpyAsync(s->dPrevN, dN + nframes, 4, hipMemcpyDeviceToDevice, s->sRun));
+    // the batch's device status word travels inside the result block (the next batch resets the word)
+    PG_HIP(c, hipMemcpyAsync(sl.dOut + s->outBytes, c->plan.status, 4, hipMemcpyDeviceToDevice, s->sRun));
+    PG_HIP(c, hipEventRecord(sl.evRun, s->sRun));
+    s->havePrev = true;
+    // copy-out
+    PG_HIP(c, hipStreamWaitEvent(s->sOut, sl.evRun, 0));
+    PG_HIP(c, hipMemcpyAsync(sl.hOut, sl.dOut, s->outBytes + 4, hipMemcpyDeviceToHost, s->sOut));
+    PG_HIP(c, hipEventRecord(sl.evOut, s->sOut));
+    PG_HIP(c, hipGetLastError());
+    sl.frames = nframes; sl.busy = true;
+    return 0;
+}
+
+int pgorb_stream_wait(pgorb_stream* s, int slot, const int32_t** n, const pgorb_keypoint** kps, const uint8_t** desc,
+                      const int32_t** best_idx, const uint16_t** best, const uint16_t** second, int* cap)
+{
+    if (!s || slot < 0 || slot >= s->depth) return PGORB_E_ARG;
+    pgorb_ctx* c = s->c;
+    pgorb_stream::Slot& sl = s->slot[slot];
+    if (!sl.busy) return fail(c, PGORB_E_ARG, "pgorb_stream_wait: slot %d has no batch in flight", slot);
+    PG_HIP(c, hipSetDevice(c->prm.device));
+    PG_HIP(c, hipEventSynchronize(sl.evOut));
+    sl.busy = false;
+    const int32_t st = *(const int32_t*)(sl.hOut + s->outBytes);      // the batch's device status word
+    if (st) return fail(c, st, "device reported status %d", st);
+    if (n) *n = (const int32_t*)(sl.hOut + s->offN) + 1;
+    if (kps) *kps = (const pgorb_keypoint*)(sl.hOut + s->offK);
+    if (desc) *desc = sl.hOut + s->offD + (size_t)s->cap * 32;
+    if (best_idx) *best_idx = (const int32_t*)(sl.hOut + s->offI);
+    if (best) *best = (const uint16_t*)(sl.hOut + s->offB1);
+    if (second) *second = (const uint16_t*)(sl.hOut + s->offB2);
+    if (cap) *cap = s->cap;
+    return sl.frames;
+}
+
+}  // extern "C"

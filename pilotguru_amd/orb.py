@@ -391,3 +391,53 @@ class ORBmatcher:
         a = np.ascontiguousarray(a, np.uint8).reshape(32)
         b = np.ascontiguousarray(b, np.uint8).reshape(32)
         return _lib.lib().pgorb_descriptor_distance(_p(a), _p(b))
+
+
+class FrameStream:
+    """Streamed ingest (include/pgorb.h, pgorb_stream_*): the frame loop around the extractor for frames that
+    start in host memory -- ImageSequenceSource::next() -> System::TrackMonocular in the reference
+    (src/slam/track_image_sequence.cc:43-47).  `depth` page-locked input slots of `batch` frames; submit() never
+    blocks, wait() returns the batch's results as numpy views of page-locked memory."""
+
+    def __init__(self, extractor, w, h, batch, depth=3):
+        self.ext, self.w, self.h, self.batch, self.depth = extractor, int(w), int(h), int(batch), int(depth)
+        self._L = extractor._L
+        hs = C.c_void_p()
+        extractor._check(self._L.pgorb_stream_create(extractor._h, self.w, self.h, self.batch, self.depth, C.byref(hs)))
+        self._s = hs
+
+    def close(self):
+        if getattr(self, "_s", None):
+            self._L.pgorb_stream_destroy(self._s)
+            self._s = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def input(self, slot):
+        """numpy view [batch, h, w] of the slot's page-locked input frames (write the decoded frames here)."""
+        p = self._L.pgorb_stream_input(self._s, slot)
+        buf = (C.c_uint8 * (self.batch * self.h * self.w)).from_address(p)
+        return np.frombuffer(buf, np.uint8).reshape(self.batch, self.h, self.w)
+
+    def reset(self):
+        self.ext._check(self._L.pgorb_stream_reset(self._s))
+
+    def submit(self, slot, nframes=None):
+        self.ext._check(self._L.pgorb_stream_submit(self._s, slot, self.batch if nframes is None else int(nframes)))
+
+    def wait(self, slot):
+        """(n[frames], kps[frames, cap], desc[frames, cap, 32], best_idx, best, second [frames, cap]) views."""
+        ptr = [C.c_void_p() for _ in range(6)]
+        cap = C.c_int32()
+        nf = self.ext._check(self._L.pgorb_stream_wait(self._s, slot, *[C.byref(p) for p in ptr], C.byref(cap)))
+        cap = cap.value
+
+        def view(p, dtype, shape):
+            nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+            return np.frombuffer((C.c_uint8 * nbytes).from_address(p.value), dtype).reshape(shape)
+        return (view(ptr[0], np.int32, (nf,)), view(ptr[1], KEYPOINT_DTYPE, (nf, cap)), view(ptr[2], np.uint8, (nf, cap, 32)),
+                view(ptr[3], np.int32, (nf, cap)), view(ptr[4], np.uint16, (nf, cap)), view(ptr[5], np.uint16, (nf, cap)))

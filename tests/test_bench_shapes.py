@@ -139,3 +139,44 @@ def test_multi_gpu_code_path_on_one_gpu():
     out = json.loads(line)
     assert out["config"]["vocab_broadcast_bytes"] > 1 << 20          # the k=10, L=5 blob went through RCCL
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["verified"] is True
+
+
+@pytest.mark.parametrize("w,h,nf,total,batch,depth", [(640, 480, 1000, 23, 8, 3), (1920, 1080, 2000, 20, 8, 2)])
+def test_streamed_ingest_bit_exact(w, h, nf, total, batch, depth):
+    """Frames that start in host memory: page-locked slots, three HIP streams (upload / kernels / download),
+    several batches in flight, a ragged last batch -- every frame's keypoints and descriptors and every frame's
+    best-2 match against its predecessor ACROSS batch borders against the oracle
+    (src/slam/track_image_sequence.cc:43-47: frame after frame of one ride)."""
+    import pilotguru_amd as pg
+    from _oracle_pool import oracle_ride
+    ride = synth_ride(21, w, h, total)
+    oext, omatch = oracle_ride(list(ride), (nf, 1.2, 8, 20, 7))
+    ext = pg.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=batch)
+    st = pg.FrameStream(ext, w, h, batch, depth)
+    chunks = [(b0, min(batch, total - b0)) for b0 in range(0, total, batch)]
+    results = {}
+    inflight = []
+    for i, (b0, nb) in enumerate(chunks):
+        slot = i % depth
+        if len(inflight) == depth:                       # the slot about to be reused must be collected first
+            j, s0 = inflight.pop(0)
+            results[j] = [np.array(a) for a in st.wait(s0)]
+        st.input(slot)[:nb] = ride[b0:b0 + nb]           # "the decoder" writes into page-locked memory
+        st.submit(slot, nb)
+        inflight.append((i, slot))
+    for j, s0 in inflight:
+        results[j] = [np.array(a) for a in st.wait(s0)]
+    st.close()
+    for i, (b0, nb) in enumerate(chunks):
+        n, kps, desc, bi, b1, b2 = results[i]
+        assert len(n) == nb
+        for k in range(nb):
+            f = b0 + k
+            okp, odesc = oext[f]
+            assert n[k] * 28 == len(okp) and kps[k, :n[k]].tobytes() == okp and desc[k, :n[k]].tobytes() == odesc, "frame %d" % f
+            if f == 0:
+                assert np.all(bi[k, :n[k]] == -1)        # no predecessor
+            else:
+                obi, ob1, ob2 = omatch[f - 1]
+                assert bi[k, :n[k]].tobytes() == obi and b1[k, :n[k]].tobytes() == ob1 and b2[k, :n[k]].tobytes() == ob2, \
+                    "match of frame %d vs %d" % (f, f - 1)
