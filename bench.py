@@ -293,12 +293,18 @@ def main():
             torch.empty((max(B - 1, 1), cap), dtype=torch.int16, device=dev))
 
     # the one collective of this path: broadcast the (synthetic) ORB vocabulary root -> peers
-    vocab_bytes = 0
+    vocab_bytes, vocab_bcast_s = 0, None
     if dist is not None:
         from pilotguru_amd import dist as pgd
-        from pilotguru_amd.vocab import synth_vocabulary_blob
-        blob = synth_vocabulary_blob(k=10, L=5, seed=7) if rank == 0 else None
+        from pilotguru_amd.vocab import pack_vocabulary, synth_vocabulary_fast
+        # the size of the real ORBvoc.txt (k = 10, L = 6: 1 111 111 nodes, 66.7 MB as a blob); the file itself
+        # needs network access (fetch-vocabulary.sh:5)
+        blob = torch.from_numpy(pack_vocabulary(10, 6, *synth_vocabulary_fast(10, 6, seed=7)).copy()) if rank == 0 else None
+        torch.cuda.synchronize()
+        tb0 = time.perf_counter()
         vocab = pgd.broadcast_vocabulary(blob, 0, dev)
+        torch.cuda.synchronize()
+        vocab_bcast_s = time.perf_counter() - tb0
         vocab_bytes = int(vocab.numel())
         # every rank makes the received blob resident in its context and transforms the same
         # probe descriptors; the word ids must agree across ranks (config 4's criterion)
@@ -430,7 +436,7 @@ def main():
                                    % (W, H, NF, B),
                        "scene": args.scene,
                        "batch": B, "keypoints_per_frame": nkp, "parallelism": "frames-sharded x%d" % world,
-                       "vocab_broadcast_bytes": vocab_bytes,
+                       "vocab_broadcast_bytes": vocab_bytes, "vocab_broadcast_s": vocab_bcast_s,
                        "matcher": matcher, "matcher_popcount_ms_per_step": popcount_ms},
             "roofline": {"bound": "hbm", "kernel": kname,
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",

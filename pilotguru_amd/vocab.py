@@ -202,3 +202,45 @@ def bow_score_l1(a, b):
     v1, v2 = np.ascontiguousarray(v1, np.float64), np.ascontiguousarray(v2, np.float64)
     p = lambda x: C.c_void_p(x.ctypes.data)
     return _lib.lib().pgorb_bow_score_l1(p(i1), p(v1), len(i1), p(i2), p(v2), len(i2))
+
+
+def synth_vocabulary_fast(k=10, L=6, seed=7):
+    """synth_vocabulary's tree, generated level by level with array operations (ORBvoc.txt's size, k = 10, L = 6,
+    is 1 111 111 nodes -- far too many for a Python loop per node).  Same structure: breadth-first file order,
+    a child's descriptor = its parent's with ~1/8 of the bits flipped, weights on the leaves."""
+    rng = np.random.RandomState(seed)
+    n = sum(k ** l for l in range(L + 1))
+    desc = np.zeros((n, 32), np.uint8)
+    parent = np.full(n, -1, np.int32)
+    weight = np.zeros(n, np.float64)
+    start, cnt = 0, 1
+    for level in range(1, L + 1):
+        nxt, m = start + cnt, cnt * k
+        par = np.repeat(np.arange(start, start + cnt, dtype=np.int32), k)
+        parent[nxt:nxt + m] = par
+        if level == 1:
+            desc[nxt:nxt + m] = rng.randint(0, 256, (m, 32)).astype(np.uint8)
+        else:
+            flips = (rng.randint(0, 256, (m, 32)) & rng.randint(0, 256, (m, 32)) & rng.randint(0, 256, (m, 32))).astype(np.uint8)
+            desc[nxt:nxt + m] = desc[par] ^ flips
+        start, cnt = nxt, m
+    weight[start:start + cnt] = np.round(rng.uniform(0.5, 12.0, cnt), 6)
+    return desc, weight, parent
+
+
+def write_vocabulary_text_fast(path, k, L, desc, weight, parent, scoring=0, weighting=0):
+    """write_vocabulary_text for ORBvoc-sized trees (one numpy.savetxt call; weights with 6 decimals, which is
+    what synth_vocabulary* produce).  No trailing newline."""
+    import io
+    n = len(parent)
+    nchild = np.bincount(np.asarray(parent[1:], np.int64), minlength=n)
+    tab = np.empty((n - 1, 35), np.float64)
+    tab[:, 0] = parent[1:]
+    tab[:, 1] = nchild[1:] == 0
+    tab[:, 2:34] = desc[1:]
+    tab[:, 34] = weight[1:]
+    buf = io.StringIO()
+    np.savetxt(buf, tab, fmt=["%d"] * 34 + ["%.6f"], delimiter=" ")
+    with open(path, "w") as f:
+        f.write("%d %d %d %d\n" % (k, L, scoring, weighting))
+        f.write(buf.getvalue().rstrip("\n"))

@@ -151,3 +151,37 @@ def test_gpu_vocab_upload_from_device_blob(oracle, tmp_path):
     word, w, node = voc.transform_features(feats, 4)
     oword, ow, onode = oracle.VocabOracle(path).transform_features(feats, 4)
     assert np.array_equal(word, oword) and np.array_equal(node, onode) and w.tobytes() == ow.tobytes()
+
+
+@pytest.mark.gpu
+def test_orbvoc_scale_vocabulary(tmp_path, oracle):
+    """The size of the real ORBvoc.txt (k = 10, L = 6: 1 111 111 nodes, 10^6 words, 146 MB of text, 66.7 MB
+    as a blob; TemplatedVocabulary.h:1337-1420): text -> blob through the product's loader equals the Python
+    packer, the tree descent of 2000 descriptors (Frame.cc:399-406: levelsup = 4) equals the oracle's, and the
+    stage times are printed (pytest -s)."""
+    import time
+    import pilotguru_amd as pg
+    desc, weight, parent = V.synth_vocabulary_fast(10, 6, seed=11)
+    weight[-5000:] = 0.0                                        # some stop words
+    path = os.path.join(str(tmp_path), "orbvoc_like.txt")
+    t0 = time.perf_counter(); V.write_vocabulary_text_fast(path, 10, 6, desc, weight, parent); t_write = time.perf_counter() - t0
+    t0 = time.perf_counter(); voc = V.ORBVocabulary(text_file=path); t_load = time.perf_counter() - t0
+    assert (voc.k, voc.L, voc.nnodes, voc.nwords) == (10, 6, 1111111, 1000000)
+    assert np.array_equal(voc.blob(), V.pack_vocabulary(10, 6, desc, weight, parent))
+    ext = pg.ORBextractor(2000, 1.2, 8, 20, 7, max_width=640, max_height=480)
+    t0 = time.perf_counter(); voc.upload(ext); t_up = time.perf_counter() - t0
+    rng = np.random.RandomState(4)
+    feats = rng.randint(0, 256, (2000, 32)).astype(np.uint8)
+    leaves = np.nonzero(np.bincount(parent[1:], minlength=len(parent)) == 0)[0]
+    feats[:500] = desc[leaves[rng.randint(0, len(leaves), 500)]]       # exact words: distance-0 paths
+    feats[500:800, 3] ^= 0x41
+    voc.transform_features(feats, 4)                                    # warm-up
+    t0 = time.perf_counter(); word, w, node = voc.transform_features(feats, 4); t_tr = time.perf_counter() - t0
+    ora = oracle.VocabOracle(path)
+    oword, ow, onode = ora.transform_features(feats, 4)
+    assert np.array_equal(word, oword) and w.tobytes() == ow.tobytes() and np.array_equal(node, onode)
+    (bid, bval), fv = voc.transform(feats, 4)
+    (obid, obval), ofv = ora.transform(feats, 4)
+    assert np.array_equal(bid, obid) and bval.tobytes() == obval.tobytes() and all(np.array_equal(g, r) for g, r in zip(fv, ofv))
+    print("ORBvoc-scale vocabulary: write text %.1f s, load text -> blob %.2f s (%.1f MB), upload %.3f s, "
+          "transform 2000 descriptors (host round trip) %.2f ms" % (t_write, t_load, voc.blob().nbytes / 1e6, t_up, t_tr * 1e3))

@@ -120,3 +120,87 @@ def test_cli_front_end_run_matches_python_path(tmp_path, oracle):
         else:
             assert out["frames"][i]["n_matches_prev"] == -1
         prevF = F
+
+
+@pytest.mark.gpu
+def test_cli_config1_ride_against_the_oracle(tmp_path, oracle):
+    """BASELINE.json configs[0]'s shape through the real CLI: a 10 s 640x480 clip (300 frames at 30 fps), 1000
+    features.  Every frame of --dump_features (cv::KeyPoint records, descriptors) and every per-frame count
+    of frontend-0.json against the ORACLE (not the Python binding of the same library): extraction
+    (ORBextractor.cc:1042-1104), Frame::ComputeBoW (Frame.cc:399-406), MonocularInitialization's
+    SearchForInitialization against the previous frame (Tracking.cc:596-597, ORBmatcher.cc:407-522); then the
+    tail of TrackImageSequence (src/slam/track_image_sequence.cc:63-109) on poses stamped with the run's own
+    frame times, against the oracle's post-processing."""
+    import sys
+    sys.path.insert(0, HERE)
+    from _oracle_pool import oracle_ride
+    from pilotguru_amd import vocab as V
+    from pilotguru_amd.synth import synth_ride
+    from oracle import orb_oracle
+    w, h, nfr, nf = 640, 480, 300, 1000
+    ride = synth_ride(33, w, h, nfr, dx=1, dy=0)
+    d = str(tmp_path)
+    ride.tofile(os.path.join(d, "clip.gray"))
+    with open(os.path.join(d, "cam.yml"), "w") as f:
+        f.write("%YAML:1.0\n---\nCamera_width: 640\nCamera_height: 480\nCamera_fps: 30.\nORBextractor_nFeatures: 1000\n"
+                "ORBextractor_scaleFactor: 1.2\nORBextractor_nLevels: 8\nORBextractor_iniThFAST: 20\nORBextractor_minThFAST: 7\n")
+    desc, weight, parent = V.synth_vocabulary(6, 4, seed=5)
+    V.write_vocabulary_text(os.path.join(d, "voc.txt"), 6, 4, desc, weight, parent)
+    r = _cli("--vocabulary_file=" + os.path.join(d, "voc.txt"), "--camera_settings=" + os.path.join(d, "cam.yml"),
+             "--in_video=" + os.path.join(d, "clip.gray"), "--out_dir=" + d, "--novisualize", "--batch=16",
+             "--dump_features=" + os.path.join(d, "feat.bin"))
+    assert r.returncode == 0, r.stderr
+    out = json.load(open(os.path.join(d, "frontend-0.json")))
+    assert len(out["frames"]) == nfr
+    oext, _ = oracle_ride(list(ride), (nf, 1.2, 8, 20, 7), match=False)
+    voc = orb_oracle.VocabOracle(os.path.join(d, "voc.txt"))
+    raw = open(os.path.join(d, "feat.bin"), "rb").read()
+    off, prev = 0, None
+    bounds = (0.0, float(w), 0.0, float(h))
+    for i in range(nfr):
+        fid, n = np.frombuffer(raw, np.int32, 2, off); off += 8
+        okp, odesc = oext[i]
+        fr = out["frames"][i]
+        assert fid == i == fr["frame_id"] and n * 28 == len(okp) and fr["n_keypoints"] == n
+        assert fr["time_usec"] == int(round(i * 1e6 / 30.0))
+        assert raw[off:off + 28 * n] == okp, "keypoints of frame %d" % i
+        off += 28 * n
+        assert raw[off:off + 32 * n] == odesc, "descriptors of frame %d" % i
+        off += 32 * n
+        kp = np.frombuffer(okp, orb_oracle.KEYPOINT_DTYPE)
+        de = np.frombuffer(odesc, np.uint8).reshape(-1, 32)
+        if i % 10 == 0:                                               # BoW of every 10th frame (the oracle's transform is slow)
+            (bid, _), fv = voc.transform(de, 4)
+            assert fr["n_bow_words"] == len(bid) and fr["n_feature_nodes"] == len(fv[0])
+        if prev is not None:
+            pk, pd = prev
+            pm = np.stack([pk["x"], pk["y"]], 1).astype(np.float32)
+            nm, _, _ = orb_oracle.search_for_initialization(pk, pd, kp, de, bounds, pm, 100, 0.9, True)
+            assert fr["n_matches_prev"] == nm, "SearchForInitialization of frame %d" % i
+        else:
+            assert fr["n_matches_prev"] == -1
+        prev = (kp, de)
+    assert off == len(raw)
+    # the tail of TrackImageSequence on poses carrying this run's frame ids and time stamps
+    sys.path.insert(0, HERE)
+    from test_trajectory_post import _ride
+    t, q = _ride(4, nfr)
+    poses = os.path.join(d, "poses.txt")
+    with open(poses, "w") as f:
+        for i, fr in enumerate(out["frames"]):
+            f.write("%d 0 %d %s\n" % (fr["time_usec"], fr["frame_id"], " ".join(repr(float(v)) for v in list(t[i]) + list(q[i]))))
+    r = _cli("--poses_in=" + poses, "--out_dir=" + d, "--rotation_smooth_sigma=3")
+    assert r.returncode == 0, r.stderr
+    tj = json.load(open(os.path.join(d, "trajectory-0.json")))
+    qs = orb_oracle.smooth_heading_directions(q, 3)
+    vec, val, _ = orb_oracle.trajectory_pca(t)
+    dirs = orb_oracle.project_directions(qs, vec[:2])
+    turn = orb_oracle.turn_angles(dirs)
+    r15 = lambda x: float("%.15g" % x)
+    assert len(tj["trajectory"]) == nfr and [[r15(v) for v in row] for row in vec[:2]] == tj["plane"]
+    for i, p in enumerate(tj["trajectory"]):
+        assert p["frame_id"] == i and p["time_usec"] == out["frames"][i]["time_usec"]
+        assert p["planar_direction"] == [r15(dirs[i, 0]), r15(dirs[i, 1])]
+        if i:
+            dt = (out["frames"][i]["time_usec"] - out["frames"][i - 1]["time_usec"]) * 1e-6
+            assert p["angular_velocity"] == r15(turn[i] / (dt + 1e-10))
