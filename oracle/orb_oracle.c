@@ -569,7 +569,7 @@ void orc_gaussian_blur7(const uint8_t* src, int w, int h, int sstride,
  * rounded once to float -- reproducible bit-for-bit on host and GPU, and
  * equal to the correctly rounded value except for ~1e-9 of inputs.  The
  * measured disagreement with this container's glibc cosf/sinf is recorded in
- * DESIGN.md (tools/sincos_sweep.c). */
+ * DESIGN.md section 5 (tools/sincos_sweep.c, profiles/r02_sincos_sweep.txt). */
 void orc_sincos_f(float angle_rad, float* s_out, float* c_out)
 {
     const double INV_PIO2 = 0.63661977236758138243;
@@ -607,6 +607,20 @@ void orc_sincos_f(float angle_rad, float* s_out, float* c_out)
         default: s = -cs; c = sn; break;
     }
     *s_out = (float)s; *c_out = (float)c;
+}
+
+/* checksum of orc_sincos_f over `count` consecutive float bit patterns (the GPU's k_sincos_checksum folds
+ * pg_sincos_f the same way): the exhaustive device-vs-host check of the sin/cos contract */
+uint64_t orc_sincos_checksum(uint32_t first_bits, uint32_t count)
+{
+    uint64_t acc = 0;
+    for (uint32_t i = 0; i < count; i++) {
+        union { uint32_t u; float f; } in, so, co;
+        in.u = first_bits + i;
+        orc_sincos_f(in.f, &so.f, &co.f);
+        acc += ((uint64_t)so.u * 0x9E3779B1ull + co.u) * (2ull * i + 1ull);
+    }
+    return acc;
 }
 
 /* ref: src/ORBextractor.cc:107-147 computeOrbDescriptor (unfused float math) */

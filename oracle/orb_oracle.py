@@ -77,6 +77,8 @@ def lib():
         L.orc_ic_angle.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, i32p]
         L.orc_gaussian_blur7.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
         L.orc_sincos_f.argtypes = [C.c_float, fp, fp]
+        L.orc_sincos_checksum.restype = C.c_uint64
+        L.orc_sincos_checksum.argtypes = [C.c_uint32, C.c_uint32]
         L.orc_orb_descriptor.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
         L.orc_rgb_to_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.orc_descriptor_distance.restype = C.c_int

@@ -452,3 +452,37 @@ void pg_launch_describe(const PgPlan& P, int nframes, pgorb_keypoint* d_kps, uin
     dim3 grid((P.selTotal + 7) & ~7, nframes), block(64);
     hipLaunchKernelGGL(k_describe, grid, block, 0, s, P, G, d_kps, d_desc, cap_per_frame, d_n);
 }
+
+// ---- exhaustive check of the sin/cos contract (tests/test_gpu_parity.py, SURVEY.md hard part 4) --------
+// Block b folds pg_sincos_f of the `count` floats whose bit patterns start at first_bits + b * count into one
+// 64-bit checksum: sum over i of (sin bits * 0x9E3779B1 + cos bits) * (2 i + 1)  (mod 2^64) -- the oracle's
+// orc_sincos_checksum computes the same sum with orc_sincos_f.
+__global__ __launch_bounds__(256) void k_sincos_checksum(uint32_t first_bits, uint32_t count, unsigned long long* out)
+{
+    const uint32_t base = first_bits + blockIdx.x * count;
+    unsigned long long acc = 0;
+    for (uint32_t i = threadIdx.x; i < count; i += 256) {
+        float s, c;
+        pg_sincos_f(__uint_as_float(base + i), &s, &c);
+        acc += ((unsigned long long)__float_as_uint(s) * 0x9E3779B1ull + __float_as_uint(c)) * (2ull * i + 1ull);
+    }
+    __shared__ unsigned long long red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
+
+extern "C" int pgorb_debug_sincos_checksum(uint32_t first_bits, uint32_t count, int nblocks, unsigned long long* out)
+{
+    if (!out || nblocks < 1 || count < 1) return PGORB_E_ARG;
+    unsigned long long* d = nullptr;
+    if (hipMalloc((void**)&d, sizeof(unsigned long long) * (size_t)nblocks) != hipSuccess) return PGORB_E_HIP;
+    hipLaunchKernelGGL(k_sincos_checksum, dim3(nblocks), dim3(256), 0, 0, first_bits, count, d);
+    const bool ok = hipMemcpy(out, d, sizeof(unsigned long long) * (size_t)nblocks, hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d);
+    return ok ? 0 : PGORB_E_HIP;
+}

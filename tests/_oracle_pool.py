@@ -41,3 +41,26 @@ def oracle_ride(frames, params=(2000, 1.2, 8, 20, 7), match=True, workers=None):
         if match and len(frames) > 1:
             m = list(ex.map(_match_one, [(ext[f][1], ext[f - 1][1]) for f in range(1, len(frames))]))
     return ext, m
+
+
+def _sincos_block(args):
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from oracle import orb_oracle
+    first, count, nblocks = args
+    L = orb_oracle.lib()
+    return [int(L.orc_sincos_checksum(first + b * count, count)) for b in range(nblocks)]
+
+
+def oracle_sincos_checksums(first_bits, count, nblocks, workers=None):
+    """orc_sincos_checksum of nblocks consecutive ranges of `count` float bit patterns, fanned over processes."""
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+    workers = workers or min(os.cpu_count() or 1, 32)
+    per = max(1, (nblocks + 4 * workers - 1) // (4 * workers))
+    jobs = [(first_bits + b0 * count, count, min(per, nblocks - b0)) for b0 in range(0, nblocks, per)]
+    with ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn")) as ex:
+        out = []
+        for part in ex.map(_sincos_block, jobs):
+            out += part
+    return out

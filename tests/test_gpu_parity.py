@@ -624,3 +624,27 @@ def test_fast_block_form_at_bench_shape(oracle):
     finally:
         ext.set_option("fast_kernel", 0)
     assert kp.tobytes() == okp.tobytes() and np.array_equal(desc, odesc)
+
+
+def test_device_sincos_equals_the_oracle_for_every_input():
+    """SURVEY.md hard part 4: the argument of computeOrbDescriptor's cos / sin (ORBextractor.cc:112-113) is a
+    float in [0, 2 pi] -- 1.09e9 bit patterns.  EVERY one of them through the device's pg_sincos_f and the
+    oracle's orc_sincos_f, compared as 64-bit checksums of 2^20 inputs each (what either differs from glibc's
+    sinf / cosf by is measured by tools/sincos_sweep.c, profiles/r02_sincos_sweep.txt)."""
+    import ctypes as C
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _oracle_pool import oracle_sincos_checksums
+    from pilotguru_amd import _lib
+    L = _lib.lib()
+    L.pgorb_debug_sincos_checksum.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+    last = int(np.float32(6.2831855).view(np.uint32))
+    count = 1 << 20
+    nblocks = last // count + 1                       # covers [0, last] and a little beyond
+    got = np.zeros(nblocks, np.uint64)
+    assert L.pgorb_debug_sincos_checksum(0, count, nblocks, C.c_void_p(got.ctypes.data)) == 0
+    want = np.array(oracle_sincos_checksums(0, count, nblocks), np.uint64)
+    bad = np.nonzero(got != want)[0]
+    assert len(bad) == 0, "blocks of 2^20 inputs that differ: %s" % bad[:10]
+    assert nblocks * count > 1.08e9

@@ -493,3 +493,44 @@ def test_ingest_geometry_is_rot90_and_flips(oracle):
                     assert np.array_equal(oracle.ingest_geometry(img, rot, vf, hf), ref), (shape, rot, vf, hf)
     with pytest.raises(ValueError):
         oracle.ingest_geometry(rng.randint(0, 256, (4, 4)).astype(np.uint8), 45)
+
+
+def test_rbrief_geometry_and_bit_order_against_scikit_image(oracle):
+    """computeOrbDescriptor (ORBextractor.cc:107-147) against scikit-image's independent steered-BRIEF loop on an
+    un-blurred image (fixture + generator: tests/golden/make_skimage_rbrief.py): tap geometry (row = x sin + y cos,
+    column = x cos - y sin), pattern row order and LSB-first bit packing -- all 64 x 256 bits equal; the fixture
+    avoids rounding near-ties, so float vs double and the tie rule cannot matter.  scikit-image ships its own copy
+    of the 256 x 4 pattern: it must equal the table the oracle and the kernels use."""
+    import os
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "skimage_rbrief.npz"))
+    img, kp, deg, want = fx["img"], fx["kp_row_col"], fx["angle_deg"], fx["desc"]
+    txt = open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "oracle", "orb_pattern31.inc")).read()
+    body = "\n".join(l for l in txt.splitlines() if not l.lstrip().startswith(("/", "*")))
+    nums = np.array([int(t) for t in body.replace(",", " ").split() if t.lstrip("-").isdigit()], np.int64)
+    assert nums.size == 1024 and np.array_equal(nums.reshape(256, 4), fx["pos"].astype(np.int64))
+    got = np.stack([oracle.orb_descriptor(img, int(c), int(r), float(a)) for (r, c), a in zip(kp, deg)])
+    assert got.shape == want.shape == (64, 32)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("tie", [0, 1])
+def test_gaussian_blur_integer_arithmetic_against_scipy_int32(oracle, tie):
+    """The blur's INTEGER arithmetic against scipy.ndimage.correlate1d run on int32 with the
+    exact Q8 taps 18 34 49 55 49 34 18 and mode='mirror' (= BORDER_REFLECT_101): row sums, column sums and the
+    final (C + 32768) >> 16 with the stated tie rule -- every pixel EQUAL, not "within one grey level"."""
+    from scipy import ndimage
+    K = np.array([18, 34, 49, 55, 49, 34, 18], np.int64)
+    rng = np.random.RandomState(21 + tie)
+    for (w, h) in [(64, 48), (131, 97), (40, 200), (7, 9)]:
+        img = rng.randint(0, 256, (h, w)).astype(np.uint8)
+        img[: h // 3] = (img[: h // 3] // 64) * 64                     # plateaus: more exact .5 ties
+        R = ndimage.correlate1d(img.astype(np.int64), K, axis=1, mode="mirror")
+        Cc = ndimage.correlate1d(R, K, axis=0, mode="mirror")
+        v = (Cc + 32768) >> 16
+        if tie == 0:                                                    # SSE2 column pass: ties to even for x < (w & ~3)
+            is_tie = (Cc & 0xFFFF) == 0x8000
+            xs = np.arange(w)[None, :] < (w & ~3)
+            v = np.where(is_tie & xs, v & ~1, v)
+        want = np.clip(v, 0, 255).astype(np.uint8)
+        got = oracle.gaussian_blur7(img, tie_mode=tie)
+        assert np.array_equal(got, want), (w, h)
