@@ -330,7 +330,7 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
     if ((rc = ensure(c, c->cand, candFrame * 8 * B))) return rc;          // uint2 key records
     if ((rc = ensure(c, c->cellCand, cellCandFrame * 4 * B))) return rc;
     if ((rc = ensure(c, c->cellCount, (size_t)cells * 4 * B + 64))) return rc;
-    if ((rc = ensure(c, c->sel, selFrame * 4 * B))) return rc;
+    if ((rc = ensure(c, c->sel, selFrame * 8 * B))) return rc;            // uint2 {record, list position} per keypoint
     if ((rc = ensure(c, c->nodes, nodeFrame * 4 * B + 64))) return rc;
     if ((rc = ensure(c, c->counters, (size_t)B * PG_MAXL * 4 * 2 + 64))) return rc;
     for (int l = 0; l < L; l++) {

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
     const int32_t* kpc = P.kpCount + frame * PG_MAXL;
     // kernel arguments the chain needs, incl. every level's selection offset, in the first batch
     const int nlevels = P.nlevels;
-    const uint32_t* selp = P.sel + (int64_t)frame * P.selFrame;
+    const uint32_t* selp = P.sel + 2 * (int64_t)frame * P.selFrame;      // uint2 {record, list position} in dispatch order (K3)
     int selOffs[PG_MAXL];                                   // (a frame's selection slab is a few thousand entries)
 #pragma unroll
     for (int q = 0; q < PG_MAXL; q++) selOffs[q] = (int)P.lvl[q].selOff;
@@ -256,14 +256,18 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
     if (found < 0) return;
     l = found; j = idx - before;
     // the selection record and the level's fields travel together
-    const uint32_t* cvp = selp + selOff + j;
+    const uint32_t* cvp = selp + 2 * (selOff + j);
     const PgLevel& L = P.lvl[l];
     const uint8_t* Limg = L.img; const int64_t Lfstride = L.fstride; const int Lpitch = L.pitch, Lw = L.w, Lh = L.h;
     const float Lscale = L.scale, LpatchSize = L.patchSize;
     uint32_t cv;
-    asm volatile("s_load_dword %0, %1, 0x0" : "=s"(cv) : "s"(cvp) : "memory");
+    typedef uint32_t pg_u32x2 __attribute__((ext_vector_type(2)));
+    pg_u32x2 cvj;
+    asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=s"(cvj) : "s"(cvp) : "memory");
     asm volatile("" :: "s"(Limg), "s"(Lfstride), "s"(Lpitch), "s"(Lw), "s"(Lh), "s"(Lscale), "s"(LpatchSize));
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(cv));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(cvj));
+    cv = cvj[0];
+    idx = before + (int)cvj[1];                             // the OUTPUT slot is the keypoint's position in the reference's list
     const int x = (int)(cv & 0xFFF) + PG_EDGE, y = (int)((cv >> 12) & 0xFFF) + PG_EDGE;   // :842-843
     const int resp = (int)(cv >> 24);
 #ifdef PGORB_DESC_TIMING

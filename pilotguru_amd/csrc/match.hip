@@ -164,20 +164,24 @@ __device__ __forceinline__ void mx_update(const pg_v4f (&acc)[4], bool valid, fl
         }
 }
 
-// grid (ceil(cap / 256), pairs) or (ceil(na / 256), 1) for a single pair (pq == nullptr); nb < 8192
+// grid (pairs padded to a multiple of 8, ceil(cap / 256)): the PAIR is the fast grid index, so the workgroup's
+// linear id mod 8 -- the XCD it is dispatched to -- is pair mod 8 and all query blocks of one pair share one XCD's
+// L2: the pair's expanded trains (128 B per descriptor) come from HBM once instead of once per query block
+// (profiles/r01_i_pmc.txt: 264 MB per step fetched for 18 MB of descriptors).  nb < 8192
 __global__ __launch_bounds__(64 * MX_WAVES) void k_match_mfma(const uint8_t* __restrict__ qdesc, const uint8_t* __restrict__ xt,
                                                               const int32_t* __restrict__ n, int cap,
                                                               const int32_t* __restrict__ pq, const int32_t* __restrict__ pt,
-                                                              int na_single, int nb_single, int blocksPerPair,
+                                                              int na_single, int nb_single, int blocksPerPair, int npairs,
                                                               int32_t* best_idx, uint16_t* best, uint16_t* second)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[(2 * MX_TILE_BLOCKS + 1) * MX_BLOCK_BYTES];    // + read-ahead slack
-    const int p = blockIdx.y;
+    const int p = blockIdx.x, qblk = blockIdx.y;
+    if (p >= npairs) return;
     const int fq = pq ? pq[p] : 0, ft = pt ? pt[p] : 0;
     const int na = pq ? min(n[fq], cap) : na_single, nb = pt ? min(n[ft], cap) : nb_single;
-    if ((int)blockIdx.x * 64 * MX_WAVES >= na) return;
+    if (qblk * 64 * MX_WAVES >= na) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int qbase = blockIdx.x * 64 * MX_WAVES + wv * 64;
+    const int qbase = qblk * 64 * MX_WAVES + wv * 64;
     const bool active = qbase < na;                              // wave-uniform
     const uint8_t* qd = qdesc + (int64_t)fq * cap * 32;
     const int64_t o = (int64_t)p * cap;
@@ -399,8 +403,8 @@ void pg_launch_best2(const uint8_t* d_a, int na, const uint8_t* d_b, int nb, uin
     const int bpp = (nb + 15) / 16;
     if (bpp > 0)
         hipLaunchKernelGGL(k_expand_trains, dim3(bpp, 1), dim3(128), 0, s, d_b, nullptr, nb, nullptr, nb, bpp, d_scratch);
-    hipLaunchKernelGGL(k_match_mfma, dim3((na + 64 * MX_WAVES - 1) / (64 * MX_WAVES), 1), dim3(64 * MX_WAVES), 0, s,
-                       d_a, d_scratch, nullptr, na, nullptr, nullptr, na, nb, bpp, d_best_idx, d_best, d_second);
+    hipLaunchKernelGGL(k_match_mfma, dim3(1, (na + 64 * MX_WAVES - 1) / (64 * MX_WAVES)), dim3(64 * MX_WAVES), 0, s,
+                       d_a, d_scratch, nullptr, na, nullptr, nullptr, na, nb, bpp, 1, d_best_idx, d_best, d_second);
 }
 
 void pg_launch_match_batch(const uint8_t* d_desc, const int32_t* d_n, int cap_per_frame,
@@ -415,6 +419,6 @@ void pg_launch_match_batch(const uint8_t* d_desc, const int32_t* d_n, int cap_pe
     }
     const int bpp = (cap_per_frame + 15) / 16;
     hipLaunchKernelGGL(k_expand_trains, dim3(bpp, npairs), dim3(128), 0, s, d_desc, d_n, cap_per_frame, d_pt, 0, bpp, d_scratch);
-    hipLaunchKernelGGL(k_match_mfma, dim3((cap_per_frame + 64 * MX_WAVES - 1) / (64 * MX_WAVES), npairs), dim3(64 * MX_WAVES), 0, s,
-                       d_desc, d_scratch, d_n, cap_per_frame, d_pq, d_pt, 0, 0, bpp, d_best_idx, d_best, d_second);
+    hipLaunchKernelGGL(k_match_mfma, dim3((npairs + 7) & ~7, (cap_per_frame + 64 * MX_WAVES - 1) / (64 * MX_WAVES)), dim3(64 * MX_WAVES), 0, s,
+                       d_desc, d_scratch, d_n, cap_per_frame, d_pq, d_pt, 0, 0, bpp, npairs, d_best_idx, d_best, d_second);
 }

@@ -626,9 +626,22 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P)
     }
     __syncthreads();
     QT_TS(6);
-    uint32_t* sel = P.sel + (int64_t)frame * P.selFrame + L.selOff;
+    // Selection records are written in a DISPATCH order for K4-6 -- 64-px (or coarser) tiles, row-major -- as pairs
+    // {record, position in the reference's output list}: K4-6 gives XCD x the x-th eighth of this order, so the
+    // 43 x 43 windows one XCD's L2 sees overlap (in list order every window line was fetched from HBM about twice).
+    // The keypoint's OUTPUT slot stays its list position.  Counting sort on the tile index, in the pyramid's LDS.
+    uint2* sel = reinterpret_cast<uint2*>(P.sel) + ((int64_t)frame * P.selFrame + L.selOff);
     const int nsel = min(size, L.selCap);
     if (size > L.selCap && tid == 0) atomicExch(P.status, PGORB_E_OVERFLOW);
+    const int tileCap = min(1024, 4 * NC - 2);              // the histogram lives in cnt4 [4 * NC]
+    int tsh = 6;
+    while ((((L.w - 2 * PG_EDGE) >> tsh) + 1) * (((L.h - 2 * PG_EDGE) >> tsh) + 1) > tileCap) tsh++;
+    const int tilesX = ((L.w - 2 * PG_EDGE) >> tsh) + 1;
+    int* hist = cnt4;                                       // generation state is dead in the epilogue
+    int* wRec = cntA;                                       // [NC] winner record of list position p
+    int* wKey = cntB;                                       // [NC] tile << 16 | arrival index inside the tile
+    for (int i = tid; i <= tileCap; i += QT_T) hist[i] = 0;
+    __syncthreads();
     for (int b0 = 0; b0 < ncand; b0 += 4 * QT_T) {
         uint2 kk[4];
 #pragma unroll
@@ -643,8 +656,18 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P)
             const uint32_t rank = ((ci * nCols + cj) * hCell + (y - ci * hCell)) * wCell + (x - cj * wCell);
             const unsigned long long key = ((unsigned long long)(k.x >> 24) << 32) | (0xFFFFFFFFu - rank);
             const int pos = pyrMode ? leafPos[k.y] : (int)(k.y & QT_POS_MASK);
-            if (pos < nsel && best[pos] == key) sel[pos] = k.x;
+            if (pos < nsel && best[pos] == key) {
+                const int t = (int)(((k.x >> 12) & 0xFFF) >> tsh) * tilesX + (int)((k.x & 0xFFF) >> tsh);
+                wRec[pos] = (int)k.x;
+                wKey[pos] = (t << 16) | atomicAdd(&hist[t], 1);
+            }
         }
+    }
+    __syncthreads();
+    qt_scan_excl(hist, tileCap + 1, sh);
+    for (int p = tid; p < nsel; p += QT_T) {
+        const int wk = wKey[p];
+        sel[hist[wk >> 16] + (wk & 0xFFFF)] = make_uint2((uint32_t)wRec[p], (uint32_t)p);
     }
     if (tid == 0) *kpc = nsel;
     QT_TS(7);
