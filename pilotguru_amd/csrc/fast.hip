@@ -134,7 +134,12 @@ template <int QW, bool STRONG>      // quads per row handled by consecutive lane
 __device__ __forceinline__ int quick_pass(const uint8_t* tile, int TP, int IW, int rowBeg, int rowEnd,
                                           int t, uint16_t* list, int lane)
 {
-    const int lq = lane & (QW - 1), lr = lane / QW;
+    // lane -> (quad, row): with 8 quads per row the 32 lanes of a bank group (ds_read_b32: lanes 0-31 / 32-63) take
+    // rows 0, 2, 4, 6 (resp. 1, 3, 5, 7) of the step: at the 48-byte tile pitch (12 dwords) those start on banks
+    // 0, 24, 16, 8 -- four disjoint runs of 8 banks.  Consecutive rows (0, 12, 24, 36 -> 4) put rows 0 and 3 on the
+    // same banks (SQ_LDS_BANK_CONFLICT was 44 % of SQ_LDS_IDX_ACTIVE, profiles/r01_i_pmc.txt).
+    const int lq = lane & (QW - 1);
+    const int lr = (QW == 8) ? (((lane >> 3) & 3) * 2 + (lane >> 5)) : lane / QW;
     const int NQ = (IW + 3) >> 2;
     const uint32_t K15 = 0x80008000u;
     const uint32_t Kd = (uint32_t)(0x8000 - t - 1) * 0x00010001u;
