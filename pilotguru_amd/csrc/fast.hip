@@ -44,8 +44,21 @@
 
 extern __shared__ __attribute__((aligned(16))) uint8_t pg_fast_smem[];
 
-__device__ __forceinline__ int imin3(int a, int b, int c) { return min(min(a, b), c); }
-__device__ __forceinline__ int imax3(int a, int b, int c) { return max(max(a, b), c); }
+// v_min3_i32 / v_max3_i32 as opaque instructions: written as min(min(a, b), c) the optimiser re-associates the
+// sliding-window chains of the exact score, shares two-input pairs between neighbouring windows and ends up with MORE
+// instructions (63 three-input + 26 two-input per score instead of 80 three-input), all in the slow issue class
+__device__ __forceinline__ int imin3(int a, int b, int c)
+{
+    int r;
+    asm("v_min3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ int imax3(int a, int b, int c)
+{
+    int r;
+    asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 // 16-ring offsets in OpenCV's order (x, y): (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)
 // (0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
@@ -69,12 +82,22 @@ __device__ __forceinline__ int fast_score16(const int d[16])
         lo3[k] = imin3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
         hi3[k] = imax3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
     }
-    int best_dark = -1000, best_bright = 1000;
+    // 9-window minima / maxima, then a 3-input reduction tree: 32 + 32 + 16 three-input operations in all
+    // (v_min3 / v_max3 issue in the slow class like the two-input forms, so every fused pair is a slot saved)
+    int lo9[16], hi9[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        best_dark = max(best_dark, imin3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]));
-        best_bright = min(best_bright, imax3(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]));
+        lo9[k] = imin3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);
+        hi9[k] = imax3(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);
     }
+    int best_dark = imax3(lo9[0], lo9[1], lo9[2]), best_bright = imin3(hi9[0], hi9[1], hi9[2]);
+#pragma unroll
+    for (int k = 3; k < 15; k += 2) {
+        best_dark = imax3(best_dark, lo9[k], lo9[k + 1]);
+        best_bright = imin3(best_bright, hi9[k], hi9[k + 1]);
+    }
+    best_dark = max(best_dark, lo9[15]);
+    best_bright = min(best_bright, hi9[15]);
     return max(best_dark, -best_bright) - 1;
 }
 
@@ -160,14 +183,17 @@ __device__ __forceinline__ int quick_pass(const uint8_t* tile, int TP, int IW, i
             const uint32_t* rd = reinterpret_cast<const uint32_t*>(tile + (iy + 6) * TP) + 1 + lq;
             const uint32_t C = rc[0], Lw = rc[-1], Rw = rc[1], U = ru[0], D = rd[0];
             // one v_perm_b32 per operand: bytes -> two 16-bit fields (selector 0x0c = zero byte)
-            const uint32_t EV = 0x0c020c00u, OD = 0x0c030c01u;       // (b0, b2) / (b1, b3) of one dword
+            const uint32_t OD = 0x0c030c01u;                          // (b1, b3) of one dword
             const uint32_t X20 = 0x0c040c02u, X31 = 0x0c050c03u;     // (lo.b2, hi.b0) / (lo.b3, hi.b1) of a dword pair
-            const uint32_t Ce = __builtin_amdgcn_perm(C, C, EV), Co = __builtin_amdgcn_perm(C, C, OD);   // pixels (0,2) / (1,3)
-            const uint32_t Ue = __builtin_amdgcn_perm(U, U, EV), Uo = __builtin_amdgcn_perm(U, U, OD);   // ring 8 (3 rows up)
-            const uint32_t De = __builtin_amdgcn_perm(D, D, EV), Do = __builtin_amdgcn_perm(D, D, OD);   // ring 0 (3 rows down)
+            // (the even-byte fields are one v_and_b32 -- gfx950 issues and / or / add / sub / lshr at 2.7 cycles per wave
+            //  instruction, v_perm_b32 and everything packed or 3-operand at 4.6: tools/ubench/valu_rate3.hip)
+            const uint32_t M02 = 0x00FF00FFu;
+            const uint32_t Ce = C & M02, Co = __builtin_amdgcn_perm(C, C, OD);   // pixels (0,2) / (1,3)
+            const uint32_t Ue = U & M02, Uo = __builtin_amdgcn_perm(U, U, OD);   // ring 8 (3 rows up)
+            const uint32_t De = D & M02, Do = __builtin_amdgcn_perm(D, D, OD);   // ring 0 (3 rows down)
             // ring 12 (x-3) and ring 4 (x+3) of the even and odd pixels
             const uint32_t W12e = __builtin_amdgcn_perm(Lw, Lw, OD);   // pixels (-3, -1)
-            const uint32_t W4o = __builtin_amdgcn_perm(Rw, Rw, EV);    // pixels (4, 6)
+            const uint32_t W4o = Rw & M02;                             // pixels (4, 6)
             const uint32_t W12o = __builtin_amdgcn_perm(C, Lw, X20);   // pixels (-2, 0)
             const uint32_t W4e = __builtin_amdgcn_perm(Rw, C, X31);    // pixels (3, 5)
             // per parity: dk = the larger of the pairs' minima, br = the smaller of their maxima
@@ -524,13 +550,14 @@ __device__ __forceinline__ void fb_quick(const bool STRONG, const uint8_t* tile,
                 const uint32_t* ru = reinterpret_cast<const uint32_t*>(base + iy * FB_TP);
                 const uint32_t* rd = reinterpret_cast<const uint32_t*>(base + (iy + 6) * FB_TP);
                 const uint32_t C = rc[0], Lw = rc[-1], Rw = rc[1], U = ru[0], D = rd[0];
-                const uint32_t EV = 0x0c020c00u, OD = 0x0c030c01u;
+                const uint32_t OD = 0x0c030c01u;
                 const uint32_t X20 = 0x0c040c02u, X31 = 0x0c050c03u;
-                const uint32_t Ce = __builtin_amdgcn_perm(C, C, EV), Co = __builtin_amdgcn_perm(C, C, OD);
-                const uint32_t Ue = __builtin_amdgcn_perm(U, U, EV), Uo = __builtin_amdgcn_perm(U, U, OD);
-                const uint32_t De = __builtin_amdgcn_perm(D, D, EV), Do = __builtin_amdgcn_perm(D, D, OD);
+                const uint32_t M02 = 0x00FF00FFu;                   // even bytes -> 16-bit fields with a fast-class v_and_b32
+                const uint32_t Ce = C & M02, Co = __builtin_amdgcn_perm(C, C, OD);
+                const uint32_t Ue = U & M02, Uo = __builtin_amdgcn_perm(U, U, OD);
+                const uint32_t De = D & M02, Do = __builtin_amdgcn_perm(D, D, OD);
                 const uint32_t W12e = __builtin_amdgcn_perm(Lw, Lw, OD);
-                const uint32_t W4o = __builtin_amdgcn_perm(Rw, Rw, EV);
+                const uint32_t W4o = Rw & M02;
                 const uint32_t W12o = __builtin_amdgcn_perm(C, Lw, X20);
                 const uint32_t W4e = __builtin_amdgcn_perm(Rw, C, X31);
                 uint32_t dkE = pg_pkmax(pg_pkmin(De, Ue), pg_pkmin(W4e, W12e)), brE = pg_pkmin(pg_pkmax(De, Ue), pg_pkmax(W4e, W12e));
