@@ -10,6 +10,7 @@
 // end (Tracking/LocalMapping/LoopClosing, pose estimation) is out of scope, so instead of
 // trajectory-<k>.json (which needs poses) the run writes <out_dir>/frontend-<k>.json; the
 // trajectory JSON writer is exercised with --trajectory_in=<poses.txt> (see trajectory_json.hpp),
+// (the frame loop streams batches through pgorb_stream_*: page-locked input slots, upload / kernels / download overlapped)
 // and --poses_in=<poses.txt> runs the whole tail of TrackImageSequence on poses from any back end
 // (src/slam/track_image_sequence.cc:63-109: heading smoothing, PCA plane, eigenvalue gate,
 // projected directions, turn angles, trajectory-<segment_id>.json).
@@ -271,52 +272,80 @@ int main(int argc, char** argv)
         check_failed("vocabulary loads (ORB vocabulary text file)");
     int vk, vL, vn, vw, vs, vwt; pgorb_vocab_info(voc, &vk, &vL, &vn, &vw, &vs, &vwt);
 
-    const int B = std::max(1, F.batch);
-    std::vector<std::vector<uint8_t>> frames(B);
-    std::vector<long long> tus(B), ids(B);
-    pgorb::ORBextractor* ext = nullptr;
+    // The frame loop of TrackImageSequence (src/slam/track_image_sequence.cc:43-52) as a stream of batches
+    // (include/pgorb.h, pgorb_stream_*): the source writes every frame straight into a page-locked slot; upload,
+    // kernels and result download of up to DEPTH batches overlap.  The per-frame host calls (BoW transform, initial
+    // matcher) use a second, small context: the streaming context must not run other calls while batches are in flight.
+    const int B = std::max(1, F.batch), DEPTH = 3;
+    std::vector<uint8_t> frame0;                              // the first frame tells the size
+    long long t0 = 0, id0 = 0;
+    if (!((F.max_frames < 0 || F.max_frames > 0) && src.next(frame0, &t0, &id0))) frame0.clear();
+    pgorb::ORBextractor* ext = nullptr;                       // streaming context (batches)
+    pgorb::ORBextractor* aux = nullptr;                       // per-frame calls
+    pgorb_stream* st = nullptr;
+    if (!frame0.empty()) {
+        flip(frame0, src.w, src.h, F.vertical_flip, F.horizontal_flip);
+        ext = new pgorb::ORBextractor(nFeatures, scaleFactor, nLevels, iniTh, minTh, src.w, src.h, B, F.device);
+        aux = new pgorb::ORBextractor(nFeatures, scaleFactor, nLevels, iniTh, minTh, src.w, src.h, 1, F.device);
+        if (pgorb_vocab_upload(aux->context(), voc) != PGORB_OK) check_failed("vocabulary upload");
+        if (pgorb_max_keypoints(ext->context(), src.w, src.h) < 0) check_failed("frame size usable for the ORB cell grid");
+        if (pgorb_stream_create(ext->context(), src.w, src.h, B, DEPTH, &st) != PGORB_OK) check_failed(pgorb_last_error(ext->context()));
+    }
+    const size_t fbytes = (size_t)src.w * src.h;
+    std::vector<std::vector<long long>> tusS(DEPTH, std::vector<long long>(B)), idsS(DEPTH, std::vector<long long>(B));
     pgorb::Frame prev; bool havePrev = false;
     std::vector<float> prevMatched;
     std::ostringstream js;
     js << "{\n  \"frames\": [";
     FILE* dump = F.dump_features.empty() ? nullptr : fopen(F.dump_features.c_str(), "wb");
-    long total = 0; bool first = true;
-    for (;;) {
-        int nb = 0;
-        while (nb < B && (F.max_frames < 0 || total + nb < F.max_frames) && src.next(frames[nb], &tus[nb], &ids[nb])) {
-            flip(frames[nb], src.w, src.h, F.vertical_flip, F.horizontal_flip);
-            nb++;
+    long total = 0, read = 0; bool first = true;
+    int submitted = 0, collected = 0; bool more = !frame0.empty();
+    while (more || collected < submitted) {
+        // keep DEPTH batches in flight: fill and submit the next slot while there are frames
+        while (more && submitted - collected < DEPTH) {
+            const int slot = submitted % DEPTH;
+            uint8_t* in = pgorb_stream_input(st, slot);
+            int nb = 0;
+            std::vector<uint8_t> tmp;
+            while (nb < B && (F.max_frames < 0 || read < F.max_frames)) {
+                if (read == 0) { memcpy(in, frame0.data(), fbytes); tusS[slot][0] = t0; idsS[slot][0] = id0; }
+                else {
+                    if (!src.next(tmp, &tusS[slot][nb], &idsS[slot][nb])) { more = false; break; }
+                    flip(tmp, src.w, src.h, F.vertical_flip, F.horizontal_flip);
+                    memcpy(in + (size_t)nb * fbytes, tmp.data(), fbytes);
+                }
+                nb++; read++;
+            }
+            if (F.max_frames >= 0 && read >= F.max_frames) more = false;
+            if (!nb) break;
+            if (pgorb_stream_submit(st, slot, nb) != PGORB_OK) check_failed(pgorb_last_error(ext->context()));
+            submitted++;
         }
-        if (!nb) break;
-        if (!ext) {
-            ext = new pgorb::ORBextractor(nFeatures, scaleFactor, nLevels, iniTh, minTh, src.w, src.h, B, F.device);
-            if (pgorb_vocab_upload(ext->context(), voc) != PGORB_OK) check_failed("vocabulary upload");
-        }
-        const int cap = pgorb_max_keypoints(ext->context(), src.w, src.h);
-        if (cap < 0) check_failed("frame size usable for the ORB cell grid");
-        std::vector<pgorb_keypoint> kps((size_t)nb * cap); std::vector<uint8_t> desc((size_t)nb * cap * 32); std::vector<int> n(nb);
-        std::vector<const uint8_t*> ptrs(nb);
-        for (int i = 0; i < nb; i++) ptrs[i] = frames[i].data();
-        if (pgorb_extract_batch(ext->context(), ptrs.data(), nb, src.w, src.h, src.w, kps.data(), desc.data(), cap, n.data()) != PGORB_OK)
-            check_failed(pgorb_last_error(ext->context()));
+        if (collected >= submitted) break;
+        const int slot = collected % DEPTH;
+        const int32_t* n = nullptr; const pgorb_keypoint* kps = nullptr; const uint8_t* desc = nullptr; int cap = 0;
+        const int nb = pgorb_stream_wait(st, slot, &n, &kps, &desc, nullptr, nullptr, nullptr, &cap);
+        if (nb < 0) check_failed(pgorb_last_error(ext->context()));
+        collected++;
+        const std::vector<long long>&tus = tusS[slot], &ids = idsS[slot];
         for (int i = 0; i < nb; i++) {
             pgorb::Frame cur;
-            cur.mvKeysUndistorted.assign(kps.begin() + (size_t)i * cap, kps.begin() + (size_t)i * cap + n[i]);
-            cur.mDescriptors.assign(desc.begin() + (size_t)i * cap * 32, desc.begin() + ((size_t)i * cap + n[i]) * 32);
+            cur.mvKeysUndistorted.assign(kps + (size_t)i * cap, kps + (size_t)i * cap + n[i]);
+            cur.mDescriptors.assign(desc + (size_t)i * cap * 32, desc + ((size_t)i * cap + n[i]) * 32);
             cur.mnMaxX = (float)src.w; cur.mnMaxY = (float)src.h;
             // Frame::ComputeBoW: transform(descriptors, BowVec, FeatVec, 4)  (Frame.cc:399-406)
             std::vector<uint32_t> word(n[i]), node(n[i]), bid(n[i] + 1), fnode(n[i] + 1), ffeat(n[i] + 1);
             std::vector<double> wt(n[i]), bval(n[i] + 1); std::vector<int32_t> fstart(n[i] + 2);
             int nbow = 0, nfv = 0;
             if (n[i]) {
-                if (pgorb_bow_transform(ext->context(), cur.mDescriptors.data(), n[i], 4, word.data(), wt.data(), node.data()) != PGORB_OK)
-                    check_failed(pgorb_last_error(ext->context()));
+                if (pgorb_bow_transform(aux->context(), cur.mDescriptors.data(), n[i], 4, word.data(), wt.data(), node.data()) != PGORB_OK)
+                    check_failed(pgorb_last_error(aux->context()));
                 pgorb_bow_vectors(n[i], word.data(), wt.data(), node.data(), vs, vwt, bid.data(), bval.data(), &nbow,
                                   fnode.data(), fstart.data(), ffeat.data(), &nfv);
             }
             int nmatches = -1;
             if (havePrev) {                              // MonocularInitialization's matcher call (Tracking.cc:596-597)
-                pgorb::ORBmatcher matcher(ext->context(), 0.9f, true);
+                pgorb::ORBmatcher matcher(aux->context(), 0.9f, true);
                 prevMatched.resize((size_t)prev.N() * 2);
                 for (int k = 0; k < prev.N(); k++) { prevMatched[2 * k] = prev.mvKeysUndistorted[k].x; prevMatched[2 * k + 1] = prev.mvKeysUndistorted[k].y; }
                 std::vector<int32_t> m12;
@@ -344,6 +373,8 @@ int main(int argc, char** argv)
     if (!o.good()) check_failed("out_dir is writable");
     o << js.str() << std::endl;
     fprintf(stderr, "optical_trajectories (front-end mode): %ld frames -> %s\n", total, out.c_str());
+    if (st) pgorb_stream_destroy(st);
+    delete aux;
     delete ext;
     pgorb_vocab_free(voc);
     return EXIT_SUCCESS;
