@@ -252,6 +252,8 @@ def main():
                     help="textured = SURVEY.md 8d's scene (the headline workload); road = sky / asphalt / texture band")
     ap.add_argument("--sustain-seconds", type=float, default=3.0,
                     help="after the timed steps, keep stepping for this long and report sustained_fps (0 = skip)")
+    ap.add_argument("--pipeline-pyramid", type=int, default=None,
+                    help="1 / 0: run the pyramid chain beside K2 on a side stream (library default when omitted)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-upload-leg", action="store_true")
@@ -277,6 +279,8 @@ def main():
     W, H, B, NF = args.width, args.height, args.batch, args.features
     ext = pg.ORBextractor(NF, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B, device=local_rank)
 
+    if args.pipeline_pyramid is not None:
+        ext.set_option("pipeline_pyramid", args.pipeline_pyramid)
     # one ride per rank (ride id = rank): B consecutive frames, resident in HBM
     from pilotguru_amd import dist as pgd0
     make_ride = synth_ride_road if args.scene == "road" else synth_ride

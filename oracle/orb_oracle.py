@@ -168,7 +168,9 @@ class OrbOracle:
     def extract(self, gray, cap=None):
         gray = np.ascontiguousarray(gray, dtype=np.uint8)
         h, w = gray.shape
-        cap = cap or (self.nfeatures + 3 * self.nlevels + 64)
+        # (a level returns up to max(quota + 3, 4 * nIni) keypoints, nIni = round(W / H) roots: panoramic frames with tiny
+        #  quotas exceed nfeatures by far more than 3 per level)
+        cap = cap or (self.nfeatures + 64 * self.nlevels + 64)
         kps = np.zeros(cap, KEYPOINT_DTYPE)
         desc = np.zeros((cap, 32), np.uint8)
         n = C.c_int32(0)

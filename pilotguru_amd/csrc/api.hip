@@ -42,6 +42,11 @@ struct pgorb_ctx {
     // device memory
     Arena pyr, cand, sel, nodes, counters, tables, cellCand, cellCount, cellTab, blockTab;
     int fastBlockCX = 4, fastBlockCY = 2;     // K2 block shape in cells (pgorb_set_option "fast_block_cx" / "_cy")
+    // K1 beside K2 (pgorb_set_option "pipeline_pyramid"): the pyramid chain on a high-priority side stream, K2 level by
+    // level on a second one as the levels appear
+    int pipePyr = 0;
+    hipStream_t sPyr = nullptr, sFast = nullptr;
+    hipEvent_t evFork = nullptr, evLevel[PG_MAXL] = {}, evPyrDone = nullptr, evFastDone = nullptr;
     Arena stageKps, stageDesc, stageN, stageA, stageB, stageOut, vocab;
     Arena xdesc;                              // matcher scratch: train descriptors as +-1 bytes (match.hip)
     void* pinned = nullptr;                   // page-locked bounce buffer for bulk result download
@@ -453,10 +458,42 @@ int run_batch(pgorb_ctx* c, const uint8_t* d_gray, bool resident_in_level0, int 
     PG_HIP(c, hipMemsetAsync(P.candCount, 0, (size_t)c->planBatch * PG_MAXL * 4 * 2 + 4, s));
     hipEvent_t* ev = (c->profExtract < c->profMax) ? &c->evExtract[5 * (size_t)c->profExtract] : nullptr;
     if (ev) PG_HIP(c, hipEventRecord(ev[0], s));
-    for (int l = 1; l < P.nlevels; l++) pg_launch_pyramid_level(P, l, nframes, s);
-    if (ev) PG_HIP(c, hipEventRecord(ev[1], s));
-    pg_launch_fast(P, nframes, s);
-    if (ev) PG_HIP(c, hipEventRecord(ev[2], s));
+    if (c->pipePyr && P.nlevels > 1 && pg_fast_is_cell_form(P)) {
+        // K1 is HBM-bound and K2 VALU-issue-bound, and K2 of level l only needs level l: the resize chain runs on a
+        // high-priority side stream, K2 level by level on another, each level's K2 behind the launch that wrote it.
+        // (Stage events: "pyramid" = start .. end of the chain, "fast" = end of the chain .. end of K2: they overlap.)
+        if (!c->sPyr) {
+            int lo = 0, hi = 0;
+            PG_HIP(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+            PG_HIP(c, hipStreamCreateWithPriority(&c->sPyr, hipStreamNonBlocking, hi));
+            PG_HIP(c, hipStreamCreateWithPriority(&c->sFast, hipStreamNonBlocking, lo));
+            PG_HIP(c, hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
+            PG_HIP(c, hipEventCreateWithFlags(&c->evPyrDone, hipEventDisableTiming));
+            PG_HIP(c, hipEventCreateWithFlags(&c->evFastDone, hipEventDisableTiming));
+            for (int l = 0; l < PG_MAXL; l++) PG_HIP(c, hipEventCreateWithFlags(&c->evLevel[l], hipEventDisableTiming));
+        }
+        PG_HIP(c, hipEventRecord(c->evFork, s));
+        PG_HIP(c, hipStreamWaitEvent(c->sPyr, c->evFork, 0));
+        PG_HIP(c, hipStreamWaitEvent(c->sFast, c->evFork, 0));
+        pg_launch_fast_levels(P, nframes, 0, 1, c->sFast);
+        for (int l = 1; l < P.nlevels; l++) {
+            pg_launch_pyramid_level(P, l, nframes, c->sPyr);
+            PG_HIP(c, hipEventRecord(c->evLevel[l], c->sPyr));
+            PG_HIP(c, hipStreamWaitEvent(c->sFast, c->evLevel[l], 0));
+            pg_launch_fast_levels(P, nframes, l, l + 1, c->sFast);
+        }
+        PG_HIP(c, hipEventRecord(c->evPyrDone, c->sPyr));
+        PG_HIP(c, hipEventRecord(c->evFastDone, c->sFast));
+        PG_HIP(c, hipStreamWaitEvent(s, c->evPyrDone, 0));
+        if (ev) PG_HIP(c, hipEventRecord(ev[1], s));
+        PG_HIP(c, hipStreamWaitEvent(s, c->evFastDone, 0));
+        if (ev) PG_HIP(c, hipEventRecord(ev[2], s));
+    } else {
+        for (int l = 1; l < P.nlevels; l++) pg_launch_pyramid_level(P, l, nframes, s);
+        if (ev) PG_HIP(c, hipEventRecord(ev[1], s));
+        pg_launch_fast(P, nframes, s);
+        if (ev) PG_HIP(c, hipEventRecord(ev[2], s));
+    }
     pg_launch_quadtree(P, nframes, s);
     if (ev) PG_HIP(c, hipEventRecord(ev[3], s));
     pg_launch_describe(P, nframes, d_kps, d_desc, cap_per_frame, d_n, s);
@@ -575,6 +612,12 @@ void pgorb_destroy(pgorb_ctx* c)
     Arena* all[] = {&c->blockTab, &c->cellTab, &c->cellCand, &c->cellCount, &c->pyr, &c->cand, &c->sel, &c->nodes, &c->counters, &c->tables,
                     &c->stageKps, &c->stageDesc, &c->stageN, &c->stageA, &c->stageB, &c->stageOut, &c->vocab, &c->xdesc};
     for (Arena* a : all) if (a->p) (void)hipFree(a->p);
+    if (c->sPyr) {
+        (void)hipStreamSynchronize(c->sPyr); (void)hipStreamSynchronize(c->sFast);
+        (void)hipStreamDestroy(c->sPyr); (void)hipStreamDestroy(c->sFast);
+        (void)hipEventDestroy(c->evFork); (void)hipEventDestroy(c->evPyrDone); (void)hipEventDestroy(c->evFastDone);
+        for (int l = 0; l < PG_MAXL; l++) (void)hipEventDestroy(c->evLevel[l]);
+    }
     if (c->pinned) (void)hipHostFree(c->pinned);
     for (hipEvent_t e : c->evExtract) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->evMatch) (void)hipEventDestroy(e);
@@ -847,6 +890,7 @@ int pgorb_set_option(pgorb_ctx* c, const char* key, int value)
     if (!key) return PGORB_E_ARG;
     if (!strcmp(key, "matcher")) { pg_match_set_popcount(value); return 0; }
     if (!strcmp(key, "fast_kernel")) { pg_fast_set_kernel(value); return 0; }
+    if (c && !strcmp(key, "pipeline_pyramid")) { c->pipePyr = value ? 1 : 0; return 0; }
     if (c && (!strcmp(key, "fast_block_cx") || !strcmp(key, "fast_block_cy"))) {
         if (value < 1 || value > 4) return fail(c, PGORB_E_ARG, "%s must be 1..4", key);
         (key[12] == 'x' ? c->fastBlockCX : c->fastBlockCY) = value;
@@ -860,6 +904,7 @@ int pgorb_get_option(const pgorb_ctx* c, const char* key)
 {
     if (!key) return PGORB_E_ARG;
     if (!strcmp(key, "fast_kernel")) return pg_fast_get_kernel();
+    if (c && !strcmp(key, "pipeline_pyramid")) return c->pipePyr;
     if (c && !strcmp(key, "fast_block_cx")) return c->fastBlockCX;
     if (c && !strcmp(key, "fast_block_cy")) return c->fastBlockCY;
     return PGORB_E_ARG;

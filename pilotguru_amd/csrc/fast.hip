@@ -330,12 +330,14 @@ extern "C" int pgorb_debug_fast_times(unsigned int* out, int nwaves)
 template <int TPC, int MPC>
 __global__ __launch_bounds__(64, 8) void k_fast_cells(const PgPlan P, int TPr, int tileRows,
                                                        int MPr, int mapRows, int cellsPerXcd,
-                                                       int chunkInv)
+                                                       int chunkInv, int cell0, int cellEnd)
 {
     const int TP = TPC ? TPC : TPr, mapPitch = MPC ? MPC : MPr;
     const int lane = threadIdx.x;
     const int frame = blockIdx.y;
-    const int cell = (blockIdx.x & 7) * cellsPerXcd + (blockIdx.x >> 3);      // XCD-contiguous
+    // cells [cell0, cellEnd) of the plan's cell table: all levels in one launch, or one level per launch when the
+    // pyramid chain runs beside K2 (api.hip, run_batch)
+    const int cell = cell0 + (blockIdx.x & 7) * cellsPerXcd + (blockIdx.x >> 3);      // XCD-contiguous
 #ifdef PGORB_FAST_TIMING
     unsigned long long ft_t0 = wall_clock64();
     const int ft_id = frame * P.totalCells + cell;
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(64, 8) void k_fast_cells(const PgPlan P, int TPr, i
     typedef uint32_t pg_u32x8 __attribute__((ext_vector_type(8)));
     pg_u32x8 rec;
     asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rec) : "s"(recp) : "memory");
-    if (cell >= totalCells) return;
+    if (cell >= cellEnd) return;
     const int iniX = rec[1] & 0xFFFF, iniY = rec[1] >> 16;
     const int W = rec[2] & 0xFF, H = (rec[2] >> 8) & 0xFF, cellCap = rec[2] >> 17;
     int32_t* cellCnt = P.cellCount + (int64_t)frame * totalCells + cell;
@@ -866,7 +868,7 @@ __global__ __launch_bounds__(FB_T, 7) void k_fast_blocks(const PgPlan P, int til
     }
 }
 
-void pg_launch_fast_cells(const PgPlan& P, int nframes, hipStream_t s);
+void pg_launch_fast_cells(const PgPlan& P, int nframes, hipStream_t s, int levelBeg, int levelEnd);
 
 // 0 = one wave per cell (default: 0.915 ms per 128-frame step at 1080p), 1 = block form (1.29 ms: fewer VALU
 // instructions per pixel once the minThFAST pass runs per cell, but four barrier-separated phases per block at 7
@@ -877,7 +879,7 @@ int pg_fast_get_kernel() { return g_fast_kernel; }
 
 void pg_launch_fast(const PgPlan& P, int nframes, hipStream_t s)
 {
-    if (g_fast_kernel != 1 || !P.blockTab) { pg_launch_fast_cells(P, nframes, s); return; }
+    if (g_fast_kernel != 1 || !P.blockTab) { pg_launch_fast_cells(P, nframes, s, 0, P.nlevels); return; }
     int tileRows = 0;
     for (int l = 0; l < P.nlevels; l++) tileRows = max(tileRows, P.lvl[l].blkCY * P.lvl[l].hCell + 6);
     const int mapRows = tileRows - 6 + 4 + 1;                  // BH + one gutter row per cell row (<= 4) + rim
@@ -892,7 +894,14 @@ void pg_launch_fast(const PgPlan& P, int nframes, hipStream_t s)
     hipLaunchKernelGGL(k_fast_blocks, grid, block, smem, s, P, tileRows, mapRows, blocksPerXcd, dbgSkip);
 }
 
-void pg_launch_fast_cells(const PgPlan& P, int nframes, hipStream_t s)
+// K2 (cell form) for the levels [levelBeg, levelEnd) only
+void pg_launch_fast_levels(const PgPlan& P, int nframes, int levelBeg, int levelEnd, hipStream_t s)
+{
+    pg_launch_fast_cells(P, nframes, s, levelBeg, levelEnd);
+}
+bool pg_fast_is_cell_form(const PgPlan& P) { return g_fast_kernel != 1 || !P.blockTab; }
+
+void pg_launch_fast_cells(const PgPlan& P, int nframes, hipStream_t s, int levelBeg, int levelEnd)
 {
     int maxW = 0, maxH = 0;
     for (int l = 0; l < P.nlevels; l++) {
@@ -909,10 +918,12 @@ void pg_launch_fast_cells(const PgPlan& P, int nframes, hipStream_t s)
     size_t smem = (size_t)tileRows * TP + (size_t)mapRows * mapPitch + FAST_LIST_CAP * 2 + 16;
     // profiling knob: extra LDS per wave lowers occupancy (occupancy sweep)
     if (const char* e = getenv("PGORB_FAST_EXTRA_LDS")) smem += (size_t)atoi(e);
-    const int cellsPerXcd = (P.totalCells + 7) / 8;
+    const int cell0 = P.lvl[levelBeg].cellBase;
+    const int cellEnd = (levelEnd < P.nlevels) ? P.lvl[levelEnd].cellBase : P.totalCells;
+    const int cellsPerXcd = (cellEnd - cell0 + 7) / 8;
     dim3 grid(cellsPerXcd * 8, nframes), block(64);
     if (common)
-        hipLaunchKernelGGL((k_fast_cells<48, 40>), grid, block, smem, s, P, TP, tileRows, mapPitch, mapRows, cellsPerXcd, chunkInv);
+        hipLaunchKernelGGL((k_fast_cells<48, 40>), grid, block, smem, s, P, TP, tileRows, mapPitch, mapRows, cellsPerXcd, chunkInv, cell0, cellEnd);
     else
-        hipLaunchKernelGGL((k_fast_cells<0, 0>), grid, block, smem, s, P, TP, tileRows, mapPitch, mapRows, cellsPerXcd, chunkInv);
+        hipLaunchKernelGGL((k_fast_cells<0, 0>), grid, block, smem, s, P, TP, tileRows, mapPitch, mapRows, cellsPerXcd, chunkInv, cell0, cellEnd);
 }

@@ -117,6 +117,8 @@ void pg_launch_color_to_gray(const PgPlan& P, const uint8_t* src, int stride, in
                              int rgb_order, int nframes, hipStream_t s);
 void pg_launch_pyramid_level(const PgPlan& P, int level, int nframes, hipStream_t s);
 void pg_launch_fast(const PgPlan& P, int nframes, hipStream_t s);
+void pg_launch_fast_levels(const PgPlan& P, int nframes, int levelBeg, int levelEnd, hipStream_t s);   // cell form only
+bool pg_fast_is_cell_form(const PgPlan& P);
 void pg_launch_quadtree(const PgPlan& P, int nframes, hipStream_t s);
 void pg_launch_describe(const PgPlan& P, int nframes, pgorb_keypoint* d_kps, uint8_t* d_desc,
                         int cap_per_frame, int32_t* d_n, hipStream_t s);

@@ -648,3 +648,34 @@ def test_device_sincos_equals_the_oracle_for_every_input():
     bad = np.nonzero(got != want)[0]
     assert len(bad) == 0, "blocks of 2^20 inputs that differ: %s" % bad[:10]
     assert nblocks * count > 1.08e9
+
+
+def test_pyramid_beside_fast_pipeline_is_bit_exact(oracle):
+    """pgorb_set_option("pipeline_pyramid", 1): the resize chain on a high-priority side stream, K2 level by level on
+    another stream behind the launch that wrote its level.  Same keypoints, descriptors and stage taps, batch of frames,
+    repeated calls (the fork / join events are reused)."""
+    import torch
+    w, h, nf, B = 640, 480, 1000, 6
+    ride = synth_ride(9, w, h, B)
+    ext = _make(nf, w, h, batch=B)
+    ext.set_option("pipeline_pyramid", 1)
+    frames = torch.from_numpy(ride).cuda()
+    ora = oracle.OrbOracle(nf, 1.2, 8, 20, 7)
+    for rep in range(3):
+        kps, desc, n = ext.extract_batch_device(frames)
+        ext.check_async()
+        torch.cuda.synchronize()
+        nh = n.cpu().numpy()
+        for f in (0, B - 1, rep + 1):
+            okp, odesc = ora.extract(ride[f])
+            assert nh[f] == len(okp) and kps[f, :nh[f]].cpu().numpy().tobytes() == okp.tobytes()
+            assert np.array_equal(desc[f, :nh[f]].cpu().numpy(), odesc)
+    for l in range(8):
+        x, y, r = ext.debug_level_candidates(B - 1, l)
+        oc = ora.level_candidates(l)                      # (the oracle's last frame is ride[rep + 1] = ride[3]; redo for B - 1)
+    ora.extract(ride[B - 1])
+    for l in range(8):
+        assert np.array_equal(ext.debug_level_image(B - 1, l), ora.level_image(l)) if l else True
+        x, y, r = ext.debug_level_candidates(B - 1, l)
+        oc = ora.level_candidates(l)
+        assert sorted(zip(y.tolist(), x.tolist(), r.tolist())) == sorted(zip(oc["y"].tolist(), oc["x"].tolist(), oc["response"].tolist()))
