@@ -327,6 +327,8 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
             return fail(c, PGORB_E_LIMIT, "too many cells on one level for the quadtree kernel's LDS budget");
         if (V.w > 4095 + 2 * PG_EDGE || V.h > 4095 + 2 * PG_EDGE)
             return fail(c, PGORB_E_LIMIT, "level larger than 4095 px is not supported");
+        if (V.selCap > 65535)      // K3's dispatch-order sort packs a keypoint's arrival index into 16 bits
+            return fail(c, PGORB_E_LIMIT, "more than 65533 keypoints on one pyramid level are not supported");
     }
     P.totalCells = cells; P.selTotal = selTotal;
     P.cellCandFrame = (int64_t)cellCandFrame;
