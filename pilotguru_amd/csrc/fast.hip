@@ -327,7 +327,9 @@ extern "C" int pgorb_debug_fast_times(unsigned int* out, int nwaves)
 // TPC / MPC: compile-time tile and score-map pitches of the common geometry (cells up to 36 px:
 // TP = 48, map pitch 40), so that ring / neighbour offsets are instruction immediates; 0 = use the
 // run-time values (larger cells).
-template <int TPC, int MPC>
+// NARROW: every cell interior of the plan is at most 32 px wide (8 quads per row): the 16-quad variant of the
+// necessary test and its per-lane set-up are compiled out (true for 1080p / 2160p / 480p: wCell <= 32).
+template <int TPC, int MPC, bool NARROW>
 __global__ __launch_bounds__(64, 8) void k_fast_cells(const PgPlan P, int TPr, int tileRows,
                                                        int MPr, int mapRows, int cellsPerXcd,
                                                        int chunkInv, int cell0, int cellEnd)
@@ -415,10 +417,10 @@ __global__ __launch_bounds__(64, 8) void k_fast_cells(const PgPlan P, int TPr, i
         // (2) necessary test + compaction
         int nlist;
         if (pass == 0)
-            nlist = (IW <= 32) ? quick_pass<8, false>(tile, TP, IW, 0, IH, t, list, lane)
+            nlist = (NARROW || IW <= 32) ? quick_pass<8, false>(tile, TP, IW, 0, IH, t, list, lane)
                                : quick_pass<16, false>(tile, TP, IW, 0, IH, t, list, lane);
         else
-            nlist = (IW <= 32) ? quick_pass<8, true>(tile, TP, IW, 0, IH, t, list, lane)
+            nlist = (NARROW || IW <= 32) ? quick_pass<8, true>(tile, TP, IW, 0, IH, t, list, lane)
                                : quick_pass<16, true>(tile, TP, IW, 0, IH, t, list, lane);
 #if defined(PGORB_FAST_SKIP) && PGORB_FAST_SKIP == 1       // timing experiment: staging + the iniTh quick test only
         if (lane == 0) *cellCnt = 0;
@@ -922,8 +924,11 @@ void pg_launch_fast_cells(const PgPlan& P, int nframes, hipStream_t s, int level
     const int cellEnd = (levelEnd < P.nlevels) ? P.lvl[levelEnd].cellBase : P.totalCells;
     const int cellsPerXcd = (cellEnd - cell0 + 7) / 8;
     dim3 grid(cellsPerXcd * 8, nframes), block(64);
-    if (common)
-        hipLaunchKernelGGL((k_fast_cells<48, 40>), grid, block, smem, s, P, TP, tileRows, mapPitch, mapRows, cellsPerXcd, chunkInv, cell0, cellEnd);
+    const bool narrow = maxW - 6 <= 32;
+    if (common && narrow)
+        hipLaunchKernelGGL((k_fast_cells<48, 40, true>), grid, block, smem, s, P, TP, tileRows, mapPitch, mapRows, cellsPerXcd, chunkInv, cell0, cellEnd);
+    else if (common)
+        hipLaunchKernelGGL((k_fast_cells<48, 40, false>), grid, block, smem, s, P, TP, tileRows, mapPitch, mapRows, cellsPerXcd, chunkInv, cell0, cellEnd);
     else
-        hipLaunchKernelGGL((k_fast_cells<0, 0>), grid, block, smem, s, P, TP, tileRows, mapPitch, mapRows, cellsPerXcd, chunkInv, cell0, cellEnd);
+        hipLaunchKernelGGL((k_fast_cells<0, 0, false>), grid, block, smem, s, P, TP, tileRows, mapPitch, mapRows, cellsPerXcd, chunkInv, cell0, cellEnd);
 }

@@ -9,7 +9,7 @@ from pilotguru_amd.synth import synth_ride
 
 W, H, NF, B = 1920, 1080, 2000, 128
 ride = torch.from_numpy(synth_ride(0, W, H, B)).cuda()
-for parts in (1, 2, 4):
+for parts in (1, 2, 4, 8, 16):
     bs = B // parts
     exts = [pg.ORBextractor(NF, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=bs) for _ in range(parts)]
     streams = [torch.cuda.Stream() for _ in range(parts)]
