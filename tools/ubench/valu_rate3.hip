@@ -52,6 +52,17 @@ KERNEL(k_min_f16, "v_min_f16_e32 %0, %0, %1")
 KERNEL(k_pk_min_f16, "v_pk_min_f16 %0, %0, %1")
 KERNEL(k_med3_f32, "v_med3_f32 %0, %0, %1, %2")
 KERNEL(k_min3_f32, "v_min3_f32 %0, %0, %1, %2")
+KERNEL(k_mul_f32, "v_mul_f32_e32 %0, %0, %1")
+KERNEL(k_fma_f32, "v_fma_f32 %0, %0, %1, %2")
+KERNEL(k_rndne_f32, "v_rndne_f32_e32 %0, %0")
+KERNEL(k_cvt_i32_f32, "v_cvt_i32_f32_e32 %0, %0")
+KERNEL(k_cvt_f32_i32, "v_cvt_f32_i32_e32 %0, %0")
+KERNEL(k_lshl_add, "v_lshl_add_u32 %0, %0, 2, %1")
+KERNEL(k_add_lshl, "v_add_lshl_u32 %0, %0, %1, 2")
+KERNEL(k_bfe_i, "v_bfe_i32 %0, %0, 4, 8")
+KERNEL(k_cmp, "v_cmp_gt_u32_e32 vcc, %0, %1")
+KERNEL(k_dot4, "v_dot4_u32_u8 %0, %0, %1, %2")
+KERNEL(k_mul_hi, "v_mul_hi_u32 %0, %0, %1")
 template <typename F> void run(const char* name, F f)
 {
     uint32_t* d; (void)hipMalloc(&d, 256 * 8 * 256 * 4);
@@ -77,5 +88,8 @@ int main()
     run("add_u32 sdwa", k_sdwa_add); run("sub_u32 sdwa", k_sdwa_sub);
     run("add_f32 e32", k_add_f32); run("max_f32 e32", k_max_f32); run("min_f16 e32", k_min_f16); run("pk_min_f16", k_pk_min_f16);
     run("med3_f32", k_med3_f32); run("min3_f32", k_min3_f32);
+    run("mul_f32 e32", k_mul_f32); run("fma_f32", k_fma_f32); run("rndne_f32", k_rndne_f32); run("cvt_i32_f32", k_cvt_i32_f32);
+    run("cvt_f32_i32", k_cvt_f32_i32); run("lshl_add_u32", k_lshl_add); run("add_lshl_u32", k_add_lshl); run("bfe_i32", k_bfe_i);
+    run("cmp_gt_u32 (vcc)", k_cmp); run("dot4_u32_u8", k_dot4); run("mul_hi_u32", k_mul_hi);
     return 0;
 }
