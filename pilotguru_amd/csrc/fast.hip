@@ -264,12 +264,15 @@ __device__ __forceinline__ int nms_score(const uint8_t* smap, int mapPitch, int 
 {
     const uint8_t* m = smap + (iy + 1) * mapPitch + ix + 1;
     const int s = m[0];
-    // short-circuit on purpose: most list entries are not corners (s == 0) and stop after ONE byte read; reading
-    // all nine bytes for every lane measured 0.65 ms slower per 128-frame step in the block form (LDS byte
-    // gathers, not VALU, bound that phase)
-    const bool keep = s && s > m[-1] && s > m[1] && s > m[-mapPitch - 1] && s > m[-mapPitch] &&
-                      s > m[-mapPitch + 1] && s > m[mapPitch - 1] && s > m[mapPitch] && s > m[mapPitch + 1];
-    return keep ? s : 0;
+    // Two-level short circuit: most list entries are not corners (s == 0) and stop after ONE byte read (reading all
+    // nine bytes for every lane measured 0.65 ms slower per step in the block form: the phase is bound by LDS round
+    // trips per wave, not by LDS throughput); corners read their eight neighbours at once and reduce them with
+    // three v_max3 + one v_max instead of eight compare-and-branch steps.
+    if (!s) return 0;
+    const int a = imax3(m[-mapPitch - 1], m[-mapPitch], m[-mapPitch + 1]);
+    const int b = imax3(m[mapPitch - 1], m[mapPitch], m[mapPitch + 1]);
+    const int c = imax3(m[-1], m[1], max(a, b));
+    return s > c ? s : 0;
 }
 
 // Slow path for one threshold when the candidate list would not fit in LDS (very noisy cell at
