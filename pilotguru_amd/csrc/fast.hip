@@ -59,6 +59,12 @@ __device__ __forceinline__ int imax3(int a, int b, int c)
     asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+__device__ __forceinline__ int imad24(int a, int b, int c)        // a * b + c on 24-bit operands: one instruction
+{
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 // 16-ring offsets in OpenCV's order (x, y): (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)
 // (0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
@@ -172,11 +178,14 @@ __device__ __forceinline__ int quick_pass(const uint8_t* tile, int TP, int IW, i
     if (4 * lq + 1 < IW) colMask |= 1u << 15;
     if (4 * lq + 2 < IW) colMask |= 1u << 30;
     if (4 * lq + 3 < IW) colMask |= 1u << 31;
-    uint32_t acc[2] = {0u, 0u};
+    // the darker-ring and the brighter-ring outcome are kept apart: a list entry carries the polarity that passed
+    // (bit 15), and the exact score then evaluates ONE polarity -- 40 instead of 80 three-input operations.  A pixel
+    // that passes both ways (rare) gets two entries; at most one of them can reach the threshold.
+    uint32_t accD[2] = {0u, 0u}, accB[2] = {0u, 0u};
     int step = 0;
     for (int row0 = rowBeg; row0 < rowEnd; row0 += 64 / QW, step++) {
         const int iy = row0 + lr;
-        uint32_t m = 0;
+        uint32_t md = 0, mb = 0;
         if (iy < rowEnd && lq < NQ) {
             const uint32_t* rc = reinterpret_cast<const uint32_t*>(tile + (iy + 3) * TP) + 1 + lq;
             const uint32_t* ru = reinterpret_cast<const uint32_t*>(tile + iy * TP) + 1 + lq;
@@ -217,44 +226,73 @@ __device__ __forceinline__ int quick_pass(const uint8_t* tile, int TP, int IW, i
             }
             const uint32_t darkE = (Ce + Kd) - dkE, brightE = brE + (Kd - Ce);
             const uint32_t darkO = (Co + Kd) - dkO, brightO = brO + (Kd - Co);
-            m = ((((darkE | brightE) & K15) >> 1) | ((darkO | brightO) & K15)) & colMask;
+            md = (((darkE & K15) >> 1) | (darkO & K15)) & colMask;
+            mb = (((brightE & K15) >> 1) | (brightO & K15)) & colMask;
         }
-        if (QW == 8) acc[0] |= m >> (2 * step);                 // <= 48 rows = 6 steps: one word
-        else acc[step >> 3] |= m >> (2 * (step & 7));
+        if (QW == 8) { accD[0] |= md >> (2 * step); accB[0] |= mb >> (2 * step); }      // <= 48 rows = 6 steps: one word
+        else { accD[step >> 3] |= md >> (2 * (step & 7)); accB[step >> 3] |= mb >> (2 * (step & 7)); }
     }
-    const int cnt = __popc(acc[0]) + __popc(acc[1]);
+    const int cnt = __popc(accD[0]) + __popc(accD[1]) + __popc(accB[0]) + __popc(accB[1]);
     const int incl = wave_incl_scan(cnt);
     const int nlist = __builtin_amdgcn_readlane(incl, 63);
     if (nlist > FAST_LIST_CAP) return -1;
     int off = incl - cnt;
 #pragma unroll
-    for (int wsel = 0; wsel < 2; wsel++) {
-        uint32_t bits = acc[wsel];
-        while (bits) {
-            const int bpos = __ffs((int)bits) - 1;
-            bits &= bits - 1;
-            const int st = wsel * 8 + 7 - ((bpos & 15) >> 1);
-            const int iy = rowBeg + st * (64 / QW) + lr;
-            list[off++] = (uint16_t)((iy << 8) | (4 * lq + ((bpos >> 4) << 1) + (bpos & 1)));
+    for (int pol = 0; pol < 2; pol++)
+#pragma unroll
+        for (int wsel = 0; wsel < 2; wsel++) {
+            uint32_t bits = pol ? accB[wsel] : accD[wsel];
+            while (bits) {
+                const int bpos = __ffs((int)bits) - 1;
+                bits &= bits - 1;
+                const int st = wsel * 8 + 7 - ((bpos & 15) >> 1);
+                const int iy = rowBeg + st * (64 / QW) + lr;                                      // < 128
+                list[off++] = (uint16_t)((pol << 15) | (iy << 8) | (4 * lq + ((bpos >> 4) << 1) + (bpos & 1)));
+            }
         }
-    }
     return nlist;
 }
 
-// (3) exact scores for the compacted pixels -> score map
+// (3) exact scores for the compacted pixels -> score map.  An entry names the polarity its pixel passed the necessary
+// test with; with sgn = +1 (darker ring) / -1 (brighter ring) the differences d = sgn * (v - ring) make both cases the
+// "darker" case: score = (largest 9-arc minimum of d) - 1, i.e. 16 v_mad_i32_i24 + 32 v_min3 + 8 v_max3 where both
+// polarities cost 16 + 80.  Entries whose pixel is not a corner at t are overwritten with 0xFFFF: NMS skips them
+// without touching the score map, and of a pixel's two entries (both polarities passed) at most one survives.
+#define FAST_DEAD 0xFFFFu
 __device__ __forceinline__ void score_list(const uint8_t* tile, int TP, uint8_t* smap, int mapPitch,
-                                           const uint16_t* list, int nlist, int t, int lane)
+                                           uint16_t* list, int nlist, int t, int lane)
 {
     for (int base = 0; base < nlist; base += 64) {
         const int i = base + lane;
         if (i < nlist) {
-            const int p = list[i] & 0x7FFF;
-            const int iy = p >> 8, ix = p & 0xFF;
-            const uint8_t* cp = tile + (iy + 3) * TP + 4 + ix;
+            const int e = list[i];
+            const int iy = (e >> 8) & 0x7F, ix = e & 0xFF;
+            const int nsg = (e >> 15) ? 1 : -1;                       // -sgn
+            const uint8_t* c = tile + (iy + 3) * TP + 4 + ix;
+            const int p = TP;
+            const int sv = -nsg * (int)c[0];                          // sgn * v
             int d[16];
-            ring_load(cp, TP, cp[0], d);
-            const int s = fast_score16(d);
-            if (s >= t) smap[(iy + 1) * mapPitch + ix + 1] = (uint8_t)s;   // else: not a corner at t
+            // ring offsets in OpenCV's order (see ring_load); d = sgn * v - sgn * ring
+            d[0] = imad24((int)c[3 * p], nsg, sv);        d[1] = imad24((int)c[3 * p + 1], nsg, sv);
+            d[2] = imad24((int)c[2 * p + 2], nsg, sv);    d[3] = imad24((int)c[p + 3], nsg, sv);
+            d[4] = imad24((int)c[3], nsg, sv);            d[5] = imad24((int)c[-p + 3], nsg, sv);
+            d[6] = imad24((int)c[-2 * p + 2], nsg, sv);   d[7] = imad24((int)c[-3 * p + 1], nsg, sv);
+            d[8] = imad24((int)c[-3 * p], nsg, sv);       d[9] = imad24((int)c[-3 * p - 1], nsg, sv);
+            d[10] = imad24((int)c[-2 * p - 2], nsg, sv);  d[11] = imad24((int)c[-p - 3], nsg, sv);
+            d[12] = imad24((int)c[-3], nsg, sv);          d[13] = imad24((int)c[p - 3], nsg, sv);
+            d[14] = imad24((int)c[2 * p - 2], nsg, sv);   d[15] = imad24((int)c[3 * p - 1], nsg, sv);
+            int lo3[16], lo9[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) lo3[k] = imin3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+#pragma unroll
+            for (int k = 0; k < 16; k++) lo9[k] = imin3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);
+            int best = imax3(lo9[0], lo9[1], lo9[2]);
+#pragma unroll
+            for (int k = 3; k < 15; k += 2) best = imax3(best, lo9[k], lo9[k + 1]);
+            const int s = max(best, lo9[15]) - 1;
+            const bool corner = s >= t;
+            if (corner) smap[(iy + 1) * mapPitch + ix + 1] = (uint8_t)s;
+            else list[i] = (uint16_t)FAST_DEAD;
         }
     }
 }
@@ -450,12 +488,12 @@ __global__ __launch_bounds__(64, 8) void k_fast_cells(const PgPlan P, int TPr, i
             int sc = 0, p = 0;
             if (i < nlist) {
                 p = list[i];
-                sc = nms_score(smap, mapPitch, p >> 8, p & 0xFF);
+                if (p != (int)FAST_DEAD) sc = nms_score(smap, mapPitch, (p >> 8) & 0x7F, p & 0xFF);   // (dead: not a corner at t)
             }
             const unsigned long long m = __ballot(sc != 0);
             if (sc) {
                 const int pos = total + wave_prefix(m);
-                const int iy = p >> 8, ix = p & 0xFF;
+                const int iy = (p >> 8) & 0x7F, ix = p & 0xFF;
                 if (pos < cellCap)
                     out[pos] = (uint32_t)(ix + xoff) | ((uint32_t)(iy + yoff) << 12) | ((uint32_t)sc << 24);
                 else
@@ -472,15 +510,9 @@ __global__ __launch_bounds__(64, 8) void k_fast_cells(const PgPlan P, int TPr, i
             FT_TS(3);
             return;
         }
-        __syncthreads();
-        // vKeysCell.empty() -> retry at minThFAST (:812-816); clear the score map first
-        for (int base = 0; base < nlist; base += 64) {
-            const int i = base + lane;
-            if (i < nlist) {
-                const int p = list[i];
-                smap[((p >> 8) + 1) * mapPitch + (p & 0xFF) + 1] = 0;
-            }
-        }
+        // vKeysCell.empty() -> retry at minThFAST (:812-816).  The score map keeps what this pass wrote: a FAST score does
+        // not depend on the threshold and every corner at iniThFAST is a candidate of the retry again (an "empty" cell
+        // can hold corners -- equal neighbouring maxima that strict NMS removed)
         __syncthreads();
     }
 }
