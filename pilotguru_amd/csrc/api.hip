@@ -40,7 +40,7 @@ struct pgorb_ctx {
     int planW = 0, planH = 0, planBatch = 0;
     bool planValid = false;
     // device memory
-    Arena pyr, cand, sel, nodes, counters, tables, cellCand, cellCount, cellTab, blockTab;
+    Arena pyr, cand, sel, nodes, counters, tables, cellCand, cellCount, cellTab, cellTabBal, blockTab;
     int fastBlockCX = 4, fastBlockCY = 2;     // K2 block shape in cells (pgorb_set_option "fast_block_cx" / "_cy")
     // K1 beside K2 (pgorb_set_option "pipeline_pyramid"): the pyramid chain on a high-priority side stream, K2 level by
     // level on a second one as the levels appear
@@ -375,7 +375,7 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
                     // skipped cells (:794, :803) and windows cv::FAST finds nothing in (< 7 px)
                     const bool skip = iniY >= maxBorderY - 3 || iniX >= maxBorderX - 6 || W < 7 || H < 7;
                     const uint64_t off = (uint64_t)(pyrOff[l] * B) + (uint64_t)iniY * V.pitch + (uint64_t)(iniX - 1);
-                    r[0] = (uint32_t)l | ((uint32_t)i << 4) | ((uint32_t)j << 16);
+                    r[0] = (uint32_t)l | ((uint32_t)(V.cellBase + cidx) << 4);
                     r[1] = (uint32_t)iniX | ((uint32_t)iniY << 16);
                     r[2] = (uint32_t)(skip ? 0 : W) | ((uint32_t)(skip ? 0 : H) << 8) | ((uint32_t)skip << 16) | ((uint32_t)V.cellCap << 17);
                     r[3] = (uint32_t)V.pitch;
@@ -388,6 +388,27 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
         PG_HIP(c, hipMemcpy(c->cellTab.p, ct.data(), ct.size() * 4, hipMemcpyHostToDevice));
         P.cellTab = (const uint32_t*)c->cellTab.p;
         P.pyrBase = (const uint8_t*)c->pyr.p;
+        // balanced dispatch order (fast.hip, k_fast_cells): XCD x takes cells [n_l x / 8, n_l (x + 1) / 8) of every level l
+        std::vector<std::vector<int>> lists(8);
+        for (int x = 0; x < 8; x++)
+            for (int l = 0; l < L; l++) {
+                const PgLevel& V = P.lvl[l];
+                const int n = V.nCols * V.nRows;
+                for (int k = (int)((int64_t)n * x / 8); k < (int)((int64_t)n * (x + 1) / 8); k++) lists[x].push_back(V.cellBase + k);
+            }
+        size_t per = 0;
+        for (auto& v : lists) per = std::max(per, v.size());
+        std::vector<uint32_t> cb(8 * per * 8, 0u);
+        for (int x = 0; x < 8; x++)
+            for (size_t k = 0; k < per; k++) {
+                uint32_t* r = &cb[((size_t)x * per + k) * 8];
+                if (k < lists[x].size()) memcpy(r, &ct[(size_t)lists[x][k] * 8], 32);
+                else { r[0] = 0xFFFFFFF0u; r[2] = 1u << 16; }                                // padding: the wave returns at once
+            }
+        if ((rc = ensure(c, c->cellTabBal, cb.size() * 4 + 8 * 32))) return rc;
+        PG_HIP(c, hipMemcpy(c->cellTabBal.p, cb.data(), cb.size() * 4, hipMemcpyHostToDevice));
+        P.cellTabBal = (const uint32_t*)c->cellTabBal.p;
+        P.cellsPerXcdBal = (int)per;
     }
     {
         // K2 block records (fast.hip, k_fast_blocks): blocks of blkCX x blkCY cells, row-major per level.
@@ -611,7 +632,7 @@ void pgorb_destroy(pgorb_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->prm.device);
-    Arena* all[] = {&c->blockTab, &c->cellTab, &c->cellCand, &c->cellCount, &c->pyr, &c->cand, &c->sel, &c->nodes, &c->counters, &c->tables,
+    Arena* all[] = {&c->blockTab, &c->cellTab, &c->cellTabBal, &c->cellCand, &c->cellCount, &c->pyr, &c->cand, &c->sel, &c->nodes, &c->counters, &c->tables,
                     &c->stageKps, &c->stageDesc, &c->stageN, &c->stageA, &c->stageB, &c->stageOut, &c->vocab, &c->xdesc};
     for (Arena* a : all) if (a->p) (void)hipFree(a->p);
     if (c->sPyr) {

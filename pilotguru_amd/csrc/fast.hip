@@ -456,14 +456,18 @@ extern "C" int pgorb_debug_fast_times(unsigned int* out, int nwaves)
 template <int TPC, int MPC, bool NARROW>
 __global__ __launch_bounds__(64, 8) void k_fast_cells(const PgPlan P, int TPr, int tileRows,
                                                        int MPr, int mapRows, int cellsPerXcd,
-                                                       int chunkInv, int cell0, int cellEnd)
+                                                       int chunkInv, int cell0, int cellEnd, const uint32_t* tab)
 {
     const int TP = TPC ? TPC : TPr, mapPitch = MPC ? MPC : MPr;
     const int lane = threadIdx.x;
     const int frame = blockIdx.y;
-    // cells [cell0, cellEnd) of the plan's cell table: all levels in one launch, or one level per launch when the
-    // pyramid chain runs beside K2 (api.hip, run_batch)
-    const int cell = cell0 + (blockIdx.x & 7) * cellsPerXcd + (blockIdx.x >> 3);      // XCD-contiguous
+    // Records [cell0, cellEnd) of `tab`.  The default table is in a BALANCED dispatch order (api.hip): XCD x -- the
+    // dispatcher deals consecutive workgroups to consecutive XCDs -- gets the x-th eighth of EVERY level's cells, a
+    // contiguous band per level, so neighbours still share L2 lines and every XCD sees the same mix of cheap cells
+    // (level 0: ~15 candidates) and expensive ones (upper levels: 40..170 candidates, several score rounds).  In plain
+    // cell order XCD 7 held only upper-level cells and the launch waited for it while XCDs 0-2 idled.
+    // The canonical-order table serves one level per launch when the pyramid chain runs beside K2.
+    const int cell = cell0 + (blockIdx.x & 7) * cellsPerXcd + (blockIdx.x >> 3);      // position in the table
 #ifdef PGORB_FAST_TIMING
     unsigned long long ft_t0 = wall_clock64();
     const int ft_id = frame * P.totalCells + cell;
@@ -476,7 +480,7 @@ __global__ __launch_bounds__(64, 8) void k_fast_cells(const PgPlan P, int TPr, i
     const int l0pitch = P.lvl[0].pitch;
     const int64_t l0fstride = P.lvl[0].fstride;
     const uint8_t* pyrBase = P.pyrBase;
-    const uint32_t* recp = P.cellTab + 8 * (int64_t)cell;          // (the table has 8 records of slack)
+    const uint32_t* recp = tab + 8 * (int64_t)cell;                // (the tables have 8 records of slack)
     const int totalCells = P.totalCells;
     asm volatile("" :: "s"(l0img), "s"(l0pitch), "s"(l0fstride), "s"(pyrBase), "s"(totalCells));
     typedef uint32_t pg_u32x8 __attribute__((ext_vector_type(8)));
@@ -485,10 +489,10 @@ __global__ __launch_bounds__(64, 8) void k_fast_cells(const PgPlan P, int TPr, i
     if (cell >= cellEnd) return;
     const int iniX = rec[1] & 0xFFFF, iniY = rec[1] >> 16;
     const int W = rec[2] & 0xFF, H = (rec[2] >> 8) & 0xFF, cellCap = rec[2] >> 17;
-    int32_t* cellCnt = P.cellCount + (int64_t)frame * totalCells + cell;
+    int32_t* cellCnt = P.cellCount + (int64_t)frame * totalCells + (rec[0] >> 4);     // the record names its cell
     FT_TS(0);
-    if (rec[2] & 0x10000u) {                             // skipped cell
-        if (lane == 0) *cellCnt = 0;
+    if (rec[2] & 0x10000u) {                             // skipped cell (or a padding position of the balanced table)
+        if (lane == 0 && (rec[0] >> 4) != 0x0FFFFFFFu) *cellCnt = 0;
         return;
     }
     const int IW = W - 6, IH = H - 6;
@@ -1040,15 +1044,17 @@ void pg_launch_fast_cells(const PgPlan& P, int nframes, hipStream_t s, int level
     size_t smem = (size_t)tileRows * TP + (size_t)mapRows * mapPitch + FAST_LIST_CAP * 2 + 16;
     // profiling knob: extra LDS per wave lowers occupancy (occupancy sweep)
     if (const char* e = getenv("PGORB_FAST_EXTRA_LDS")) smem += (size_t)atoi(e);
-    const int cell0 = P.lvl[levelBeg].cellBase;
-    const int cellEnd = (levelEnd < P.nlevels) ? P.lvl[levelEnd].cellBase : P.totalCells;
-    const int cellsPerXcd = (cellEnd - cell0 + 7) / 8;
+    const bool all = levelBeg == 0 && levelEnd == P.nlevels && P.cellTabBal;
+    const uint32_t* tab = all ? P.cellTabBal : P.cellTab;
+    const int cell0 = all ? 0 : P.lvl[levelBeg].cellBase;
+    const int cellEnd = all ? 8 * P.cellsPerXcdBal : (levelEnd < P.nlevels) ? P.lvl[levelEnd].cellBase : P.totalCells;
+    const int cellsPerXcd = all ? P.cellsPerXcdBal : (cellEnd - cell0 + 7) / 8;
     dim3 grid(cellsPerXcd * 8, nframes), block(64);
     const bool narrow = maxW - 6 <= 32 && maxH - 6 <= 40;      // 8 quads per row, at most 5 steps of 8 rows (quick_pass_u)
     if (common && narrow)
-        hipLaunchKernelGGL((k_fast_cells<48, 40, true>), grid, block, smem, s, P, TP, tileRows, mapPitch, mapRows, cellsPerXcd, chunkInv, cell0, cellEnd);
+        hipLaunchKernelGGL((k_fast_cells<48, 40, true>), grid, block, smem, s, P, TP, tileRows, mapPitch, mapRows, cellsPerXcd, chunkInv, cell0, cellEnd, tab);
     else if (common)
-        hipLaunchKernelGGL((k_fast_cells<48, 40, false>), grid, block, smem, s, P, TP, tileRows, mapPitch, mapRows, cellsPerXcd, chunkInv, cell0, cellEnd);
+        hipLaunchKernelGGL((k_fast_cells<48, 40, false>), grid, block, smem, s, P, TP, tileRows, mapPitch, mapRows, cellsPerXcd, chunkInv, cell0, cellEnd, tab);
     else
-        hipLaunchKernelGGL((k_fast_cells<0, 0, false>), grid, block, smem, s, P, TP, tileRows, mapPitch, mapRows, cellsPerXcd, chunkInv, cell0, cellEnd);
+        hipLaunchKernelGGL((k_fast_cells<0, 0, false>), grid, block, smem, s, P, TP, tileRows, mapPitch, mapRows, cellsPerXcd, chunkInv, cell0, cellEnd, tab);
 }

@@ -90,12 +90,16 @@ struct PgPlan {
     // [totalCells] 32-byte record per cell, built with the plan (api.hip): everything K2 needs to
     // find its window in ONE scalar load -- the wave start used to be a chain of four dependent
     // scalar round trips (kernarg -> cell table -> level -> level fields).
-    //   w0 level | cell row << 4 | cell col << 16      w1 iniX | iniY << 16
+    //   w0 level | cell index in the frame's cellCount array << 4      w1 iniX | iniY << 16
     //   w2 W | H << 8 | skip << 16 | cellCap << 17      w3 level pitch
     //   w4,w5 byte offset of (iniY, iniX - 1) in frame 0 of the level, relative to pyrBase
     //   w6 level frame stride                           w7 slot offset of the cell in the frame's slab
     // Level 0 may alias the caller's buffer: its base / pitch / frame stride come from lvl[0].
     const uint32_t* cellTab;
+    // the same records in K2's balanced dispatch order: [8 XCDs][cellsPerXcdBal], XCD x = the x-th eighth of every
+    // level's cells; unused tail positions hold a padding record (cell index 0x0FFFFFFF): the wave returns at once
+    const uint32_t* cellTabBal;
+    int32_t  cellsPerXcdBal;
     // [totalBlocks] 64-byte record per K2 block of blkCX x blkCY cells (fast.hip: k_fast_blocks), or null
     const uint32_t* blockTab;
     int32_t  totalBlocks;
