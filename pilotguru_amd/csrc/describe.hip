@@ -191,6 +191,12 @@ __device__ __forceinline__ int pg_blur_at(const uint32_t* hT, int Y, int X, cons
     return min(v, 255);
 }
 
+// wave-local "barrier": a k_describe workgroup is ONE wave, LDS operations of a wave execute in order, so the only
+// thing to enforce is that the compiler keeps LDS accesses on their side of the point.  __syncthreads() costs a full
+// s_waitcnt vmcnt(0) lgkmcnt(0) each time (K2: 4 % of the kernel).
+#define PG_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
 __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 G,
                                                   pgorb_keypoint* __restrict__ kps,
                                                   uint8_t* __restrict__ desc, int cap_per_frame,
@@ -298,7 +304,7 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
                 img[(int64_t)pg_reflect101(y0 + r, h) * Lpitch + pg_reflect101(x0 + c, w)];
         }
     }
-    __syncthreads();
+    PG_WAVE_SYNC();
     DT_TS(1);
 
     // ---- IC_Angle: integer moments over the radius-15 disc (:77-104) -------------------
@@ -345,7 +351,7 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
             Aop[rb] = *reinterpret_cast<const pg_v4i*>(raw + (16 * rb + (lane & 15)) * DW_PITCH + 16 * (lane >> 4));
             Aop[rb].x ^= (int)0x80808080; Aop[rb].y ^= (int)0x80808080; Aop[rb].z ^= (int)0x80808080; Aop[rb].w ^= (int)0x80808080;
         }
-        __syncthreads();
+        PG_WAVE_SYNC();
 #pragma unroll
         for (int rb = 0; rb < 3; rb++) {
             const int pair = 8 * rb + 2 * (lane >> 4);
@@ -360,7 +366,7 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
             }
         }
     }
-    __syncthreads();
+    PG_WAVE_SYNC();
     DT_TS(4);
     // column pass: on demand.  Only the 512 rotated tap positions of the 37x37 blurred tile are
     // ever read, so each lane blurs its own 8 taps from the row-pass sums (4 LDS dwords, 3

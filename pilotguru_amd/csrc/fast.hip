@@ -127,6 +127,11 @@ __device__ __forceinline__ int wave_prefix(unsigned long long m)
     return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
 }
 
+// wave-local "barrier": the cell form never synchronises ACROSS waves (one wave = one cell); LDS operations of one
+// wave are executed in order, so all it needs is that the compiler does not move LDS accesses across the point
+#define PG_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
 // tile layout: row r at tile + r*TP; window column c at byte 1 + c, so interior column 0
 // (window column 3) is at byte 4.
 #define FAST_LIST_CAP 768          // compacted candidates held in LDS (u16 each)
@@ -403,16 +408,16 @@ __device__ __noinline__ int fast_pass_chunked(const uint8_t* tile, int TP, uint8
                                               int mapRows, int IW, int IH, int t, uint16_t* list,
                                               uint32_t* out, int cap, int xoff, int yoff, int lane)
 {
-    __syncthreads();
+    PG_WAVE_SYNC();
     for (int i = lane; i < (mapRows * mapPitch) >> 2; i += 64) reinterpret_cast<uint32_t*>(smap)[i] = 0;
-    __syncthreads();
+    PG_WAVE_SYNC();
     const int rowsPer = (IW <= 32) ? 16 : 8;                 // <= 512 candidates per block
     for (int r = 0; r < IH; r += rowsPer) {
         const int n = (IW <= 32) ? quick_pass<8, true>(tile, TP, IW, r, min(r + rowsPer, IH), t, list, lane)
                                  : quick_pass<16, true>(tile, TP, IW, r, min(r + rowsPer, IH), t, list, lane);
-        __syncthreads();
+        PG_WAVE_SYNC();
         score_list(tile, TP, smap, mapPitch, list, n, t, lane);
-        __syncthreads();
+        PG_WAVE_SYNC();
     }
     int done = 0;
     for (int iy = 0; iy < IH; iy++)
@@ -425,9 +430,9 @@ __device__ __noinline__ int fast_pass_chunked(const uint8_t* tile, int TP, uint8
             }
             done += __popcll(m);
         }
-    __syncthreads();
+    PG_WAVE_SYNC();
     for (int i = lane; i < (mapRows * mapPitch) >> 2; i += 64) reinterpret_cast<uint32_t*>(smap)[i] = 0;
-    __syncthreads();
+    PG_WAVE_SYNC();
     return done;
 }
 
@@ -453,13 +458,16 @@ extern "C" int pgorb_debug_fast_times(unsigned int* out, int nwaves)
 // run-time values (larger cells).
 // NARROW: every cell interior of the plan is at most 32 px wide (8 quads per row): the 16-quad variant of the
 // necessary test and its per-lane set-up are compiled out (true for 1080p / 2160p / 480p: wCell <= 32).
-template <int TPC, int MPC, bool NARROW>
-__global__ __launch_bounds__(64, 8) void k_fast_cells(const PgPlan P, int TPr, int tileRows,
+// WPB waves per workgroup, each wave an independent cell (no workgroup barrier anywhere: the waves only share the
+// launch and the LDS allocation, 4 x fewer workgroups for the dispatcher).
+template <int TPC, int MPC, bool NARROW, int WPB>
+__global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgPlan P, int TPr, int tileRows,
                                                        int MPr, int mapRows, int cellsPerXcd,
-                                                       int chunkInv, int cell0, int cellEnd, const uint32_t* tab)
+                                                       int chunkInv, int cell0, int cellEnd, const uint32_t* tab, int waveLds)
 {
     const int TP = TPC ? TPC : TPr, mapPitch = MPC ? MPC : MPr;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wv = (WPB > 1) ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
     const int frame = blockIdx.y;
     // Records [cell0, cellEnd) of `tab`.  The default table is in a BALANCED dispatch order (api.hip): XCD x -- the
     // dispatcher deals consecutive workgroups to consecutive XCDs -- gets the x-th eighth of EVERY level's cells, a
@@ -467,7 +475,7 @@ __global__ __launch_bounds__(64, 8) void k_fast_cells(const PgPlan P, int TPr, i
     // (level 0: ~15 candidates) and expensive ones (upper levels: 40..170 candidates, several score rounds).  In plain
     // cell order XCD 7 held only upper-level cells and the launch waited for it while XCDs 0-2 idled.
     // The canonical-order table serves one level per launch when the pyramid chain runs beside K2.
-    const int cell = cell0 + (blockIdx.x & 7) * cellsPerXcd + (blockIdx.x >> 3);      // position in the table
+    const int cell = cell0 + (blockIdx.x & 7) * cellsPerXcd + (blockIdx.x >> 3) * WPB + wv;      // position in the table
 #ifdef PGORB_FAST_TIMING
     unsigned long long ft_t0 = wall_clock64();
     const int ft_id = frame * P.totalCells + cell;
@@ -486,7 +494,7 @@ __global__ __launch_bounds__(64, 8) void k_fast_cells(const PgPlan P, int TPr, i
     typedef uint32_t pg_u32x8 __attribute__((ext_vector_type(8)));
     pg_u32x8 rec;
     asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rec) : "s"(recp) : "memory");
-    if (cell >= cellEnd) return;
+    if (cell >= cellEnd || (int)(blockIdx.x >> 3) * WPB + wv >= cellsPerXcd) return;
     const int iniX = rec[1] & 0xFFFF, iniY = rec[1] >> 16;
     const int W = rec[2] & 0xFF, H = (rec[2] >> 8) & 0xFF, cellCap = rec[2] >> 17;
     int32_t* cellCnt = P.cellCount + (int64_t)frame * totalCells + (rec[0] >> 4);     // the record names its cell
@@ -502,7 +510,7 @@ __global__ __launch_bounds__(64, 8) void k_fast_cells(const PgPlan P, int TPr, i
     const uint8_t* win = l0 ? l0img + (int64_t)frame * l0fstride + (int64_t)iniY * l0pitch + (iniX - 1)
                             : pyrBase + (((uint64_t)rec[5] << 32) | rec[4]) + (uint64_t)frame * rec[6];
 
-    uint8_t* tile = pg_fast_smem;                                  // [tileRows][TP]
+    uint8_t* tile = pg_fast_smem + wv * waveLds;                   // [tileRows][TP], this wave's slice
     uint8_t* smap = tile + tileRows * TP;                          // [mapRows][mapPitch], 1-px zero rim
     uint16_t* list = reinterpret_cast<uint16_t*>(smap + mapRows * mapPitch);   // [FAST_LIST_CAP]
 
@@ -534,7 +542,7 @@ __global__ __launch_bounds__(64, 8) void k_fast_cells(const PgPlan P, int TPr, i
             reinterpret_cast<uint4*>(smap)[i] = make_uint4(0u, 0u, 0u, 0u);
         __builtin_amdgcn_s_waitcnt(0);                     // vmcnt(0): the DMA has landed
     }
-    __syncthreads();
+    PG_WAVE_SYNC();
     FT_TS(2);
 
     uint32_t* out = P.cellCand + (int64_t)frame * P.cellCandFrame + rec[7];
@@ -565,10 +573,10 @@ __global__ __launch_bounds__(64, 8) void k_fast_cells(const PgPlan P, int TPr, i
             }
             continue;
         }
-        __syncthreads();
+        PG_WAVE_SYNC();
         // (3) exact scores for the compacted pixels
         score_list(tile, TP, smap, mapPitch, list, nlist, t, lane);
-        __syncthreads();
+        PG_WAVE_SYNC();
         // (4) NMS (strictly greater than all 8 neighbours; outside the interior = 0); survivors go
         // straight into this cell's slots
         int total = 0;
@@ -602,7 +610,7 @@ __global__ __launch_bounds__(64, 8) void k_fast_cells(const PgPlan P, int TPr, i
         // vKeysCell.empty() -> retry at minThFAST (:812-816).  The score map keeps what this pass wrote: a FAST score does
         // not depend on the threshold and every corner at iniThFAST is a candidate of the retry again (an "empty" cell
         // can hold corners -- equal neighbouring maxima that strict NMS removed)
-        __syncthreads();
+        PG_WAVE_SYNC();
     }
 }
 
@@ -1049,12 +1057,21 @@ void pg_launch_fast_cells(const PgPlan& P, int nframes, hipStream_t s, int level
     const int cell0 = all ? 0 : P.lvl[levelBeg].cellBase;
     const int cellEnd = all ? 8 * P.cellsPerXcdBal : (levelEnd < P.nlevels) ? P.lvl[levelEnd].cellBase : P.totalCells;
     const int cellsPerXcd = all ? P.cellsPerXcdBal : (cellEnd - cell0 + 7) / 8;
-    dim3 grid(cellsPerXcd * 8, nframes), block(64);
     const bool narrow = maxW - 6 <= 32 && maxH - 6 <= 40;      // 8 quads per row, at most 5 steps of 8 rows (quick_pass_u)
-    if (common && narrow)
-        hipLaunchKernelGGL((k_fast_cells<48, 40, true>), grid, block, smem, s, P, TP, tileRows, mapPitch, mapRows, cellsPerXcd, chunkInv, cell0, cellEnd, tab);
-    else if (common)
-        hipLaunchKernelGGL((k_fast_cells<48, 40, false>), grid, block, smem, s, P, TP, tileRows, mapPitch, mapRows, cellsPerXcd, chunkInv, cell0, cellEnd, tab);
-    else
-        hipLaunchKernelGGL((k_fast_cells<0, 0, false>), grid, block, smem, s, P, TP, tileRows, mapPitch, mapRows, cellsPerXcd, chunkInv, cell0, cellEnd, tab);
+    static const int wpbEnv = getenv("PGORB_FAST_WPB") ? atoi(getenv("PGORB_FAST_WPB")) : 1;     // 4 independent waves per workgroup measured 13 % slower
+    const int wpb = (wpbEnv == 4) ? 4 : 1;
+    const int waveLds = (int)((smem + 15) & ~(size_t)15);
+    dim3 grid(((cellsPerXcd + wpb - 1) / wpb) * 8, nframes), block(64 * wpb);
+#define PG_LAUNCH_CELLS(TPC, MPC, NAR, W) hipLaunchKernelGGL((k_fast_cells<TPC, MPC, NAR, W>), grid, block, (size_t)waveLds * W, s, P, TP, \
+        tileRows, mapPitch, mapRows, cellsPerXcd, chunkInv, cell0, cellEnd, tab, waveLds)
+    if (wpb == 4) {
+        if (common && narrow) PG_LAUNCH_CELLS(48, 40, true, 4);
+        else if (common) PG_LAUNCH_CELLS(48, 40, false, 4);
+        else PG_LAUNCH_CELLS(0, 0, false, 4);
+    } else {
+        if (common && narrow) PG_LAUNCH_CELLS(48, 40, true, 1);
+        else if (common) PG_LAUNCH_CELLS(48, 40, false, 1);
+        else PG_LAUNCH_CELLS(0, 0, false, 1);
+    }
+#undef PG_LAUNCH_CELLS
 }
