@@ -174,8 +174,11 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
     if (rc) return fail(c, rc, "frame %dx%d too small: every pyramid level needs >= 62 px per side "
                                "and aspect >= 0.5", w, h);
     // the old plan dies here: a failure below (allocation, copy, limit) must not leave planValid set for
-    // arenas that were already resized or a plan that is half written
+    // arenas that were already resized or a plan that is half written.  Work still in flight on any stream
+    // (pgorb_stream_* batches, *_device calls on the caller's stream) reads the old tables and arenas: drain it
+    // before they are overwritten.
     c->planValid = false;
+    PG_HIP(c, hipDeviceSynchronize());
     PgPlan& P = c->plan;
     memset(&P, 0, sizeof(P));
     P.nlevels = L; P.iniTh = c->prm.ini_th_fast; P.minTh = c->prm.min_th_fast;

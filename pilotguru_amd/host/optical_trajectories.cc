@@ -14,6 +14,9 @@
 // and --poses_in=<poses.txt> runs the whole tail of TrackImageSequence on poses from any back end
 // (src/slam/track_image_sequence.cc:63-109: heading smoothing, PCA plane, eigenvalue gate,
 // projected directions, turn angles, trajectory-<segment_id>.json).
+// --shard=rank/world (with --device): one ride over several processes, one per GPU -- SURVEY.md section 8(e): contiguous
+// chunks of frames with a one-frame overlap, nothing exchanged; process `rank` writes frontend-<rank>.json (and its
+// --dump_features file) for the frames it owns, the same rule as pilotguru_amd/dist.py frame_chunk_for_rank.
 // No libav here: --in_video takes a .y4m (Y plane), a printf pattern of PGM files
 // (frames/%06d.pgm) or a headerless .gray file sized by Camera_width/Camera_height.
 #include <algorithm>
@@ -38,6 +41,7 @@ struct Flags {
     bool visualize = true, vertical_flip = false, horizontal_flip = false, output_per_segment_videos = false;
     long long rotation_smooth_sigma = -1;
     int device = 0, batch = 8, max_frames = -1, segment_id = 0;
+    int shard_rank = 0, shard_world = 1;          // --shard=rank/world: this process takes its chunk of the ride
 };
 
 [[noreturn]] void check_failed(const char* what)
@@ -67,6 +71,10 @@ bool parse_flags(int argc, char** argv, Flags& F)
         else if (name == "batch") F.batch = atoi(val.c_str());
         else if (name == "max_frames") F.max_frames = atoi(val.c_str());
         else if (name == "segment_id") F.segment_id = atoi(val.c_str());
+        else if (name == "shard") {
+            if (sscanf(val.c_str(), "%d/%d", &F.shard_rank, &F.shard_world) != 2 || F.shard_world < 1 || F.shard_rank < 0 ||
+                F.shard_rank >= F.shard_world) { fprintf(stderr, "ERROR: --shard wants rank/world with 0 <= rank < world\n"); return false; }
+        }
         else { fprintf(stderr, "ERROR: unknown command line flag '%s'\n", name.c_str()); return false; }
     }
     return true;
@@ -143,6 +151,29 @@ struct FrameSource {                  // ImageSequenceSource (include/io/image_s
         w = sw; h = sh;
         return w > 0 && h > 0;
     }
+    // number of frames of the sequence (pattern: probe for the first missing file)
+    long count()
+    {
+        if (pattern) {
+            long k = 0;
+            for (;; k++) { FILE* f = fopen(frame_name(k).c_str(), "rb"); if (!f) break; fclose(f); }
+            return k;
+        }
+        const long at = ftell(fp);
+        fseek(fp, 0, SEEK_END);
+        const long end = ftell(fp);
+        fseek(fp, at, SEEK_SET);
+        if (y4m) return (long)((size_t)(end - at) / (y4mFrameBytes + 6));      // "FRAME\n" + planes (frame headers without parameters)
+        return (long)((size_t)end / ((size_t)w * h));
+    }
+    // start at frame k (frame ids and timestamps stay those of the whole sequence)
+    bool skip(long k)
+    {
+        if (pattern) { frame = k; return true; }
+        std::vector<uint8_t> g; long long t, id;
+        while (frame < k) if (!next(g, &t, &id)) return false;
+        return true;
+    }
     bool next(std::vector<uint8_t>& gray, long long* time_usec, long long* frame_id)
     {
         if (pattern) {
@@ -151,7 +182,7 @@ struct FrameSource {                  // ImageSequenceSource (include/io/image_s
             char magic[3] = {0}; int maxv = 0, fw = 0, fh = 0;
             if (fscanf(f, "%2s %d %d %d", magic, &fw, &fh, &maxv) != 4 || strcmp(magic, "P5") || maxv != 255) { fclose(f); return false; }
             // every frame of a sequence has the first frame's size (the context and the buffers are sized once)
-            if (fw <= 0 || fh <= 0 || (frame > 0 && (fw != w || fh != h))) {
+            if (fw <= 0 || fh <= 0 || (w > 0 && (fw != w || fh != h))) {
                 fclose(f);
                 fprintf(stderr, "ERROR: frame %ld is %dx%d, the sequence started with %dx%d\n", frame, fw, fh, w, h);
                 return false;
@@ -277,6 +308,19 @@ int main(int argc, char** argv)
     // kernels and result download of up to DEPTH batches overlap.  The per-frame host calls (BoW transform, initial
     // matcher) use a second, small context: the streaming context must not run other calls while batches are in flight.
     const int B = std::max(1, F.batch), DEPTH = 3;
+    // --shard: frames [firstExtracted, stop) are read, frames from firstOwned on are reported (the frame before
+    // firstOwned is extracted only as the predecessor of the first owned match)
+    long firstOwned = 0;
+    if (F.shard_world > 1) {
+        long nframes = src.count();
+        if (F.max_frames >= 0) nframes = std::min<long>(nframes, F.max_frames);
+        const long per = nframes / F.shard_world, extra = nframes % F.shard_world;
+        const long first = F.shard_rank * per + std::min<long>(F.shard_rank, extra), stop = first + per + (F.shard_rank < extra ? 1 : 0);
+        const long firstExtracted = stop > first ? std::max<long>(first - 1, 0) : first;
+        firstOwned = first;
+        if (!src.skip(firstExtracted)) check_failed("input video holds the frames of this shard");
+        F.max_frames = (int)(stop - firstExtracted);
+    }
     std::vector<uint8_t> frame0;                              // the first frame tells the size
     long long t0 = 0, id0 = 0;
     if (!((F.max_frames < 0 || F.max_frames > 0) && src.next(frame0, &t0, &id0))) frame0.clear();
@@ -333,6 +377,7 @@ int main(int argc, char** argv)
             cur.mvKeysUndistorted.assign(kps + (size_t)i * cap, kps + (size_t)i * cap + n[i]);
             cur.mDescriptors.assign(desc + (size_t)i * cap * 32, desc + ((size_t)i * cap + n[i]) * 32);
             cur.mnMaxX = (float)src.w; cur.mnMaxY = (float)src.h;
+            if (ids[i] < firstOwned) { prev = cur; havePrev = true; continue; }      // the overlap frame of a shard: only a predecessor
             // Frame::ComputeBoW: transform(descriptors, BowVec, FeatVec, 4)  (Frame.cc:399-406)
             std::vector<uint32_t> word(n[i]), node(n[i]), bid(n[i] + 1), fnode(n[i] + 1), ffeat(n[i] + 1);
             std::vector<double> wt(n[i]), bval(n[i] + 1); std::vector<int32_t> fstart(n[i] + 2);
@@ -368,7 +413,7 @@ int main(int argc, char** argv)
        << ", \"minThFAST\": " << minTh << "},\n  \"vocabulary\": {\"k\": " << vk << ", \"L\": " << vL << ", \"nodes\": " << vn << ", \"words\": " << vw
        << "}\n}";
     if (dump) fclose(dump);
-    const std::string out = (F.out_dir.empty() ? std::string(".") : F.out_dir) + "/frontend-0.json";
+    const std::string out = (F.out_dir.empty() ? std::string(".") : F.out_dir) + "/frontend-" + std::to_string(F.shard_world > 1 ? F.shard_rank : 0) + ".json";
     std::ofstream o(out);
     if (!o.good()) check_failed("out_dir is writable");
     o << js.str() << std::endl;

@@ -204,3 +204,57 @@ def test_cli_config1_ride_against_the_oracle(tmp_path, oracle):
         if i:
             dt = (out["frames"][i]["time_usec"] - out["frames"][i - 1]["time_usec"]) * 1e-6
             assert p["angular_velocity"] == r15(turn[i] / (dt + 1e-10))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["gray", "pgm", "y4m"])
+def test_cli_shard_reproduces_the_unsharded_ride(tmp_path, kind):
+    """--shard=rank/world (single ride over several GPUs from C++, one process per GPU): contiguous
+    chunks with a one-frame overlap, nothing exchanged.  The shards' frontend-<rank>.json entries and --dump_features
+    records, concatenated in rank order, equal the unsharded run -- including n_matches_prev of the first frame of every
+    chunk (its predecessor lives in the previous chunk and is extracted twice) and the whole-ride frame ids / time stamps
+    (src/slam/track_image_sequence.cc:43-52)."""
+    from pilotguru_amd import vocab as V
+    from pilotguru_amd.synth import synth_ride
+    w, h, nfr, world = 320, 240, 11, 3
+    ride = synth_ride(17, w, h, nfr, dx=3, dy=1)
+    d = str(tmp_path)
+    if kind == "gray":
+        video = os.path.join(d, "clip.gray")
+        ride.tofile(video)
+    elif kind == "pgm":
+        video = os.path.join(d, "f%04d.pgm")
+        for i in range(nfr):
+            with open(video % i, "wb") as f:
+                f.write(b"P5\n%d %d\n255\n" % (w, h) + ride[i].tobytes())
+    else:
+        video = os.path.join(d, "clip.y4m")
+        with open(video, "wb") as f:
+            f.write(b"YUV4MPEG2 W%d H%d F30:1 Ip A1:1 Cmono\n" % (w, h))
+            for i in range(nfr):
+                f.write(b"FRAME\n" + ride[i].tobytes())
+    with open(os.path.join(d, "cam.yml"), "w") as f:
+        f.write("%%YAML:1.0\n---\nCamera_width: %d\nCamera_height: %d\nCamera_fps: 30.\nORBextractor_nFeatures: 500\n" % (w, h))
+    desc, weight, parent = V.synth_vocabulary(5, 3, seed=9)
+    V.write_vocabulary_text(os.path.join(d, "voc.txt"), 5, 3, desc, weight, parent)
+    common = ["--vocabulary_file=" + os.path.join(d, "voc.txt"), "--camera_settings=" + os.path.join(d, "cam.yml"),
+              "--in_video=" + video, "--novisualize", "--batch=4"]
+    whole = os.path.join(d, "whole"); os.mkdir(whole)
+    r = _cli(*common, "--out_dir=" + whole, "--dump_features=" + os.path.join(whole, "feat.bin"))
+    assert r.returncode == 0, r.stderr
+    want = json.load(open(os.path.join(whole, "frontend-0.json")))["frames"]
+    assert [fr["frame_id"] for fr in want] == list(range(nfr))
+    got, dump = [], b""
+    for rank in range(world):
+        od = os.path.join(d, "s%d" % rank); os.mkdir(od)
+        r = _cli(*common, "--out_dir=" + od, "--shard=%d/%d" % (rank, world), "--dump_features=" + os.path.join(od, "feat.bin"))
+        assert r.returncode == 0, r.stderr
+        got += json.load(open(os.path.join(od, "frontend-%d.json" % rank)))["frames"]
+        dump += open(os.path.join(od, "feat.bin"), "rb").read()
+    assert got == want
+    assert dump == open(os.path.join(whole, "feat.bin"), "rb").read()
+    # more shards than frames: the surplus ranks own nothing and say so
+    od = os.path.join(d, "empty"); os.mkdir(od)
+    r = _cli(*common, "--out_dir=" + od, "--shard=12/13")
+    assert r.returncode == 0 and json.load(open(os.path.join(od, "frontend-12.json")))["frames"] == []
+    assert _cli(*common, "--out_dir=" + od, "--shard=3/3").returncode != 0
