@@ -414,6 +414,21 @@ int      pgorb_stream_reset(pgorb_stream* s);                    /* the next bat
 int      pgorb_stream_submit(pgorb_stream* s, int slot, int nframes);
 int      pgorb_stream_wait(pgorb_stream* s, int slot, const int32_t** n, const pgorb_keypoint** kps, const uint8_t** desc,
                            const int32_t** best_idx, const uint16_t** best, const uint16_t** second, int* cap);
+/* Optional front-end stage of the stream: what the reference's tracking thread does with every fresh Frame, run on
+ * the device for the whole batch behind K7 -- Frame::AssignFeaturesToGrid with the given image bounds
+ * (src/Frame.cc:234-249), ORBmatcher(nnratio, check_orientation).SearchForInitialization(previous frame, frame,
+ * vbPrevMatched = the previous frame's keypoint positions, matches, window_size) as MonocularInitialization calls it
+ * (Tracking.cc:583-597; frame 0 of a batch against the last frame of the previous one) and, when bow_levelsup >= 0
+ * and a vocabulary is resident in the context, Frame::ComputeBoW's ORBVocabulary::transform (Frame.cc:399-406; per
+ * feature word / weight / node, pgorb_bow_vectors turns them into BowVector / FeatureVector on the host).
+ * Call with no batch in flight; the next batch starts a new ride.  After pgorb_stream_wait(slot):
+ * pgorb_stream_frontend_results -> matches12[f * cap + i1] (-1 = none) and nmatches[f] for the pair (frame f - 1,
+ * frame f) -- the first frame of a ride has no predecessor and reports 0 matches --, word / weight / node
+ * [f * cap + i] (nullptr without BoW); valid until the slot is submitted again. */
+int      pgorb_stream_frontend(pgorb_stream* s, float min_x, float max_x, float min_y, float max_y, int window_size,
+                               float nnratio, int check_orientation, int bow_levelsup);
+int      pgorb_stream_frontend_results(pgorb_stream* s, int slot, const int32_t** matches12, const int32_t** nmatches,
+                                       const uint32_t** word, const double** weight, const uint32_t** node);
 
 /* Measurement switches (no counterpart in the reference; results never depend on them -- the parity suite
  * runs under each).  key "matcher": 0 = the default (fp4 block-scaled MFMA for < 8192 descriptors per

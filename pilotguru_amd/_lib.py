@@ -30,7 +30,7 @@ SYMBOLS = (
     "pgorb_search_by_projection_points", "pgorb_search_by_projection_frame", "pgorb_search_by_bow",
     "pgorb_undistort_keypoints", "pgorb_undistort_keypoints_batch_device", "pgorb_image_bounds",
     "pgorb_host_alloc", "pgorb_host_free", "pgorb_stream_create", "pgorb_stream_destroy", "pgorb_stream_input", "pgorb_stream_reset", "pgorb_stream_submit",
-    "pgorb_stream_wait", "pgorb_set_option", "pgorb_get_option", "pgorb_matcher_is_popcount",
+    "pgorb_stream_wait", "pgorb_stream_frontend", "pgorb_stream_frontend_results", "pgorb_set_option", "pgorb_get_option", "pgorb_matcher_is_popcount",
     "pgorb_smooth_heading_directions", "pgorb_smooth_time_series", "pgorb_trajectory_pca",
     "pgorb_project_directions", "pgorb_project_translations", "pgorb_turn_angles",
     "pgorb_principal_rotation_axes", "pgorb_angular_velocities_around_axis",
@@ -107,6 +107,8 @@ def lib():
     L.pgorb_stream_reset.argtypes = [vp]
     L.pgorb_stream_submit.argtypes = [vp, C.c_int, C.c_int]
     L.pgorb_stream_wait.argtypes = [vp, C.c_int] + [C.POINTER(vp)] * 6 + [i32p]
+    L.pgorb_stream_frontend.argtypes = [vp] + [C.c_float] * 4 + [C.c_int, C.c_float, C.c_int, C.c_int]
+    L.pgorb_stream_frontend_results.argtypes = [vp, C.c_int] + [C.POINTER(vp)] * 5
     L.pgorb_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     L.pgorb_get_option.argtypes = [vp, C.c_char_p]
     L.pgorb_matcher_is_popcount.argtypes = [vp, C.c_int]

@@ -1044,9 +1044,30 @@ struct pgorb_stream {
     // best_idx[B][cap] | best[B][cap] | second[B][cap]
     size_t offN = 0, offK = 0, offD = 0, offI = 0, offB1 = 0, offB2 = 0, outBytes = 0;
     int32_t *dPq = nullptr, *dPt = nullptr;                // pairs (f, f-1), f = 1..B, in desc[] indexing
-    uint8_t* dPrevDesc = nullptr; int32_t* dPrevN = nullptr;
+    uint8_t* dPrevDesc = nullptr; int32_t* dPrevN = nullptr; pgorb_keypoint* dPrevKps = nullptr;
     bool havePrev = false;
+    // optional front-end stage (pgorb_stream_frontend): + matches12[B][cap] | nmatches[B] | word[B][cap] | weight[B][cap] | node[B][cap]
+    bool fe = false; int feWindow = 100, feCheckOri = 1, feLevelsUp = -1; float feRatio = 0.9f, feBounds[4] = {0, 0, 0, 0};
+    size_t offM12 = 0, offNM = 0, offW = 0, offWt = 0, offNd = 0;
+    int32_t *dGridStart = nullptr, *dGridIdx = nullptr; float* dPrevMatched = nullptr;     // device scratch, [B+1] frames
 };
+
+// result-block layout for the stream's current settings (kps and desc hold B+1 frames: index 0 = the previous batch's last frame)
+static void stream_layout(pgorb_stream* s)
+{
+    const size_t cap = (size_t)s->cap, B = (size_t)s->B;
+    auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+    s->offN = 0; s->offK = al((B + 1) * 4); s->offD = s->offK + al((B + 1) * cap * sizeof(pgorb_keypoint));
+    s->offI = s->offD + al((B + 1) * cap * 32); s->offB1 = s->offI + al(B * cap * 4);
+    s->offB2 = s->offB1 + al(B * cap * 2); s->outBytes = s->offB2 + al(B * cap * 2);
+    if (s->fe) {
+        s->offM12 = s->outBytes; s->offNM = s->offM12 + al(B * cap * 4); s->outBytes = s->offNM + al(B * 4);
+        if (s->feLevelsUp >= 0) {
+            s->offWt = s->outBytes; s->offW = s->offWt + al(B * cap * 8); s->offNd = s->offW + al(B * cap * 4);
+            s->outBytes = s->offNd + al(B * cap * 4);
+        }
+    }                                                        // (+ the status word behind it)
+}
 
 extern "C" {
 
@@ -1062,10 +1083,7 @@ int pgorb_stream_create(pgorb_ctx* c, int w, int h, int batch, int depth, pgorb_
     pgorb_stream* s = new pgorb_stream();
     s->c = c; s->w = w; s->h = h; s->B = batch; s->depth = depth; s->cap = c->plan.selTotal;
     const size_t cap = (size_t)s->cap, B = (size_t)batch;
-    auto al = [](size_t v) { return (v + 255) / 256 * 256; };
-    s->offN = 0; s->offK = al((B + 1) * 4); s->offD = s->offK + al(B * cap * sizeof(pgorb_keypoint));
-    s->offI = s->offD + al((B + 1) * cap * 32); s->offB1 = s->offI + al(B * cap * 4);
-    s->offB2 = s->offB1 + al(B * cap * 2); s->outBytes = s->offB2 + al(B * cap * 2);      // (+ the status word behind it)
+    stream_layout(s);
     bool ok = hipStreamCreateWithFlags(&s->sIn, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&s->sRun, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&s->sOut, hipStreamNonBlocking) == hipSuccess;
@@ -1083,6 +1101,7 @@ int pgorb_stream_create(pgorb_ctx* c, int w, int h, int batch, int depth, pgorb_
     for (int f = 0; f < batch; f++) { pq[f] = f + 1; pt[f] = f; }
     ok = ok && hipMalloc((void**)&s->dPq, B * 4) == hipSuccess && hipMalloc((void**)&s->dPt, B * 4) == hipSuccess;
     ok = ok && hipMalloc((void**)&s->dPrevDesc, cap * 32) == hipSuccess && hipMalloc((void**)&s->dPrevN, 4) == hipSuccess;
+    ok = ok && hipMalloc((void**)&s->dPrevKps, cap * sizeof(pgorb_keypoint)) == hipSuccess;
     ok = ok && hipMemcpy(s->dPq, pq.data(), B * 4, hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemcpy(s->dPt, pt.data(), B * 4, hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && ensure(c, c->xdesc, pg_match_scratch_bytes(s->cap, batch) + 16) == 0;
@@ -1111,6 +1130,10 @@ void pgorb_stream_destroy(pgorb_stream* s)
     if (s->dPt) (void)hipFree(s->dPt);
     if (s->dPrevDesc) (void)hipFree(s->dPrevDesc);
     if (s->dPrevN) (void)hipFree(s->dPrevN);
+    if (s->dPrevKps) (void)hipFree(s->dPrevKps);
+    if (s->dGridStart) (void)hipFree(s->dGridStart);
+    if (s->dGridIdx) (void)hipFree(s->dGridIdx);
+    if (s->dPrevMatched) (void)hipFree(s->dPrevMatched);
     if (s->sIn) (void)hipStreamDestroy(s->sIn);
     if (s->sRun) (void)hipStreamDestroy(s->sRun);
     if (s->sOut) (void)hipStreamDestroy(s->sOut);
@@ -1153,13 +1176,30 @@ int pgorb_stream_submit(pgorb_stream* s, int slot, int nframes)
     if (s->havePrev) {
         PG_HIP(c, hipMemcpyAsync(dD, s->dPrevDesc, cap * 32, hipMemcpyDeviceToDevice, s->sRun));
         PG_HIP(c, hipMemcpyAsync(dN, s->dPrevN, 4, hipMemcpyDeviceToDevice, s->sRun));
+        if (s->fe) PG_HIP(c, hipMemcpyAsync(dK, s->dPrevKps, cap * sizeof(pgorb_keypoint), hipMemcpyDeviceToDevice, s->sRun));
     } else {
         PG_HIP(c, hipMemsetAsync(dN, 0, 4, s->sRun));
     }
-    rc = run_batch(c, sl.dIn, false, nframes, s->w, s->h, s->w, (int64_t)fbytes, dK, dD + cap * 32, s->cap, dN + 1, s->sRun);
+    rc = run_batch(c, sl.dIn, false, nframes, s->w, s->h, s->w, (int64_t)fbytes, dK + cap, dD + cap * 32, s->cap, dN + 1, s->sRun);
     if (rc) return rc;
     pg_launch_match_batch(dD, dN, s->cap, s->dPq, s->dPt, nframes, (uint8_t*)c->xdesc.p, (int32_t*)(sl.dOut + s->offI),
                           (uint16_t*)(sl.dOut + s->offB1), (uint16_t*)(sl.dOut + s->offB2), s->sRun);
+    if (s->fe) {
+        // what the tracking thread does with a fresh Frame, for the whole batch: the 64x48 grid of every frame
+        // (Frame.cc:234-249), SearchForInitialization(previous, current) with vbPrevMatched = the previous frame's
+        // keypoints (Tracking.cc:583-597), ORBVocabulary::transform of every descriptor (Frame.cc:399-406)
+        const float* b = s->feBounds;
+        if ((rc = pgorb_frame_grid_batch_device(c, dK + cap, dN + 1, nframes, s->cap, b[0], b[1], b[2], b[3],
+                                                s->dGridStart + (PGORB_GRID_CELLS + 1), s->dGridIdx + cap, s->sRun))) return rc;
+        pg_launch_prev_matched_init(dK, (int64_t)nframes * cap, s->dPrevMatched, s->sRun);
+        if ((rc = pgorb_search_for_initialization_batch_device(c, dK, dD, dN, s->cap, s->dGridStart, s->dGridIdx, s->dPt, s->dPq, nframes,
+                                                               b[0], b[1], b[2], b[3], s->dPrevMatched, (int32_t*)(sl.dOut + s->offM12),
+                                                               (int32_t*)(sl.dOut + s->offNM), s->feWindow, s->feRatio, s->feCheckOri, s->sRun))) return rc;
+        if (s->feLevelsUp >= 0 &&
+            (rc = pgorb_bow_transform_device(c, dD + cap * 32, nframes * s->cap, s->feLevelsUp, (uint32_t*)(sl.dOut + s->offW),
+                                             (double*)(sl.dOut + s->offWt), (uint32_t*)(sl.dOut + s->offNd), s->sRun))) return rc;
+        PG_HIP(c, hipMemcpyAsync(s->dPrevKps, dK + (size_t)nframes * cap, cap * sizeof(pgorb_keypoint), hipMemcpyDeviceToDevice, s->sRun));
+    }
     PG_HIP(c, hipMemcpyAsync(s->dPrevDesc, dD + (size_t)nframes * cap * 32, cap * 32, hipMemcpyDeviceToDevice, s->sRun));
     PG_HIP(c, hipMemcpyAsync(s->dPrevN, dN + nframes, 4, hipMemcpyDeviceToDevice, s->sRun));
     // the batch's device status word travels inside the result block (the next batch resets the word)
@@ -1188,13 +1228,67 @@ int pgorb_stream_wait(pgorb_stream* s, int slot, const int32_t** n, const pgorb_
     const int32_t st = *(const int32_t*)(sl.hOut + s->outBytes);      // the batch's device status word
     if (st) return fail(c, st, "device reported status %d", st);
     if (n) *n = (const int32_t*)(sl.hOut + s->offN) + 1;
-    if (kps) *kps = (const pgorb_keypoint*)(sl.hOut + s->offK);
+    if (kps) *kps = (const pgorb_keypoint*)(sl.hOut + s->offK) + s->cap;
     if (desc) *desc = sl.hOut + s->offD + (size_t)s->cap * 32;
     if (best_idx) *best_idx = (const int32_t*)(sl.hOut + s->offI);
     if (best) *best = (const uint16_t*)(sl.hOut + s->offB1);
     if (second) *second = (const uint16_t*)(sl.hOut + s->offB2);
     if (cap) *cap = s->cap;
     return sl.frames;
+}
+
+int pgorb_stream_frontend(pgorb_stream* s, float min_x, float max_x, float min_y, float max_y, int window_size, float nnratio,
+                          int check_orientation, int bow_levelsup)
+{
+    if (!s) return PGORB_E_ARG;
+    pgorb_ctx* c = s->c;
+    if (!(max_x > min_x) || !(max_y > min_y) || window_size < 0) return fail(c, PGORB_E_ARG, "pgorb_stream_frontend: bounds / window");
+    for (auto& sl : s->slot) if (sl.busy) return fail(c, PGORB_E_ARG, "pgorb_stream_frontend: a batch is in flight");
+    if (s->cap > 16000) return fail(c, PGORB_E_LIMIT, "more than 16000 keypoints per frame");
+    if (bow_levelsup >= 0) {
+        const uint8_t* blob; int k, L, nn;
+        int rc = pg_ctx_vocab_get(c, &blob, &k, &L, &nn);     // "no vocabulary resident" is reported here, not at the first submit
+        if (rc) return rc;
+    }
+    PG_HIP(c, hipSetDevice(c->prm.device));
+    PG_HIP(c, hipDeviceSynchronize());
+    s->fe = true; s->feWindow = window_size; s->feRatio = nnratio; s->feCheckOri = check_orientation ? 1 : 0; s->feLevelsUp = bow_levelsup;
+    s->feBounds[0] = min_x; s->feBounds[1] = max_x; s->feBounds[2] = min_y; s->feBounds[3] = max_y;
+    stream_layout(s);
+    const size_t cap = (size_t)s->cap, B = (size_t)s->B;
+    bool ok = true;
+    for (auto& sl : s->slot) {
+        if (sl.dOut) (void)hipFree(sl.dOut);
+        if (sl.hOut) (void)hipHostFree(sl.hOut);
+        sl.dOut = nullptr; sl.hOut = nullptr;
+        ok = ok && hipMalloc((void**)&sl.dOut, s->outBytes + 256) == hipSuccess;
+        ok = ok && hipHostMalloc((void**)&sl.hOut, s->outBytes + 256, hipHostMallocDefault) == hipSuccess;
+    }
+    if (!s->dGridStart) {
+        ok = ok && hipMalloc((void**)&s->dGridStart, (B + 1) * (PGORB_GRID_CELLS + 1) * 4) == hipSuccess;
+        ok = ok && hipMalloc((void**)&s->dGridIdx, (B + 1) * cap * 4) == hipSuccess;
+        ok = ok && hipMalloc((void**)&s->dPrevMatched, B * cap * 8) == hipSuccess;
+    }
+    if (!ok) return fail(c, PGORB_E_HIP, "pgorb_stream_frontend: allocation failed");
+    s->havePrev = false;
+    return 0;
+}
+
+int pgorb_stream_frontend_results(pgorb_stream* s, int slot, const int32_t** matches12, const int32_t** nmatches,
+                                  const uint32_t** word, const double** weight, const uint32_t** node)
+{
+    if (!s || slot < 0 || slot >= s->depth) return PGORB_E_ARG;
+    pgorb_ctx* c = s->c;
+    pgorb_stream::Slot& sl = s->slot[slot];
+    if (!s->fe) return fail(c, PGORB_E_ARG, "pgorb_stream_frontend_results: the front-end stage is not enabled");
+    if (sl.busy) return fail(c, PGORB_E_ARG, "pgorb_stream_frontend_results: collect slot %d with pgorb_stream_wait first", slot);
+    if (matches12) *matches12 = (const int32_t*)(sl.hOut + s->offM12);
+    if (nmatches) *nmatches = (const int32_t*)(sl.hOut + s->offNM);
+    const bool bow = s->feLevelsUp >= 0;
+    if (word) *word = bow ? (const uint32_t*)(sl.hOut + s->offW) : nullptr;
+    if (weight) *weight = bow ? (const double*)(sl.hOut + s->offWt) : nullptr;
+    if (node) *node = bow ? (const uint32_t*)(sl.hOut + s->offNd) : nullptr;
+    return 0;
 }
 
 }  // extern "C"

@@ -104,6 +104,17 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
     return v;
 }
 
+// vbPrevMatched of MonocularInitialization: the reference frame's keypoint positions (Tracking.cc:583-585)
+__global__ __launch_bounds__(256) void k_prev_matched_init(const pgorb_keypoint* __restrict__ kps, int64_t rows, float2* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < rows) out[i] = make_float2(kps[i].x, kps[i].y);
+}
+void pg_launch_prev_matched_init(const pgorb_keypoint* d_kps, int64_t rows, float* d_out, hipStream_t s)
+{
+    if (rows > 0) hipLaunchKernelGGL(k_prev_matched_init, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, d_kps, rows, reinterpret_cast<float2*>(d_out));
+}
+
 extern __shared__ __attribute__((aligned(16))) uint8_t pg_sfi_smem[];
 
 __global__ __launch_bounds__(64) void k_search_for_initialization(

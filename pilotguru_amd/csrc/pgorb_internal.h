@@ -128,6 +128,7 @@ void pg_launch_describe(const PgPlan& P, int nframes, pgorb_keypoint* d_kps, uin
                         int cap_per_frame, int32_t* d_n, hipStream_t s);
 void pg_launch_hamming_matrix(const uint8_t* d_a, int na, const uint8_t* d_b, int nb,
                               uint16_t* d_out, hipStream_t s);
+void pg_launch_prev_matched_init(const pgorb_keypoint* d_kps, int64_t rows, float* d_out, hipStream_t s);   // frame.hip
 size_t pg_match_scratch_bytes(int nb_max, int npairs);
 void pg_launch_match_batch(const uint8_t* d_desc, const int32_t* d_n, int cap_per_frame,
                            const int32_t* d_pq, const int32_t* d_pt, int npairs, uint8_t* d_scratch,

@@ -426,6 +426,26 @@ class FrameStream:
     def reset(self):
         self.ext._check(self._L.pgorb_stream_reset(self._s))
 
+    def frontend(self, bounds, window_size=100, nnratio=0.9, check_orientation=True, bow_levelsup=-1):
+        """Enable the per-frame front-end stage: grid, SearchForInitialization(previous, current) and -- with
+        bow_levelsup >= 0 and a vocabulary uploaded to the extractor -- the BoW transform, on the device per batch."""
+        self.ext._check(self._L.pgorb_stream_frontend(self._s, *[float(b) for b in bounds], int(window_size), float(nnratio),
+                                                      int(bool(check_orientation)), int(bow_levelsup)))
+        self._fe_bow = bow_levelsup >= 0
+
+    def frontend_results(self, slot, nframes, cap):
+        """(matches12[frames, cap], nmatches[frames], word, weight, node [frames, cap] or None) of a collected slot."""
+        ptr = [C.c_void_p() for _ in range(5)]
+        self.ext._check(self._L.pgorb_stream_frontend_results(self._s, slot, *[C.byref(p) for p in ptr]))
+
+        def view(p, dtype, shape):
+            if not p.value:
+                return None
+            nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+            return np.frombuffer((C.c_uint8 * nbytes).from_address(p.value), dtype).reshape(shape)
+        return (view(ptr[0], np.int32, (nframes, cap)), view(ptr[1], np.int32, (nframes,)), view(ptr[2], np.uint32, (nframes, cap)),
+                view(ptr[3], np.float64, (nframes, cap)), view(ptr[4], np.uint32, (nframes, cap)))
+
     def submit(self, slot, nframes=None):
         self.ext._check(self._L.pgorb_stream_submit(self._s, slot, self.batch if nframes is None else int(nframes)))
 

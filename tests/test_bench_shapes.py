@@ -180,3 +180,66 @@ def test_streamed_ingest_bit_exact(w, h, nf, total, batch, depth):
                 obi, ob1, ob2 = omatch[f - 1]
                 assert bi[k, :n[k]].tobytes() == obi and b1[k, :n[k]].tobytes() == ob1 and b2[k, :n[k]].tobytes() == ob2, \
                     "match of frame %d vs %d" % (f, f - 1)
+
+
+@pytest.mark.parametrize("w,h,nf,total,batch,depth,bow", [(640, 480, 1000, 11, 4, 3, True), (1280, 720, 1500, 7, 3, 2, False)])
+def test_streamed_front_end_stage_against_the_oracle(w, h, nf, total, batch, depth, bow, tmp_path):
+    """pgorb_stream_frontend: what the tracking thread does with every fresh Frame, on the device per batch -- the
+    SearchForInitialization of (previous frame, frame) as MonocularInitialization calls it (Tracking.cc:583-597,
+    ORBmatcher.cc:407-522) ACROSS batch borders, and ORBVocabulary::transform of every descriptor (Frame.cc:399-406) --
+    against the oracle, frame by frame."""
+    import pilotguru_amd as pg
+    from pilotguru_amd import vocab as V
+    from oracle import orb_oracle
+    from _oracle_pool import oracle_ride
+    ride = synth_ride(5, w, h, total, dx=3, dy=1)
+    oext, _ = oracle_ride(list(ride), (nf, 1.2, 8, 20, 7), match=False)
+    ext = pg.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=batch)
+    voc = None
+    if bow:
+        desc, weight, parent = V.synth_vocabulary(6, 4, seed=2)
+        path = os.path.join(str(tmp_path), "voc.txt")
+        V.write_vocabulary_text(path, 6, 4, desc, weight, parent)
+        V.ORBVocabulary(text_file=path).upload(ext)
+        voc = orb_oracle.VocabOracle(path)
+    st = pg.FrameStream(ext, w, h, batch, depth)
+    bounds = (0.0, float(w), 0.0, float(h))
+    st.frontend(bounds, 100, 0.9, True, 4 if bow else -1)
+    chunks = [(b0, min(batch, total - b0)) for b0 in range(0, total, batch)]
+    res, inflight = {}, []
+
+    def collect(j, s0):
+        out = [np.array(a) for a in st.wait(s0)]
+        nb, cap = out[1].shape
+        res[j] = out + [None if a is None else np.array(a) for a in st.frontend_results(s0, nb, cap)]
+    for i, (b0, nb) in enumerate(chunks):
+        slot = i % depth
+        if len(inflight) == depth:
+            collect(*inflight.pop(0))
+        st.input(slot)[:nb] = ride[b0:b0 + nb]
+        st.submit(slot, nb)
+        inflight.append((i, slot))
+    for j, s0 in inflight:
+        collect(j, s0)
+    st.close()
+    prev = None
+    for i, (b0, nb) in enumerate(chunks):
+        n, kps, desc, _, _, _, m12, nm, word, wt, node = res[i]
+        for k in range(nb):
+            f = b0 + k
+            okp, odesc = oext[f]
+            assert kps[k, :n[k]].tobytes() == okp and desc[k, :n[k]].tobytes() == odesc, "frame %d" % f
+            kp = np.frombuffer(okp, orb_oracle.KEYPOINT_DTYPE)
+            de = np.frombuffer(odesc, np.uint8).reshape(-1, 32)
+            if prev is None:
+                assert nm[k] == 0
+            else:
+                pk, pd = prev
+                onm, om12, _ = orb_oracle.search_for_initialization(pk, pd, kp, de, bounds, np.stack([pk["x"], pk["y"]], 1).astype(np.float32),
+                                                                    100, 0.9, True)
+                assert nm[k] == onm and onm > 30, "SearchForInitialization count of frame %d" % f
+                assert np.array_equal(m12[k, :len(pk)], om12), "vnMatches12 of frame %d" % f
+            if bow:
+                ow, owt, on = voc.transform_features(de, 4)
+                assert np.array_equal(word[k, :n[k]], ow) and np.array_equal(wt[k, :n[k]], owt) and np.array_equal(node[k, :n[k]], on)
+            prev = (kp, de)

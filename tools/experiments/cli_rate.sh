@@ -1,0 +1,25 @@
+#!/bin/bash
+# Throughput of the drop-in CLI (front-end mode) on a 1080p ride held in /dev/shm: frames/s end to end.
+set -e
+D=/dev/shm/pgcli; rm -rf $D; mkdir -p $D
+N=${1:-256}
+python - <<PY
+import sys; sys.path.insert(0, '.')
+from pilotguru_amd.synth import synth_ride
+from pilotguru_amd import vocab as V
+r = synth_ride(0, 1920, 1080, 32)
+import numpy as np
+with open('$D/clip.gray', 'wb') as f:
+    for k in range($N // 32): r.tofile(f)
+open('$D/cam.yml', 'w').write("%YAML:1.0\n---\nCamera_width: 1920\nCamera_height: 1080\nCamera_fps: 30.\nORBextractor_nFeatures: 2000\n")
+d, w, p = V.synth_vocabulary(10, 4, seed=5)
+V.write_vocabulary_text('$D/voc.txt', 10, 4, d, w, p)
+PY
+for b in 8 32; do
+  t0=$(date +%s.%N)
+  pilotguru_amd/host/optical_trajectories --vocabulary_file=$D/voc.txt --camera_settings=$D/cam.yml \
+    --in_video=$D/clip.gray --out_dir=$D --novisualize --batch=$b 2>&1 | tail -1
+  t1=$(date +%s.%N)
+  python -c "print('batch $b: %.2f s wall, %.0f frames/s (incl. process start, vocabulary load, context creation)' % ($t1 - $t0, $N / ($t1 - $t0)))"
+done
+rm -rf $D

@@ -1,0 +1,106 @@
+"""Device time of the kernels either side of the hot path on the benchmark's batch:
+128 frames of 1920x1080 / 2000 keypoints resident in HBM.  HIP events on the stream the calls are issued on, median of 9;
+next to each, the oracle's CPU time for the same work (1 thread, a few frames, scaled to the batch).
+
+  ingest       RGB -> grey (Tracking.cc:247-260) + horizontal flip (image_sequence_reader.cc:53-58) in front of K1
+  undistort    Frame::UndistortKeyPoints (Frame.cc:408-438), k1 != 0
+  grid         Frame::AssignFeaturesToGrid (Frame.cc:234-249), 64 x 48 cells, CSR
+  init-match   ORBmatcher::SearchForInitialization (ORBmatcher.cc:407-522), window 100, every frame vs its predecessor
+  bow          ORBVocabulary::transform (TemplatedVocabulary.h:1126-1259) on an ORBvoc-sized tree (k = 10, L = 6)
+
+usage: python tools/next_tier_bench.py [--batch 128] [--out profiles/r02_next_tier.txt]"""
+import argparse, ctypes as C, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import pilotguru_amd as pg
+from pilotguru_amd import vocab as V
+from pilotguru_amd.synth import synth_ride
+from oracle import orb_oracle
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=128)
+ap.add_argument("--out", default="")
+a = ap.parse_args()
+w, h, nf, B = 1920, 1080, 2000, a.batch
+ride = synth_ride(0, w, h, B)
+ext = pg.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B)
+fr = torch.from_numpy(ride).cuda()
+p = lambda t: C.c_void_p(t.data_ptr())
+s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def timed(fn, reps=9):
+    fn(); torch.cuda.synchronize()
+    ms = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        ms.append(e0.elapsed_time(e1))
+    return float(np.median(ms))
+
+
+rows = []
+t_plain = timed(lambda: ext.extract_batch_device(fr))
+rgb = fr.flip(2).unsqueeze(-1).expand(B, h, w, 3).contiguous()          # grey value in all channels, mirrored: ingest undoes it
+t_ing = timed(lambda: ext.extract_batch_ingest_device(rgb, True, 0, False, True))
+k2, d2, n2 = ext.extract_batch_ingest_device(rgb, True, 0, False, True)
+kps, desc, n = ext.extract_batch_device(fr)
+ext.check_async(); torch.cuda.synchronize()
+assert torch.equal(n, n2) and all(torch.equal(d2[f, :n[f]], desc[f, :n[f]]) and torch.equal(k2[f, :n[f]].view(torch.int32), kps[f, :n[f]].view(torch.int32)) for f in range(B))   # (4899 + 9617 + 1868) v + 8192 >> 14 == v
+kps, desc, n = kps.clone(), desc.clone(), n.clone()
+cap = kps.shape[1]
+nh = n.cpu().numpy()
+r0 = rgb[0].cpu().numpy()
+t0 = time.time(); g = orb_oracle.ingest_geometry(orb_oracle.rgb_to_gray(r0), 0, False, True); c_ing = (time.time() - t0) * B * 1e3
+assert np.array_equal(g, ride[0])
+rows.append(("ingest (RGB->grey + hflip), beyond plain extraction", t_ing - t_plain, 3 * w * h * B, c_ing))
+
+cam = (C.c_float * 4)(1400.0, 1400.0, 960.0, 540.0); dist = (C.c_float * 5)(-0.28, 0.07, 0.0002, 0.00002, 0.0)
+und = torch.empty_like(kps)
+t_und = timed(lambda: ext._check(ext._L.pgorb_undistort_keypoints_batch_device(ext._h, p(kps), p(n), B, cap, cam, dist, p(und), s)))
+kh = kps.cpu().numpy().view(np.uint8).reshape(B, cap, 28)
+k0 = kh[0, :nh[0]].copy().view(orb_oracle.KEYPOINT_DTYPE).reshape(-1)
+t0 = time.time(); orb_oracle.undistort_keypoints(k0, list(cam), list(dist)); c_und = (time.time() - t0) * B * 1e3
+rows.append(("undistort keypoints", t_und, int(nh.sum()) * 56, c_und))
+
+gs = torch.empty((B, 3073), dtype=torch.int32, device="cuda"); gi = torch.empty((B, cap), dtype=torch.int32, device="cuda")
+t_grid = timed(lambda: ext._check(ext._L.pgorb_frame_grid_batch_device(ext._h, p(kps), p(n), B, cap, 0.0, float(w), 0.0, float(h), p(gs), p(gi), s)))
+t0 = time.time(); orb_oracle.frame_grid(k0, (0.0, float(w), 0.0, float(h))); c_grid = (time.time() - t0) * B * 1e3
+rows.append(("frame grid 64x48", t_grid, int(nh.sum()) * 28 + B * 3073 * 4, c_grid))
+
+f1 = torch.arange(0, B - 1, dtype=torch.int32, device="cuda"); f2 = torch.arange(1, B, dtype=torch.int32, device="cuda")
+prev0 = kps[:B - 1, :, :2].contiguous()
+prev = prev0.clone(); m12 = torch.empty((B - 1, cap), dtype=torch.int32, device="cuda"); nm = torch.empty(B - 1, dtype=torch.int32, device="cuda")
+def init_match():
+    prev.copy_(prev0)
+    ext._check(ext._L.pgorb_search_for_initialization_batch_device(ext._h, p(kps), p(desc), p(n), cap, p(gs), p(gi), p(f1), p(f2), B - 1,
+               0.0, float(w), 0.0, float(h), p(prev), p(m12), p(nm), 100, C.c_float(0.9), 1, s))
+t_copy = timed(lambda: prev.copy_(prev0))
+t_sfi = timed(init_match) - t_copy
+dh = desc.cpu().numpy()
+k1 = kh[1, :nh[1]].copy().view(orb_oracle.KEYPOINT_DTYPE).reshape(-1)
+t0 = time.time()
+onm, _, _ = orb_oracle.search_for_initialization(k0, dh[0, :nh[0]], k1, dh[1, :nh[1]], (0.0, float(w), 0.0, float(h)), np.stack([k0["x"], k0["y"]], 1))
+c_sfi = (time.time() - t0) * (B - 1) * 1e3
+assert int(nm[0]) == onm
+rows.append(("SearchForInitialization (%d pairs, %d matches/pair)" % (B - 1, int(nm.float().mean())), t_sfi, int(nh.sum()) * (28 + 32) * 2, c_sfi))
+
+dsc, wgt, par = V.synth_vocabulary_fast(10, 6, seed=7)
+voc = V.ORBVocabulary(blob=V.pack_vocabulary(10, 6, dsc, wgt, par))
+voc.upload(ext)
+flat = torch.cat([desc[f, :nh[f]] for f in range(B)]).contiguous()
+nd = flat.shape[0]
+word = torch.empty(nd, dtype=torch.int32, device="cuda"); wt = torch.empty(nd, dtype=torch.float64, device="cuda"); node = torch.empty(nd, dtype=torch.int32, device="cuda")
+t_bow = timed(lambda: ext._check(ext._L.pgorb_bow_transform_device(ext._h, p(flat), nd, 4, p(word), p(wt), p(node), s)))
+rows.append(("BoW transform, k=10 L=6 (%d descriptors)" % nd, t_bow, nd * (32 + 6 * 10 * 32), float("nan")))
+
+lines = ["# python tools/next_tier_bench.py --batch %d   (MI355X; ms per %d-frame 1080p batch; CPU = oracle, 1 thread, one frame or pair scaled to the batch)" % (B, B),
+         "# extraction alone (K1-K6): %.3f ms" % t_plain,
+         "%-58s %10s %12s %12s %10s" % ("kernel", "GPU ms", "us / frame", "GB/s (alg.)", "CPU ms")]
+for name, ms, byts, cpu in rows:
+    lines.append("%-58s %10.3f %12.2f %12.1f %10.0f" % (name, ms, ms * 1e3 / B, byts / ms / 1e6, cpu))
+print("\n".join(lines))
+if a.out:
+    open(a.out, "w").write("\n".join(lines) + "\n")
