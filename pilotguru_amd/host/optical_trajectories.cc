@@ -20,6 +20,7 @@
 // No libav here: --in_video takes a .y4m (Y plane), a printf pattern of PGM files
 // (frames/%06d.pgm) or a headerless .gray file sized by Camera_width/Camera_height.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -29,6 +30,11 @@
 #include <sstream>
 #include <string>
 #include <vector>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "orb_extractor.hpp"
 #include "trajectory_json.hpp"
@@ -40,7 +46,7 @@ struct Flags {
     std::string vocabulary_file, camera_settings, out_dir, in_video, trajectory_in, poses_in, dump_features;
     bool visualize = true, vertical_flip = false, horizontal_flip = false, output_per_segment_videos = false;
     long long rotation_smooth_sigma = -1;
-    int device = 0, batch = 8, max_frames = -1, segment_id = 0;
+    int device = 0, batch = 32, max_frames = -1, segment_id = 0;
     int shard_rank = 0, shard_world = 1;          // --shard=rank/world: this process takes its chunk of the ride
 };
 
@@ -101,7 +107,10 @@ std::map<std::string, double> read_settings(const std::string& path)
 
 struct FrameSource {                  // ImageSequenceSource (include/io/image_sequence_reader.hpp:23-28), grey only
     std::string path; int w = 0, h = 0; double fps = 30; long frame = 0;
-    FILE* fp = nullptr; bool y4m = false, pattern = false; size_t y4mFrameBytes = 0;
+    bool y4m = false, pattern = false; size_t y4mFrameBytes = 0;
+    // .y4m / .gray files are mapped: a frame goes from the page cache into the page-locked slot with ONE user-space
+    // copy (read() straight into page-locked memory measured 25 % slower than read() + memcpy, the mapping is faster than both)
+    const uint8_t* map = nullptr; size_t mapSize = 0, pos = 0;
     std::string patHead, patTail; int patWidth = 0; bool patZero = false;      // "<head>%0Nd<tail>", parsed once
     // The user's path is never handed to printf as a format: exactly one %d / %Nd / %0Nd conversion is
     // accepted ("%%" is a literal per cent sign) and the frame name is assembled by hand.
@@ -132,11 +141,22 @@ struct FrameSource {                  // ImageSequenceSource (include/io/image_s
     {
         path = p; fps = f;
         if (p.find('%') != std::string::npos) { pattern = true; return parse_pattern(p); }
-        fp = fopen(p.c_str(), "rb");
-        if (!fp) return false;
+        const int fd = ::open(p.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat sb;
+        if (fstat(fd, &sb) != 0 || sb.st_size <= 0) { ::close(fd); return false; }
+        mapSize = (size_t)sb.st_size;
+        void* m = mmap(nullptr, mapSize, PROT_READ, MAP_PRIVATE, fd, 0);
+        ::close(fd);
+        if (m == MAP_FAILED) { map = nullptr; return false; }
+        map = static_cast<const uint8_t*>(m);
+        (void)madvise(m, mapSize, MADV_SEQUENTIAL);
         if (p.size() > 4 && p.substr(p.size() - 4) == ".y4m") {
             y4m = true;
-            char hdr[512]; if (!fgets(hdr, sizeof(hdr), fp)) return false;
+            const void* nl = memchr(map, '\n', std::min<size_t>(mapSize, 511));
+            if (!nl) return false;
+            char hdr[512]; const size_t hl = (size_t)((const uint8_t*)nl - map);
+            memcpy(hdr, map, hl); hdr[hl] = 0; pos = hl + 1;
             int chroma = 420; char* t = strtok(hdr, " \n");
             while (t) {
                 if (t[0] == 'W') w = atoi(t + 1); else if (t[0] == 'H') h = atoi(t + 1);
@@ -151,6 +171,7 @@ struct FrameSource {                  // ImageSequenceSource (include/io/image_s
         w = sw; h = sh;
         return w > 0 && h > 0;
     }
+    ~FrameSource() { if (map) munmap(const_cast<uint8_t*>(map), mapSize); }
     // number of frames of the sequence (pattern: probe for the first missing file)
     long count()
     {
@@ -159,22 +180,20 @@ struct FrameSource {                  // ImageSequenceSource (include/io/image_s
             for (;; k++) { FILE* f = fopen(frame_name(k).c_str(), "rb"); if (!f) break; fclose(f); }
             return k;
         }
-        const long at = ftell(fp);
-        fseek(fp, 0, SEEK_END);
-        const long end = ftell(fp);
-        fseek(fp, at, SEEK_SET);
-        if (y4m) return (long)((size_t)(end - at) / (y4mFrameBytes + 6));      // "FRAME\n" + planes (frame headers without parameters)
-        return (long)((size_t)end / ((size_t)w * h));
+        if (y4m) return (long)((mapSize - pos) / (y4mFrameBytes + 6));         // "FRAME\n" + planes (frame headers without parameters)
+        return (long)(mapSize / ((size_t)w * h));
     }
     // start at frame k (frame ids and timestamps stay those of the whole sequence)
     bool skip(long k)
     {
         if (pattern) { frame = k; return true; }
         std::vector<uint8_t> g; long long t, id;
-        while (frame < k) if (!next(g, &t, &id)) return false;
+        while (frame < k) if (!next(g, &t, &id, nullptr, false)) return false;      // (walks the frame headers, copies nothing)
         return true;
     }
-    bool next(std::vector<uint8_t>& gray, long long* time_usec, long long* frame_id)
+    // The next frame's grey plane goes to `dst` (w * h bytes: the page-locked slot of the stream, no staging copy) or,
+    // when dst is null (the first frame: its size is not known yet for a PGM sequence), into `gray`.
+    bool next(std::vector<uint8_t>& gray, long long* time_usec, long long* frame_id, uint8_t* dst = nullptr, bool copy = true)
     {
         if (pattern) {
             FILE* f = fopen(frame_name(frame).c_str(), "rb");
@@ -189,19 +208,26 @@ struct FrameSource {                  // ImageSequenceSource (include/io/image_s
             }
             w = fw; h = fh;
             fgetc(f);
-            gray.resize((size_t)w * h);
-            const bool ok = fread(gray.data(), 1, gray.size(), f) == gray.size();
+            if (!dst) { gray.resize((size_t)w * h); dst = gray.data(); }
+            const bool ok = fread(dst, 1, (size_t)w * h, f) == (size_t)w * h;
             fclose(f);
             if (!ok) return false;
-        } else if (y4m) {
-            char line[64];
-            if (!fgets(line, sizeof(line), fp) || strncmp(line, "FRAME", 5)) return false;
-            std::vector<uint8_t> buf(y4mFrameBytes);
-            if (fread(buf.data(), 1, buf.size(), fp) != buf.size()) return false;
-            gray.assign(buf.begin(), buf.begin() + (size_t)w * h);
         } else {
-            gray.resize((size_t)w * h);
-            if (fread(gray.data(), 1, gray.size(), fp) != gray.size()) return false;
+            const size_t y = (size_t)w * h;
+            size_t skip = 0;
+            if (y4m) {                                                 // "FRAME[ params]\n" then the planes; only Y is used
+                if (pos + 5 > mapSize || memcmp(map + pos, "FRAME", 5)) return false;
+                const void* nl = memchr(map + pos, '\n', std::min<size_t>(mapSize - pos, 63));
+                if (!nl) return false;
+                pos = (size_t)((const uint8_t*)nl - map) + 1;
+                skip = y4mFrameBytes - y;
+            }
+            if (pos + y + skip > mapSize) return false;
+            if (copy) {
+                if (!dst) { gray.resize(y); dst = gray.data(); }
+                memcpy(dst, map + pos, y);
+            }
+            pos += y + skip;
         }
         *frame_id = frame;
         *time_usec = (long long)llround((double)frame * 1e6 / fps);
@@ -210,10 +236,10 @@ struct FrameSource {                  // ImageSequenceSource (include/io/image_s
     }
 };
 
-void flip(std::vector<uint8_t>& g, int w, int h, bool vertical, bool horizontal)
+void flip(uint8_t* g, int w, int h, bool vertical, bool horizontal)      // in place (image_sequence_reader.cc:53-58)
 {
-    if (vertical) for (int y = 0; y < h / 2; y++) std::swap_ranges(g.begin() + (size_t)y * w, g.begin() + (size_t)(y + 1) * w, g.begin() + (size_t)(h - 1 - y) * w);
-    if (horizontal) for (int y = 0; y < h; y++) std::reverse(g.begin() + (size_t)y * w, g.begin() + (size_t)(y + 1) * w);
+    if (vertical) for (int y = 0; y < h / 2; y++) std::swap_ranges(g + (size_t)y * w, g + (size_t)(y + 1) * w, g + (size_t)(h - 1 - y) * w);
+    if (horizontal) for (int y = 0; y < h; y++) std::reverse(g + (size_t)y * w, g + (size_t)(y + 1) * w);
 }
 
 int write_trajectory_from_text(const Flags& F)
@@ -305,8 +331,10 @@ int main(int argc, char** argv)
 
     // The frame loop of TrackImageSequence (src/slam/track_image_sequence.cc:43-52) as a stream of batches
     // (include/pgorb.h, pgorb_stream_*): the source writes every frame straight into a page-locked slot; upload,
-    // kernels and result download of up to DEPTH batches overlap.  The per-frame host calls (BoW transform, initial
-    // matcher) use a second, small context: the streaming context must not run other calls while batches are in flight.
+    // kernels and result download of up to DEPTH batches overlap.  The per-frame work of the tracking thread --
+    // Frame::ComputeBoW's transform and MonocularInitialization's SearchForInitialization(previous, current) -- runs on
+    // the device for the whole batch as the stream's front-end stage (pgorb_stream_frontend); the host only folds the
+    // per-feature words into BowVector / FeatureVector and writes the report.
     const int B = std::max(1, F.batch), DEPTH = 3;
     // --shard: frames [firstExtracted, stop) are read, frames from firstOwned on are reported (the frame before
     // firstOwned is extracted only as the predecessor of the first owned match)
@@ -324,26 +352,28 @@ int main(int argc, char** argv)
     std::vector<uint8_t> frame0;                              // the first frame tells the size
     long long t0 = 0, id0 = 0;
     if (!((F.max_frames < 0 || F.max_frames > 0) && src.next(frame0, &t0, &id0))) frame0.clear();
-    pgorb::ORBextractor* ext = nullptr;                       // streaming context (batches)
-    pgorb::ORBextractor* aux = nullptr;                       // per-frame calls
+    pgorb::ORBextractor* ext = nullptr;
     pgorb_stream* st = nullptr;
     if (!frame0.empty()) {
-        flip(frame0, src.w, src.h, F.vertical_flip, F.horizontal_flip);
+        flip(frame0.data(), src.w, src.h, F.vertical_flip, F.horizontal_flip);
         ext = new pgorb::ORBextractor(nFeatures, scaleFactor, nLevels, iniTh, minTh, src.w, src.h, B, F.device);
-        aux = new pgorb::ORBextractor(nFeatures, scaleFactor, nLevels, iniTh, minTh, src.w, src.h, 1, F.device);
-        if (pgorb_vocab_upload(aux->context(), voc) != PGORB_OK) check_failed("vocabulary upload");
+        if (pgorb_vocab_upload(ext->context(), voc) != PGORB_OK) check_failed("vocabulary upload");
         if (pgorb_max_keypoints(ext->context(), src.w, src.h) < 0) check_failed("frame size usable for the ORB cell grid");
         if (pgorb_stream_create(ext->context(), src.w, src.h, B, DEPTH, &st) != PGORB_OK) check_failed(pgorb_last_error(ext->context()));
+        // Frame::ComputeImageBounds without distortion: [0, cols] x [0, rows] (Frame.cc:462-466); ORBmatcher(0.9, true)
+        // .SearchForInitialization(mInitialFrame, mCurrentFrame, mvbPrevMatched, mvIniMatches, 100) (Tracking.cc:596-597);
+        // transform(..., 4) (Frame.cc:404)
+        if (pgorb_stream_frontend(st, 0.f, (float)src.w, 0.f, (float)src.h, 100, 0.9f, 1, 4) != PGORB_OK) check_failed(pgorb_last_error(ext->context()));
     }
     const size_t fbytes = (size_t)src.w * src.h;
     std::vector<std::vector<long long>> tusS(DEPTH, std::vector<long long>(B)), idsS(DEPTH, std::vector<long long>(B));
-    pgorb::Frame prev; bool havePrev = false;
-    std::vector<float> prevMatched;
     std::ostringstream js;
     js << "{\n  \"frames\": [";
     FILE* dump = F.dump_features.empty() ? nullptr : fopen(F.dump_features.c_str(), "wb");
-    long total = 0, read = 0; bool first = true;
+    long total = 0, read = 0; bool first = true, firstOfRide = true;
     int submitted = 0, collected = 0; bool more = !frame0.empty();
+    const auto loopStart = std::chrono::steady_clock::now();
+    std::vector<uint32_t> bid, fnode, ffeat; std::vector<double> bval; std::vector<int32_t> fstart;
     while (more || collected < submitted) {
         // keep DEPTH batches in flight: fill and submit the next slot while there are frames
         while (more && submitted - collected < DEPTH) {
@@ -354,9 +384,8 @@ int main(int argc, char** argv)
             while (nb < B && (F.max_frames < 0 || read < F.max_frames)) {
                 if (read == 0) { memcpy(in, frame0.data(), fbytes); tusS[slot][0] = t0; idsS[slot][0] = id0; }
                 else {
-                    if (!src.next(tmp, &tusS[slot][nb], &idsS[slot][nb])) { more = false; break; }
-                    flip(tmp, src.w, src.h, F.vertical_flip, F.horizontal_flip);
-                    memcpy(in + (size_t)nb * fbytes, tmp.data(), fbytes);
+                    if (!src.next(tmp, &tusS[slot][nb], &idsS[slot][nb], in + (size_t)nb * fbytes)) { more = false; break; }
+                    flip(in + (size_t)nb * fbytes, src.w, src.h, F.vertical_flip, F.horizontal_flip);
                 }
                 nb++; read++;
             }
@@ -370,42 +399,32 @@ int main(int argc, char** argv)
         const int32_t* n = nullptr; const pgorb_keypoint* kps = nullptr; const uint8_t* desc = nullptr; int cap = 0;
         const int nb = pgorb_stream_wait(st, slot, &n, &kps, &desc, nullptr, nullptr, nullptr, &cap);
         if (nb < 0) check_failed(pgorb_last_error(ext->context()));
+        const int32_t* nmatch = nullptr; const uint32_t *word = nullptr, *node = nullptr; const double* wt = nullptr;
+        if (pgorb_stream_frontend_results(st, slot, nullptr, &nmatch, &word, &wt, &node) != PGORB_OK) check_failed(pgorb_last_error(ext->context()));
         collected++;
         const std::vector<long long>&tus = tusS[slot], &ids = idsS[slot];
         for (int i = 0; i < nb; i++) {
-            pgorb::Frame cur;
-            cur.mvKeysUndistorted.assign(kps + (size_t)i * cap, kps + (size_t)i * cap + n[i]);
-            cur.mDescriptors.assign(desc + (size_t)i * cap * 32, desc + ((size_t)i * cap + n[i]) * 32);
-            cur.mnMaxX = (float)src.w; cur.mnMaxY = (float)src.h;
-            if (ids[i] < firstOwned) { prev = cur; havePrev = true; continue; }      // the overlap frame of a shard: only a predecessor
-            // Frame::ComputeBoW: transform(descriptors, BowVec, FeatVec, 4)  (Frame.cc:399-406)
-            std::vector<uint32_t> word(n[i]), node(n[i]), bid(n[i] + 1), fnode(n[i] + 1), ffeat(n[i] + 1);
-            std::vector<double> wt(n[i]), bval(n[i] + 1); std::vector<int32_t> fstart(n[i] + 2);
+            const bool hadPrev = !firstOfRide;
+            firstOfRide = false;
+            if (ids[i] < firstOwned) continue;               // the overlap frame of a shard: only a predecessor
+            // Frame::ComputeBoW: BowVector / FeatureVector of transform(descriptors, ..., 4)  (Frame.cc:399-406)
+            const size_t o = (size_t)i * cap;
             int nbow = 0, nfv = 0;
             if (n[i]) {
-                if (pgorb_bow_transform(aux->context(), cur.mDescriptors.data(), n[i], 4, word.data(), wt.data(), node.data()) != PGORB_OK)
-                    check_failed(pgorb_last_error(aux->context()));
-                pgorb_bow_vectors(n[i], word.data(), wt.data(), node.data(), vs, vwt, bid.data(), bval.data(), &nbow,
+                bid.resize(n[i] + 1); bval.resize(n[i] + 1); fnode.resize(n[i] + 1); ffeat.resize(n[i] + 1); fstart.resize(n[i] + 2);
+                pgorb_bow_vectors(n[i], word + o, wt + o, node + o, vs, vwt, bid.data(), bval.data(), &nbow,
                                   fnode.data(), fstart.data(), ffeat.data(), &nfv);
             }
-            int nmatches = -1;
-            if (havePrev) {                              // MonocularInitialization's matcher call (Tracking.cc:596-597)
-                pgorb::ORBmatcher matcher(aux->context(), 0.9f, true);
-                prevMatched.resize((size_t)prev.N() * 2);
-                for (int k = 0; k < prev.N(); k++) { prevMatched[2 * k] = prev.mvKeysUndistorted[k].x; prevMatched[2 * k + 1] = prev.mvKeysUndistorted[k].y; }
-                std::vector<int32_t> m12;
-                nmatches = matcher.SearchForInitialization(prev, cur, prevMatched, m12, 100);
-            }
+            const int nmatches = hadPrev ? nmatch[i] : -1;   // MonocularInitialization's matcher call (Tracking.cc:596-597)
             js << (first ? "\n" : ",\n") << "    {\"frame_id\": " << ids[i] << ", \"time_usec\": " << tus[i] << ", \"n_keypoints\": " << n[i]
                << ", \"n_bow_words\": " << nbow << ", \"n_feature_nodes\": " << nfv << ", \"n_matches_prev\": " << nmatches << "}";
             first = false;
             if (dump) {
                 const int32_t hdr[2] = {(int32_t)ids[i], n[i]};
                 fwrite(hdr, 4, 2, dump);
-                fwrite(cur.mvKeysUndistorted.data(), sizeof(pgorb_keypoint), n[i], dump);
-                fwrite(cur.mDescriptors.data(), 32, n[i], dump);
+                fwrite(kps + o, sizeof(pgorb_keypoint), n[i], dump);
+                fwrite(desc + o * 32, 32, n[i], dump);
             }
-            prev = cur; havePrev = true;
         }
         total += nb;
     }
@@ -417,9 +436,10 @@ int main(int argc, char** argv)
     std::ofstream o(out);
     if (!o.good()) check_failed("out_dir is writable");
     o << js.str() << std::endl;
-    fprintf(stderr, "optical_trajectories (front-end mode): %ld frames -> %s\n", total, out.c_str());
+    const double loopSec = std::chrono::duration<double>(std::chrono::steady_clock::now() - loopStart).count();
+    fprintf(stderr, "optical_trajectories (front-end mode): %ld frames -> %s (frame loop: %.3f s, %.0f frames/s)\n", total, out.c_str(),
+            loopSec, loopSec > 0 ? total / loopSec : 0.0);
     if (st) pgorb_stream_destroy(st);
-    delete aux;
     delete ext;
     pgorb_vocab_free(voc);
     return EXIT_SUCCESS;

@@ -15,7 +15,7 @@ open('$D/cam.yml', 'w').write("%YAML:1.0\n---\nCamera_width: 1920\nCamera_height
 d, w, p = V.synth_vocabulary(10, 4, seed=5)
 V.write_vocabulary_text('$D/voc.txt', 10, 4, d, w, p)
 PY
-for b in 8 32; do
+for b in 8 32 64; do
   t0=$(date +%s.%N)
   pilotguru_amd/host/optical_trajectories --vocabulary_file=$D/voc.txt --camera_settings=$D/cam.yml \
     --in_video=$D/clip.gray --out_dir=$D --novisualize --batch=$b 2>&1 | tail -1
