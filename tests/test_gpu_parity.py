@@ -453,13 +453,14 @@ def test_device_entry_points_are_graph_capture_safe(oracle):
 
 @pytest.mark.parametrize("rot", [0, 90, 180, 270])
 @pytest.mark.parametrize("cn,rgb", [(1, True), (3, True), (4, False)])
-def test_ingest_rotation_flip_colour_on_device(oracle, rot, cn, rgb):
+@pytest.mark.parametrize("w,h", [(333, 251), (336, 252)])     # rows of 336 pixels take the dword-per-channel kernel for rotation 0 / 180
+def test_ingest_rotation_flip_colour_on_device(oracle, rot, cn, rgb, w, h):
     """pgorb_extract_batch_ingest_device: frames as decoded (grey / RGB / BGRA) go through the
     reader's rotation and flips and Tracking's grey conversion on the device; keypoints and
     descriptors equal the oracle run on the oracle-ingested frame, for all four flip settings."""
     import torch
     import pilotguru_amd as pg
-    w, h, nf = 333, 251, 500
+    nf = 500
     rng = np.random.RandomState(rot + cn)
     base = synth_scene(60 + rot // 90, w, h)
     if cn == 1:
