@@ -47,7 +47,7 @@ struct pgorb_ctx {
     int pipePyr = 0;
     hipStream_t sPyr = nullptr, sFast = nullptr;
     hipEvent_t evFork = nullptr, evLevel[PG_MAXL] = {}, evPyrDone = nullptr, evFastDone = nullptr;
-    Arena stageKps, stageDesc, stageN, stageA, stageB, stageOut, vocab;
+    Arena stageKps, stageDesc, stageN, stageA, stageB, stageOut, stageSfi, vocab;
     Arena xdesc;                              // matcher scratch: train descriptors as +-1 bytes (match.hip)
     void* pinned = nullptr;                   // page-locked bounce buffer for bulk result download
     size_t pinnedBytes = 0;
@@ -536,7 +536,7 @@ int pg_ctx_fail(pgorb_ctx* c, int code, const char* msg) { return fail(c, code, 
 int pg_ctx_device(pgorb_ctx* c) { return c->prm.device; }
 int pg_ctx_stage(pgorb_ctx* c, int which, size_t bytes, void** p)
 {
-    Arena* a = which == 0 ? &c->stageA : which == 1 ? &c->stageB : &c->stageOut;
+    Arena* a = which == 0 ? &c->stageA : which == 1 ? &c->stageB : which == 3 ? &c->stageSfi : &c->stageOut;
     PG_HIP(c, hipSetDevice(c->prm.device));
     int rc = ensure(c, *a, bytes);
     if (rc) return rc;
@@ -636,7 +636,7 @@ void pgorb_destroy(pgorb_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->prm.device);
     Arena* all[] = {&c->blockTab, &c->cellTab, &c->cellTabBal, &c->cellCand, &c->cellCount, &c->pyr, &c->cand, &c->sel, &c->nodes, &c->counters, &c->tables,
-                    &c->stageKps, &c->stageDesc, &c->stageN, &c->stageA, &c->stageB, &c->stageOut, &c->vocab, &c->xdesc};
+                    &c->stageKps, &c->stageDesc, &c->stageN, &c->stageA, &c->stageB, &c->stageOut, &c->stageSfi, &c->vocab, &c->xdesc};
     for (Arena* a : all) if (a->p) (void)hipFree(a->p);
     if (c->sPyr) {
         (void)hipStreamSynchronize(c->sPyr); (void)hipStreamSynchronize(c->sFast);

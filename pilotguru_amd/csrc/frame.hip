@@ -8,13 +8,23 @@
 //
 // The matcher is sequential over F1's keypoints by construction: whether candidate i2 is
 // considered depends on vMatchedDistance[i2], which earlier keypoints wrote (:445-446, :469).
-// So one 64-lane wave owns one frame pair and walks i1 in order; everything inside one i1 is
-// wave-parallel: lanes gather the grid cells of the search window (CSR ranges, wave prefix sum
-// -> candidate list in the reference's (column, row, insertion) order), lanes evaluate the
-// 256-bit Hamming distance of one candidate each (the query descriptor is wave-uniform), and a
-// wave argmin on (distance << 16 | list position) reproduces "first minimum wins" (:448-457).
-// All per-pair state (vMatchedDistance, vnMatches21, vnMatches12, histogram bins) lives in LDS.
-// Throughput comes from pairs in parallel; the path is used a few times per ride.
+// What does NOT depend on that order is the expensive part: which keypoints of F2 lie in the
+// window of vbPrevMatched[i1] (it is only updated after the loop, :516-519) and their Hamming
+// distances.  So the work is split:
+//   k_sfi_candidates   one wave per (pair, F1 keypoint), all in parallel: lanes gather the grid
+//       cells of the window (CSR ranges, wave prefix sum -> candidate list in the reference's
+//       (column, row, insertion) order), filter by level and window (Frame.cc:354-376), evaluate
+//       one 256-bit distance each and store the survivors in order as (distance << 16 | i2),
+//       at most 64 per keypoint (more: the count says "overflow").
+//   k_search_for_initialization   one wave per pair walks F1's keypoints that have candidates, in
+//       order, with the stored lists prefetched two groups ahead: per keypoint one LDS gather of
+//       vMatchedDistance, two wave reductions ("first minimum wins", :448-457: argmin on
+//       distance << 16 | list position; second best over the other entries) and the update by one
+//       lane -- no global round trip inside the chain (it was four per keypoint, 3.4 us each:
+//       1.46 ms per pair; tools/next_tier_bench.py).  Overflowed keypoints are evaluated in place,
+//       cell by cell.  The rotation histogram only needs (i1, the i2 it was matched to when pushed):
+//       the bins are computed after the loop, in parallel.
+// All per-pair state (vMatchedDistance, vnMatches21, vnMatches12) lives in LDS.
 #include "pgorb_internal.h"
 #include <algorithm>
 #include <vector>
@@ -88,20 +98,47 @@ __global__ __launch_bounds__(256) void k_frame_grid(const pgorb_keypoint* __rest
     }
 }
 
-__device__ __forceinline__ int wave_incl_scan(int v, int lane)
+// wave-wide inclusive sum / minimum on DPP row shifts and broadcasts (6 cross-lane moves on the VALU; the __shfl forms
+// go through the LDS crossbar, ~100 cycles each, and the sequential matcher pass pays every one of them in full)
+__device__ __forceinline__ int wave_incl_scan(int x, int lane)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(v, d);
-        if (lane >= d) v += o;
-    }
+    (void)lane;
+    int v = x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);      // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);      // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);      // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);      // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);     // row_bcast:15
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);     // row_bcast:31
     return v;
 }
-__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+__device__ __forceinline__ unsigned wave_min_u32(unsigned x)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, d));
-    return v;
+    int v = (int)x;                                                      // lanes a shift does not reach keep their own value
+    v = (int)min((unsigned)v, (unsigned)__builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));
+    v = (int)min((unsigned)v, (unsigned)__builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));
+    v = (int)min((unsigned)v, (unsigned)__builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false));
+    v = (int)min((unsigned)v, (unsigned)__builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false));   // lane 15 of every row: the row's minimum
+    v = (int)min((unsigned)v, (unsigned)__builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1, 3
+    v = (int)min((unsigned)v, (unsigned)__builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2, 3
+    return (unsigned)__builtin_amdgcn_readlane(v, 63);
+}
+
+// smallest and second-smallest of the lanes' (distinct or 0xFFFFFFFF) keys in ONE pass: every step merges two (min, second) pairs
+__device__ __forceinline__ void wave_min2_u32(unsigned x, unsigned& best, unsigned& second)
+{
+    int a = (int)x, b = -1;                                              // (min, second) of the lanes seen so far; -1 = 0xFFFFFFFF
+#define PG_MIN2_STEP(CTRL, ROWMASK) do { \
+        const unsigned oa = (unsigned)__builtin_amdgcn_update_dpp(-1, a, CTRL, ROWMASK, 0xf, false); \
+        const unsigned ob = (unsigned)__builtin_amdgcn_update_dpp(-1, b, CTRL, ROWMASK, 0xf, false); \
+        const unsigned hi = max((unsigned)a, oa); \
+        a = (int)min((unsigned)a, oa); \
+        b = (int)min(min((unsigned)b, ob), hi); } while (0)
+    PG_MIN2_STEP(0x111, 0xf); PG_MIN2_STEP(0x112, 0xf); PG_MIN2_STEP(0x114, 0xf); PG_MIN2_STEP(0x118, 0xf);
+    PG_MIN2_STEP(0x142, 0xa); PG_MIN2_STEP(0x143, 0xc);
+#undef PG_MIN2_STEP
+    best = (unsigned)__builtin_amdgcn_readlane(a, 63);
+    second = (unsigned)__builtin_amdgcn_readlane(b, 63);
 }
 
 // vbPrevMatched of MonocularInitialization: the reference frame's keypoint positions (Tracking.cc:583-585)
@@ -117,13 +154,145 @@ void pg_launch_prev_matched_init(const pgorb_keypoint* d_kps, int64_t rows, floa
 
 extern __shared__ __attribute__((aligned(16))) uint8_t pg_sfi_smem[];
 
+#define SFI_K 64                 // stored candidates per F1 keypoint (one per lane of the sequential pass)
+#define SFI_OVER 255             // count value: more than SFI_K survivors, evaluate in place
+#define SFI_G 8                  // keypoints per prefetch group
+
+// GetFeaturesInArea's cell window (Frame.cc:336-350); false = the reference returns an empty vector
+__device__ __forceinline__ bool sfi_window(float x, float y, float r, float minX, float minY, float invW, float invH,
+                                           int& cx0, int& cx1, int& cy0, int& cy1)
+{
+    cx0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, minX), r), invW)));
+    if (cx0 >= GRID_COLS) return false;
+    cx1 = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, minX), r), invW)));
+    if (cx1 < 0) return false;
+    cy0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, minY), r), invH)));
+    if (cy0 >= GRID_ROWS) return false;
+    cy1 = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, minY), r), invH)));
+    if (cy1 < 0) return false;
+    return cx1 >= cx0 && cy1 >= cy0;
+}
+
+__device__ __forceinline__ int sfi_distance(const uint4 q0, const uint4 q1, const uint8_t* d)
+{
+    const uint4 d0 = reinterpret_cast<const uint4*>(d)[0], d1 = reinterpret_cast<const uint4*>(d)[1];
+    return __popc(q0.x ^ d0.x) + __popc(q0.y ^ d0.y) + __popc(q0.z ^ d0.z) + __popc(q0.w ^ d0.w) +
+           __popc(q1.x ^ d1.x) + __popc(q1.y ^ d1.y) + __popc(q1.z ^ d1.z) + __popc(q1.w ^ d1.w);
+}
+
+// Phase 1: candidate lists.  Workgroup = 4 waves = 4 consecutive F1 keypoints of pair blockIdx.y.
+__global__ __launch_bounds__(256) void k_sfi_candidates(
+    const pgorb_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc, const int32_t* __restrict__ nper,
+    int cap, const int32_t* __restrict__ gstart, const int32_t* __restrict__ gidx,
+    const int32_t* __restrict__ pairF1, const int32_t* __restrict__ pairF2,
+    float minX, float minY, float invW, float invH, const float* __restrict__ prevMatched, int windowSize,
+    uint32_t* __restrict__ lists, uint8_t* __restrict__ listCnt)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, p = blockIdx.y;
+    const int i1 = blockIdx.x * 4 + wv;
+    const int f1 = pairF1[p], f2 = pairF2[p];
+    const int n1 = min(nper[f1], cap);
+    if (i1 >= n1) return;
+    uint8_t* cntOut = listCnt + (int64_t)p * cap + i1;
+    const pgorb_keypoint kp1 = kps[(int64_t)f1 * cap + i1];
+    int cx0, cx1, cy0, cy1;
+    const float x = prevMatched[((int64_t)p * cap + i1) * 2], y = prevMatched[((int64_t)p * cap + i1) * 2 + 1];
+    const float r = (float)windowSize;
+    if (kp1.octave > 0 || !sfi_window(x, y, r, minX, minY, invW, invH, cx0, cx1, cy0, cy1)) {        // :424-426
+        if (lane == 0) *cntOut = 0;
+        return;
+    }
+    const int level1 = kp1.octave;
+    const pgorb_keypoint* K2 = kps + (int64_t)f2 * cap;
+    const uint8_t* D2 = desc + (int64_t)f2 * cap * 32;
+    const int32_t* start2 = gstart + (int64_t)f2 * (GRID_CELLS + 1);
+    const int32_t* idx2 = gidx + (int64_t)f2 * cap;
+    uint16_t* candList = reinterpret_cast<uint16_t*>(pg_sfi_smem) + (size_t)wv * cap;      // this wave's vIndices2 before filtering
+    const int ncy = cy1 - cy0 + 1, T = (cx1 - cx0 + 1) * ncy;
+    int M = 0;
+    for (int base = 0; base < T; base += 64) {                  // window cells in (ix, iy) order, entries in insertion order
+        const int t = base + lane;
+        int s0 = 0, cnt = 0;
+        if (t < T) {
+            const int c = (cx0 + t / ncy) * GRID_ROWS + cy0 + t % ncy;
+            s0 = start2[c]; cnt = start2[c + 1] - s0;
+        }
+        const int incl = wave_incl_scan(cnt, lane);
+        const int off = M + incl - cnt;
+        for (int j = 0; j < cnt; j++) candList[off + j] = (uint16_t)idx2[s0 + j];
+        M += __builtin_amdgcn_readlane(incl, 63);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint4 q0 = reinterpret_cast<const uint4*>(desc + ((int64_t)f1 * cap + i1) * 32)[0];
+    const uint4 q1 = reinterpret_cast<const uint4*>(desc + ((int64_t)f1 * cap + i1) * 32)[1];
+    uint32_t* out = lists + ((int64_t)p * cap + i1) * SFI_K;
+    int total = 0;
+    for (int base = 0; base < M; base += 64) {
+        const int k = base + lane;
+        bool ok = false; uint32_t e = 0;
+        if (k < M) {
+            const int i2 = candList[k];
+            const pgorb_keypoint kp2 = K2[i2];
+            // bCheckLevels is true for minLevel = maxLevel = 0 (Frame.cc:354): octave must equal level1
+            const float distx = __fsub_rn(kp2.x, x), disty = __fsub_rn(kp2.y, y);
+            if (kp2.octave == level1 && fabsf(distx) < r && fabsf(disty) < r) {
+                ok = true;
+                e = ((uint32_t)sfi_distance(q0, q1, D2 + (int64_t)i2 * 32) << 16) | (uint32_t)i2;
+            }
+        }
+        const unsigned long long m = __ballot(ok);
+        const int pos = total + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+        if (ok && pos < SFI_K) out[pos] = e;
+        total += __popcll(m);
+    }
+    if (lane == 0) *cntOut = (uint8_t)(total > SFI_K ? SFI_OVER : total);
+}
+
+// A keypoint of F1 with more than SFI_K candidates in its window (rare: every keypoint of a dense patch within 100 px):
+// distances and the vMatchedDistance filter evaluated in place, cell by cell in the reference's (column, row, insertion)
+// order.  Out: smallest (distance << 16 | running position), the second-smallest distance, the winner's i2.
+// (results by value: reference parameters of a non-inlined function live in scratch memory, and the common path paid for it)
+__device__ __noinline__ uint3 sfi_eval_in_place(const pgorb_keypoint kp1, float x, float y, float r, float minX, float minY, float invW,
+                                                float invH, const uint8_t* d1, const pgorb_keypoint* K2, const uint8_t* D2,
+                                                const int32_t* start2, const int32_t* idx2, const uint16_t* matchedDist, int lane)
+{
+    int cx0, cx1, cy0, cy1;
+    sfi_window(x, y, r, minX, minY, invW, invH, cx0, cx1, cy0, cy1);          // (true: phase 1 got here)
+    const uint4 q0 = reinterpret_cast<const uint4*>(d1)[0], q1 = reinterpret_cast<const uint4*>(d1)[1];
+    unsigned b1key = 0xFFFFFFFFu, b1idx = 0; int b2 = 0x7fffffff; int posBase = 0;
+    for (int ix = cx0; ix <= cx1; ix++)
+        for (int iy = cy0; iy <= cy1; iy++) {
+            const int c = ix * GRID_ROWS + iy, s0 = start2[c], cnt = start2[c + 1] - s0;
+            for (int k = lane; k < cnt; k += 64) {
+                const int i2 = idx2[s0 + k];
+                const pgorb_keypoint kp2 = K2[i2];
+                const float distx = __fsub_rn(kp2.x, x), disty = __fsub_rn(kp2.y, y);
+                if (kp2.octave != kp1.octave || !(fabsf(distx) < r && fabsf(disty) < r)) continue;
+                const int dist = sfi_distance(q0, q1, D2 + (int64_t)i2 * 32);
+                if ((int)matchedDist[i2] <= dist) continue;
+                const unsigned key = ((unsigned)dist << 16) | (unsigned)(posBase + k);     // posBase + k < cap < 2^16
+                if (key < b1key) { if (b1key != 0xFFFFFFFFu) b2 = min(b2, (int)(b1key >> 16)); b1key = key; b1idx = (unsigned)i2; }
+                else b2 = min(b2, dist);
+            }
+            posBase += cnt;
+        }
+    const unsigned wkey = wave_min_u32(b1key);
+    if (wkey == 0xFFFFFFFFu) return make_uint3(wkey, 0x7fffffffu, 0u);
+    const unsigned long long who = __ballot(b1key == wkey);
+    const int bestIdx2 = __shfl((int)b1idx, __ffsll((long long)who) - 1);
+    const unsigned mine = (b1key == wkey) ? (unsigned)b2 : (b1key == 0xFFFFFFFFu ? 0x7fffffffu : (b1key >> 16));
+    return make_uint3(wkey, wave_min_u32(min(mine, (unsigned)b2)), (unsigned)bestIdx2);
+}
+
+// Phase 2: the sequential pass, one wave per pair.
 __global__ __launch_bounds__(64) void k_search_for_initialization(
     const pgorb_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc, const int32_t* __restrict__ nper,
     int cap, const int32_t* __restrict__ gstart, const int32_t* __restrict__ gidx,
     const int32_t* __restrict__ pairF1, const int32_t* __restrict__ pairF2,
     float minX, float minY, float invW, float invH,
     float* __restrict__ prevMatched, int32_t* __restrict__ matches12out, int32_t* __restrict__ nmatchesOut,
-    int windowSize, float nnratio, int checkOrientation)
+    int windowSize, float nnratio, int checkOrientation,
+    const uint32_t* __restrict__ lists, const uint8_t* __restrict__ listCnt)
 {
     const int lane = threadIdx.x, p = blockIdx.x;
     const int f1 = pairF1[p], f2 = pairF2[p];
@@ -136,88 +305,73 @@ __global__ __launch_bounds__(64) void k_search_for_initialization(
     const int32_t* idx2 = gidx + (int64_t)f2 * cap;
     float* prev = prevMatched + (int64_t)p * cap * 2;
     int32_t* m12out = matches12out + (int64_t)p * cap;
+    const uint32_t* L = lists + (int64_t)p * cap * SFI_K;
+    const uint8_t* LC = listCnt + (int64_t)p * cap;
 
     uint16_t* matchedDist = reinterpret_cast<uint16_t*>(pg_sfi_smem);      // [cap] vMatchedDistance (0xFFFF = INT_MAX)
     int16_t* m21 = reinterpret_cast<int16_t*>(matchedDist + cap);          // [cap] vnMatches21
     int16_t* m12 = m21 + cap;                                              // [cap] vnMatches12
-    uint16_t* candList = reinterpret_cast<uint16_t*>(m12 + cap);           // [cap] vIndices2
-    int8_t* rotBin = reinterpret_cast<int8_t*>(candList + cap);            // [cap] bin an i1 was pushed to
-    for (int i = lane; i < cap; i += 64) { matchedDist[i] = 0xFFFF; m21[i] = -1; m12[i] = -1; rotBin[i] = -1; }
+    int16_t* push2 = m12 + cap;                                            // [cap] i2 an i1 was matched to when it entered the histogram, or -1
+    uint16_t* active = reinterpret_cast<uint16_t*>(push2 + cap);           // [cap] F1 keypoints with candidates, in order
+    for (int i = lane; i < cap; i += 64) { matchedDist[i] = 0xFFFF; m21[i] = -1; m12[i] = -1; push2[i] = -1; }
+    int nact = 0;
+    for (int base = 0; base < n1; base += 512) {                             // (8 count loads in flight, not one round trip per 64 keypoints)
+        uint8_t cv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = base + 64 * u + lane; cv[u] = i < n1 ? LC[i] : (uint8_t)0; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const bool on = cv[u] != 0;
+            const unsigned long long m = __ballot(on);
+            if (on) active[nact + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] = (uint16_t)(base + 64 * u + lane);
+            nact += __popcll(m);
+        }
+    }
     __syncthreads();
 
     const float r = (float)windowSize;
-    const float factor = 1.0f / HISTO_LENGTH;
     int nmatches = 0;
-    for (int i1 = 0; i1 < n1; i1++) {
-        const pgorb_keypoint kp1 = K1[i1];
-        if (kp1.octave > 0) continue;                                       // :424-426
-        const int level1 = kp1.octave;
-        const float x = prev[2 * i1], y = prev[2 * i1 + 1];
-        // GetFeaturesInArea(x, y, r, level1, level1)  (Frame.cc:336-350)
-        const int nMinCellX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, minX), r), invW)));
-        if (nMinCellX >= GRID_COLS) continue;
-        const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, minX), r), invW)));
-        if (nMaxCellX < 0) continue;
-        const int nMinCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, minY), r), invH)));
-        if (nMinCellY >= GRID_ROWS) continue;
-        const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, minY), r), invH)));
-        if (nMaxCellY < 0) continue;
-        const int ncy = nMaxCellY - nMinCellY + 1;
-        const int T = max(0, (nMaxCellX - nMinCellX + 1)) * max(0, ncy);
-        // gather the window's cell ranges into the candidate list, in (ix, iy, j) order
-        int M = 0;
-        for (int base = 0; base < T; base += 64) {
-            const int t = base + lane;
-            int s = 0, cnt = 0;
-            if (t < T) {
-                const int ix = nMinCellX + t / ncy, iy = nMinCellY + t % ncy;
-                const int c = ix * GRID_ROWS + iy;
-                s = start2[c]; cnt = start2[c + 1] - s;
+    // group g = active[g * SFI_G .. ): entry `lane` of each member's list and its count, loaded one group ahead
+    uint32_t curE[SFI_G], nxtE[SFI_G]; int curC[SFI_G], nxtC[SFI_G], curI[SFI_G], nxtI[SFI_G];
+    auto load_group = [&](int g, uint32_t (&E)[SFI_G], int (&Cn)[SFI_G], int (&I)[SFI_G]) {
+#pragma unroll
+        for (int j = 0; j < SFI_G; j++) {
+            const int a = g * SFI_G + j;
+            I[j] = -1; Cn[j] = 0; E[j] = 0;
+            if (a < nact) {
+                const int i1 = active[a];
+                I[j] = i1; Cn[j] = LC[i1];
+                E[j] = L[(int64_t)i1 * SFI_K + lane];                        // (all 64 slots: no wait for the count; slots past it are masked below)
             }
-            const int incl = wave_incl_scan(cnt, lane);
-            const int off = M + incl - cnt;
-            for (int j = 0; j < cnt; j++) candList[off + j] = (uint16_t)idx2[s + j];
-            M += __shfl(incl, 63);
         }
-        __syncthreads();
-        if (M == 0) continue;                                               // vIndices2.empty() (before filtering it can only be larger)
-        // distances: one candidate per lane
-        const uint4 q0 = reinterpret_cast<const uint4*>(D1 + (int64_t)i1 * 32)[0];
-        const uint4 q1 = reinterpret_cast<const uint4*>(D1 + (int64_t)i1 * 32)[1];
-        unsigned b1key = 0xFFFFFFFFu;          // (dist << 16 | list position) of this lane's best
-        int b2 = 0x7fffffff;                   // this lane's second-smallest distance
-        for (int k = lane; k < M; k += 64) {
-            const int i2 = candList[k];
-            const pgorb_keypoint kp2 = K2[i2];
-            // bCheckLevels is true for minLevel = maxLevel = 0 (Frame.cc:354): octave must equal level1
-            if (kp2.octave < level1 || kp2.octave > level1) continue;
-            const float distx = __fsub_rn(kp2.x, x), disty = __fsub_rn(kp2.y, y);
-            if (!(fabsf(distx) < r && fabsf(disty) < r)) continue;
-            const uint4 d0 = reinterpret_cast<const uint4*>(D2 + (int64_t)i2 * 32)[0];
-            const uint4 d1 = reinterpret_cast<const uint4*>(D2 + (int64_t)i2 * 32)[1];
-            const int dist = __popc(q0.x ^ d0.x) + __popc(q0.y ^ d0.y) + __popc(q0.z ^ d0.z) + __popc(q0.w ^ d0.w) +
-                             __popc(q1.x ^ d1.x) + __popc(q1.y ^ d1.y) + __popc(q1.z ^ d1.z) + __popc(q1.w ^ d1.w);
-            if ((int)matchedDist[i2] <= dist) continue;                     // :445-446
-            const unsigned key = ((unsigned)dist << 16) | (unsigned)k;
-            if (key < b1key) { if (b1key != 0xFFFFFFFFu) b2 = min(b2, (int)(b1key >> 16)); b1key = key; }
-            else b2 = min(b2, dist);
-        }
-        const unsigned wkey = wave_min_u32(b1key);
-        if (wkey != 0xFFFFFFFFu) {
+    };
+    const int ngroups = (nact + SFI_G - 1) / SFI_G;
+    if (ngroups) load_group(0, curE, curC, curI);
+    for (int g = 0; g < ngroups; g++) {
+        if (g + 1 < ngroups) load_group(g + 1, nxtE, nxtC, nxtI);
+#pragma unroll
+        for (int j = 0; j < SFI_G; j++) {
+            const int i1 = curI[j];
+            if (i1 < 0) break;                                              // (wave-uniform)
+            unsigned wkey; int bestIdx2 = -1; unsigned second;
+            if (curC[j] != SFI_OVER) {
+                const int i2 = (int)(curE[j] & 0xFFFFu), dist = (int)(curE[j] >> 16);
+                const bool keep = lane < curC[j] && !((int)matchedDist[i2] <= dist);       // :445-446
+                const unsigned key = keep ? (((unsigned)dist << 16) | (unsigned)lane) : 0xFFFFFFFFu;
+                wave_min2_u32(key, wkey, second);                           // smallest key, and the smallest of the others
+                if (wkey == 0xFFFFFFFFu) continue;
+                bestIdx2 = __builtin_amdgcn_readlane(i2, (int)(wkey & 0xFFFFu));
+                second = (second == 0xFFFFFFFFu) ? 0x7fffffffu : (second >> 16);
+            } else {
+                // more than SFI_K candidates: evaluate in place, cell by cell in the reference's order
+                const uint3 ev = sfi_eval_in_place(K1[i1], prev[2 * i1], prev[2 * i1 + 1], r, minX, minY, invW, invH, D1 + (int64_t)i1 * 32, K2, D2,
+                                                   start2, idx2, matchedDist, lane);
+                wkey = ev.x; second = ev.y; bestIdx2 = (int)ev.z;
+                if (wkey == 0xFFFFFFFFu) continue;
+            }
             const int bestDist = (int)(wkey >> 16);
-            const int bestIdx2 = candList[wkey & 0xFFFF];
-            // second best: the other lanes' best, the winning lane's second
-            const unsigned mine = (b1key == wkey) ? (unsigned)b2 : (b1key == 0xFFFFFFFFu ? 0x7fffffffu : (b1key >> 16));
-            const unsigned lane2 = wave_min_u32(min(mine, (unsigned)b2));
-            const float bestDist2 = (lane2 >= 0x7fffffffu) ? 2147483648.0f : (float)(int)lane2;   // (float)INT_MAX
-            if (bestDist <= TH_LOW && (float)bestDist < __fmul_rn(bestDist2, nnratio)) {          // :460-462
-                int bin = -1;
-                if (checkOrientation) {                                      // :473-483
-                    float rot = __fsub_rn(kp1.angle, K2[bestIdx2].angle);
-                    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
-                    bin = (int)roundf(__fmul_rn(rot, factor));
-                    if (bin == HISTO_LENGTH) bin = 0;
-                }
+            const float bestDist2 = (second >= 0x7fffffffu) ? 2147483648.0f : (float)(int)second;   // (float)INT_MAX
+            if (bestDist <= TH_LOW && (float)bestDist < __fmul_rn(bestDist2, nnratio)) {            // :460-462
                 const int old = m21[bestIdx2];
                 if (old >= 0) nmatches--;                                    // :464-468
                 nmatches++;
@@ -226,16 +380,48 @@ __global__ __launch_bounds__(64) void k_search_for_initialization(
                     m12[i1] = (int16_t)bestIdx2;
                     m21[bestIdx2] = (int16_t)i1;
                     matchedDist[bestIdx2] = (uint16_t)bestDist;
-                    rotBin[i1] = (int8_t)bin;
+                    push2[i1] = (int16_t)bestIdx2;
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < SFI_G; j++) { curE[j] = nxtE[j]; curC[j] = nxtC[j]; curI[j] = nxtI[j]; }
+    }
+    __syncthreads();
+    if (checkOrientation) {
+        // histogram sizes = number of pushes per bin (a displaced i1 stays in its list, :481); the bin of a push is
+        // a function of the two keypoints' angles (:473-483)
+        const float factor = 1.0f / HISTO_LENGTH;
+        int8_t* rotBin = reinterpret_cast<int8_t*>(active);                  // [n1] (the active list is done)
+        int* hist = reinterpret_cast<int*>(pg_sfi_smem + (((size_t)cap * 10 + 3) & ~(size_t)3));      // [32] behind the arrays
+        if (lane < 32) hist[lane] = 0;
+        __syncthreads();
+        for (int base = 0; base < n1; base += 256) {                         // (the angle loads of 4 x 64 keypoints in flight)
+            int i2v[4]; float a1[4], a2[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = base + 64 * u + lane;
+                i2v[u] = i < n1 ? (int)push2[i] : -1;
+                a1[u] = 0.f; a2[u] = 0.f;
+                if (i2v[u] >= 0) { a1[u] = K1[i].angle; a2[u] = K2[i2v[u]].angle; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = base + 64 * u + lane;
+                int bin = -1;
+                if (i2v[u] >= 0) {
+                    float rot = __fsub_rn(a1[u], a2[u]);
+                    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                    bin = (int)roundf(__fmul_rn(rot, factor));
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    atomicAdd(&hist[bin], 1);
+                }
+                if (i < n1) rotBin[i] = (int8_t)bin;
             }
         }
         __syncthreads();
-    }
-    if (checkOrientation) {
-        // histogram sizes = number of pushes per bin (a displaced i1 stays in its list, :481)
-        int h = 0;                                                           // lane b < 30 counts bin b
-        for (int i = 0; i < n1; i++) h += (rotBin[i] == lane);
+        const int h = lane < HISTO_LENGTH ? hist[lane] : 0;                  // lane b < 30 holds the size of bin b
         int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
         for (int i = 0; i < HISTO_LENGTH; i++) {                             // ComputeThreeMaxima (:1605-1646)
             const int s = __shfl(h, i);
@@ -255,10 +441,21 @@ __global__ __launch_bounds__(64) void k_search_for_initialization(
         nmatches -= removed;
         __syncthreads();
     }
-    for (int i = lane; i < n1; i += 64) {                                    // :516-519
-        const int m = m12[i];
-        m12out[i] = m;
-        if (m >= 0) { prev[2 * i] = K2[m].x; prev[2 * i + 1] = K2[m].y; }
+    for (int base = 0; base < n1; base += 256) {                             // :516-519
+        int mv[4]; float2 xy[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = base + 64 * u + lane;
+            mv[u] = i < n1 ? (int)m12[i] : -1;
+            xy[u] = make_float2(0.f, 0.f);
+            if (mv[u] >= 0) xy[u] = *reinterpret_cast<const float2*>(&K2[mv[u]].x);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = base + 64 * u + lane;
+            if (i < n1) m12out[i] = mv[u];
+            if (mv[u] >= 0) *reinterpret_cast<float2*>(prev + 2 * i) = xy[u];
+        }
     }
     if (lane == 0) nmatchesOut[p] = nmatches;
 }
@@ -688,16 +885,28 @@ int pgorb_search_for_initialization_batch_device(pgorb_ctx* c, const pgorb_keypo
     if (!npairs) return 0;
     if (hipSetDevice(pg_ctx_device(c)) != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "hipSetDevice failed");
     const float invW = (float)GRID_COLS / (max_x - min_x), invH = (float)GRID_ROWS / (max_y - min_y);
-    const size_t lds = (size_t)cap * 9 + 64;
-    static size_t configured = 0;
-    if (lds > configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_for_initialization),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        configured = lds;
+    // scratch of the two passes: lists[npairs][cap][SFI_K] u32 | count[npairs][cap] u8
+    const size_t szL = (size_t)npairs * cap * SFI_K * 4;
+    void* scratch;
+    int rc = pg_ctx_stage(c, 3, szL + (size_t)npairs * cap + 256, &scratch);
+    if (rc) return rc;
+    uint32_t* lists = (uint32_t*)scratch;
+    uint8_t* listCnt = (uint8_t*)scratch + szL;
+    const size_t ldsA = (size_t)4 * cap * 2, ldsB = (size_t)cap * 10 + 192;      // (+ the 32-bin histogram)
+    static size_t configuredA = 0, configuredB = 0;
+    if (ldsA > configuredA) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sfi_candidates), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA);
+        configuredA = ldsA;
     }
-    hipLaunchKernelGGL(k_search_for_initialization, dim3(npairs), dim3(64), lds, (hipStream_t)stream, d_kps, d_desc,
+    if (ldsB > configuredB) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_for_initialization), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
+        configuredB = ldsB;
+    }
+    hipLaunchKernelGGL(k_sfi_candidates, dim3((cap + 3) / 4, npairs), dim3(256), ldsA, (hipStream_t)stream, d_kps, d_desc, d_n, cap,
+                       d_grid_start, d_grid_idx, d_pair_f1, d_pair_f2, min_x, min_y, invW, invH, d_prev_matched, window_size, lists, listCnt);
+    hipLaunchKernelGGL(k_search_for_initialization, dim3(npairs), dim3(64), ldsB, (hipStream_t)stream, d_kps, d_desc,
                        d_n, cap, d_grid_start, d_grid_idx, d_pair_f1, d_pair_f2, min_x, min_y, invW, invH,
-                       d_prev_matched, d_matches12, d_nmatches, window_size, nnratio, check_orientation);
+                       d_prev_matched, d_matches12, d_nmatches, window_size, nnratio, check_orientation, lists, listCnt);
     if (hipGetLastError() != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "k_search_for_initialization launch failed");
     return 0;
 }
