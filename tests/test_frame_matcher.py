@@ -74,6 +74,29 @@ def test_gpu_grid_and_search_for_initialization(oracle, ratio, ori, win):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("w,h,nf,nlev,win", [(480, 360, 3000, 2, 100), (400, 300, 2500, 1, 250), (640, 480, 1500, 8, 30)])
+def test_gpu_search_for_initialization_dense_windows(oracle, w, h, nf, nlev, win):
+    """Windows that hold more level-0 keypoints of F2 than the 64 candidates the parallel pass stores per F1 keypoint
+    (k_sfi_candidates): those keypoints are evaluated in place by the sequential pass, in the reference's (column, row,
+    insertion) order with the vMatchedDistance filter live (ORBmatcher.cc:440-457) -- mixed with stored lists in one
+    frame pair.  The last case is the all-lists control."""
+    import pilotguru_amd as pg
+    ride = synth_ride(14, w, h, 2, dx=5, dy=2)
+    ext = pg.ORBextractor(nf, 1.2, nlev, 20, 7, max_width=w, max_height=h)
+    F1, F2 = pg.Frame(ext, ride[0]), pg.Frame(ext, ride[1])
+    prev = np.stack([F1.mvKeys["x"], F1.mvKeys["y"]], 1).astype(np.float32)
+    lvl0 = F2.mvKeys[F2.mvKeys["octave"] == 0]
+    per_window = [int(((np.abs(lvl0["x"] - x) < win) & (np.abs(lvl0["y"] - y) < win)).sum()) for x, y in prev[F1.mvKeys["octave"] == 0][::7]]
+    if win >= 100:
+        assert max(per_window) > 64 and min(per_window) >= 1     # overflowed keypoints are present
+    else:
+        assert max(per_window) <= 64
+    onm, om12, oprev = oracle.search_for_initialization(F1.mvKeys, F1.mDescriptors, F2.mvKeys, F2.mDescriptors, F2.bounds, prev, win, 0.9, True)
+    nm, m12 = pg.ORBmatcher(0.9, True).SearchForInitialization(F1, F2, prev, win)
+    assert nm == onm and onm > 50 and np.array_equal(m12, om12) and prev.tobytes() == oprev.tobytes()
+
+
+@pytest.mark.gpu
 def test_gpu_search_for_initialization_batch_device(oracle):
     import ctypes as C
     import torch

@@ -1,6 +1,7 @@
 """One-off soak, batch paths: random configurations, a batch of 2-6 frames of MIXED scene kinds through
-(a) pgorb_extract_batch, (b) the streamed ingest (pgorb_stream_*, ragged batches, depth 2-3), plus the best-2 Hamming
-match of consecutive frames -- HIP path vs oracle, bit for bit.  tools/experiments/fuzz_parity.py is the single-frame soak.
+(a) pgorb_extract_batch, (b) the streamed ingest (pgorb_stream_*, ragged batches, depth 2-3) with its front-end stage
+(SearchForInitialization of every frame against its predecessor, random window / ratio / orientation check), plus the best-2
+Hamming match of consecutive frames -- HIP path vs oracle, bit for bit.  tools/experiments/fuzz_parity.py is the single-frame soak.
 usage: fuzz_batch_parity.py [cases] [seed]"""
 import sys, time
 sys.path.insert(0, '/root/repo')
@@ -49,22 +50,33 @@ for it in range(N):
     # streamed ingest with a ragged tail
     sb = int(rng.randint(1, B + 1)); depth = int(rng.randint(2, 4))
     st = pg.FrameStream(ext, w, h, sb, depth)
+    win = int(rng.choice([100, 100, 30, 250])); ratio = float(rng.choice([0.9, 0.7])); ori = bool(rng.randint(0, 2))
+    bounds = (0.0, float(w), 0.0, float(h))
+    st.frontend(bounds, win, ratio, ori, -1)
     res = {}; inflight = []; chunks = [(b0, min(sb, B - b0)) for b0 in range(0, B, sb)]
+    def collect(j, s0):
+        out = [np.array(a) for a in st.wait(s0)]
+        fe = st.frontend_results(s0, out[1].shape[0], out[1].shape[1])
+        res[j] = out + [np.array(fe[0]), np.array(fe[1])]
     for i, (b0, nb) in enumerate(chunks):
         slot = i % depth
-        if len(inflight) == depth:
-            j, s0 = inflight.pop(0); res[j] = [np.array(a) for a in st.wait(s0)]
+        if len(inflight) == depth: collect(*inflight.pop(0))
         st.input(slot)[:nb] = np.stack(frames[b0:b0 + nb]); st.submit(slot, nb); inflight.append((i, slot))
-    for j, s0 in inflight: res[j] = [np.array(a) for a in st.wait(s0)]
+    for j, s0 in inflight: collect(j, s0)
     st.close()
     for i, (b0, nb) in enumerate(chunks):
-        n, kps, desc, bi, b1, b2 = res[i]
+        n, kps, desc, bi, b1, b2, m12, nm = res[i]
         for k in range(nb):
             f = b0 + k
             okp, od = want[f]
             if n[k] != len(okp) or kps[k, :n[k]].tobytes() != okp.tobytes() or not np.array_equal(desc[k, :n[k]], od):
                 print("MISMATCH stream", it, f, w, h, scale, nlev, nf, ini, mn); bad += 1; continue
-            if f == 0 or n[k] == 0: continue
+            if f == 0: continue
+            pk, pdd = want[f - 1]
+            onm, om12, _ = orb_oracle.search_for_initialization(pk, pdd, okp, od, bounds, np.stack([pk["x"], pk["y"]], 1).astype(np.float32), win, ratio, ori)
+            if nm[k] != onm or not np.array_equal(m12[k, :len(pk)], om12):
+                print("MISMATCH init-match", it, f, w, h, nf, win, ratio, ori, int(nm[k]), onm); bad += 1
+            if n[k] == 0: continue
             pd = want[f - 1][1]
             if len(pd) == 0:
                 ok = np.all(bi[k, :n[k]] == -1)
