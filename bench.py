@@ -190,7 +190,7 @@ def verify_against_oracle(ride, kps, desc, n, mout, nfeatures):
     return True
 
 
-def upload_leg(pg, ext, ride, NF, W, H, B, seconds=2.0, depth=3):
+def upload_leg(pg, ext, ride, NF, W, H, B, seconds=2.0, depth=3, frontend=False, link=True):
     """The same step (extract + best-2 match of every frame against its predecessor) with frames that start in
     page-locked HOST memory: pgorb_stream_* with `depth` batches in flight (upload, kernels and result download on
     three HIP streams).  Reported next to the resident number, never as `value`.  Also measures what the link
@@ -198,6 +198,12 @@ def upload_leg(pg, ext, ride, NF, W, H, B, seconds=2.0, depth=3):
     import numpy as np
     import torch
     st = pg.FrameStream(ext, W, H, B, depth)
+    if frontend:
+        # + what the tracking thread does with every fresh Frame, on the device per batch: 64x48 grid,
+        # SearchForInitialization(previous, current) (Tracking.cc:583-597), ORBVocabulary::transform (Frame.cc:399-406)
+        from pilotguru_amd import vocab as V
+        V.ORBVocabulary(blob=V.synth_vocabulary_blob(10, 5, seed=7)).upload(ext)
+        st.frontend((0.0, float(W), 0.0, float(H)), 100, 0.9, True, 4)
     for sl in range(depth):
         st.input(sl)[:] = ride                              # "the decoder" has filled every slot
     # warm-up: fill the pipeline once
@@ -221,6 +227,10 @@ def upload_leg(pg, ext, ride, NF, W, H, B, seconds=2.0, depth=3):
     t1 = time.perf_counter()
     st.close()
     fps = done * B / (t1 - t0)
+    if not link:
+        return {"value": fps, "unit": "frames/s", "batches": done, "seconds": t1 - t0, "depth": depth,
+                "note": "as frames_uploaded, plus the stream's front-end stage per batch: grid, SearchForInitialization of every "
+                        "frame against its predecessor (window 100, ratio 0.9), BoW transform on a k=10 L=5 tree"}
     # the link: one pinned H2D copy of a batch, repeated
     host = torch.empty((B, H, W), dtype=torch.uint8).pin_memory()
     devt = torch.empty((B, H, W), dtype=torch.uint8, device="cuda")
@@ -400,6 +410,7 @@ def main():
     uploaded = None
     if not args.no_upload_leg and dist is None:
         uploaded = upload_leg(pg, ext, ride, NF, W, H, B, seconds=2.0)
+        uploaded["with_front_end_stage"] = upload_leg(pg, ext, ride, NF, W, H, B, seconds=1.5, frontend=True, link=False)
 
     if rank == 0:
         frames_total = world * B * args.steps
