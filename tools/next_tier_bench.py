@@ -97,11 +97,54 @@ word = torch.empty(nd, dtype=torch.int32, device="cuda"); wt = torch.empty(nd, d
 t_bow = timed(lambda: ext._check(ext._L.pgorb_bow_transform_device(ext._h, p(flat), nd, 4, p(word), p(wt), p(node), s)))
 rows.append(("BoW transform, k=10 L=6 (%d descriptors)" % nd, t_bow, nd * (32 + 6 * 10 * 32), float("nan")))
 
+# ---- the SLAM-state matchers (a11): single host calls (H2D + kernel + D2H, wall clock), median of 9, one frame pair ----------
+def wall(fn, reps=9):
+    fn(); ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); fn(); ts.append((time.perf_counter() - t0) * 1e3)
+    return float(np.median(ts))
+
+
+F1, F2 = pg.Frame(ext, ride[0]), pg.Frame(ext, ride[1])
+rng = np.random.RandomState(5)
+nk = F1.N
+sel = np.concatenate([rng.permutation(nk)[: int(nk * 0.8)]] * 1)
+px = (F1.mvKeys["x"][sel] - 2 + rng.uniform(-1.5, 1.5, len(sel))).astype(np.float32)       # the ride moves (2, 1) px per frame
+py = (F1.mvKeys["y"][sel] - 1 + rng.uniform(-1.5, 1.5, len(sel))).astype(np.float32)
+valid = (rng.uniform(size=len(sel)) > 0.05).astype(np.uint8); obs = (rng.uniform(size=len(sel)) > 0.1).astype(np.uint8)
+lvl = F1.mvKeys["octave"][sel].astype(np.int32); vc = np.full(len(sel), 0.9995, np.float32); pdsc = F1.mDescriptors[sel]
+mp = pg.MapPoints(valid, px, py, lvl, vc, pdsc, obs)
+sf = ext.GetScaleFactors()
+host_rows = []
+m = pg.ORBmatcher(0.8, True)
+g_ms = wall(lambda: m.SearchByProjection(F2, mp, 3.0, None))
+t0 = time.perf_counter(); onm, _ = orb_oracle.search_by_projection_points(F2.mvKeys, F2.mDescriptors, F2.bounds, sf, None, valid, px, py, lvl, vc, pdsc, obs, 3.0, 0.8); c_ms = (time.perf_counter() - t0) * 1e3
+host_rows.append(("SearchByProjection(Frame, MapPoints, th 3), %d points -> %d" % (len(sel), onm), g_ms, c_ms))
+m = pg.ORBmatcher(0.9, True)
+ang = F1.mvKeys["angle"][sel].copy()
+g_ms = wall(lambda: m.SearchByProjectionLastFrame(F2, valid, px, py, lvl, ang, pdsc, obs, 15.0))
+t0 = time.perf_counter(); onm, _ = orb_oracle.search_by_projection_frame(F2.mvKeys, F2.mDescriptors, F2.bounds, sf, None, valid, px, py, lvl, ang, pdsc, obs, 15.0, True); c_ms = (time.perf_counter() - t0) * 1e3
+host_rows.append(("SearchByProjection(Frame, LastFrame, th 15), %d points -> %d" % (len(sel), onm), g_ms, c_ms))
+_, fvK = voc.transform(F1.mDescriptors, 4); _, fvF = voc.transform(F2.mDescriptors, 4)
+kvalid = (rng.uniform(size=F1.N) > 0.3).astype(np.uint8)
+m = pg.ORBmatcher(0.7, True)
+g_ms = wall(lambda: m.SearchByBoW(ext, F1.mDescriptors, F1.mvKeys["angle"], kvalid, fvK, F2, fvF))
+t0 = time.perf_counter(); onm, _ = orb_oracle.search_by_bow(F1.mDescriptors, F1.mvKeys["angle"], kvalid, fvK, F2.mDescriptors, F2.mvKeys["angle"], fvF, 0.7, True); c_ms = (time.perf_counter() - t0) * 1e3
+host_rows.append(("SearchByBoW(KeyFrame, Frame), %d nodes -> %d" % (len(fvK[0]), onm), g_ms, c_ms))
+sm = pg.ORBmatcher(0.9, True)
+prevm = np.stack([F1.mvKeys["x"], F1.mvKeys["y"]], 1).astype(np.float32)
+g_ms = wall(lambda: sm.SearchForInitialization(F1, F2, prevm.copy(), 100))
+host_rows.append(("SearchForInitialization(F1, F2, 100), one pair through the host API", g_ms, c_sfi / (B - 1)))
+
 lines = ["# python tools/next_tier_bench.py --batch %d   (MI355X; ms per %d-frame 1080p batch; CPU = oracle, 1 thread, one frame or pair scaled to the batch)" % (B, B),
          "# extraction alone (K1-K6): %.3f ms" % t_plain,
          "%-58s %10s %12s %12s %10s" % ("kernel", "GPU ms", "us / frame", "GB/s (alg.)", "CPU ms")]
 for name, ms, byts, cpu in rows:
     lines.append("%-58s %10.3f %12.2f %12.1f %10.0f" % (name, ms, ms * 1e3 / B, byts / ms / 1e6, cpu))
+lines.append("# single host calls on one 1080p frame pair (upload + kernel + download, wall clock ms) next to the oracle's")
+lines.append("%-72s %10s %10s" % ("call", "GPU ms", "CPU ms"))
+for name, g, cc in host_rows:
+    lines.append("%-72s %10.3f %10.2f" % (name, g, cc))
 print("\n".join(lines))
 if a.out:
     open(a.out, "w").write("\n".join(lines) + "\n")
