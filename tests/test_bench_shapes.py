@@ -243,3 +243,32 @@ def test_streamed_front_end_stage_against_the_oracle(w, h, nf, total, batch, dep
                 ow, owt, on = voc.transform_features(de, 4)
                 assert np.array_equal(word[k, :n[k]], ow) and np.array_equal(wt[k, :n[k]], owt) and np.array_equal(node[k, :n[k]], on)
             prev = (kp, de)
+
+
+def test_stream_error_paths():
+    """The stream refuses what it cannot do, with a message: results of a slot that holds no batch, a second submit of an
+    uncollected slot, the front-end stage with a BoW transform but no vocabulary, front-end results when the stage is off."""
+    import pilotguru_amd as pg
+    from pilotguru_amd import _lib
+    w, h, nf, batch = 320, 240, 500, 2
+    ext = pg.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=batch)
+    st = pg.FrameStream(ext, w, h, batch, 2)
+    with pytest.raises(_lib.PgorbError, match="no batch in flight"):
+        st.wait(0)
+    with pytest.raises(_lib.PgorbError, match="not enabled"):
+        st.frontend_results(0, batch, ext.max_keypoints(w, h))
+    with pytest.raises(_lib.PgorbError):                       # BoW asked for, no vocabulary resident
+        st.frontend((0.0, float(w), 0.0, float(h)), 100, 0.9, True, 4)
+    with pytest.raises(_lib.PgorbError):
+        st.frontend((0.0, 0.0, 0.0, float(h)), 100, 0.9, True, -1)      # empty image bounds
+    st.input(0)[:] = synth_ride(2, w, h, batch)
+    st.submit(0)
+    with pytest.raises(_lib.PgorbError, match="not collected"):
+        st.submit(0)
+    with pytest.raises(_lib.PgorbError, match="in flight"):
+        st.frontend((0.0, float(w), 0.0, float(h)), 100, 0.9, True, -1)
+    n = st.wait(0)[0]
+    assert len(n) == batch and n.min() > 100
+    with pytest.raises(Exception):
+        pg.FrameStream(ext, w, h, batch + 1, 2)                 # more than max_batch
+    st.close()
