@@ -423,7 +423,7 @@ int      pgorb_stream_wait(pgorb_stream* s, int slot, const int32_t** n, const p
  * feature word / weight / node, pgorb_bow_vectors turns them into BowVector / FeatureVector on the host).
  * Call with no batch in flight; the next batch starts a new ride.  After pgorb_stream_wait(slot):
  * pgorb_stream_frontend_results -> matches12[f * cap + i1] (-1 = none) and nmatches[f] for the pair (frame f - 1,
- * frame f) -- the first frame of a ride has no predecessor and reports 0 matches --, word / weight / node
+ * frame f) -- the first frame of a ride has no predecessor: it reports 0 matches and its matches12 row is undefined --, word / weight / node
  * [f * cap + i] (nullptr without BoW); valid until the slot is submitted again. */
 int      pgorb_stream_frontend(pgorb_stream* s, float min_x, float max_x, float min_y, float max_y, int window_size,
                                float nnratio, int check_orientation, int bow_levelsup);
