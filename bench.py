@@ -260,6 +260,7 @@ def main():
     ap.add_argument("--features", type=int, default=2000)
     ap.add_argument("--scene", choices=("textured", "road"), default="textured",
                     help="textured = SURVEY.md 8d's scene (the headline workload); road = sky / asphalt / texture band")
+    ap.add_argument("--no-overlap-leg", action="store_true", help="skip the two-batches-in-flight leg (second context)")
     ap.add_argument("--sustain-seconds", type=float, default=3.0,
                     help="after the timed steps, keep stepping for this long and report sustained_fps (0 = skip)")
     ap.add_argument("--pipeline-pyramid", type=int, default=None,
@@ -390,6 +391,44 @@ def main():
         ext.check_async()
         sustained = {"fps": ksteps * B / (te - ts), "seconds": te - ts, "steps": ksteps}
 
+    # two batches in flight: a second context on a second HIP stream takes every other batch, so that kernels with
+    # different bottlenecks (K1 HBM, K2 / K4-6 VALU issue, K3 latency, K7 matrix pipe) of neighbouring batches share the
+    # chip.  Same work per batch; reported next to `value`, not as it (the kernels' own durations stretch when they share
+    # the GPU, so `roofline` and the stage times stay those of the one-batch-at-a-time loop above).
+    inflight2 = None
+    if not args.no_overlap_leg and dist is None and B > 1:
+        ext2 = pg.ORBextractor(NF, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B, device=local_rank)
+        outs2 = (torch.empty_like(kps), torch.empty_like(desc), torch.empty_like(n))
+        mout2 = tuple(torch.empty_like(t) for t in mout)
+        sA, sB = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+
+        def step2(k):
+            if k & 1:
+                ext2.extract_batch_device(frames, *outs2, stream=sB.cuda_stream)
+                ext2.match_batch_device(outs2[1], outs2[2], pq, pt, mout2, stream=sB.cuda_stream)
+            else:
+                ext.extract_batch_device(frames, kps, desc, n, stream=sA.cuda_stream)
+                ext.match_batch_device(desc, n, pq, pt, mout, stream=sA.cuda_stream)
+        torch.cuda.synchronize()
+        for k in range(4):
+            step2(k)
+        torch.cuda.synchronize()
+        ts = time.perf_counter(); ksteps = 0
+        while time.perf_counter() - ts < 1.5:
+            for k in range(40):
+                step2(k)
+            torch.cuda.synchronize()
+            ksteps += 40
+        te = time.perf_counter()
+        ext.check_async(); ext2.check_async()
+        nh2 = n.cpu().tolist()
+        same = torch.equal(n, outs2[2]) and all(torch.equal(desc[f, :nh2[f]], outs2[1][f, :nh2[f]]) and
+                                                torch.equal(kps[f, :nh2[f]].view(torch.int32), outs2[0][f, :nh2[f]].view(torch.int32)) for f in range(B))
+        inflight2 = {"fps": ksteps * B / (te - ts), "seconds": te - ts, "steps": ksteps, "contexts": 2, "streams": 2,
+                     "second_context_equal": bool(same),
+                     "note": "two contexts on two HIP streams take alternate batches of the same size; nothing else changes"}
+        del ext2
+
     # the matcher the north star describes (ballot / popcount), timed on the same descriptors
     matcher = ext.matcher_name(cap)
     popcount_ms = None
@@ -467,6 +506,8 @@ def main():
         if sustained is not None:
             out["sustained_fps"] = sustained["fps"]
             out["sustained"] = sustained
+        if inflight2 is not None:
+            out["two_batches_in_flight"] = inflight2
         if uploaded is not None:
             out["frames_uploaded"] = uploaded
         if not args.no_cpu_baseline and world == 1:            # rank 0 at N=1 only

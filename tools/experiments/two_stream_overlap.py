@@ -9,8 +9,8 @@ from pilotguru_amd.synth import synth_ride
 
 W, H, NF, B = 1920, 1080, 2000, 128
 ride = torch.from_numpy(synth_ride(0, W, H, B)).cuda()
-for parts in (1, 2, 4, 8, 16):
-    bs = B // parts
+ride = torch.cat([ride, ride, ride, ride])
+for parts, bs in ((1, 128), (2, 64), (4, 32), (2, 128), (3, 128), (2, 256)):
     exts = [pg.ORBextractor(NF, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=bs) for _ in range(parts)]
     streams = [torch.cuda.Stream() for _ in range(parts)]
     cap = exts[0].max_keypoints(W, H)
@@ -30,5 +30,5 @@ for parts in (1, 2, 4, 8, 16):
     for _ in range(20): step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 20
-    print("%d context(s) x %d frames on %d stream(s): %.3f ms per %d frames -> %.0f frames/s" % (parts, bs, parts, dt * 1e3, B, B / dt))
+    print("%d context(s) x %d frames on %d stream(s): %.3f ms per %d frames -> %.0f frames/s" % (parts, bs, parts, dt * 1e3, parts * bs, parts * bs / dt))
     del exts
