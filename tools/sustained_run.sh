@@ -6,10 +6,10 @@ OUT=gpurun_out/${TAG}_sustained.txt
 mkdir -p gpurun_out
 ( while true; do echo "t=$(date +%s.%N)"; rocm-smi --showclocks --showpower --showuse 2>/dev/null | grep -E "sclk|mclk|fclk|Power|GPU use" ; sleep 0.5; done ) > gpurun_out/${TAG}_smi.log 2>&1 &
 SMI=$!
-python bench.py --steps 20 --warmup 5 --sustain-seconds ${SUSTAIN:-6} --no-cpu-baseline --no-upload-leg > gpurun_out/${TAG}_sustained_line.json 2> gpurun_out/${TAG}_sustained.err
+python bench.py --steps 20 --warmup 5 --sustain-seconds ${SUSTAIN:-6} --no-cpu-baseline --no-upload-leg --no-overlap-leg > gpurun_out/${TAG}_sustained_line.json 2> gpurun_out/${TAG}_sustained.err
 kill $SMI 2>/dev/null
 {
-  echo "# python bench.py --steps 20 --warmup 5 --sustain-seconds ${SUSTAIN:-6} --no-cpu-baseline --no-upload-leg ; rocm-smi sampled every 0.5 s beside it"
+  echo "# python bench.py --steps 20 --warmup 5 --sustain-seconds ${SUSTAIN:-6} --no-cpu-baseline --no-upload-leg --no-overlap-leg ; rocm-smi sampled every 0.5 s beside it"
   python - <<PY
 import json
 d = json.loads(open("gpurun_out/${TAG}_sustained_line.json").read().strip().splitlines()[-1])
