@@ -7,7 +7,7 @@ TAG=${1:-r01_x}; shift || true
 OUT=gpurun_out/$TAG
 export TMPDIR=/tmp
 mkdir -p "$OUT"
-ARGS="--steps 20 --warmup 5 --no-cpu-baseline $*"
+ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-overlap-leg $*"
 run() { name=$1; shift; rocprofv3 "$@" -d "$OUT/$name" -- python bench.py $ARGS > "$OUT/$name.log" 2>&1 || true; find "$OUT/$name" -name '*.db' | head -1; }
 db=$(run stats --kernel-trace --stats)
 { echo "# rocprofv3 --kernel-trace --stats -- python bench.py $ARGS   (durations in us)"; python tools/rocpd_summary.py stats "$db"; } > "$OUT/${TAG}_kernel_stats.txt"
