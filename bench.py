@@ -9,6 +9,9 @@ against its predecessor in the ride.  Workload = BASELINE.json configs[1].
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches its own N ranks (it
+re-executes itself under torch.distributed.run on 127.0.0.1 with a free port), so both command shapes work.
+
 Multi-GPU: frames are independent, so every rank runs its own ride on its own GPU (weak
 scaling, no data-path collective); the only collective is one RCCL broadcast of the ORB
 vocabulary at start-up (outside the timed region), plus the barrier / max-over-ranks timing.
@@ -249,6 +252,99 @@ def upload_leg(pg, ext, ride, NF, W, H, B, seconds=2.0, depth=3, frontend=False,
                     "three HIP streams (pgorb_stream_*); PCIe-inclusive, not the headline value"}
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU
+    (rank r -> device r), rendezvous on 127.0.0.1.  The children's stdout is ours, so rank 0's JSON line is the
+    last line this process prints; the exit code is the launcher's."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this host driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        sys.stderr.write("bench.py: self-launched %d-rank job failed with exit code %d\n" % (n, rc))
+    raise SystemExit(rc)
+
+
+def timed_steps(step, steps, dist, dev, sync):
+    """The contract's timed region: barrier + device sync on both sides of exactly `steps` steps.  Returns
+    (max-over-ranks seconds, [every rank's own seconds])."""
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    t_own = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is None:
+        return elapsed, [elapsed]
+    import torch
+    from pilotguru_amd import dist as pgd
+    mine = torch.tensor([t_own], dtype=torch.float64, device=dev)
+    allt = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(allt, mine)
+    return pgd.max_over_ranks(elapsed, dev), [float(t.item()) for t in allt]
+
+
+def scaling_fields(world, frames_per_rank, elapsed, per_rank_s, n1_fps):
+    """Per-rank rates and, when the caller supplies the N = 1 figure (--n1-fps), the efficiency that follows
+    from them.  (The driver computes its own efficiency from the per-N `value`s; this is a convenience.)"""
+    out = {"per_rank_fps": [frames_per_rank / t for t in per_rank_s], "max_rank_seconds": elapsed}
+    if n1_fps:
+        out["n1_fps"] = n1_fps
+        out["scaling_efficiency"] = (world * frames_per_rank / elapsed) / (world * n1_fps)
+    return out
+
+
+def launcher_test_rank(args):
+    """PGORB_BENCH_LAUNCHER_TEST=1: the rank plumbing alone on a box WITHOUT a GPU (tests/test_bench_launcher.py) --
+    gloo instead of RCCL, the vocabulary broadcast on CPU tensors, the step replaced by a fixed sleep.  The line it
+    prints is labelled as such and is not a measurement."""
+    import torch
+    import torch.distributed as dist
+    from pilotguru_amd import dist as pgd
+    from pilotguru_amd.vocab import synth_vocabulary_blob
+    rank, _, world = pgd.env_world()
+    dist.init_process_group("gloo")
+    dev = torch.device("cpu")
+    blob = synth_vocabulary_blob(k=4, L=3, seed=7) if rank == 0 else None
+    tb0 = time.perf_counter()
+    vocab = pgd.broadcast_vocabulary(blob, 0, dev)
+    tb = time.perf_counter() - tb0
+    sig = torch.tensor([int(vocab.to(torch.int64).sum())])
+    sigs = [torch.empty_like(sig) for _ in range(world)]
+    dist.all_gather(sigs, sig)
+    assert all(torch.equal(sigs[0], x) for x in sigs)
+    elapsed, per_rank = timed_steps(lambda: time.sleep(0.002 * (1 + rank)), args.steps, dist, dev, lambda: None)
+    if rank == 0:
+        out = {"metric": "LAUNCHER TEST (no GPU work)", "value": world * args.batch * args.steps / elapsed, "unit": "frames/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+               "launcher_test": True, "rides": [pgd.ride_for_rank(r, world) for r in range(world)],
+               "config": {"vocab_broadcast_bytes": int(vocab.numel()), "vocab_broadcast_s": tb}}
+        out.update(scaling_fields(world, args.batch * args.steps, elapsed, per_rank, args.n1_fps))
+        line = json.dumps(out)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(line, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -268,7 +364,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-upload-leg", action="store_true")
+    ap.add_argument("--n1-fps", type=float, default=None,
+                    help="the N = 1 frames/s of the same configuration; adds scaling_efficiency to the line")
     args = ap.parse_args()
+
+    if (args.gpus > 1 or os.environ.get("PGORB_BENCH_FORCE_LAUNCH")) and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)                                  # does not return
+    if os.environ.get("PGORB_BENCH_LAUNCHER_TEST"):
+        if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+            raise SystemExit("--gpus %d but WORLD_SIZE=%s" % (args.gpus, os.environ.get("WORLD_SIZE")))
+        return launcher_test_rank(args)
 
     import numpy as np
     import torch
@@ -280,6 +385,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d: local rank %d but only %d GPU(s) visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -353,20 +460,7 @@ def main():
     counts = n.cpu().numpy()
 
     ext.profile_begin(args.steps)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if dist is not None:
-        from pilotguru_amd import dist as pgd
-        elapsed = pgd.max_over_ranks(elapsed, dev)
+    elapsed, per_rank_s = timed_steps(step, args.steps, dist, dev, torch.cuda.synchronize)
     ncalls, stage_ms = ext.profile_read()
     ext.check_async()
 
@@ -503,6 +597,7 @@ def main():
             "whole_path_algorithmic_GBps": sum(abytes.values()) * fps / world / 1e9,
             "verified": verified,
         }
+        out.update(scaling_fields(world, B * args.steps, elapsed, per_rank_s, args.n1_fps))
         if sustained is not None:
             out["sustained_fps"] = sustained["fps"]
             out["sustained"] = sustained
