@@ -408,8 +408,18 @@ int  pgorb_profile_read(pgorb_ctx* ctx, double* ms);
  * One stream per context at a time; the context's other calls must not run between submit and wait. */
 typedef struct pgorb_stream pgorb_stream;
 int      pgorb_stream_create(pgorb_ctx* ctx, int w, int h, int batch, int depth, pgorb_stream** out);
-void     pgorb_stream_destroy(pgorb_stream* s);
-uint8_t* pgorb_stream_input(pgorb_stream* s, int slot);          /* batch * h * w bytes, row pitch w */
+/* The same stream for frames EXACTLY AS THE DECODER PRODUCES THEM: the reference's reader hands out RGB24 frames
+ * (src/io/image_sequence_reader.cc:138-208, per-pixel copy :174-183), rotates them by the video metadata (:186-205),
+ * the wrapper source flips them (:53-58, :212-222) and Tracking::GrabImageMonocular converts to grey
+ * (thirdparty/orb-slam2/src/Tracking.cc:247-260) -- all on the host.  Here a slot holds src_w x src_h frames of
+ * `channels` (1, 3, 4) interleaved bytes per pixel, row pitch src_w * channels, rgb_order as in
+ * pgorb_extract_batch_ingest_device; rotation, flips and the grey conversion run on the device in front of K1 (one
+ * pass: k_ingest / k_ingest_rows) and the extractor sees the upright (src_h x src_w for 90 / 270) grey frame.  Results,
+ * matches across batch borders and the front-end stage are those of pgorb_stream_create on the host-converted frames. */
+int      pgorb_stream_create_ingest(pgorb_ctx* ctx, int src_w, int src_h, int channels, int rgb_order, int rotate_degrees,
+                                    int vertical_flip, int horizontal_flip, int batch, int depth, pgorb_stream** out);
+void     pgorb_stream_destroy(pgorb_stream* s);                  /* pgorb_destroy(ctx) also destroys the context's live streams */
+uint8_t* pgorb_stream_input(pgorb_stream* s, int slot);          /* batch * src_h * src_w * channels bytes, row pitch src_w * channels */
 int      pgorb_stream_reset(pgorb_stream* s);                    /* the next batch starts a new ride */
 int      pgorb_stream_submit(pgorb_stream* s, int slot, int nframes);
 int      pgorb_stream_wait(pgorb_stream* s, int slot, const int32_t** n, const pgorb_keypoint** kps, const uint8_t** desc,

@@ -58,6 +58,7 @@ struct pgorb_ctx {
     std::vector<hipEvent_t> evExtract;        // 5 per armed extract call
     std::vector<hipEvent_t> evMatch;          // 2 per armed match call
     int profMax = 0, profExtract = 0, profMatch = 0;
+    std::vector<pgorb_stream*> streams;       // live pgorb_stream_* objects of this context (pgorb_destroy takes them along)
 };
 
 namespace {
@@ -635,6 +636,7 @@ void pgorb_destroy(pgorb_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->prm.device);
+    while (!c->streams.empty()) pgorb_stream_destroy(c->streams.back());      // a stream holds a pointer to its context
     Arena* all[] = {&c->blockTab, &c->cellTab, &c->cellTabBal, &c->cellCand, &c->cellCount, &c->pyr, &c->cand, &c->sel, &c->nodes, &c->counters, &c->tables,
                     &c->stageKps, &c->stageDesc, &c->stageN, &c->stageA, &c->stageB, &c->stageOut, &c->stageSfi, &c->vocab, &c->xdesc};
     for (Arena* a : all) if (a->p) (void)hipFree(a->p);
@@ -1029,11 +1031,17 @@ int pgorb_debug_level_keypoints(pgorb_ctx* c, int frame, int level)
 // the three streams per slot; nothing blocks the host until pgorb_stream_wait.
 struct pgorb_stream {
     pgorb_ctx* c = nullptr;
-    int w = 0, h = 0, B = 0, depth = 0, cap = 0;
+    int w = 0, h = 0, B = 0, depth = 0, cap = 0;               // w x h: the UPRIGHT frame the extractor sees
+    // input format of the slots (pgorb_stream_create_ingest): frames exactly as decoded -- srcW x srcH pixels of `ch`
+    // interleaved bytes, rotation / flips / grey conversion done on the device in front of K1 (k_ingest*, pyramid.hip)
+    int srcW = 0, srcH = 0, ch = 1, rgbOrder = 1, rot = 0, vflip = 0, hflip = 0;
+    bool ingest = false;                                      // false: grey, upright -> level 0 aliases the slot's device frames
+    size_t inBytes = 0;                                       // bytes per input frame
+    bool dead = false;                                        // a submit failed half way: the stream only accepts destroy
     hipStream_t sIn = nullptr, sRun = nullptr, sOut = nullptr;
     struct Slot {
-        uint8_t* hIn = nullptr;            // pinned [B][h][w]
-        uint8_t* dIn = nullptr;            // device  [B][h][w]
+        uint8_t* hIn = nullptr;            // pinned [B][srcH][srcW][ch]
+        uint8_t* dIn = nullptr;            // device copy of it
         uint8_t* dOut = nullptr;           // device result block (layout below)
         uint8_t* hOut = nullptr;           // pinned copy of it
         hipEvent_t evIn = nullptr, evRun = nullptr, evOut = nullptr;
@@ -1051,6 +1059,8 @@ struct pgorb_stream {
     size_t offM12 = 0, offNM = 0, offW = 0, offWt = 0, offNd = 0;
     int32_t *dGridStart = nullptr, *dGridIdx = nullptr; float* dPrevMatched = nullptr;     // device scratch, [B+1] frames
 };
+
+static int stream_submit_queue(pgorb_stream* s, pgorb_stream::Slot& sl, int nframes);
 
 // result-block layout for the stream's current settings (kps and desc hold B+1 frames: index 0 = the previous batch's last frame)
 static void stream_layout(pgorb_stream* s)
@@ -1071,17 +1081,28 @@ static void stream_layout(pgorb_stream* s)
 
 extern "C" {
 
-int pgorb_stream_create(pgorb_ctx* c, int w, int h, int batch, int depth, pgorb_stream** out)
+int pgorb_stream_create_ingest(pgorb_ctx* c, int src_w, int src_h, int channels, int rgb_order, int rotate_degrees,
+                               int vertical_flip, int horizontal_flip, int batch, int depth, pgorb_stream** out)
 {
     if (!c || !out) return PGORB_E_ARG;
     *out = nullptr;
-    if (batch < 1 || batch > c->prm.max_batch || depth < 2 || depth > 8 || w < 1 || h < 1)
+    if (batch < 1 || batch > c->prm.max_batch || depth < 2 || depth > 8 || src_w < 1 || src_h < 1)
         return fail(c, PGORB_E_ARG, "pgorb_stream_create: batch 1..max_batch, depth 2..8");
+    if (channels != 1 && channels != 3 && channels != 4)
+        return fail(c, PGORB_E_ARG, "pgorb_stream_create_ingest: channels must be 1, 3 or 4");
+    if (rotate_degrees != 0 && rotate_degrees != 90 && rotate_degrees != 180 && rotate_degrees != 270)
+        return fail(c, PGORB_E_ARG, "unsupported rotation %d: only multiples of 90 degrees", rotate_degrees);   // reader :203-207
+    const bool swap = rotate_degrees == 90 || rotate_degrees == 270;
+    const int w = swap ? src_h : src_w, h = swap ? src_w : src_h;
     PG_HIP(c, hipSetDevice(c->prm.device));
     int rc = make_plan(c, w, h, batch);
     if (rc) return rc;
     pgorb_stream* s = new pgorb_stream();
     s->c = c; s->w = w; s->h = h; s->B = batch; s->depth = depth; s->cap = c->plan.selTotal;
+    s->srcW = src_w; s->srcH = src_h; s->ch = channels; s->rgbOrder = rgb_order ? 1 : 0; s->rot = rotate_degrees / 90;
+    s->vflip = vertical_flip ? 1 : 0; s->hflip = horizontal_flip ? 1 : 0;
+    s->ingest = channels != 1 || s->rot || s->vflip || s->hflip;
+    s->inBytes = (size_t)src_w * src_h * channels;
     const size_t cap = (size_t)s->cap, B = (size_t)batch;
     stream_layout(s);
     bool ok = hipStreamCreateWithFlags(&s->sIn, hipStreamNonBlocking) == hipSuccess &&
@@ -1089,8 +1110,8 @@ int pgorb_stream_create(pgorb_ctx* c, int w, int h, int batch, int depth, pgorb_
               hipStreamCreateWithFlags(&s->sOut, hipStreamNonBlocking) == hipSuccess;
     s->slot.resize(depth);
     for (auto& sl : s->slot) {
-        ok = ok && hipHostMalloc((void**)&sl.hIn, B * w * h, hipHostMallocDefault) == hipSuccess;
-        ok = ok && hipMalloc((void**)&sl.dIn, B * w * h + 256) == hipSuccess;
+        ok = ok && hipHostMalloc((void**)&sl.hIn, B * s->inBytes, hipHostMallocDefault) == hipSuccess;
+        ok = ok && hipMalloc((void**)&sl.dIn, B * s->inBytes + 256) == hipSuccess;
         ok = ok && hipMalloc((void**)&sl.dOut, s->outBytes + 256) == hipSuccess;
         ok = ok && hipHostMalloc((void**)&sl.hOut, s->outBytes + 256, hipHostMallocDefault) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&sl.evIn, hipEventDisableTiming) == hipSuccess;
@@ -1106,14 +1127,24 @@ int pgorb_stream_create(pgorb_ctx* c, int w, int h, int batch, int depth, pgorb_
     ok = ok && hipMemcpy(s->dPt, pt.data(), B * 4, hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && ensure(c, c->xdesc, pg_match_scratch_bytes(s->cap, batch) + 16) == 0;
     if (!ok) { pgorb_stream_destroy(s); return fail(c, PGORB_E_HIP, "pgorb_stream_create: allocation failed"); }
+    c->streams.push_back(s);
     *out = s;
     return 0;
+}
+
+int pgorb_stream_create(pgorb_ctx* c, int w, int h, int batch, int depth, pgorb_stream** out)
+{
+    return pgorb_stream_create_ingest(c, w, h, 1, 1, 0, 0, 0, batch, depth, out);
 }
 
 void pgorb_stream_destroy(pgorb_stream* s)
 {
     if (!s) return;
     (void)hipSetDevice(s->c->prm.device);
+    {
+        auto& v = s->c->streams;
+        v.erase(std::remove(v.begin(), v.end(), s), v.end());
+    }
     if (s->sIn) (void)hipStreamSynchronize(s->sIn);
     if (s->sRun) (void)hipStreamSynchronize(s->sRun);
     if (s->sOut) (void)hipStreamSynchronize(s->sOut);
@@ -1157,12 +1188,31 @@ int pgorb_stream_submit(pgorb_stream* s, int slot, int nframes)
     if (!s || slot < 0 || slot >= s->depth) return PGORB_E_ARG;
     pgorb_ctx* c = s->c;
     if (nframes < 1 || nframes > s->B) return fail(c, PGORB_E_ARG, "pgorb_stream_submit: 1..batch frames");
+    if (s->dead) return fail(c, PGORB_E_HIP, "pgorb_stream_submit: an earlier submit failed half way; destroy the stream");
     pgorb_stream::Slot& sl = s->slot[slot];
     if (sl.busy) return fail(c, PGORB_E_ARG, "pgorb_stream_submit: slot %d not collected with pgorb_stream_wait", slot);
     PG_HIP(c, hipSetDevice(c->prm.device));
     int rc = make_plan(c, s->w, s->h, nframes);
     if (rc) return rc;
-    const size_t fbytes = (size_t)s->w * s->h, cap = (size_t)s->cap;
+    rc = stream_submit_queue(s, sl, nframes);
+    if (rc) {
+        // part of the batch may be queued on the three streams with no event recorded for the slot: drain them, so
+        // that nothing is still writing into the slot's buffers, and retire the stream
+        (void)hipStreamSynchronize(s->sIn); (void)hipStreamSynchronize(s->sRun); (void)hipStreamSynchronize(s->sOut);
+        s->dead = true;
+        return rc;
+    }
+    sl.frames = nframes; sl.busy = true;
+    return 0;
+}
+
+}  // extern "C"
+
+static int stream_submit_queue(pgorb_stream* s, pgorb_stream::Slot& sl, int nframes)
+{
+    pgorb_ctx* c = s->c;
+    int rc;
+    const size_t fbytes = s->inBytes, cap = (size_t)s->cap;
     // copy-in: after the kernels of this slot's previous batch have read its device frames
     PG_HIP(c, hipStreamWaitEvent(s->sIn, sl.evRun, 0));
     PG_HIP(c, hipMemcpyAsync(sl.dIn, sl.hIn, fbytes * nframes, hipMemcpyHostToDevice, s->sIn));
@@ -1180,7 +1230,15 @@ int pgorb_stream_submit(pgorb_stream* s, int slot, int nframes)
     } else {
         PG_HIP(c, hipMemsetAsync(dN, 0, 4, s->sRun));
     }
-    rc = run_batch(c, sl.dIn, false, nframes, s->w, s->h, s->w, (int64_t)fbytes, dK + cap, dD + cap * 32, s->cap, dN + 1, s->sRun);
+    if (s->ingest) {
+        // frames as decoded: rotation / flips / cvtColor on the device into level 0 (image_sequence_reader.cc:53-58,186-205;
+        // Tracking.cc:247-260), then the extractor on the upright grey planes
+        pg_launch_ingest(c->plan, sl.dIn, s->srcW * s->ch, (int64_t)fbytes, s->srcW, s->srcH, s->ch, s->rgbOrder, s->rot,
+                         s->vflip != 0, s->hflip != 0, nframes, s->sRun);
+        rc = run_batch(c, nullptr, true, nframes, s->w, s->h, s->w, 0, dK + cap, dD + cap * 32, s->cap, dN + 1, s->sRun);
+    } else {
+        rc = run_batch(c, sl.dIn, false, nframes, s->w, s->h, s->w, (int64_t)fbytes, dK + cap, dD + cap * 32, s->cap, dN + 1, s->sRun);
+    }
     if (rc) return rc;
     pg_launch_match_batch(dD, dN, s->cap, s->dPq, s->dPt, nframes, (uint8_t*)c->xdesc.p, (int32_t*)(sl.dOut + s->offI),
                           (uint16_t*)(sl.dOut + s->offB1), (uint16_t*)(sl.dOut + s->offB2), s->sRun);
@@ -1211,9 +1269,10 @@ int pgorb_stream_submit(pgorb_stream* s, int slot, int nframes)
     PG_HIP(c, hipMemcpyAsync(sl.hOut, sl.dOut, s->outBytes + 4, hipMemcpyDeviceToHost, s->sOut));
     PG_HIP(c, hipEventRecord(sl.evOut, s->sOut));
     PG_HIP(c, hipGetLastError());
-    sl.frames = nframes; sl.busy = true;
     return 0;
 }
+
+extern "C" {
 
 int pgorb_stream_wait(pgorb_stream* s, int slot, const int32_t** n, const pgorb_keypoint** kps, const uint8_t** desc,
                       const int32_t** best_idx, const uint16_t** best, const uint16_t** second, int* cap)
@@ -1252,24 +1311,38 @@ int pgorb_stream_frontend(pgorb_stream* s, float min_x, float max_x, float min_y
     }
     PG_HIP(c, hipSetDevice(c->prm.device));
     PG_HIP(c, hipDeviceSynchronize());
+    // new result blocks first; the stream's settings and buffers change only when every allocation succeeded
+    pgorb_stream t = *s;                                       // (layout arithmetic on a copy)
+    t.fe = true; t.feLevelsUp = bow_levelsup;
+    stream_layout(&t);
+    const size_t cap = (size_t)s->cap, B = (size_t)s->B;
+    std::vector<uint8_t*> nd(s->slot.size(), nullptr), nh(s->slot.size(), nullptr);
+    int32_t *gs = s->dGridStart, *gi = s->dGridIdx; float* pm = s->dPrevMatched;
+    bool ok = true;
+    for (size_t i = 0; i < s->slot.size(); i++) {
+        ok = ok && hipMalloc((void**)&nd[i], t.outBytes + 256) == hipSuccess;
+        ok = ok && hipHostMalloc((void**)&nh[i], t.outBytes + 256, hipHostMallocDefault) == hipSuccess;
+    }
+    if (!s->dGridStart) {
+        gs = nullptr; gi = nullptr; pm = nullptr;
+        ok = ok && hipMalloc((void**)&gs, (B + 1) * (PGORB_GRID_CELLS + 1) * 4) == hipSuccess;
+        ok = ok && hipMalloc((void**)&gi, (B + 1) * cap * 4) == hipSuccess;
+        ok = ok && hipMalloc((void**)&pm, B * cap * 8) == hipSuccess;
+    }
+    if (!ok) {
+        for (uint8_t* q : nd) if (q) (void)hipFree(q);
+        for (uint8_t* q : nh) if (q) (void)hipHostFree(q);
+        if (!s->dGridStart) { if (gs) (void)hipFree(gs); if (gi) (void)hipFree(gi); if (pm) (void)hipFree(pm); }
+        return fail(c, PGORB_E_HIP, "pgorb_stream_frontend: allocation failed (the stream is unchanged)");
+    }
+    for (size_t i = 0; i < s->slot.size(); i++) {
+        (void)hipFree(s->slot[i].dOut); (void)hipHostFree(s->slot[i].hOut);
+        s->slot[i].dOut = nd[i]; s->slot[i].hOut = nh[i];
+    }
+    s->dGridStart = gs; s->dGridIdx = gi; s->dPrevMatched = pm;
     s->fe = true; s->feWindow = window_size; s->feRatio = nnratio; s->feCheckOri = check_orientation ? 1 : 0; s->feLevelsUp = bow_levelsup;
     s->feBounds[0] = min_x; s->feBounds[1] = max_x; s->feBounds[2] = min_y; s->feBounds[3] = max_y;
     stream_layout(s);
-    const size_t cap = (size_t)s->cap, B = (size_t)s->B;
-    bool ok = true;
-    for (auto& sl : s->slot) {
-        if (sl.dOut) (void)hipFree(sl.dOut);
-        if (sl.hOut) (void)hipHostFree(sl.hOut);
-        sl.dOut = nullptr; sl.hOut = nullptr;
-        ok = ok && hipMalloc((void**)&sl.dOut, s->outBytes + 256) == hipSuccess;
-        ok = ok && hipHostMalloc((void**)&sl.hOut, s->outBytes + 256, hipHostMallocDefault) == hipSuccess;
-    }
-    if (!s->dGridStart) {
-        ok = ok && hipMalloc((void**)&s->dGridStart, (B + 1) * (PGORB_GRID_CELLS + 1) * 4) == hipSuccess;
-        ok = ok && hipMalloc((void**)&s->dGridIdx, (B + 1) * cap * 4) == hipSuccess;
-        ok = ok && hipMalloc((void**)&s->dPrevMatched, B * cap * 8) == hipSuccess;
-    }
-    if (!ok) return fail(c, PGORB_E_HIP, "pgorb_stream_frontend: allocation failed");
     s->havePrev = false;
     return 0;
 }

@@ -341,12 +341,118 @@ __device__ __forceinline__ int quick_pass_u(const uint8_t* tile, int IW, int IH,
     return nlist;
 }
 
+// (2b) round 3: the necessary test of the narrow geometry on FOUR pixels per 32-bit operation, bytes in place -- no
+// unpacking into 16-bit fields at all.  With nC = ~C (the quad's four centre pixels, complemented) one v_lerp_u8 per ring
+// operand R (the dword of the four ring pixels that belong to the four centres) gives, byte for byte, without carries
+//     E = (R + 255 - C + 1) >> 1 = 128 + floor((R - C) / 2)
+// and with T = t + 1:  ring darker   (R - C <= -T)  =>  E <= 128 + floor(-T / 2) = Kd   (exact for odd T, one grey level
+//                                                                                         weaker for even T)
+//                      ring brighter (R - C >=  T)  =>  E >= 128 + floor( T / 2) = Kb   (exact for even T, one weaker for odd)
+// -- a NECESSARY condition is all this stage has to be (the exact score decides), the weaker side lets ~4 % more
+// pixels through.  The two byte-wise threshold compares run on the low seven bits, where an add cannot carry into the
+// next byte:   low = E & 0x7f..;  A = low + (256 - Kb): bit 7 <=> low >= Kb - 128;  Q = low + (127 - Kd): bit 7 <=> low > Kd
+//              brighter <=> bit 7 of (E & A),   darker <=> bit 7 of ~(E | Q).
+// Ring operands: rows y-3 / y+3 are the dwords above / below (no shuffle), x-3 / x+3 are one v_alignbyte_b32 each of the
+// centre row's three dwords; STRONG adds the diagonals (x+-2, y+-2), four more v_alignbyte_b32.  Per step: 6 slow-class
+// (lerp, alignbyte) + 28 fast-class (and / add / bitop3 / shift) operations against 18 + 18 in the 16-bit-field form
+// (tools/ubench/valu_rate4.hip: v_lerp_u8, v_alignbyte_b32, v_perm_b32, v_pk_* 4.7 cycles, the others 2.7).
+// Result bits: byte p of the accumulator = pixel p of the quad, bit 4 + s = darker-ring outcome of step s, bit s =
+// brighter-ring outcome (s = 0..3; a fifth step, interiors taller than 32 rows, fills a second word).  ONE 32-bit word
+// holds a lane's 16 pixels x 2 polarities, so the compaction loop runs max-over-lanes(count) times instead of once per
+// polarity, and a list entry is just (lane << 6) | (word << 5) | bit position: the (row, column) arithmetic is done
+// by the scoring round, for 64 entries at once, not per entry by the lane that found it.
+#define FAST_BFMT_ENTRY(lane, word, bpos) (uint16_t)(((lane) << 6) | ((word) << 5) | (bpos))
+__device__ __forceinline__ void bfmt_decode(int e, int& iy, int& ix, int& bright)
+{
+    const int ln = e >> 6;
+    const int lr = ((ln >> 3) & 3) * 2 + (ln >> 5);                  // the lane -> row map of the test (see quick_pass)
+    iy = 8 * ((e & 3) + ((e >> 3) & 4)) + lr;
+    ix = 4 * (ln & 7) + ((e >> 3) & 3);
+    bright = ((e >> 2) & 1) ^ 1;
+}
+
+template <bool STRONG>
+__device__ __forceinline__ int quick_pass_b(const uint8_t* tile, int IW, int IH, int t, uint16_t* list, int lane)
+{
+    constexpr int TP = 48;
+    const int lq = lane & 7;
+    const int lr = ((lane >> 3) & 3) * 2 + (lane >> 5);
+    const int T = t + 1;
+    const uint32_t M7 = 0x7F7F7F7Fu, M80 = 0x80808080u, ONES = 0x01010101u;
+    const uint32_t KA = (uint32_t)(256 - (128 + (T >> 1))) * ONES;          // 256 - Kb
+    const uint32_t KQ = (uint32_t)(127 - (128 - ((T + 1) >> 1))) * ONES;    // 127 - Kd,  Kd = 128 - ceil(T / 2)
+    const uint32_t* b0 = reinterpret_cast<const uint32_t*>(tile + lr * TP) + 1 + lq;   // (row lr, interior quad lq)
+    uint32_t acc = 0u, acc2 = 0u;
+#define PG_RING(R, E, A, Q) const uint32_t E = __builtin_amdgcn_lerp(R, nC, ONES); \
+                            const uint32_t A = (E & M7) + KA, Q = (E & M7) + KQ
+#pragma unroll
+    for (int s = 0; s < 5; s++) {
+        if (8 * s >= IH) break;                                       // wave-uniform
+        const uint32_t* ru = b0 + (8 * s) * (TP / 4);
+        const uint32_t* rc = b0 + (8 * s + 3) * (TP / 4);
+        const uint32_t* rd = b0 + (8 * s + 6) * (TP / 4);
+        const uint32_t C = rc[0], Lw = rc[-1], Rw = rc[1], U = ru[0], D = rd[0];
+        const uint32_t nC = ~C;
+        const uint32_t W12 = __builtin_amdgcn_alignbyte(C, Lw, 1);    // pixels x-3 of the quad: (Lw.b1, Lw.b2, Lw.b3, C.b0)
+        const uint32_t W4 = __builtin_amdgcn_alignbyte(Rw, C, 3);     // pixels x+3: (C.b3, Rw.b0, Rw.b1, Rw.b2)
+        PG_RING(U, eU, aU, qU); PG_RING(D, eD, aD, qD); PG_RING(W12, eL, aL, qL); PG_RING(W4, eR, aR, qR);
+        // brighter in a pair: (E & A) of either member; in every pair: the AND of the pairs.     bitop3 0xF8 = a | (b & c)
+        uint32_t br = __builtin_amdgcn_bitop3_b32(eU & aU, eD, aD, 0xF8) & __builtin_amdgcn_bitop3_b32(eL & aL, eR, aR, 0xF8);
+        // NOT darker in a pair: (E | Q) of both members; darker in every pair <=> no pair's bit set.   0xE0 = a & (b | c)
+        uint32_t nd = __builtin_amdgcn_bitop3_b32(eU | qU, eD, qD, 0xE0) | __builtin_amdgcn_bitop3_b32(eL | qL, eR, qR, 0xE0);
+        if (STRONG) {
+            // diagonals: rows y+2 / y-2 at x+2 / x-2 -- rings 2 (+2,+2), 14 (-2,+2), 6 (+2,-2), 10 (-2,-2); opposite pairs (2,10), (6,14)
+            const uint32_t* rp = b0 + (8 * s + 5) * (TP / 4);
+            const uint32_t* rm = b0 + (8 * s + 1) * (TP / 4);
+            const uint32_t Pc = rp[0], Pl = rp[-1], Pr = rp[1], Mc = rm[0], Ml = rm[-1], Mr = rm[1];
+            const uint32_t r2 = __builtin_amdgcn_alignbyte(Pr, Pc, 2), r14 = __builtin_amdgcn_alignbyte(Pc, Pl, 2);
+            const uint32_t r6 = __builtin_amdgcn_alignbyte(Mr, Mc, 2), r10 = __builtin_amdgcn_alignbyte(Mc, Ml, 2);
+            PG_RING(r2, e2, a2, q2); PG_RING(r10, e10, a10, q10); PG_RING(r6, e6, a6, q6); PG_RING(r14, e14, a14, q14);
+            br &= __builtin_amdgcn_bitop3_b32(e2 & a2, e10, a10, 0xF8) & __builtin_amdgcn_bitop3_b32(e6 & a6, e14, a14, 0xF8);
+            nd |= __builtin_amdgcn_bitop3_b32(e2 | q2, e10, q10, 0xE0) | __builtin_amdgcn_bitop3_b32(e6 | q6, e14, q14, 0xE0);
+        }
+        // bit 7 := darker (= ~nd), bit 3 := brighter;  0x4E = c ? ~a : b with c = 0x80808080
+        const uint32_t comb = __builtin_amdgcn_bitop3_b32(nd, br >> 4, M80, 0x4E);
+        if (s < 4) acc = __builtin_amdgcn_bitop3_b32(acc, comb >> (3 - s), 0x88888888u >> (3 - s), 0xF8);
+        else acc2 = (comb >> 3) & 0x11111111u;
+    }
+#undef PG_RING
+    // validity, once: pixels of this quad inside the interior (whole bytes) x steps whose row 8 s + lr lies inside it
+    const int npx = min(max(IW - 4 * lq, 0), 4), ns = min(max((IH - lr + 7) >> 3, 0), 5);
+    const uint32_t colBytes = npx >= 4 ? 0xFFFFFFFFu : ((1u << (8 * npx)) - 1u);
+    const uint32_t stepBits = ((1u << min(ns, 4)) - 1u) * 0x11111111u;
+    acc &= colBytes & stepBits;
+    acc2 &= ns > 4 ? colBytes : 0u;
+    const int cnt = __popc(acc) + __popc(acc2);
+    const int incl = wave_incl_scan(cnt);
+    const int nlist = __builtin_amdgcn_readlane(incl, 63);
+    if (nlist > FAST_LIST_CAP) return -1;
+    uint16_t* lp = list + (incl - cnt);
+    const int base = lane << 6;
+    uint32_t bits = acc;
+    while (bits) {
+        const int bpos = __ffs((int)bits) - 1;
+        bits &= bits - 1;
+        *lp++ = (uint16_t)(base | bpos);
+    }
+    if (IH > 32) {                                                    // wave-uniform
+        bits = acc2;
+        while (bits) {
+            const int bpos = __ffs((int)bits) - 1;
+            bits &= bits - 1;
+            *lp++ = (uint16_t)(base | 32 | bpos);
+        }
+    }
+    return nlist;
+}
+
 // (3) exact scores for the compacted pixels -> score map.  An entry names the polarity its pixel passed the necessary
 // test with; with sgn = +1 (darker ring) / -1 (brighter ring) the differences d = sgn * (v - ring) make both cases the
 // "darker" case: score = (largest 9-arc minimum of d) - 1, i.e. 16 v_mad_i32_i24 + 32 v_min3 + 8 v_max3 where both
 // polarities cost 16 + 80.  Entries whose pixel is not a corner at t are overwritten with 0xFFFF: NMS skips them
 // without touching the score map, and of a pixel's two entries (both polarities passed) at most one survives.
 #define FAST_DEAD 0xFFFFu
+template <bool BFMT>     // entry format: quick_pass_b's (lane, bit position) or the older (polarity << 15) | (iy << 8) | ix
 __device__ __forceinline__ void score_list(const uint8_t* tile, int TP, uint8_t* smap, int mapPitch,
                                            uint16_t* list, int nlist, int t, int lane)
 {
@@ -354,8 +460,10 @@ __device__ __forceinline__ void score_list(const uint8_t* tile, int TP, uint8_t*
         const int i = base + lane;
         if (i < nlist) {
             const int e = list[i];
-            const int iy = (e >> 8) & 0x7F, ix = e & 0xFF;
-            const int nsg = (e >> 15) ? 1 : -1;                       // -sgn
+            int iy, ix, bright;
+            if (BFMT) bfmt_decode(e, iy, ix, bright);
+            else { iy = (e >> 8) & 0x7F; ix = e & 0xFF; bright = e >> 15; }
+            const int nsg = bright ? 1 : -1;                          // -sgn
             const uint8_t* c = tile + (iy + 3) * TP + 4 + ix;
             const int p = TP;
             const int sv = -nsg * (int)c[0];                          // sgn * v
@@ -380,7 +488,9 @@ __device__ __forceinline__ void score_list(const uint8_t* tile, int TP, uint8_t*
             const int s = max(best, lo9[15]) - 1;
             const bool corner = s >= t;
             if (corner) smap[(iy + 1) * mapPitch + ix + 1] = (uint8_t)s;
-            else list[i] = (uint16_t)FAST_DEAD;
+            // NMS reads (iy << 8) | ix: corners are re-filed in that form, everything else is marked dead
+            if (BFMT) list[i] = corner ? (uint16_t)((iy << 8) | ix) : (uint16_t)FAST_DEAD;
+            else if (!corner) list[i] = (uint16_t)FAST_DEAD;
         }
     }
 }
@@ -416,7 +526,7 @@ __device__ __noinline__ int fast_pass_chunked(const uint8_t* tile, int TP, uint8
         const int n = (IW <= 32) ? quick_pass<8, true>(tile, TP, IW, r, min(r + rowsPer, IH), t, list, lane)
                                  : quick_pass<16, true>(tile, TP, IW, r, min(r + rowsPer, IH), t, list, lane);
         PG_WAVE_SYNC();
-        score_list(tile, TP, smap, mapPitch, list, n, t, lane);
+        score_list<false>(tile, TP, smap, mapPitch, list, n, t, lane);
         PG_WAVE_SYNC();
     }
     int done = 0;
@@ -553,11 +663,11 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgPlan P, int 
         // (2) necessary test + compaction
         int nlist;
         if (pass == 0)
-            nlist = NARROW ? quick_pass_u<false>(tile, IW, IH, t, list, lane)
+            nlist = NARROW ? quick_pass_b<false>(tile, IW, IH, t, list, lane)
                   : (IW <= 32) ? quick_pass<8, false>(tile, TP, IW, 0, IH, t, list, lane)
                                : quick_pass<16, false>(tile, TP, IW, 0, IH, t, list, lane);
         else
-            nlist = NARROW ? quick_pass_u<true>(tile, IW, IH, t, list, lane)
+            nlist = NARROW ? quick_pass_b<true>(tile, IW, IH, t, list, lane)
                   : (IW <= 32) ? quick_pass<8, true>(tile, TP, IW, 0, IH, t, list, lane)
                                : quick_pass<16, true>(tile, TP, IW, 0, IH, t, list, lane);
 #if defined(PGORB_FAST_SKIP) && PGORB_FAST_SKIP == 1       // timing experiment: staging + the iniTh quick test only
@@ -574,9 +684,11 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgPlan P, int 
             continue;
         }
         PG_WAVE_SYNC();
+        if (pass == 0) FT_TS(5);
         // (3) exact scores for the compacted pixels
-        score_list(tile, TP, smap, mapPitch, list, nlist, t, lane);
+        score_list<NARROW>(tile, TP, smap, mapPitch, list, nlist, t, lane);
         PG_WAVE_SYNC();
+        if (pass == 0) FT_TS(6);
         // (4) NMS (strictly greater than all 8 neighbours; outside the interior = 0); survivors go
         // straight into this cell's slots
         int total = 0;

@@ -21,8 +21,9 @@ log = np.zeros((n, 8), np.uint32)
 fn(log.ctypes.data, n)
 log = log[(log[:, 2] > 0) & (log[:, 3] > 0)]              # waves that ran a full cell
 print("waves", len(log))
-names = ["start -> cell record", "-> window loads issued", "-> window in LDS", "-> done (compute)", "(record -> addresses ready)"]
-for i, nm in enumerate(names):
+names = {0: "start -> cell record", 4: "-> addresses ready", 1: "-> window loads issued", 2: "-> window in LDS",
+         5: "-> iniTh test + compaction", 6: "-> iniTh scores", 3: "-> done (NMS, emission, retry)"}
+for i, nm in names.items():
     v = log[:, i] * 0.01
     print("   %-28s mean %6.2f us   median %6.2f   p90 %6.2f" % (nm, v.mean(), np.median(v), np.percentile(v, 90)))
 print("   total mean %.2f us" % (log.sum(axis=1).mean() * 0.01))
