@@ -600,14 +600,22 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgPlan P, int 
     const uint8_t* pyrBase = P.pyrBase;
     const uint32_t* recp = tab + 8 * (int64_t)cell;                // (the tables have 8 records of slack)
     const int totalCells = P.totalCells;
-    asm volatile("" :: "s"(l0img), "s"(l0pitch), "s"(l0fstride), "s"(pyrBase), "s"(totalCells));
+    // (everything else the wave will need from the argument block rides in the same batch of scalar loads: a field
+    //  fetched where it is first used costs the wave one more trip to the scalar cache in the middle of its prologue)
+    int32_t* const cellCountBase = P.cellCount;
+    uint32_t* const cellCandBase = P.cellCand;
+    const int64_t cellCandFrame = P.cellCandFrame;
+    const int iniTh = P.iniTh, minTh = P.minTh;
+    asm volatile("" :: "s"(l0img), "s"(l0pitch), "s"(l0fstride), "s"(pyrBase), "s"(totalCells), "s"(cellCountBase),
+                 "s"(cellCandBase), "s"(cellCandFrame), "s"(iniTh), "s"(minTh), "s"(TPr), "s"(tileRows), "s"(MPr), "s"(mapRows),
+                 "s"(chunkInv), "s"(waveLds));
     typedef uint32_t pg_u32x8 __attribute__((ext_vector_type(8)));
     pg_u32x8 rec;
     asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rec) : "s"(recp) : "memory");
     if (cell >= cellEnd || (int)(blockIdx.x >> 3) * WPB + wv >= cellsPerXcd) return;
     const int iniX = rec[1] & 0xFFFF, iniY = rec[1] >> 16;
     const int W = rec[2] & 0xFF, H = (rec[2] >> 8) & 0xFF, cellCap = rec[2] >> 17;
-    int32_t* cellCnt = P.cellCount + (int64_t)frame * totalCells + (rec[0] >> 4);     // the record names its cell
+    int32_t* cellCnt = cellCountBase + (int64_t)frame * totalCells + (rec[0] >> 4);     // the record names its cell
     FT_TS(0);
     if (rec[2] & 0x10000u) {                             // skipped cell (or a padding position of the balanced table)
         if (lane == 0 && (rec[0] >> 4) != 0x0FFFFFFFu) *cellCnt = 0;
@@ -634,32 +642,56 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgPlan P, int 
     {
         const int CH = TP >> 4, rowsPer = 64 / CH;
         const int r0 = (lane * chunkInv) >> 16, ch = lane - r0 * CH;       // lane / CH, lane % CH
-        const uint8_t* g = win + (int64_t)r0 * pitch + ch * 16;
+        // the lane's offset from the window start fits 32 bits (a window is a few dozen rows): scalar 64-bit base +
+        // 32-bit lane offset lets the load take its base from SGPRs (no 64-bit VALU address arithmetic per instruction)
+        const uint32_t voff = (uint32_t)(r0 * pitch + ch * 16);
 #ifdef PGORB_FAST_TIMING
-        asm volatile("" :: "v"(g));
+        asm volatile("" :: "v"(voff));
         FT_TS(4);
 #endif
+        // the score map is cleared FIRST (16 B per lane and step; the map starts 16-byte aligned and the candidate list
+        // behind it absorbs the last partial step): behind the window loads the compiler waits for the DMA before every
+        // ds_write (it cannot tell the two LDS targets apart), which put the clearing after the landing instead of under it
+        const int nz = (mapRows * mapPitch + 15) >> 4;
+        if (MPC == 40) {                                           // <= 42 rows of 40 bytes: at most two steps
+            if (lane < nz) reinterpret_cast<uint4*>(smap)[lane] = make_uint4(0u, 0u, 0u, 0u);
+            if (lane + 64 < nz) reinterpret_cast<uint4*>(smap)[lane + 64] = make_uint4(0u, 0u, 0u, 0u);
+        } else {
+            for (int i = lane; i < nz; i += 64) reinterpret_cast<uint4*>(smap)[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
         const bool laneOn = r0 < rowsPer;
-        for (int k = 0; k * rowsPer < H; k++) {
-            if (laneOn && r0 + k * rowsPer < H)
-                __builtin_amdgcn_global_load_lds((pg_gptr_t)(g + (int64_t)(k * rowsPer) * pitch),
-                                                 (pg_lptr_t)(tile + k * rowsPer * TP), 16, 0, 0);
+        if (TPC == 48) {
+            // 3 chunks per row, 21 rows per instruction, windows of at most 46 rows: at most three instructions, straight
+            // line (the loop form compiled into a 4 x unrolled loop with a remainder loop and a division for the trip count),
+            // written out so that the address is SGPR base + 32-bit VGPR offset (the builtin takes a flat 64-bit VGPR address)
+            const uint32_t ldsTile = (uint32_t)(uintptr_t)(pg_lptr_t)tile;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                if (k * 21 < H) {                                          // wave-uniform
+                    const uint8_t* gk = win + (int64_t)(k * 21) * pitch;   // scalar
+                    if (laneOn && r0 + k * 21 < H)
+                        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                                     :: "v"(voff), "s"(gk), "s"(ldsTile + k * 21 * 48) : "memory");      // (m0 is reserved: the compiler never keeps a value in it across statements, and this instantiation has no other user)
+                }
+            }
+        } else {
+            for (int k = 0; k * rowsPer < H; k++) {
+                const uint8_t* gk = win + (int64_t)(k * rowsPer) * pitch;
+                if (laneOn && r0 + k * rowsPer < H)
+                    __builtin_amdgcn_global_load_lds((pg_gptr_t)(gk + voff), (pg_lptr_t)(tile + k * rowsPer * TP), 16, 0, 0);
+            }
         }
         FT_TS(1);
-        // (the score map, 16 B per lane and step, is zeroed in the shadow of the loads; the map
-        //  starts 16-byte aligned and the candidate list behind it absorbs the last partial step)
-        for (int i = lane; i < (mapRows * mapPitch + 15) >> 4; i += 64)
-            reinterpret_cast<uint4*>(smap)[i] = make_uint4(0u, 0u, 0u, 0u);
         __builtin_amdgcn_s_waitcnt(0);                     // vmcnt(0): the DMA has landed
     }
     PG_WAVE_SYNC();
     FT_TS(2);
 
-    uint32_t* out = P.cellCand + (int64_t)frame * P.cellCandFrame + rec[7];
+    uint32_t* out = cellCandBase + (int64_t)frame * cellCandFrame + rec[7];
     const int xoff = 3 + iniX - PG_EDGE, yoff = 3 + iniY - PG_EDGE;   // window-local -> region-relative (:822-823)
 
     for (int pass = 0; pass < 2; pass++) {
-        const int t = pass == 0 ? P.iniTh : P.minTh;
+        const int t = pass == 0 ? iniTh : minTh;
         // (2) necessary test + compaction
         int nlist;
         if (pass == 0)
