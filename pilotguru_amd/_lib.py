@@ -29,7 +29,7 @@ SYMBOLS = (
     "pgorb_extract_batch_ingest_device",
     "pgorb_search_by_projection_points", "pgorb_search_by_projection_frame", "pgorb_search_by_bow",
     "pgorb_undistort_keypoints", "pgorb_undistort_keypoints_batch_device", "pgorb_image_bounds",
-    "pgorb_host_alloc", "pgorb_host_free", "pgorb_stream_create", "pgorb_stream_destroy", "pgorb_stream_input", "pgorb_stream_reset", "pgorb_stream_submit",
+    "pgorb_host_alloc", "pgorb_host_free", "pgorb_stream_create", "pgorb_stream_create_ingest", "pgorb_stream_destroy", "pgorb_stream_input", "pgorb_stream_reset", "pgorb_stream_submit",
     "pgorb_stream_wait", "pgorb_stream_frontend", "pgorb_stream_frontend_results", "pgorb_set_option", "pgorb_get_option", "pgorb_matcher_is_popcount",
     "pgorb_smooth_heading_directions", "pgorb_smooth_time_series", "pgorb_trajectory_pca",
     "pgorb_project_directions", "pgorb_project_translations", "pgorb_turn_angles",
@@ -100,6 +100,7 @@ def lib():
     L.pgorb_debug_level_candidates.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int]
     L.pgorb_debug_level_keypoints.argtypes = [vp, C.c_int, C.c_int]
     L.pgorb_stream_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.pgorb_stream_create_ingest.argtypes = [vp] + [C.c_int] * 9 + [C.POINTER(vp)]
     L.pgorb_stream_destroy.restype = None
     L.pgorb_stream_destroy.argtypes = [vp]
     L.pgorb_stream_input.restype = vp

@@ -399,14 +399,22 @@ class FrameStream:
     (src/slam/track_image_sequence.cc:43-47).  `depth` page-locked input slots of `batch` frames; submit() never
     blocks, wait() returns the batch's results as numpy views of page-locked memory."""
 
-    def __init__(self, extractor, w, h, batch, depth=3):
+    def __init__(self, extractor, w, h, batch, depth=3, channels=1, rgb_order=True, rotate_degrees=0,
+                 vertical_flip=False, horizontal_flip=False):
+        """w x h: the frames AS DECODED (before rotation); channels 1 (grey), 3 (RGB24 / BGR24) or 4.  With anything but
+        upright grey the slots hold the decoder's frames and rotation / flips / cvtColor run on the device in front of
+        the pyramid (pgorb_stream_create_ingest; image_sequence_reader.cc:53-58,186-205, Tracking.cc:247-260)."""
         self.ext, self.w, self.h, self.batch, self.depth = extractor, int(w), int(h), int(batch), int(depth)
+        self.channels = int(channels)
         self._L = extractor._L
         hs = C.c_void_p()
-        extractor._check(self._L.pgorb_stream_create(extractor._h, self.w, self.h, self.batch, self.depth, C.byref(hs)))
+        extractor._check(self._L.pgorb_stream_create_ingest(extractor._h, self.w, self.h, self.channels, int(bool(rgb_order)),
+                                                            int(rotate_degrees), int(bool(vertical_flip)), int(bool(horizontal_flip)),
+                                                            self.batch, self.depth, C.byref(hs)))
         self._s = hs
 
     def close(self):
+        """Frees the page-locked slots: every array input() / wait() / frontend_results() returned is invalid afterwards."""
         if getattr(self, "_s", None):
             self._L.pgorb_stream_destroy(self._s)
             self._s = None
@@ -417,11 +425,21 @@ class FrameStream:
         except Exception:
             pass
 
+    def _view(self, address, dtype, shape):
+        """numpy view of page-locked memory the C stream owns.  The view keeps THIS object alive (its ctypes base holds a
+        reference), so the memory is not freed by garbage collection while a result array is still in use; an explicit
+        close() -- or submitting the slot again -- still invalidates it."""
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        buf = (C.c_uint8 * nbytes).from_address(address)
+        buf._pgorb_owner = self
+        return np.frombuffer(buf, dtype).reshape(shape)
+
     def input(self, slot):
-        """numpy view [batch, h, w] of the slot's page-locked input frames (write the decoded frames here)."""
+        """numpy view [batch, h, w] (grey) or [batch, h, w, channels] of the slot's page-locked input frames: the decoder
+        writes its frames here."""
         p = self._L.pgorb_stream_input(self._s, slot)
-        buf = (C.c_uint8 * (self.batch * self.h * self.w)).from_address(p)
-        return np.frombuffer(buf, np.uint8).reshape(self.batch, self.h, self.w)
+        shape = (self.batch, self.h, self.w) if self.channels == 1 else (self.batch, self.h, self.w, self.channels)
+        return self._view(p, np.uint8, shape)
 
     def reset(self):
         self.ext._check(self._L.pgorb_stream_reset(self._s))
@@ -439,10 +457,7 @@ class FrameStream:
         self.ext._check(self._L.pgorb_stream_frontend_results(self._s, slot, *[C.byref(p) for p in ptr]))
 
         def view(p, dtype, shape):
-            if not p.value:
-                return None
-            nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
-            return np.frombuffer((C.c_uint8 * nbytes).from_address(p.value), dtype).reshape(shape)
+            return self._view(p.value, dtype, shape) if p.value else None
         return (view(ptr[0], np.int32, (nframes, cap)), view(ptr[1], np.int32, (nframes,)), view(ptr[2], np.uint32, (nframes, cap)),
                 view(ptr[3], np.float64, (nframes, cap)), view(ptr[4], np.uint32, (nframes, cap)))
 
@@ -457,7 +472,6 @@ class FrameStream:
         cap = cap.value
 
         def view(p, dtype, shape):
-            nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
-            return np.frombuffer((C.c_uint8 * nbytes).from_address(p.value), dtype).reshape(shape)
+            return self._view(p.value, dtype, shape)
         return (view(ptr[0], np.int32, (nf,)), view(ptr[1], KEYPOINT_DTYPE, (nf, cap)), view(ptr[2], np.uint8, (nf, cap, 32)),
                 view(ptr[3], np.int32, (nf, cap)), view(ptr[4], np.uint16, (nf, cap)), view(ptr[5], np.uint16, (nf, cap)))
