@@ -193,14 +193,16 @@ def verify_against_oracle(ride, kps, desc, n, mout, nfeatures):
     return True
 
 
-def upload_leg(pg, ext, ride, NF, W, H, B, seconds=2.0, depth=3, frontend=False, link=True):
+def upload_leg(pg, ext, ride, NF, W, H, B, seconds=2.0, depth=3, frontend=False, link=True, channels=1):
     """The same step (extract + best-2 match of every frame against its predecessor) with frames that start in
     page-locked HOST memory: pgorb_stream_* with `depth` batches in flight (upload, kernels and result download on
     three HIP streams).  Reported next to the resident number, never as `value`.  Also measures what the link
     itself gives: one large pinned hipMemcpyAsync H2D."""
     import numpy as np
     import torch
-    st = pg.FrameStream(ext, W, H, B, depth)
+    # channels = 3: the slots hold RGB24 frames, what the reference's reader decodes (image_sequence_reader.cc:138-208);
+    # Tracking's cvtColor (Tracking.cc:247-260) then runs on the device in front of the pyramid (k_ingest_rows)
+    st = pg.FrameStream(ext, W, H, B, depth, channels=channels)
     if frontend:
         # + what the tracking thread does with every fresh Frame, on the device per batch: 64x48 grid,
         # SearchForInitialization(previous, current) (Tracking.cc:583-597), ORBVocabulary::transform (Frame.cc:399-406)
@@ -208,7 +210,11 @@ def upload_leg(pg, ext, ride, NF, W, H, B, seconds=2.0, depth=3, frontend=False,
         V.ORBVocabulary(blob=V.synth_vocabulary_blob(10, 5, seed=7)).upload(ext)
         st.frontend((0.0, float(W), 0.0, float(H)), 100, 0.9, True, 4)
     for sl in range(depth):
-        st.input(sl)[:] = ride                              # "the decoder" has filled every slot
+        if channels == 1:
+            st.input(sl)[:] = ride                          # "the decoder" has filled every slot
+        else:
+            for ch in range(channels):
+                st.input(sl)[..., ch] = ride
     # warm-up: fill the pipeline once
     for sl in range(depth):
         st.submit(sl)
@@ -230,6 +236,11 @@ def upload_leg(pg, ext, ride, NF, W, H, B, seconds=2.0, depth=3, frontend=False,
     t1 = time.perf_counter()
     st.close()
     fps = done * B / (t1 - t0)
+    if channels != 1:
+        return {"value": fps, "unit": "frames/s", "batches": done, "seconds": t1 - t0, "depth": depth, "channels": channels,
+                "h2d_GBps_used": fps * W * H * channels / 1e9,
+                "note": "as frames_uploaded with RGB24 frames in the page-locked slots (%d bytes per pixel over the link); grey "
+                        "conversion on the device" % channels}
     if not link:
         return {"value": fps, "unit": "frames/s", "batches": done, "seconds": t1 - t0, "depth": depth,
                 "note": "as frames_uploaded, plus the stream's front-end stage per batch: grid, SearchForInitialization of every "
@@ -544,6 +555,10 @@ def main():
     if not args.no_upload_leg and dist is None:
         uploaded = upload_leg(pg, ext, ride, NF, W, H, B, seconds=2.0)
         uploaded["with_front_end_stage"] = upload_leg(pg, ext, ride, NF, W, H, B, seconds=1.5, frontend=True, link=False)
+        rgb = upload_leg(pg, ext, ride, NF, W, H, B, seconds=1.5, link=False, channels=3)
+        rgb["link_bound_fps"] = uploaded["link_bound_fps"] / 3.0
+        rgb["fraction_of_link"] = rgb["value"] / rgb["link_bound_fps"]
+        uploaded["rgb24"] = rgb
 
     if rank == 0:
         frames_total = world * B * args.steps

@@ -442,9 +442,10 @@ int      pgorb_stream_frontend_results(pgorb_stream* s, int slot, const int32_t*
 
 /* Measurement switches (no counterpart in the reference; results never depend on them -- the parity suite
  * runs under each).  key "matcher": 0 = the default (fp4 block-scaled MFMA for < 8192 descriptors per
- * frame), 1 = the ballot / popcount kernels BASELINE.json's north star describes, for every size.
+ * frame; the PGORB_MATCH_POPCOUNT environment switch applies again), 1 = the ballot / popcount kernels BASELINE.json's north star describes, for every size.
  * Process-wide.  Returns PGORB_E_ARG for an unknown key.
- * key "fast_kernel": 0 = K2 as one wave per 30-px cell (default), 1 = K2 as one workgroup per block of
+ * key "fast_kernel": 0 = K2 as one wave per 30-px cell (default), 1 (developer builds with -DPGORB_FAST_BLOCKS only; the
+ * product library answers PGORB_E_ARG) = K2 as one workgroup per block of
  * "fast_block_cx" x "fast_block_cy" cells (1..4 each, default 4 x 2; changing them rebuilds the plan) -- the tile
  * shapes of BASELINE.json configs[2]'s sweep. */
 int  pgorb_set_option(pgorb_ctx* ctx, const char* key, int value);

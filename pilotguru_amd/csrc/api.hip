@@ -414,8 +414,10 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
         P.cellTabBal = (const uint32_t*)c->cellTabBal.p;
         P.cellsPerXcdBal = (int)per;
     }
+    P.blockTab = nullptr; P.totalBlocks = 0;
+#ifdef PGORB_FAST_BLOCKS
     {
-        // K2 block records (fast.hip, k_fast_blocks): blocks of blkCX x blkCY cells, row-major per level.
+        // K2 block records (fast.hip, k_fast_blocks; developer build only): blocks of blkCX x blkCY cells, row-major per level.
         // A block's interior must fit 128 x 128 px (32 quads per tile row, 16 steps of 8 rows).
         std::vector<uint32_t> bt;
         bool ok = true;
@@ -456,6 +458,7 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
             P.totalBlocks = (int)(bt.size() / 16);
         }
     }
+#endif
     P.cand = (uint32_t*)c->cand.p; P.sel = (uint32_t*)c->sel.p;
     P.nodeScratch = (int32_t*)c->nodes.p;
     P.candCount = (int32_t*)c->counters.p;
@@ -555,8 +558,8 @@ int pg_ctx_vocab_store(pgorb_ctx* c, const void* src, size_t nbytes, bool src_on
     if (hdr[0] != 0x43564750 || hdr[1] != 1 || hdr[4] < 2)
         return fail(c, PGORB_E_ARG, "not a pgorb vocabulary blob");
     {
-        // the sections the header implies must fit (bow.hip, blob layout); the structure itself is checked
-        // by pgorb_vocab_from_blob / the loader, and the kernel stops at a node without children
+        // the sections the header implies must fit (bow.hip, blob layout); the structure itself is checked by
+        // pgorb_vocab_from_blob / the loader on the host path and by k_vocab_validate on the device path
         const size_t n = (size_t)hdr[4];
         auto pad = [](size_t v) { return (v + 63) / 64 * 64; };
         size_t need = 64;
@@ -573,6 +576,7 @@ int pg_ctx_vocab_store(pgorb_ctx* c, const void* src, size_t nbytes, bool src_on
     c->vocabK = hdr[2]; c->vocabL = hdr[3]; c->vocabNodes = hdr[4];
     return 0;
 }
+void pg_ctx_vocab_drop(pgorb_ctx* c) { c->vocabK = c->vocabL = c->vocabNodes = 0; }
 int pg_ctx_vocab_get(pgorb_ctx* c, const uint8_t** d_blob, int* k, int* L, int* nnodes)
 {
     if (!c->vocab.p || !c->vocabNodes) return fail(c, PGORB_E_ARG, "no vocabulary uploaded");
@@ -917,7 +921,10 @@ int pgorb_set_option(pgorb_ctx* c, const char* key, int value)
 {
     if (!key) return PGORB_E_ARG;
     if (!strcmp(key, "matcher")) { pg_match_set_popcount(value); return 0; }
-    if (!strcmp(key, "fast_kernel")) { pg_fast_set_kernel(value); return 0; }
+    if (!strcmp(key, "fast_kernel")) {
+        if (pg_fast_set_kernel(value)) return c ? fail(c, PGORB_E_ARG, "fast_kernel %d: the block form is a developer build (make EXTRA=-DPGORB_FAST_BLOCKS)", value) : PGORB_E_ARG;
+        return 0;
+    }
     if (c && !strcmp(key, "pipeline_pyramid")) { c->pipePyr = value ? 1 : 0; return 0; }
     if (c && (!strcmp(key, "fast_block_cx") || !strcmp(key, "fast_block_cy"))) {
         if (value < 1 || value > 4) return fail(c, PGORB_E_ARG, "%s must be 1..4", key);

@@ -110,9 +110,33 @@ std::vector<uint8_t> pack_blob(int k, int L, int scoring, int weighting, const s
 // lives in api.hip
 int pg_ctx_vocab_store(pgorb_ctx* c, const void* src, size_t nbytes, bool src_on_device, hipStream_t s);
 int pg_ctx_vocab_get(pgorb_ctx* c, const uint8_t** d_blob, int* k, int* L, int* nnodes);
+void pg_ctx_vocab_drop(pgorb_ctx* c);
 int pg_ctx_fail(pgorb_ctx* c, int code, const char* msg);
 int pg_ctx_stage(pgorb_ctx* c, int which, size_t bytes, void** p);
 int pg_ctx_device(pgorb_ctx* c);
+
+// structural checks of a blob that is already on the device (the host path runs view_blob): child ranges inside
+// children[], child ids and parents inside [0, n); *bad != 0 when any node violates them
+__global__ __launch_bounds__(256) void k_vocab_validate(const uint8_t* __restrict__ blob, int n, int* __restrict__ bad)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    auto pad = [](size_t v) { return (v + 63) / 64 * 64; };
+    size_t off = 64;
+    off = pad(off + (size_t)n * 32); off = pad(off + (size_t)n * 8);
+    const int32_t* parent = reinterpret_cast<const int32_t*>(blob + off); off = pad(off + (size_t)n * 4);
+    const int32_t* child0 = reinterpret_cast<const int32_t*>(blob + off); off = pad(off + (size_t)n * 4);
+    const int32_t* nchild = reinterpret_cast<const int32_t*>(blob + off); off = pad(off + (size_t)n * 4);
+    off = pad(off + (size_t)n * 4);
+    const int32_t* children = reinterpret_cast<const int32_t*>(blob + off);
+    const long long c0 = child0[i], nc = nchild[i];
+    bool ok = c0 >= 0 && nc >= 0 && c0 + nc <= (long long)n - 1;
+    if (i && (parent[i] < 0 || parent[i] >= n)) ok = false;
+    if (i == 0 && nc < 1) ok = false;
+    if (i + 1 < n && (children[i] < 1 || children[i] >= n)) ok = false;
+    if (!ok) atomicExch(bad, 1);
+}
+
 
 __global__ __launch_bounds__(64) void k_bow_transform(const uint8_t* __restrict__ blob, int nnodes, int L,
                                                        const uint8_t* __restrict__ desc, int n, int levelsup,
@@ -267,7 +291,24 @@ int pgorb_vocab_upload(pgorb_ctx* c, const pgorb_vocab* v)
 int pgorb_vocab_upload_device(pgorb_ctx* c, const void* d_blob, int64_t nbytes, void* stream)
 {
     if (!c || !d_blob || nbytes < 64) return PGORB_E_ARG;
-    return pg_ctx_vocab_store(c, d_blob, (size_t)nbytes, true, (hipStream_t)stream);
+    int rc = pg_ctx_vocab_store(c, d_blob, (size_t)nbytes, true, (hipStream_t)stream);
+    if (rc) return rc;
+    // A blob that arrives on the device (a broadcast) never passed view_blob's structural checks on this rank:
+    // the same checks as a kernel, so that a corrupt blob is an error code here and not a fault inside k_bow_transform
+    const uint8_t* blob; int k, L, nn;
+    if ((rc = pg_ctx_vocab_get(c, &blob, &k, &L, &nn))) return rc;
+    void* flag;
+    if ((rc = pg_ctx_stage(c, 2, 64, &flag))) return rc;
+    if (hipMemsetAsync(flag, 0, 4, (hipStream_t)stream) != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "hipMemsetAsync failed");
+    hipLaunchKernelGGL(k_vocab_validate, dim3((nn + 255) / 256), dim3(256), 0, (hipStream_t)stream, blob, nn, (int*)flag);
+    int bad = 0;
+    if (hipMemcpyAsync(&bad, flag, 4, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+        hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "vocabulary validation failed to run");
+    if (bad) {
+        pg_ctx_vocab_drop(c);
+        return pg_ctx_fail(c, PGORB_E_ARG, "vocabulary blob is structurally invalid (child ranges / ids out of bounds)");
+    }
+    return 0;
 }
 
 int pgorb_bow_transform_device(pgorb_ctx* c, const uint8_t* d_desc, int n, int levelsup, uint32_t* d_word,

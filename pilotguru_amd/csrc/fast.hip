@@ -758,6 +758,7 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgPlan P, int 
     }
 }
 
+#ifdef PGORB_FAST_BLOCKS   // developer build (make EXTRA=-DPGORB_FAST_BLOCKS): the tile-shape sweep of BASELINE.json configs[2]; it lost on every shape and is not part of the product library
 // ================================================================================================
 // K2, block form: one workgroup of 256 threads (4 waves) per BLOCK of CX x CY cells (4 x 2 for the
 // common 30..32-px cells), all blocks of all levels of all frames in one grid.
@@ -1148,28 +1149,39 @@ __global__ __launch_bounds__(FB_T, 7) void k_fast_blocks(const PgPlan P, int til
 
 void pg_launch_fast_cells(const PgPlan& P, int nframes, hipStream_t s, int levelBeg, int levelEnd);
 
+#endif  // PGORB_FAST_BLOCKS
+
 // 0 = one wave per cell (default: 0.915 ms per 128-frame step at 1080p), 1 = block form (1.29 ms: fewer VALU
 // instructions per pixel once the minThFAST pass runs per cell, but four barrier-separated phases per block at 7
 // workgroups per CU leave the SIMDs idle a third of the time -- DESIGN.md section 6); pgorb_set_option "fast_kernel"
 static int g_fast_kernel = 0;
-void pg_fast_set_kernel(int k) { g_fast_kernel = k; }
+void pg_launch_fast_cells(const PgPlan& P, int nframes, hipStream_t s, int levelBeg, int levelEnd);
+#ifdef PGORB_FAST_BLOCKS
+int pg_fast_set_kernel(int k) { g_fast_kernel = k; return 0; }
+#else
+int pg_fast_set_kernel(int k) { return k == 0 ? 0 : -1; }      // the block form is not in this build
+#endif
 int pg_fast_get_kernel() { return g_fast_kernel; }
 
 void pg_launch_fast(const PgPlan& P, int nframes, hipStream_t s)
 {
-    if (g_fast_kernel != 1 || !P.blockTab) { pg_launch_fast_cells(P, nframes, s, 0, P.nlevels); return; }
-    int tileRows = 0;
-    for (int l = 0; l < P.nlevels; l++) tileRows = max(tileRows, P.lvl[l].blkCY * P.lvl[l].hCell + 6);
-    const int mapRows = tileRows - 6 + 4 + 1;                  // BH + one gutter row per cell row (<= 4) + rim
-    size_t smem = (size_t)tileRows * FB_TP + (size_t)mapRows * FB_MP + FB_LCAP * 2 + 18 * 4 + 64;
-    if (const char* e = getenv("PGORB_FAST_EXTRA_LDS")) smem += (size_t)atoi(e);
-    static bool attrSet = false;
-    if (!attrSet) { (void)hipFuncSetAttribute((const void*)k_fast_blocks, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attrSet = true; }
-    const int blocksPerXcd = (P.totalBlocks + 7) / 8;
-    dim3 grid(blocksPerXcd * 8, nframes), block(FB_T);
-    int dbgSkip = 0;
-    if (const char* e = getenv("PGORB_FAST_DBGSKIP")) dbgSkip = atoi(e);
-    hipLaunchKernelGGL(k_fast_blocks, grid, block, smem, s, P, tileRows, mapRows, blocksPerXcd, dbgSkip);
+#ifdef PGORB_FAST_BLOCKS
+    if (g_fast_kernel == 1 && P.blockTab) {
+        int tileRows = 0;
+        for (int l = 0; l < P.nlevels; l++) tileRows = max(tileRows, P.lvl[l].blkCY * P.lvl[l].hCell + 6);
+        const int mapRows = tileRows - 6 + 4 + 1;                  // BH + one gutter row per cell row (<= 4) + rim
+        size_t smem = (size_t)tileRows * FB_TP + (size_t)mapRows * FB_MP + FB_LCAP * 2 + 18 * 4 + 64;
+        if (const char* e = getenv("PGORB_FAST_EXTRA_LDS")) smem += (size_t)atoi(e);
+        (void)hipFuncSetAttribute((const void*)k_fast_blocks, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   // per device, cheap
+        const int blocksPerXcd = (P.totalBlocks + 7) / 8;
+        dim3 grid(blocksPerXcd * 8, nframes), block(FB_T);
+        int dbgSkip = 0;
+        if (const char* e = getenv("PGORB_FAST_DBGSKIP")) dbgSkip = atoi(e);
+        hipLaunchKernelGGL(k_fast_blocks, grid, block, smem, s, P, tileRows, mapRows, blocksPerXcd, dbgSkip);
+        return;
+    }
+#endif
+    pg_launch_fast_cells(P, nframes, s, 0, P.nlevels);
 }
 
 // K2 (cell form) for the levels [levelBeg, levelEnd) only

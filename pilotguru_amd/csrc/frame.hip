@@ -893,14 +893,16 @@ int pgorb_search_for_initialization_batch_device(pgorb_ctx* c, const pgorb_keypo
     uint32_t* lists = (uint32_t*)scratch;
     uint8_t* listCnt = (uint8_t*)scratch + szL;
     const size_t ldsA = (size_t)4 * cap * 2, ldsB = (size_t)cap * 10 + 192;      // (+ the 32-bin histogram)
-    static size_t configuredA = 0, configuredB = 0;
-    if (ldsA > configuredA) {
+    // (the attribute is per DEVICE: a process-wide "already configured" flag left a second GPU's kernels at the 64 KB default)
+    static size_t configuredA[64] = {0}, configuredB[64] = {0};
+    const int dv = pg_ctx_device(c) & 63;
+    if (ldsA > configuredA[dv]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sfi_candidates), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA);
-        configuredA = ldsA;
+        configuredA[dv] = ldsA;
     }
-    if (ldsB > configuredB) {
+    if (ldsB > configuredB[dv]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_for_initialization), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
-        configuredB = ldsB;
+        configuredB[dv] = ldsB;
     }
     hipLaunchKernelGGL(k_sfi_candidates, dim3((cap + 3) / 4, npairs), dim3(256), ldsA, (hipStream_t)stream, d_kps, d_desc, d_n, cap,
                        d_grid_start, d_grid_idx, d_pair_f1, d_pair_f2, min_x, min_y, invW, invH, d_prev_matched, window_size, lists, listCnt);

@@ -377,7 +377,7 @@ void pg_launch_hamming_matrix(const uint8_t* d_a, int na, const uint8_t* d_b, in
 // PGORB_MATCH_POPCOUNT=1 forces the v_bcnt kernels for every size (the variant BASELINE.json's north star
 // describes), so both matchers can be timed on the same frames; results are identical.
 static int g_mx_force_popcount = -1;                     // -1: environment decides; pgorb_set_option("matcher", ...)
-void pg_match_set_popcount(int on) { g_mx_force_popcount = on ? 1 : 0; }
+void pg_match_set_popcount(int on) { g_mx_force_popcount = on ? 1 : -1; }      // 0 = back to the default (the environment decides)
 static bool mx_use_popcount()
 {
     static const bool v = getenv("PGORB_MATCH_POPCOUNT") != nullptr;

@@ -182,6 +182,77 @@ def test_streamed_ingest_bit_exact(w, h, nf, total, batch, depth):
                     "match of frame %d vs %d" % (f, f - 1)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,nf,total,batch,depth,cn,rgb,rot,vf,hf", [
+    (640, 480, 1000, 9, 4, 3, 3, True, 90, False, True),       # phone video: RGB24, rotated by the metadata, --horizontal_flip
+    (1280, 720, 1500, 5, 2, 2, 3, False, 180, True, False),    # BGR24, upside down, --vertical_flip
+    (640, 480, 1000, 5, 3, 2, 4, True, 270, False, False),     # RGBA
+    (1920, 1080, 2000, 3, 2, 2, 3, True, 0, False, False),     # the bench's RGB24 leg
+    (640, 480, 1000, 5, 3, 2, 1, True, 90, True, True)])       # grey, geometry only
+def test_streamed_rgb_ride_with_the_readers_geometry(oracle, w, h, nf, total, batch, depth, cn, rgb, rot, vf, hf):
+    """pgorb_stream_create_ingest: the slots hold the frames EXACTLY as the reference's reader decodes them (RGB24,
+    src/io/image_sequence_reader.cc:138-208), rotation by the metadata (:186-205), the wrapper's flips (:53-58) and
+    Tracking's cvtColor (Tracking.cc:247-260) run on the device in front of the pyramid; every frame and every match
+    across batch borders against the oracle run on the oracle-ingested grey frames."""
+    import pilotguru_amd as pg
+    from _oracle_pool import oracle_ride
+    ride = synth_ride(33, w, h, total)
+    if cn == 1:
+        src = ride
+    else:
+        planes = [ride, np.roll(ride, 3, axis=2), 255 - ride] + ([np.full_like(ride, 255)] if cn == 4 else [])
+        src = np.ascontiguousarray(np.stack(planes, axis=3))
+    upright = []
+    for f in range(total):
+        up = oracle.ingest_geometry(src[f], rot, vf, hf)
+        if cn > 1:
+            up = oracle.rgb_to_gray(np.ascontiguousarray(up[:, :, :3] if rgb else up[:, :, 2::-1]))
+        upright.append(np.ascontiguousarray(up))
+    ow, oh = (h, w) if rot in (90, 270) else (w, h)
+    assert upright[0].shape == (oh, ow)
+    oext, omatch = oracle_ride(upright, (nf, 1.2, 8, 20, 7))
+    ext = pg.ORBextractor(nf, 1.2, 8, 20, 7, max_width=ow, max_height=oh, max_batch=batch)
+    st = pg.FrameStream(ext, w, h, batch, depth, channels=cn, rgb_order=rgb, rotate_degrees=rot, vertical_flip=vf, horizontal_flip=hf)
+    assert st.input(0).shape == ((batch, h, w) if cn == 1 else (batch, h, w, cn))
+    chunks = [(b0, min(batch, total - b0)) for b0 in range(0, total, batch)]
+    results, inflight = {}, []
+    for i, (b0, nb) in enumerate(chunks):
+        slot = i % depth
+        if len(inflight) == depth:
+            j, s0 = inflight.pop(0)
+            results[j] = [np.array(a) for a in st.wait(s0)]
+        st.input(slot)[:nb] = src[b0:b0 + nb]
+        st.submit(slot, nb)
+        inflight.append((i, slot))
+    for j, s0 in inflight:
+        results[j] = [np.array(a) for a in st.wait(s0)]
+    st.close()
+    for i, (b0, nb) in enumerate(chunks):
+        n, kps, desc, bi, b1, b2 = results[i]
+        for k in range(nb):
+            f = b0 + k
+            okp, odesc = oext[f]
+            assert n[k] * 28 == len(okp) and kps[k, :n[k]].tobytes() == okp and desc[k, :n[k]].tobytes() == odesc, "frame %d" % f
+            if f:
+                obi, ob1, ob2 = omatch[f - 1]
+                assert bi[k, :n[k]].tobytes() == obi and b1[k, :n[k]].tobytes() == ob1 and b2[k, :n[k]].tobytes() == ob2, "match %d" % f
+
+
+@pytest.mark.gpu
+def test_destroying_the_context_takes_its_streams_along():
+    """pgorb_destroy with a live stream used to leave the stream pointing at a freed context."""
+    import ctypes as C
+    import pilotguru_amd as pg
+    ext = pg.ORBextractor(500, 1.2, 8, 20, 7, max_width=320, max_height=240, max_batch=2)
+    st = pg.FrameStream(ext, 320, 240, 2, 2)
+    st.input(0)[:] = synth_ride(1, 320, 240, 2)
+    st.submit(0)
+    L, h = ext._L, ext._h
+    ext._h = None                                  # the Python object must not destroy it a second time
+    st._s = None
+    L.pgorb_destroy(h)                             # waits for the batch in flight, frees the stream, then the context
+
+
 @pytest.mark.parametrize("w,h,nf,total,batch,depth,bow", [(640, 480, 1000, 11, 4, 3, True), (1280, 720, 1500, 7, 3, 2, False)])
 def test_streamed_front_end_stage_against_the_oracle(w, h, nf, total, batch, depth, bow, tmp_path):
     """pgorb_stream_frontend: what the tracking thread does with every fresh Frame, on the device per batch -- the

@@ -154,6 +154,36 @@ def test_gpu_vocab_upload_from_device_blob(oracle, tmp_path):
 
 
 @pytest.mark.gpu
+def test_corrupt_device_blob_is_an_error_code_not_a_fault(tmp_path):
+    """a blob that arrives on the device (the broadcast path) is checked structurally by a kernel --
+    a child id or child range outside the tree must be refused, and the context must end up without a vocabulary."""
+    import ctypes as C
+    import torch
+    import pilotguru_amd as pg
+    from pilotguru_amd.vocab import unpack_vocabulary
+    path, desc, weight, parent = _vocab_file(tmp_path, k=4, L=3, seed=3)
+    blob = V.ORBVocabulary(text_file=path).blob()
+    n = unpack_vocabulary(blob)["nnodes"]
+    pad = lambda v: (v + 63) // 64 * 64
+    off = 64
+    off = pad(off + n * 32); off = pad(off + n * 8); off_parent = off
+    off = pad(off + n * 4); off_child0 = off
+    off = pad(off + n * 4); off = pad(off + n * 4); off = pad(off + n * 4); off_children = off
+    for where, value in ((off_children + 4 * 3, n + 5), (off_child0 + 4 * 2, n), (off_parent + 4 * 5, -2)):
+        bad = blob.copy()
+        bad[where:where + 4] = np.frombuffer(np.int32(value).tobytes(), np.uint8)
+        ext = pg.ORBextractor(500, 1.2, 8, 20, 7, max_width=320, max_height=240)
+        t = torch.from_numpy(bad).cuda()
+        rc = ext._L.pgorb_vocab_upload_device(ext._h, C.c_void_p(t.data_ptr()), t.numel(), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == -1, rc                                   # PGORB_E_ARG
+        d = torch.zeros((4, 32), dtype=torch.uint8, device="cuda")
+        w = torch.zeros(4, dtype=torch.int32, device="cuda"); wt = torch.zeros(4, dtype=torch.float64, device="cuda")
+        rc = ext._L.pgorb_bow_transform_device(ext._h, C.c_void_p(d.data_ptr()), 4, 4, C.c_void_p(w.data_ptr()), C.c_void_p(wt.data_ptr()),
+                                               C.c_void_p(w.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc != 0                                        # no vocabulary resident
+
+
+@pytest.mark.gpu
 def test_orbvoc_scale_vocabulary(tmp_path, oracle):
     """The size of the real ORBvoc.txt (k = 10, L = 6: 1 111 111 nodes, 10^6 words, 146 MB of text, 66.7 MB
     as a blob; TemplatedVocabulary.h:1337-1420): text -> blob through the product's loader equals the Python

@@ -582,13 +582,29 @@ def test_popcount_matcher_switch_gives_the_same_matches(tmp_path):
     assert np.all(outs[0]["d1"][:200] == 0)
 
 
+def _block_form_available():
+    import pilotguru_amd as pg
+    ext = pg.ORBextractor(100, 1.2, 2, 20, 7, max_width=320, max_height=240)
+    try:
+        ext.set_option("fast_kernel", 1)
+    except Exception:
+        return False
+    ext.set_option("fast_kernel", 0)
+    return True
+
+
 @pytest.mark.parametrize("cx,cy", [(4, 2), (2, 2), (1, 1), (4, 4), (3, 1), (1, 3)])
 def test_fast_block_form_every_tile_shape_bit_exact(oracle, cx, cy):
-    """K2's block form (pgorb_set_option "fast_kernel" = 1) for the tile shapes of BASELINE.json configs[2]'s
-    sweep: textured, driving-like (minThFAST retry per cell), pure noise (pooled list overflow -> strips) and
-    panoramic frames (cells up to 59 px, partial blocks), candidate sets and final output against the oracle."""
+    """K2's block form (pgorb_set_option "fast_kernel" = 1; a developer build since round 3: make EXTRA=-DPGORB_FAST_BLOCKS)
+    for the tile shapes of BASELINE.json configs[2]'s sweep: textured, driving-like (minThFAST retry per cell), pure noise
+    (candidate list overflow -> row-chunked passes) and panoramic frames (cells up to 59 px, partial blocks), candidate
+    sets and final output against the oracle.  With the product library the same hard cases run once through the
+    shipped cell form."""
     import pilotguru_amd as pg
     from pilotguru_amd.synth import synth_scene_road
+    block_form = _block_form_available()
+    if not block_form and (cx, cy) != (4, 2):
+        pytest.skip("block form not in this build (make EXTRA=-DPGORB_FAST_BLOCKS)")
     rng = np.random.RandomState(1)
     cases = [(synth_scene(7, 641, 479), 1000, 8), (synth_scene_road(2, 640, 480), 1000, 8),
              ((128 + rng.randint(-9, 10, (300, 400))).astype(np.uint8), 500, 8),
@@ -599,10 +615,11 @@ def test_fast_block_form_every_tile_shape_bit_exact(oracle, cx, cy):
             ora = oracle.OrbOracle(nf, 1.2, nlevels, 20, 7)
             okp, odesc = ora.extract(img)
             ext = pg.ORBextractor(nf, 1.2, nlevels, 20, 7, max_width=w, max_height=h)
-            ext.set_option("fast_kernel", 1)
-            ext.set_option("fast_block_cx", cx)
-            ext.set_option("fast_block_cy", cy)
-            assert ext.fast_kernel_name() == "k_fast_blocks"
+            if block_form:
+                ext.set_option("fast_kernel", 1)
+                ext.set_option("fast_block_cx", cx)
+                ext.set_option("fast_block_cy", cy)
+                assert ext.fast_kernel_name() == "k_fast_blocks"
             kp, desc = ext(img)
             for l in range(nlevels):
                 x, y, r = ext.debug_level_candidates(0, l)
@@ -616,6 +633,8 @@ def test_fast_block_form_every_tile_shape_bit_exact(oracle, cx, cy):
 
 def test_fast_block_form_at_bench_shape(oracle):
     import pilotguru_amd as pg
+    if not _block_form_available():
+        pytest.skip("block form not in this build (make EXTRA=-DPGORB_FAST_BLOCKS)")
     img = synth_scene(2, 1920, 1080)
     okp, odesc = oracle.OrbOracle(2000, 1.2, 8, 20, 7).extract(img)
     ext = _make(2000, 1920, 1080)

@@ -3,6 +3,8 @@
 # (k2_tile_sweep.py) and HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; one run each).
 # usage: tools/experiments/k2_tile_sweep.sh [W,H,NF,B]    -> gpurun_out/k2_sweep_<W>x<H>.txt
 export TMPDIR=/tmp
+# the block form is a developer build since round 3
+touch pilotguru_amd/csrc/fast.hip pilotguru_amd/csrc/api.hip; make -C pilotguru_amd/csrc -j8 EXTRA=-DPGORB_FAST_BLOCKS > /dev/null 2>&1
 CFG=${1:-1920,1080,2000,128}
 W=$(echo $CFG | cut -d, -f1); H=$(echo $CFG | cut -d, -f2)
 OUT=gpurun_out/k2_sweep_${W}x${H}.txt
