@@ -17,8 +17,12 @@
 // --shard=rank/world (with --device): one ride over several processes, one per GPU -- SURVEY.md section 8(e): contiguous
 // chunks of frames with a one-frame overlap, nothing exchanged; process `rank` writes frontend-<rank>.json (and its
 // --dump_features file) for the frames it owns, the same rule as pilotguru_amd/dist.py frame_chunk_for_rank.
-// No libav here: --in_video takes a .y4m (Y plane), a printf pattern of PGM files
-// (frames/%06d.pgm) or a headerless .gray file sized by Camera_width/Camera_height.
+// No libav here: --in_video takes a .y4m (Y plane), a printf pattern of PGM (grey) or PPM (RGB24) files
+// (frames/%06d.pgm), or a headerless .gray / .rgb (interleaved RGB24, what the reference's reader decodes to:
+// src/io/image_sequence_reader.cc:138-208) file sized by Camera_width / Camera_height.  Frames go into the stream's
+// page-locked slots exactly as read; --vertical_flip / --horizontal_flip (:53-58), --rotation=0|90|180|270 (the
+// reader takes it from the container's metadata, :186-205) and Tracking's cvtColor (Tracking.cc:247-260, channel
+// order by Camera_RGB) run on the device in front of the pyramid (pgorb_stream_create_ingest).
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -29,6 +33,7 @@
 #include <map>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <fcntl.h>
@@ -46,7 +51,7 @@ struct Flags {
     std::string vocabulary_file, camera_settings, out_dir, in_video, trajectory_in, poses_in, dump_features;
     bool visualize = true, vertical_flip = false, horizontal_flip = false, output_per_segment_videos = false;
     long long rotation_smooth_sigma = -1;
-    int device = 0, batch = 32, max_frames = -1, segment_id = 0;
+    int device = 0, batch = 32, max_frames = -1, segment_id = 0, rotation = 0, copy_threads = 8;
     int shard_rank = 0, shard_world = 1;          // --shard=rank/world: this process takes its chunk of the ride
 };
 
@@ -77,6 +82,12 @@ bool parse_flags(int argc, char** argv, Flags& F)
         else if (name == "batch") F.batch = atoi(val.c_str());
         else if (name == "max_frames") F.max_frames = atoi(val.c_str());
         else if (name == "segment_id") F.segment_id = atoi(val.c_str());
+        else if (name == "copy_threads") F.copy_threads = atoi(val.c_str());
+        else if (name == "rotation") {
+            F.rotation = atoi(val.c_str());
+            if (F.rotation != 0 && F.rotation != 90 && F.rotation != 180 && F.rotation != 270) {
+                fprintf(stderr, "ERROR: unsupported rotation %d: only multiples of 90 degrees\n", F.rotation); return false; }   // reader :203-207
+        }
         else if (name == "shard") {
             if (sscanf(val.c_str(), "%d/%d", &F.shard_rank, &F.shard_world) != 2 || F.shard_world < 1 || F.shard_rank < 0 ||
                 F.shard_rank >= F.shard_world) { fprintf(stderr, "ERROR: --shard wants rank/world with 0 <= rank < world\n"); return false; }
@@ -105,12 +116,14 @@ std::map<std::string, double> read_settings(const std::string& path)
     return m;
 }
 
-struct FrameSource {                  // ImageSequenceSource (include/io/image_sequence_reader.hpp:23-28), grey only
+struct FrameSource {                  // ImageSequenceSource (include/io/image_sequence_reader.hpp:23-28)
     std::string path; int w = 0, h = 0; double fps = 30; long frame = 0;
+    int channels = 1;                 // 1 = grey plane, 3 = interleaved RGB24 (.rgb file, PPM sequence)
     bool y4m = false, pattern = false; size_t y4mFrameBytes = 0;
     // .y4m / .gray files are mapped: a frame goes from the page cache into the page-locked slot with ONE user-space
     // copy (read() straight into page-locked memory measured 25 % slower than read() + memcpy, the mapping is faster than both)
     const uint8_t* map = nullptr; size_t mapSize = 0, pos = 0;
+    const uint8_t* lastPtr = nullptr;     // where the frame next() just stepped over starts in the mapping
     std::string patHead, patTail; int patWidth = 0; bool patZero = false;      // "<head>%0Nd<tail>", parsed once
     // The user's path is never handed to printf as a format: exactly one %d / %Nd / %0Nd conversion is
     // accepted ("%%" is a literal per cent sign) and the frame name is assembled by hand.
@@ -169,8 +182,10 @@ struct FrameSource {                  // ImageSequenceSource (include/io/image_s
             return w > 0 && h > 0;
         }
         w = sw; h = sh;
+        if (p.size() > 4 && p.substr(p.size() - 4) == ".rgb") channels = 3;
         return w > 0 && h > 0;
     }
+    size_t frame_bytes() const { return (size_t)w * h * channels; }
     ~FrameSource() { if (map) munmap(const_cast<uint8_t*>(map), mapSize); }
     // number of frames of the sequence (pattern: probe for the first missing file)
     long count()
@@ -181,7 +196,7 @@ struct FrameSource {                  // ImageSequenceSource (include/io/image_s
             return k;
         }
         if (y4m) return (long)((mapSize - pos) / (y4mFrameBytes + 6));         // "FRAME\n" + planes (frame headers without parameters)
-        return (long)(mapSize / ((size_t)w * h));
+        return (long)(mapSize / frame_bytes());
     }
     // start at frame k (frame ids and timestamps stay those of the whole sequence)
     bool skip(long k)
@@ -199,7 +214,10 @@ struct FrameSource {                  // ImageSequenceSource (include/io/image_s
             FILE* f = fopen(frame_name(frame).c_str(), "rb");
             if (!f) return false;
             char magic[3] = {0}; int maxv = 0, fw = 0, fh = 0;
-            if (fscanf(f, "%2s %d %d %d", magic, &fw, &fh, &maxv) != 4 || strcmp(magic, "P5") || maxv != 255) { fclose(f); return false; }
+            if (fscanf(f, "%2s %d %d %d", magic, &fw, &fh, &maxv) != 4 || (strcmp(magic, "P5") && strcmp(magic, "P6")) || maxv != 255) { fclose(f); return false; }
+            const int fch = magic[1] == '6' ? 3 : 1;
+            if (frame > 0 && w > 0 && fch != channels) { fclose(f); fprintf(stderr, "ERROR: frame %ld changes the pixel format\n", frame); return false; }
+            channels = fch;
             // every frame of a sequence has the first frame's size (the context and the buffers are sized once)
             if (fw <= 0 || fh <= 0 || (w > 0 && (fw != w || fh != h))) {
                 fclose(f);
@@ -208,12 +226,12 @@ struct FrameSource {                  // ImageSequenceSource (include/io/image_s
             }
             w = fw; h = fh;
             fgetc(f);
-            if (!dst) { gray.resize((size_t)w * h); dst = gray.data(); }
-            const bool ok = fread(dst, 1, (size_t)w * h, f) == (size_t)w * h;
+            if (!dst) { gray.resize(frame_bytes()); dst = gray.data(); }
+            const bool ok = fread(dst, 1, frame_bytes(), f) == frame_bytes();
             fclose(f);
             if (!ok) return false;
         } else {
-            const size_t y = (size_t)w * h;
+            const size_t y = frame_bytes();
             size_t skip = 0;
             if (y4m) {                                                 // "FRAME[ params]\n" then the planes; only Y is used
                 if (pos + 5 > mapSize || memcmp(map + pos, "FRAME", 5)) return false;
@@ -223,6 +241,7 @@ struct FrameSource {                  // ImageSequenceSource (include/io/image_s
                 skip = y4mFrameBytes - y;
             }
             if (pos + y + skip > mapSize) return false;
+            lastPtr = map + pos;
             if (copy) {
                 if (!dst) { gray.resize(y); dst = gray.data(); }
                 memcpy(dst, map + pos, y);
@@ -235,12 +254,6 @@ struct FrameSource {                  // ImageSequenceSource (include/io/image_s
         return true;
     }
 };
-
-void flip(uint8_t* g, int w, int h, bool vertical, bool horizontal)      // in place (image_sequence_reader.cc:53-58)
-{
-    if (vertical) for (int y = 0; y < h / 2; y++) std::swap_ranges(g + (size_t)y * w, g + (size_t)(y + 1) * w, g + (size_t)(h - 1 - y) * w);
-    if (horizontal) for (int y = 0; y < h; y++) std::reverse(g + (size_t)y * w, g + (size_t)(y + 1) * w);
-}
 
 int write_trajectory_from_text(const Flags& F)
 {
@@ -354,18 +367,22 @@ int main(int argc, char** argv)
     if (!((F.max_frames < 0 || F.max_frames > 0) && src.next(frame0, &t0, &id0))) frame0.clear();
     pgorb::ORBextractor* ext = nullptr;
     pgorb_stream* st = nullptr;
+    // the upright frame the extractor sees (the reader's rotation swaps the sides for 90 / 270)
+    const bool swapSides = F.rotation == 90 || F.rotation == 270;
+    const int upW = swapSides ? src.h : src.w, upH = swapSides ? src.w : src.h;
     if (!frame0.empty()) {
-        flip(frame0.data(), src.w, src.h, F.vertical_flip, F.horizontal_flip);
-        ext = new pgorb::ORBextractor(nFeatures, scaleFactor, nLevels, iniTh, minTh, src.w, src.h, B, F.device);
+        ext = new pgorb::ORBextractor(nFeatures, scaleFactor, nLevels, iniTh, minTh, upW, upH, B, F.device);
         if (pgorb_vocab_upload(ext->context(), voc) != PGORB_OK) check_failed("vocabulary upload");
-        if (pgorb_max_keypoints(ext->context(), src.w, src.h) < 0) check_failed("frame size usable for the ORB cell grid");
-        if (pgorb_stream_create(ext->context(), src.w, src.h, B, DEPTH, &st) != PGORB_OK) check_failed(pgorb_last_error(ext->context()));
+        if (pgorb_max_keypoints(ext->context(), upW, upH) < 0) check_failed("frame size usable for the ORB cell grid");
+        // frames as read; rotation, flips and the grey conversion on the device (Camera_RGB: 1 = RGB, 0 = BGR; Tracking.cc:247-260)
+        if (pgorb_stream_create_ingest(ext->context(), src.w, src.h, src.channels, (int)get("Camera_RGB", 1) != 0, F.rotation,
+                                       F.vertical_flip, F.horizontal_flip, B, DEPTH, &st) != PGORB_OK) check_failed(pgorb_last_error(ext->context()));
         // Frame::ComputeImageBounds without distortion: [0, cols] x [0, rows] (Frame.cc:462-466); ORBmatcher(0.9, true)
         // .SearchForInitialization(mInitialFrame, mCurrentFrame, mvbPrevMatched, mvIniMatches, 100) (Tracking.cc:596-597);
         // transform(..., 4) (Frame.cc:404)
-        if (pgorb_stream_frontend(st, 0.f, (float)src.w, 0.f, (float)src.h, 100, 0.9f, 1, 4) != PGORB_OK) check_failed(pgorb_last_error(ext->context()));
+        if (pgorb_stream_frontend(st, 0.f, (float)upW, 0.f, (float)upH, 100, 0.9f, 1, 4) != PGORB_OK) check_failed(pgorb_last_error(ext->context()));
     }
-    const size_t fbytes = (size_t)src.w * src.h;
+    const size_t fbytes = src.frame_bytes();
     std::vector<std::vector<long long>> tusS(DEPTH, std::vector<long long>(B)), idsS(DEPTH, std::vector<long long>(B));
     std::ostringstream js;
     js << "{\n  \"frames\": [";
@@ -381,13 +398,26 @@ int main(int argc, char** argv)
             uint8_t* in = pgorb_stream_input(st, slot);
             int nb = 0;
             std::vector<uint8_t> tmp;
+            // a mapped file's frames are copied into the page-locked slot by several threads at once (one thread moves
+            // ~6-9 GB/s out of the page cache: 3 000 grey / 1 400 RGB24 1080p frames per second, a third of the link)
+            std::vector<std::pair<const uint8_t*, uint8_t*>> copies;
             while (nb < B && (F.max_frames < 0 || read < F.max_frames)) {
                 if (read == 0) { memcpy(in, frame0.data(), fbytes); tusS[slot][0] = t0; idsS[slot][0] = id0; }
-                else {
+                else if (src.map) {
+                    if (!src.next(tmp, &tusS[slot][nb], &idsS[slot][nb], nullptr, false)) { more = false; break; }
+                    copies.emplace_back(src.lastPtr, in + (size_t)nb * fbytes);
+                } else {
                     if (!src.next(tmp, &tusS[slot][nb], &idsS[slot][nb], in + (size_t)nb * fbytes)) { more = false; break; }
-                    flip(in + (size_t)nb * fbytes, src.w, src.h, F.vertical_flip, F.horizontal_flip);
                 }
                 nb++; read++;
+            }
+            if (!copies.empty()) {
+                const int nthreads = (int)std::min<size_t>(copies.size(), (size_t)std::max(1, F.copy_threads));
+                std::vector<std::thread> pool;
+                for (int t = 1; t < nthreads; t++)
+                    pool.emplace_back([&, t] { for (size_t k = t; k < copies.size(); k += nthreads) memcpy(copies[k].second, copies[k].first, fbytes); });
+                for (size_t k = 0; k < copies.size(); k += nthreads) memcpy(copies[k].second, copies[k].first, fbytes);
+                for (auto& th : pool) th.join();
             }
             if (F.max_frames >= 0 && read >= F.max_frames) more = false;
             if (!nb) break;
@@ -426,7 +456,7 @@ int main(int argc, char** argv)
                 fwrite(desc + o * 32, 32, n[i], dump);
             }
         }
-        total += nb;
+        for (int i = 0; i < nb; i++) total += ids[i] >= firstOwned;      // (a shard's overlap frame is not one of its frames)
     }
     js << "\n  ],\n  \"orb\": {\"nFeatures\": " << nFeatures << ", \"nLevels\": " << nLevels << ", \"iniThFAST\": " << iniTh
        << ", \"minThFAST\": " << minTh << "},\n  \"vocabulary\": {\"k\": " << vk << ", \"L\": " << vL << ", \"nodes\": " << vn << ", \"words\": " << vw

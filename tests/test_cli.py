@@ -78,6 +78,52 @@ def test_cli_rejects_hostile_frame_patterns(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,rot,vf,hf,camera_rgb", [("ppm", 90, False, True, 1), ("rgb", 180, True, False, 0), ("rgb", 0, False, False, 1)])
+def test_cli_reads_rgb_frames_and_ingests_on_the_device(tmp_path, oracle, kind, rot, vf, hf, camera_rgb):
+    """RGB24 frames as the reference's reader decodes them (image_sequence_reader.cc:138-208): a PPM sequence or a raw
+    .rgb file goes into the page-locked slots as read; rotation (:186-205), --vertical_flip / --horizontal_flip (:53-58)
+    and cvtColor by Camera_RGB (Tracking.cc:247-260) run on the device.  Every frame's keypoints and descriptors
+    against the oracle on the oracle-ingested grey frame."""
+    from pilotguru_amd import vocab as V
+    from pilotguru_amd.synth import synth_ride
+    w, h, nfr, nf = 400, 300, 5, 600
+    ride = synth_ride(14, w, h, nfr, dx=4, dy=2)
+    rgb = np.ascontiguousarray(np.stack([ride, np.roll(ride, 5, axis=2), 255 - ride], axis=3))
+    d = str(tmp_path)
+    if kind == "ppm":
+        for i in range(nfr):
+            with open(os.path.join(d, "%04d.ppm" % i), "wb") as f:
+                f.write(b"P6\n%d %d\n255\n" % (w, h) + rgb[i].tobytes())
+        video = os.path.join(d, "%04d.ppm")
+    else:
+        video = os.path.join(d, "ride.rgb")
+        rgb.tofile(video)
+    with open(os.path.join(d, "cam.yml"), "w") as f:
+        f.write("%%YAML:1.0\n---\nCamera_width: %d\nCamera_height: %d\nCamera_fps: 30.\nCamera_RGB: %d\nORBextractor_nFeatures: %d\n" % (w, h, camera_rgb, nf))
+    desc, weight, parent = V.synth_vocabulary(4, 3, seed=3)
+    V.write_vocabulary_text(os.path.join(d, "voc.txt"), 4, 3, desc, weight, parent)
+    args = ["--vocabulary_file=" + os.path.join(d, "voc.txt"), "--camera_settings=" + os.path.join(d, "cam.yml"), "--in_video=" + video,
+            "--out_dir=" + d, "--novisualize", "--batch=2", "--rotation=%d" % rot, "--dump_features=" + os.path.join(d, "feat.bin")]
+    if vf: args.append("--vertical_flip")
+    if hf: args.append("--horizontal_flip")
+    r = _cli(*args)
+    assert r.returncode == 0, r.stderr
+    raw = open(os.path.join(d, "feat.bin"), "rb").read()
+    ora = oracle.OrbOracle(nf, 1.2, 8, 20, 7)
+    off = 0
+    for i in range(nfr):
+        up = oracle.ingest_geometry(rgb[i], rot, vf, hf)
+        gray = oracle.rgb_to_gray(np.ascontiguousarray(up if camera_rgb else up[:, :, ::-1]))
+        okp, odesc = ora.extract(gray)
+        fid, n = np.frombuffer(raw, np.int32, 2, off); off += 8
+        assert fid == i and n == len(okp) > 300
+        assert raw[off:off + 28 * n] == okp.tobytes(); off += 28 * n
+        assert raw[off:off + 32 * n] == odesc.tobytes(); off += 32 * n
+    assert off == len(raw)
+    assert _cli(*(args + ["--rotation=45"])).returncode != 0
+
+
+@pytest.mark.gpu
 def test_cli_front_end_run_matches_python_path(tmp_path, oracle):
     import pilotguru_amd as pg
     from pilotguru_amd import vocab as V
