@@ -264,6 +264,41 @@ int  pgorb_search_by_bow(pgorb_ctx* ctx,
         const uint32_t* f_fv_node, const int32_t* f_fv_start, const uint32_t* f_fv_feat, int f_nfv,
         float nnratio, int check_orientation, int32_t* matches /*[nf]*/);
 
+/* Batched, resident forms of the three matchers above (round 3; the single calls are one-pair batches of these).
+ * Frames live in the layout of pgorb_extract_batch_device (keypoints / descriptors `cap_per_frame` apart, counts d_n),
+ * grids as pgorb_frame_grid_batch_device writes them; pair p matches its queries against frame d_pair_frame[p]
+ * (NULL: frame p).  Query arrays are [npairs][qcap] with d_nq[p] entries in use; d_kp_has_point (NULL = none) and
+ * d_assigned are [npairs][cap_per_frame], d_nmatches [npairs].  One wave per pair, all pairs concurrently: the
+ * reference's order dependence (an assignment is seen by every later query, ORBmatcher.cc:75-79, :1398-1402, :236-240)
+ * stays inside a pair.  Call sites: Tracking::SearchLocalPoints (Tracking.cc:1175), TrackWithMotionModel (:876, :882),
+ * TrackReferenceKeyFrame (:758). */
+int  pgorb_search_by_projection_points_batch_device(pgorb_ctx* ctx,
+        const pgorb_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, int cap_per_frame,
+        const int32_t* d_grid_start, const int32_t* d_grid_idx, const int32_t* d_pair_frame, int npairs,
+        float min_x, float max_x, float min_y, float max_y, const uint8_t* d_kp_has_point,
+        int qcap, const int32_t* d_nq, const uint8_t* d_valid, const float* d_proj_x, const float* d_proj_y,
+        const int32_t* d_level, const float* d_view_cos, const uint8_t* d_point_desc, const uint8_t* d_point_has_obs,
+        float th, float nnratio, int32_t* d_assigned, int32_t* d_nmatches, void* hip_stream);
+int  pgorb_search_by_projection_frame_batch_device(pgorb_ctx* ctx,
+        const pgorb_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, int cap_per_frame,
+        const int32_t* d_grid_start, const int32_t* d_grid_idx, const int32_t* d_pair_frame, int npairs,
+        float min_x, float max_x, float min_y, float max_y, const uint8_t* d_kp_has_point,
+        int qcap, const int32_t* d_nq, const uint8_t* d_valid, const float* d_u, const float* d_v,
+        const int32_t* d_last_octave, const float* d_last_angle, const uint8_t* d_point_desc, const uint8_t* d_point_has_obs,
+        float th, int check_orientation, int32_t* d_assigned, int32_t* d_nmatches, void* hip_stream);
+/* FeatureVector of every frame on the device: from the per-feature node ids pgorb_bow_transform_device wrote
+ * (d_node [nframes][cap]) the CSR arrays of DBoW2's FeatureVector (FeatureVector.cpp:31-45: node ids ascending,
+ * feature indices of a node in feature order): d_fv_node / d_fv_feat [nframes][cap], d_fv_start [nframes][cap + 1],
+ * d_nfv [nframes].  Equal to what pgorb_bow_vectors returns as fv_node / fv_start / fv_feat. */
+int  pgorb_feature_vectors_batch_device(pgorb_ctx* ctx, const uint32_t* d_node, const int32_t* d_n, int nframes, int cap_per_frame,
+        uint32_t* d_fv_node, int32_t* d_fv_start, uint32_t* d_fv_feat, int32_t* d_nfv, void* hip_stream);
+/* pair p: key frame d_pair_kf[p], frame d_pair_f[p] of the same batch; d_kf_point_valid and d_matches [npairs][cap]. */
+int  pgorb_search_by_bow_batch_device(pgorb_ctx* ctx,
+        const pgorb_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, int cap_per_frame,
+        const uint32_t* d_fv_node, const int32_t* d_fv_start, const uint32_t* d_fv_feat, const int32_t* d_nfv,
+        const int32_t* d_pair_kf, const int32_t* d_pair_f, int npairs, const uint8_t* d_kf_point_valid,
+        float nnratio, int check_orientation, int32_t* d_matches, int32_t* d_nmatches, void* hip_stream);
+
 /* ---- ORB vocabulary (DBoW2 TemplatedVocabulary<FORB::TDescriptor, FORB>) -----------------
  *   pgorb_vocab_load_text     ORBVocabulary(text_file) -> TemplatedVocabulary::loadFromTextFile
  *                             thirdparty/orb-slam2/src/ORBVocabulary.cc:7-9,

@@ -28,6 +28,8 @@ SYMBOLS = (
     "pgorb_search_for_initialization_batch_device", "pgorb_extract_batch_color_device",
     "pgorb_extract_batch_ingest_device",
     "pgorb_search_by_projection_points", "pgorb_search_by_projection_frame", "pgorb_search_by_bow",
+    "pgorb_search_by_projection_points_batch_device", "pgorb_search_by_projection_frame_batch_device",
+    "pgorb_feature_vectors_batch_device", "pgorb_search_by_bow_batch_device",
     "pgorb_undistort_keypoints", "pgorb_undistort_keypoints_batch_device", "pgorb_image_bounds",
     "pgorb_host_alloc", "pgorb_host_free", "pgorb_stream_create", "pgorb_stream_create_ingest", "pgorb_stream_destroy", "pgorb_stream_input", "pgorb_stream_reset", "pgorb_stream_submit",
     "pgorb_stream_wait", "pgorb_stream_frontend", "pgorb_stream_frontend_results", "pgorb_set_option", "pgorb_get_option", "pgorb_matcher_is_popcount",
@@ -125,6 +127,13 @@ def lib():
     L.pgorb_search_by_projection_frame.argtypes = [vp, vp, vp, C.c_int] + f4 + [vp, C.c_int] + [vp] * 7 + [C.c_float, C.c_int, vp]
     L.pgorb_search_by_bow.argtypes = [vp] + [vp] * 3 + [C.c_int] + [vp] * 3 + [C.c_int] + [vp] * 2 + [C.c_int] + [vp] * 3 + \
         [C.c_int, C.c_float, C.c_int, vp]
+    # (ctx, kps, desc, n, cap, grid_start, grid_idx, pair_frame, npairs, bounds x 4, kp_has_point, qcap, nq, 7 query arrays, th, ratio | check, assigned, nmatches, stream)
+    L.pgorb_search_by_projection_points_batch_device.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int] + f4 + [vp, C.c_int, vp] + [vp] * 7 + \
+        [C.c_float, C.c_float, vp, vp, vp]
+    L.pgorb_search_by_projection_frame_batch_device.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int] + f4 + [vp, C.c_int, vp] + [vp] * 7 + \
+        [C.c_float, C.c_int, vp, vp, vp]
+    L.pgorb_feature_vectors_batch_device.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+    L.pgorb_search_by_bow_batch_device.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_float, C.c_int, vp, vp, vp]
     L.pgorb_undistort_keypoints.argtypes = [vp, vp, C.c_int, vp, vp, vp]
     L.pgorb_undistort_keypoints_batch_device.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     L.pgorb_image_bounds.argtypes = [C.c_int, C.c_int, vp, vp, vp]

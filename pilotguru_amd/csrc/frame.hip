@@ -463,39 +463,63 @@ __global__ __launch_bounds__(64) void k_search_for_initialization(
 // ---- SearchByProjection (local map points / last frame), src/ORBmatcher.cc:46-131, 1355-1474 ----
 // One wave per frame; queries in order.  mode 0: best + second with the same-level ratio test
 // (:83-125); mode 1: best only + rotation histogram (:1390-1469).
-struct PgProjQuery {
-    const uint8_t* valid; const float* x; const float* y; const float* radius;
-    const int32_t* minLevel; const int32_t* maxLevel; const float* angle;
+// Batch layout (round 3): pair p = blockIdx.x matches its nq[p] queries against frame pairFrame[p] of an extract batch
+// (keypoints / descriptors `cap` apart, grids (GRID_CELLS + 1) / cap apart); query arrays are [npairs][qcap].  The search
+// radius and the level window of a query are derived here from what the caller holds (predicted level + viewing cosine,
+// or the last frame's octave) exactly as the reference does, so the host never touches the queries.
+struct PgProjBatch {
+    const pgorb_keypoint* K; const uint8_t* D; const int32_t* n; int cap;
+    const int32_t* gstart; const int32_t* gidx; const int32_t* pairFrame;
+    const uint8_t* kpHasPoint;             // [npairs][cap] or null
+    int qcap; const int32_t* nq;
+    const uint8_t* valid; const float* x; const float* y; const int32_t* level; const float* aux;   // aux: view cos (mode 0) / angle (mode 1)
     const uint8_t* desc; const uint8_t* hasObs;
+    float sf[PG_MAXL + 1]; int nlevels; float th;
 };
 
 #define TH_HIGH 100
 
 __global__ __launch_bounds__(64) void k_search_by_projection(
-    const pgorb_keypoint* __restrict__ K, const uint8_t* __restrict__ D, int n,
-    const int32_t* __restrict__ gstart, const int32_t* __restrict__ gidx,
-    float minX, float minY, float invW, float invH, const uint8_t* __restrict__ kpHasPoint,
-    PgProjQuery Q, int nq, int mode, float nnratio, int checkOrientation,
+    PgProjBatch B, float minX, float minY, float invW, float invH, int mode, float nnratio, int checkOrientation,
     int32_t* __restrict__ assignedOut, int32_t* __restrict__ nmatchesOut)
 {
+    const int p = blockIdx.x, frame = B.pairFrame ? B.pairFrame[p] : p;
+    const int cap = B.cap, n = min(B.n[frame], cap), nq = min(B.nq[p], B.qcap);
+    const pgorb_keypoint* __restrict__ K = B.K + (int64_t)frame * cap;
+    const uint8_t* __restrict__ D = B.D + (int64_t)frame * cap * 32;
+    const int32_t* __restrict__ gstart = B.gstart + (int64_t)frame * (GRID_CELLS + 1);
+    const int32_t* __restrict__ gidx = B.gidx + (int64_t)frame * cap;
+    const uint8_t* kpHasPoint = B.kpHasPoint ? B.kpHasPoint + (int64_t)p * cap : nullptr;
+    const int64_t qo = (int64_t)p * B.qcap;
+    assignedOut += (int64_t)p * cap; nmatchesOut += p;
     const int lane = threadIdx.x;
     // state in LDS: taken[i] = keypoint i holds a point with observations (before or by this
     // call); asg[i] = query assigned to keypoint i by this call; candList = vIndices;
     // rotBin[q] / qBest[q] = histogram bin and keypoint of accepted query q (mode 1)
-    uint8_t* taken = pg_sfi_smem;                                         // [n]
-    int32_t* asg = reinterpret_cast<int32_t*>(pg_sfi_smem + ((n + 15) & ~15));      // [n]
-    uint16_t* candList = reinterpret_cast<uint16_t*>(asg + n);            // [n]
-    uint16_t* qBest = candList + n;                                       // [nq]
-    int8_t* rotBin = reinterpret_cast<int8_t*>(qBest + nq);               // [nq]
+    uint8_t* taken = pg_sfi_smem;                                         // [cap]
+    int32_t* asg = reinterpret_cast<int32_t*>(pg_sfi_smem + ((cap + 15) & ~15));    // [cap]
+    uint16_t* candList = reinterpret_cast<uint16_t*>(asg + cap);          // [cap]
+    uint16_t* qBest = candList + cap;                                     // [qcap]
+    int8_t* rotBin = reinterpret_cast<int8_t*>(qBest + B.qcap);           // [qcap]
     for (int i = lane; i < n; i += 64) { taken[i] = kpHasPoint ? (kpHasPoint[i] != 0) : 0; asg[i] = -1; }
     if (mode == 1) for (int i = lane; i < nq; i += 64) rotBin[i] = -1;
     __syncthreads();
     const float factor = 1.0f / HISTO_LENGTH;
     int nmatches = 0;
     for (int q = 0; q < nq; q++) {
-        if (!Q.valid[q]) continue;
-        const float x = Q.x[q], y = Q.y[q], r = Q.radius[q];
-        const int minLevel = Q.minLevel[q], maxLevel = Q.maxLevel[q];
+        const int lvl = B.level[qo + q];
+        if (!B.valid[qo + q] || lvl < 0 || lvl >= B.nlevels) continue;
+        const float x = B.x[qo + q], y = B.y[qo + q];
+        float r; int minLevel, maxLevel;
+        if (mode == 0) {
+            r = ((double)B.aux[qo + q] > 0.998) ? 2.5f : 4.0f;            // RadiusByViewingCos (:133-139)
+            if (B.th != 1.0f) r = __fmul_rn(r, B.th);                     // bFactor (:50, :65-66)
+            r = __fmul_rn(r, B.sf[lvl]);                                  // r * F.mvScaleFactors[nPredictedLevel] (:69)
+            minLevel = lvl - 1; maxLevel = lvl;                           // :69-70
+        } else {
+            r = __fmul_rn(B.th, B.sf[lvl]);                               // th * CurrentFrame.mvScaleFactors[nLastOctave] (:1383)
+            minLevel = lvl - 1; maxLevel = lvl + 1;                       // :1392 (mono: neither forward nor backward)
+        }
         // GetFeaturesInArea(x, y, r, minLevel, maxLevel)  (Frame.cc:336-350)
         const int nMinCellX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, minX), r), invW)));
         if (nMinCellX >= GRID_COLS) continue;
@@ -523,8 +547,8 @@ __global__ __launch_bounds__(64) void k_search_by_projection(
         }
         __syncthreads();
         if (M == 0) continue;
-        const uint4 q0 = reinterpret_cast<const uint4*>(Q.desc + (int64_t)q * 32)[0];
-        const uint4 q1 = reinterpret_cast<const uint4*>(Q.desc + (int64_t)q * 32)[1];
+        const uint4 q0 = reinterpret_cast<const uint4*>(B.desc + (qo + q) * 32)[0];
+        const uint4 q1 = reinterpret_cast<const uint4*>(B.desc + (qo + q) * 32)[1];
         unsigned b1key = 0xFFFFFFFFu, b2key = 0xFFFFFFFFu;     // (dist << 16 | list position): two smallest of this lane
         for (int k = lane; k < M; k += 64) {
             const int i2 = candList[k];
@@ -559,7 +583,7 @@ __global__ __launch_bounds__(64) void k_search_by_projection(
             } else {
                 accept = bestDist <= TH_HIGH;                  // :1421
                 if (accept && checkOrientation) {              // :1426-1436
-                    float rot = __fsub_rn(Q.angle[q], K[bestIdx].angle);
+                    float rot = __fsub_rn(B.aux[qo + q], K[bestIdx].angle);
                     if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
                     bin = (int)roundf(__fmul_rn(rot, factor));
                     if (bin == HISTO_LENGTH) bin = 0;
@@ -569,7 +593,7 @@ __global__ __launch_bounds__(64) void k_search_by_projection(
                 nmatches++;
                 if (lane == 0) {
                     asg[bestIdx] = q;                          // F.mvpMapPoints[bestIdx] = pMP
-                    taken[bestIdx] = Q.hasObs[q] != 0;
+                    taken[bestIdx] = B.hasObs[qo + q] != 0;
                     if (mode == 1) { rotBin[q] = (int8_t)bin; qBest[q] = (uint16_t)bestIdx; }
                 }
             }
@@ -600,7 +624,7 @@ __global__ __launch_bounds__(64) void k_search_by_projection(
         nmatches -= removed;
         __syncthreads();
     }
-    for (int i = lane; i < n; i += 64) assignedOut[i] = asg[i];
+    for (int i = lane; i < cap; i += 64) assignedOut[i] = i < n ? asg[i] : -1;
     if (lane == 0) *nmatchesOut = nmatches;
 }
 
@@ -608,13 +632,30 @@ __global__ __launch_bounds__(64) void k_search_by_projection(
 // One wave per (key frame, frame) pair: merge-join of the two node lists; inside a common node the
 // key frame's features are visited in order (each assignment removes a candidate for the later
 // ones, :211-212) and the frame's features of that node are scanned one per lane.
-__global__ __launch_bounds__(64) void k_search_by_bow(
-    const uint8_t* __restrict__ kfDesc, const float* __restrict__ kfAngle, const uint8_t* __restrict__ kfValid,
-    const uint32_t* __restrict__ aNode, const int32_t* __restrict__ aStart, const uint32_t* __restrict__ aFeat, int nA,
-    const uint8_t* __restrict__ fDesc, const float* __restrict__ fAngle, int nf,
-    const uint32_t* __restrict__ bNode, const int32_t* __restrict__ bStart, const uint32_t* __restrict__ bFeat, int nB,
-    float nnratio, int checkOrientation, int32_t* __restrict__ matchesOut, int32_t* __restrict__ nmatchesOut)
+// Batch layout (round 3): pair p = blockIdx.x, key frame pairKF[p] and frame pairF[p] of ONE extract batch (descriptors and
+// keypoint angles `cap` apart); the FeatureVectors are the per-frame CSR arrays k_feature_vectors builds on the device
+// (fvNode / fvFeat `cap` apart, fvStart cap + 1 apart); kfValid and the outputs are [npairs][cap].
+struct PgBowBatch {
+    const pgorb_keypoint* K; const uint8_t* D; const int32_t* n; int cap;
+    const uint32_t* fvNode; const int32_t* fvStart; const uint32_t* fvFeat; const int32_t* nfv;
+    const int32_t* pairKF; const int32_t* pairF; const uint8_t* kfValid;
+};
+
+__global__ __launch_bounds__(64) void k_search_by_bow(PgBowBatch B, float nnratio, int checkOrientation,
+                                                       int32_t* __restrict__ matchesOut, int32_t* __restrict__ nmatchesOut)
 {
+    const int p = blockIdx.x, fa = B.pairKF[p], fb = B.pairF[p], cap = B.cap;
+    const uint8_t* __restrict__ kfDesc = B.D + (int64_t)fa * cap * 32;
+    const uint8_t* __restrict__ fDesc = B.D + (int64_t)fb * cap * 32;
+    const pgorb_keypoint* __restrict__ kfK = B.K + (int64_t)fa * cap;
+    const pgorb_keypoint* __restrict__ fK = B.K + (int64_t)fb * cap;
+    const uint8_t* __restrict__ kfValid = B.kfValid + (int64_t)p * cap;
+    const uint32_t* __restrict__ aNode = B.fvNode + (int64_t)fa * cap; const int32_t* __restrict__ aStart = B.fvStart + (int64_t)fa * (cap + 1);
+    const uint32_t* __restrict__ aFeat = B.fvFeat + (int64_t)fa * cap;
+    const uint32_t* __restrict__ bNode = B.fvNode + (int64_t)fb * cap; const int32_t* __restrict__ bStart = B.fvStart + (int64_t)fb * (cap + 1);
+    const uint32_t* __restrict__ bFeat = B.fvFeat + (int64_t)fb * cap;
+    const int nA = B.nfv[fa], nB = B.nfv[fb], nf = min(B.n[fb], cap);
+    matchesOut += (int64_t)p * cap; nmatchesOut += p;
     const int lane = threadIdx.x;
     int32_t* asg = reinterpret_cast<int32_t*>(pg_sfi_smem);               // [nf] vpMapPointMatches (as KF index)
     int8_t* rotBin = reinterpret_cast<int8_t*>(asg + nf);                 // [nf]
@@ -652,7 +693,7 @@ __global__ __launch_bounds__(64) void k_search_by_bow(
                 if (bestDist1 <= TH_LOW && (float)bestDist1 < __fmul_rn(nnratio, (float)bestDist2)) {   // :233-235
                     int bin = -1;
                     if (checkOrientation) {                               // :241-250
-                        float rot = __fsub_rn(kfAngle[realIdxKF], fAngle[bestIdxF]);
+                        float rot = __fsub_rn(kfK[realIdxKF].angle, fK[bestIdxF].angle);
                         if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
                         bin = (int)roundf(__fmul_rn(rot, factor));
                         if (bin == HISTO_LENGTH) bin = 0;
@@ -687,8 +728,44 @@ __global__ __launch_bounds__(64) void k_search_by_bow(
         nmatches -= removed;
         __syncthreads();
     }
-    for (int i = lane; i < nf; i += 64) matchesOut[i] = asg[i];
+    for (int i = lane; i < cap; i += 64) matchesOut[i] = i < nf ? asg[i] : -1;
     if (lane == 0) *nmatchesOut = nmatches;
+}
+
+// FeatureVector of every frame of a batch (DBoW2 FeatureVector::addFeature, FeatureVector.cpp:31-45, as
+// TemplatedVocabulary::transform fills it, TemplatedVocabulary.h:1180-1186): map<node id, vector<feature index>> with the
+// indices appended in feature order = the features sorted by (node id, index), as CSR.  One workgroup per frame: rank of
+// every feature by counting (n <= a few thousand: n^2 / 1024 compares per thread on LDS), scatter, group heads by a scan.
+__global__ __launch_bounds__(1024) void k_feature_vectors(const uint32_t* __restrict__ node, const int32_t* __restrict__ nIn, int cap,
+                                                          uint32_t* __restrict__ fvNode, int32_t* __restrict__ fvStart,
+                                                          uint32_t* __restrict__ fvFeat, int32_t* __restrict__ nfv)
+{
+    const int f = blockIdx.x, tid = threadIdx.x, n = min(nIn[f], cap);
+    uint32_t* key = reinterpret_cast<uint32_t*>(pg_sfi_smem);            // [cap] node id of feature i
+    uint32_t* snode = key + cap;                                          // [cap] sorted node ids
+    int* scan = reinterpret_cast<int*>(snode + cap);                      // [1024 + 1]
+    node += (int64_t)f * cap; fvNode += (int64_t)f * cap; fvFeat += (int64_t)f * cap; fvStart += (int64_t)f * (cap + 1);
+    for (int i = tid; i < n; i += 1024) key[i] = node[i];
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const uint32_t k = key[i];
+        int r = 0;
+        for (int j = 0; j < n; j++) { const uint32_t kj = key[j]; r += (kj < k) || (kj == k && j < i); }
+        snode[r] = k; fvFeat[r] = (uint32_t)i;
+    }
+    __syncthreads();
+    // group heads: position r starts a group when its node differs from its predecessor's; exclusive scan of the flags
+    const int per = (n + 1023) / 1024, r0 = tid * per, r1 = min(n, r0 + per);
+    int heads = 0;
+    for (int r = r0; r < r1; r++) heads += (r == 0 || snode[r] != snode[r - 1]);
+    scan[tid] = heads;
+    __syncthreads();
+    if (tid == 0) { int acc = 0; for (int t = 0; t < 1024; t++) { const int h = scan[t]; scan[t] = acc; acc += h; } scan[1024] = acc; }
+    __syncthreads();
+    int g = scan[tid];
+    for (int r = r0; r < r1; r++)
+        if (r == 0 || snode[r] != snode[r - 1]) { fvNode[g] = snode[r]; fvStart[g] = r; g++; }
+    if (tid == 0) { fvStart[scan[1024]] = n; nfv[f] = scan[1024]; }
 }
 
 // ---- cv::undistortPoints (OpenCV 2.4 imgproc/undistort.cpp cvUndistortPoints), 5 fixed-point
@@ -804,6 +881,55 @@ int pgorb_image_bounds(int cols, int rows, const float camera[4], const float di
     return 0;
 }
 
+// per-device "dynamic LDS limit already raised to" bookkeeping of the three latency kernels below
+static bool pg_raise_lds(pgorb_ctx* c, const void* fn, int which, size_t lds)
+{
+    static size_t configured[3][64] = {{0}};
+    const int dv = pg_ctx_device(c) & 63;
+    if (lds > 160 * 1024) return false;
+    if (lds > configured[which][dv]) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+        configured[which][dv] = lds;
+    }
+    return true;
+}
+
+int pgorb_feature_vectors_batch_device(pgorb_ctx* c, const uint32_t* d_node, const int32_t* d_n, int nframes, int cap,
+                                       uint32_t* d_fv_node, int32_t* d_fv_start, uint32_t* d_fv_feat, int32_t* d_nfv, void* stream)
+{
+    if (!c) return PGORB_E_ARG;
+    if (!d_node || !d_n || nframes < 1 || cap < 1 || !d_fv_node || !d_fv_start || !d_fv_feat || !d_nfv)
+        return pg_ctx_fail(c, PGORB_E_ARG, "bad argument to pgorb_feature_vectors_batch_device");
+    if (cap > 16000) return pg_ctx_fail(c, PGORB_E_LIMIT, "more than 16000 keypoints per frame");
+    if (hipSetDevice(pg_ctx_device(c)) != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "hipSetDevice failed");
+    const size_t lds = (size_t)cap * 8 + 1025 * 4;
+    if (!pg_raise_lds(c, reinterpret_cast<const void*>(k_feature_vectors), 2, lds)) return pg_ctx_fail(c, PGORB_E_LIMIT, "feature vector scratch exceeds the LDS");
+    hipLaunchKernelGGL(k_feature_vectors, dim3(nframes), dim3(1024), lds, (hipStream_t)stream, d_node, d_n, cap, d_fv_node, d_fv_start, d_fv_feat, d_nfv);
+    if (hipGetLastError() != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "k_feature_vectors launch failed");
+    return 0;
+}
+
+int pgorb_search_by_bow_batch_device(pgorb_ctx* c, const pgorb_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, int cap,
+                                     const uint32_t* d_fv_node, const int32_t* d_fv_start, const uint32_t* d_fv_feat, const int32_t* d_nfv,
+                                     const int32_t* d_pair_kf, const int32_t* d_pair_f, int npairs, const uint8_t* d_kf_point_valid,
+                                     float nnratio, int check_orientation, int32_t* d_matches, int32_t* d_nmatches, void* stream)
+{
+    if (!c) return PGORB_E_ARG;
+    if (!d_kps || !d_desc || !d_n || cap < 1 || !d_fv_node || !d_fv_start || !d_fv_feat || !d_nfv || npairs < 0 ||
+        (npairs && (!d_pair_kf || !d_pair_f || !d_kf_point_valid || !d_matches || !d_nmatches)))
+        return pg_ctx_fail(c, PGORB_E_ARG, "bad argument to pgorb_search_by_bow_batch_device");
+    if (cap > 16000) return pg_ctx_fail(c, PGORB_E_LIMIT, "more than 16000 keypoints per frame");
+    if (!npairs) return 0;
+    if (hipSetDevice(pg_ctx_device(c)) != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "hipSetDevice failed");
+    const size_t lds = (size_t)cap * 5 + 64;
+    if (!pg_raise_lds(c, reinterpret_cast<const void*>(k_search_by_bow), 1, lds)) return pg_ctx_fail(c, PGORB_E_LIMIT, "SearchByBoW state exceeds the LDS");
+    PgBowBatch B = {d_kps, d_desc, d_n, cap, d_fv_node, d_fv_start, d_fv_feat, d_nfv, d_pair_kf, d_pair_f, d_kf_point_valid};
+    hipLaunchKernelGGL(k_search_by_bow, dim3(npairs), dim3(64), lds, (hipStream_t)stream, B, nnratio, check_orientation, d_matches, d_nmatches);
+    if (hipGetLastError() != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "k_search_by_bow launch failed");
+    return 0;
+}
+
+// single pair through host buffers: the pair becomes a two-frame batch (key frame = frame 0, frame = frame 1)
 int pgorb_search_by_bow(pgorb_ctx* c, const uint8_t* kf_desc, const float* kf_angle, const uint8_t* kf_point_valid, int nkf,
                         const uint32_t* kf_fv_node, const int32_t* kf_fv_start, const uint32_t* kf_fv_feat, int kf_nfv,
                         const uint8_t* f_desc, const float* f_angle, int nf, const uint32_t* f_fv_node,
@@ -818,35 +944,34 @@ int pgorb_search_by_bow(pgorb_ctx* c, const uint8_t* kf_desc, const float* kf_an
     for (int i = 0; i < nf; i++) matches[i] = -1;
     if (!nkf || !nf || !kf_nfv || !f_nfv) return 0;
     if (nf > 16000 || nkf > 16000) return pg_ctx_fail(c, PGORB_E_LIMIT, "more than 16000 keypoints");
-    const int nfeatA = kf_fv_start[kf_nfv], nfeatB = f_fv_start[f_nfv];
+    const int cap = std::max(nkf, nf);
+    if (kf_nfv > cap || f_nfv > cap || kf_fv_start[kf_nfv] > nkf || f_fv_start[f_nfv] > nf)
+        return pg_ctx_fail(c, PGORB_E_ARG, "pgorb_search_by_bow: FeatureVector names more features than the frame has");
     auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
     size_t off = 0;
     auto place = [&](size_t bytes) { const size_t o = off; off += al(bytes); return o; };
-    const size_t oKD = place((size_t)nkf * 32), oKA = place((size_t)nkf * 4), oKV = place(nkf), oAN = place((size_t)kf_nfv * 4),
-                 oAS = place((size_t)(kf_nfv + 1) * 4), oAF = place((size_t)nfeatA * 4 + 4), oFD = place((size_t)nf * 32),
-                 oFA = place((size_t)nf * 4), oBN = place((size_t)f_nfv * 4), oBS = place((size_t)(f_nfv + 1) * 4),
-                 oBF = place((size_t)nfeatB * 4 + 4), oM = place((size_t)nf * 4), oNM = place(64);
+    const size_t oK = place((size_t)2 * cap * sizeof(pgorb_keypoint)), oD = place((size_t)2 * cap * 32), oN = place(8), oV = place(cap),
+                 oFN = place((size_t)2 * cap * 4), oFS = place((size_t)2 * (cap + 1) * 4), oFF = place((size_t)2 * cap * 4), oNF = place(8),
+                 oP = place(8), oM = place((size_t)cap * 4), oNM = place(64);
     void* dv;
     int rc = pg_ctx_stage(c, 0, off, &dv);
     if (rc) return rc;
     uint8_t* d = (uint8_t*)dv;
+    std::vector<pgorb_keypoint> kk((size_t)2 * cap);
+    for (int i = 0; i < nkf; i++) kk[i].angle = kf_angle[i];
+    for (int i = 0; i < nf; i++) kk[(size_t)cap + i].angle = f_angle[i];
+    const int32_t nn[2] = {nkf, nf}, nfvs[2] = {kf_nfv, f_nfv}, pr[2] = {0, 1};
     auto up = [&](size_t o, const void* p, size_t n) { return n == 0 || hipMemcpy(d + o, p, n, hipMemcpyHostToDevice) == hipSuccess; };
-    if (!(up(oKD, kf_desc, (size_t)nkf * 32) && up(oKA, kf_angle, (size_t)nkf * 4) && up(oKV, kf_point_valid, nkf) &&
-          up(oAN, kf_fv_node, (size_t)kf_nfv * 4) && up(oAS, kf_fv_start, (size_t)(kf_nfv + 1) * 4) && up(oAF, kf_fv_feat, (size_t)nfeatA * 4) &&
-          up(oFD, f_desc, (size_t)nf * 32) && up(oFA, f_angle, (size_t)nf * 4) && up(oBN, f_fv_node, (size_t)f_nfv * 4) &&
-          up(oBS, f_fv_start, (size_t)(f_nfv + 1) * 4) && up(oBF, f_fv_feat, (size_t)nfeatB * 4)))
+    if (!(up(oK, kk.data(), kk.size() * sizeof(pgorb_keypoint)) && up(oD, kf_desc, (size_t)nkf * 32) && up(oD + (size_t)cap * 32, f_desc, (size_t)nf * 32) &&
+          up(oN, nn, 8) && up(oV, kf_point_valid, nkf) && up(oFN, kf_fv_node, (size_t)kf_nfv * 4) && up(oFN + (size_t)cap * 4, f_fv_node, (size_t)f_nfv * 4) &&
+          up(oFS, kf_fv_start, (size_t)(kf_nfv + 1) * 4) && up(oFS + (size_t)(cap + 1) * 4, f_fv_start, (size_t)(f_nfv + 1) * 4) &&
+          up(oFF, kf_fv_feat, (size_t)kf_fv_start[kf_nfv] * 4) && up(oFF + (size_t)cap * 4, f_fv_feat, (size_t)f_fv_start[f_nfv] * 4) &&
+          up(oNF, nfvs, 8) && up(oP, pr, 8)))
         return pg_ctx_fail(c, PGORB_E_HIP, "hipMemcpy H2D failed");
-    const size_t lds = (size_t)nf * 5 + 64;
-    static size_t configured = 0;
-    if (lds > configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_by_bow), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        configured = lds;
-    }
-    hipLaunchKernelGGL(k_search_by_bow, dim3(1), dim3(64), lds, 0, d + oKD, (const float*)(d + oKA), d + oKV,
-                       (const uint32_t*)(d + oAN), (const int32_t*)(d + oAS), (const uint32_t*)(d + oAF), kf_nfv, d + oFD,
-                       (const float*)(d + oFA), nf, (const uint32_t*)(d + oBN), (const int32_t*)(d + oBS),
-                       (const uint32_t*)(d + oBF), f_nfv, nnratio, check_orientation, (int32_t*)(d + oM), (int32_t*)(d + oNM));
-    if (hipGetLastError() != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "k_search_by_bow launch failed");
+    rc = pgorb_search_by_bow_batch_device(c, (const pgorb_keypoint*)(d + oK), d + oD, (const int32_t*)(d + oN), cap, (const uint32_t*)(d + oFN),
+                                          (const int32_t*)(d + oFS), (const uint32_t*)(d + oFF), (const int32_t*)(d + oNF), (const int32_t*)(d + oP),
+                                          (const int32_t*)(d + oP) + 1, 1, d + oV, nnratio, check_orientation, (int32_t*)(d + oM), (int32_t*)(d + oNM), nullptr);
+    if (rc) return rc;
     int32_t nm = 0;
     if (hipMemcpy(matches, d + oM, (size_t)nf * 4, hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(&nm, d + oNM, 4, hipMemcpyDeviceToHost) != hipSuccess)
@@ -913,14 +1038,68 @@ int pgorb_search_for_initialization_batch_device(pgorb_ctx* c, const pgorb_keypo
     return 0;
 }
 
+static int pg_search_by_projection_batch(pgorb_ctx* c, int mode, const pgorb_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, int cap,
+                                         const int32_t* d_grid_start, const int32_t* d_grid_idx, const int32_t* d_pair_frame, int npairs,
+                                         float min_x, float max_x, float min_y, float max_y, const uint8_t* d_kp_has_point, int qcap,
+                                         const int32_t* d_nq, const uint8_t* d_valid, const float* d_x, const float* d_y, const int32_t* d_level,
+                                         const float* d_aux, const uint8_t* d_qdesc, const uint8_t* d_qobs, float th, float nnratio,
+                                         int check_orientation, int32_t* d_assigned, int32_t* d_nmatches, hipStream_t stream)
+{
+    if (!d_kps || !d_desc || !d_n || cap < 1 || !d_grid_start || !d_grid_idx || npairs < 0 || qcap < 0 ||
+        (npairs && (!d_nq || !d_assigned || !d_nmatches)) || (npairs && qcap && (!d_valid || !d_x || !d_y || !d_level || !d_aux || !d_qdesc || !d_qobs)) ||
+        !(max_x > min_x) || !(max_y > min_y))
+        return pg_ctx_fail(c, PGORB_E_ARG, "bad argument to pgorb_search_by_projection_*");
+    if (cap > 16000 || qcap > 16000) return pg_ctx_fail(c, PGORB_E_LIMIT, "more than 16000 keypoints / queries");
+    if (!npairs) return 0;
+    if (hipSetDevice(pg_ctx_device(c)) != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "hipSetDevice failed");
+    PgProjBatch B;
+    B.K = d_kps; B.D = d_desc; B.n = d_n; B.cap = cap; B.gstart = d_grid_start; B.gidx = d_grid_idx; B.pairFrame = d_pair_frame;
+    B.kpHasPoint = d_kp_has_point; B.qcap = qcap; B.nq = d_nq; B.valid = d_valid; B.x = d_x; B.y = d_y; B.level = d_level; B.aux = d_aux;
+    B.desc = d_qdesc; B.hasObs = d_qobs; B.nlevels = pgorb_levels(c); B.th = th;
+    pgorb_scale_tables(c, B.sf, nullptr, nullptr, nullptr);
+    const float invW = (float)GRID_COLS / (max_x - min_x), invH = (float)GRID_ROWS / (max_y - min_y);
+    const size_t lds = (size_t)((cap + 15) & ~15) + (size_t)cap * 6 + (size_t)qcap * 3 + 64;
+    if (!pg_raise_lds(c, reinterpret_cast<const void*>(k_search_by_projection), 0, lds)) return pg_ctx_fail(c, PGORB_E_LIMIT, "SearchByProjection state exceeds the LDS");
+    hipLaunchKernelGGL(k_search_by_projection, dim3(npairs), dim3(64), lds, stream, B, min_x, min_y, invW, invH, mode, nnratio,
+                       check_orientation, d_assigned, d_nmatches);
+    if (hipGetLastError() != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "k_search_by_projection launch failed");
+    return 0;
+}
+
+int pgorb_search_by_projection_points_batch_device(pgorb_ctx* c, const pgorb_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n,
+        int cap_per_frame, const int32_t* d_grid_start, const int32_t* d_grid_idx, const int32_t* d_pair_frame, int npairs,
+        float min_x, float max_x, float min_y, float max_y, const uint8_t* d_kp_has_point, int qcap, const int32_t* d_nq,
+        const uint8_t* d_valid, const float* d_proj_x, const float* d_proj_y, const int32_t* d_level, const float* d_view_cos,
+        const uint8_t* d_point_desc, const uint8_t* d_point_has_obs, float th, float nnratio, int32_t* d_assigned, int32_t* d_nmatches,
+        void* stream)
+{
+    if (!c) return PGORB_E_ARG;
+    return pg_search_by_projection_batch(c, 0, d_kps, d_desc, d_n, cap_per_frame, d_grid_start, d_grid_idx, d_pair_frame, npairs, min_x, max_x,
+                                         min_y, max_y, d_kp_has_point, qcap, d_nq, d_valid, d_proj_x, d_proj_y, d_level, d_view_cos, d_point_desc,
+                                         d_point_has_obs, th, nnratio, 0, d_assigned, d_nmatches, (hipStream_t)stream);
+}
+
+int pgorb_search_by_projection_frame_batch_device(pgorb_ctx* c, const pgorb_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n,
+        int cap_per_frame, const int32_t* d_grid_start, const int32_t* d_grid_idx, const int32_t* d_pair_frame, int npairs,
+        float min_x, float max_x, float min_y, float max_y, const uint8_t* d_kp_has_point, int qcap, const int32_t* d_nq,
+        const uint8_t* d_valid, const float* d_u, const float* d_v, const int32_t* d_last_octave, const float* d_last_angle,
+        const uint8_t* d_point_desc, const uint8_t* d_point_has_obs, float th, int check_orientation, int32_t* d_assigned,
+        int32_t* d_nmatches, void* stream)
+{
+    if (!c) return PGORB_E_ARG;
+    return pg_search_by_projection_batch(c, 1, d_kps, d_desc, d_n, cap_per_frame, d_grid_start, d_grid_idx, d_pair_frame, npairs, min_x, max_x,
+                                         min_y, max_y, d_kp_has_point, qcap, d_nq, d_valid, d_u, d_v, d_last_octave, d_last_angle, d_point_desc,
+                                         d_point_has_obs, th, 0.f, check_orientation, d_assigned, d_nmatches, (hipStream_t)stream);
+}
+
+// single frame through host buffers: a one-pair batch
 static int pg_search_by_projection_host(pgorb_ctx* c, int mode, const pgorb_keypoint* kps, const uint8_t* desc, int n,
                                         float min_x, float max_x, float min_y, float max_y, const uint8_t* kp_has_point,
-                                        int nq, const uint8_t* valid, const float* qx, const float* qy,
-                                        const float* radius, const int32_t* minLevel, const int32_t* maxLevel,
-                                        const float* angle, const uint8_t* qdesc, const uint8_t* qobs, float nnratio,
+                                        int nq, const uint8_t* valid, const float* qx, const float* qy, const int32_t* level,
+                                        const float* aux, const uint8_t* qdesc, const uint8_t* qobs, float th, float nnratio,
                                         int check_orientation, int32_t* assigned)
 {
-    if (n < 0 || nq < 0 || (n && (!kps || !desc || !assigned)) || (nq && (!valid || !qx || !qy || !qdesc || !qobs)) ||
+    if (n < 0 || nq < 0 || (n && (!kps || !desc || !assigned)) || (nq && (!valid || !qx || !qy || !level || !aux || !qdesc || !qobs)) ||
         !(max_x > min_x) || !(max_y > min_y))
         return pg_ctx_fail(c, PGORB_E_ARG, "bad argument to pgorb_search_by_projection_*");
     for (int i = 0; i < n; i++) assigned[i] = -1;
@@ -929,47 +1108,36 @@ static int pg_search_by_projection_host(pgorb_ctx* c, int mode, const pgorb_keyp
     auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
     const size_t oK = 0, oD = oK + al((size_t)n * sizeof(pgorb_keypoint)), oGS = oD + al((size_t)n * 32),
                  oGI = oGS + al((size_t)(GRID_CELLS + 1) * 4), oH = oGI + al((size_t)n * 4), oV = oH + al(n),
-                 oX = oV + al(nq), oY = oX + al((size_t)nq * 4), oR = oY + al((size_t)nq * 4), oMin = oR + al((size_t)nq * 4),
-                 oMax = oMin + al((size_t)nq * 4), oA = oMax + al((size_t)nq * 4), oQD = oA + al((size_t)nq * 4),
-                 oO = oQD + al((size_t)nq * 32), oAs = oO + al(nq), oN = oAs + al((size_t)n * 4), total = oN + 64;
+                 oX = oV + al(nq), oY = oX + al((size_t)nq * 4), oL = oY + al((size_t)nq * 4), oA = oL + al((size_t)nq * 4),
+                 oQD = oA + al((size_t)nq * 4), oO = oQD + al((size_t)nq * 32), oAs = oO + al(nq), oN = oAs + al((size_t)n * 4),
+                 total = oN + 64;
     void* dv;
     int rc = pg_ctx_stage(c, 0, total, &dv);
     if (rc) return rc;
     uint8_t* d = (uint8_t*)dv;
-    std::vector<uint8_t> zeros((size_t)std::max(n, nq) * 4, 0);
+    const int32_t cnt[2] = {n, nq};
     bool ok = hipMemcpy(d + oK, kps, (size_t)n * sizeof(pgorb_keypoint), hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(d + oD, desc, (size_t)n * 32, hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(d + oH, kp_has_point ? kp_has_point : zeros.data(), n, hipMemcpyHostToDevice) == hipSuccess &&
+              (!kp_has_point || hipMemcpy(d + oH, kp_has_point, n, hipMemcpyHostToDevice) == hipSuccess) &&
               hipMemcpy(d + oV, valid, nq, hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(d + oX, qx, (size_t)nq * 4, hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(d + oY, qy, (size_t)nq * 4, hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(d + oR, radius, (size_t)nq * 4, hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(d + oMin, minLevel, (size_t)nq * 4, hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(d + oMax, maxLevel, (size_t)nq * 4, hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(d + oA, angle ? (const void*)angle : (const void*)zeros.data(), (size_t)nq * 4, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(d + oL, level, (size_t)nq * 4, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(d + oA, aux, (size_t)nq * 4, hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(d + oQD, qdesc, (size_t)nq * 32, hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(d + oO, qobs, nq, hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(d + oN, &n, 4, hipMemcpyHostToDevice) == hipSuccess;
+              hipMemcpy(d + oN, cnt, 8, hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) return pg_ctx_fail(c, PGORB_E_HIP, "hipMemcpy H2D failed");
     if ((rc = pgorb_frame_grid_batch_device(c, (pgorb_keypoint*)(d + oK), (int32_t*)(d + oN), 1, n, min_x, max_x, min_y,
                                             max_y, (int32_t*)(d + oGS), (int32_t*)(d + oGI), 0))) return rc;
-    const float invW = (float)GRID_COLS / (max_x - min_x), invH = (float)GRID_ROWS / (max_y - min_y);
-    PgProjQuery Q = {d + oV, (float*)(d + oX), (float*)(d + oY), (float*)(d + oR), (int32_t*)(d + oMin), (int32_t*)(d + oMax),
-                     (float*)(d + oA), d + oQD, d + oO};
-    const size_t lds = (size_t)((n + 15) & ~15) + (size_t)n * 6 + (size_t)nq * 3 + 64;
-    static size_t configured = 0;
-    if (lds > configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_by_projection),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        configured = lds;
-    }
-    hipLaunchKernelGGL(k_search_by_projection, dim3(1), dim3(64), lds, 0, (pgorb_keypoint*)(d + oK), d + oD, n,
-                       (int32_t*)(d + oGS), (int32_t*)(d + oGI), min_x, min_y, invW, invH, d + oH, Q, nq, mode, nnratio,
-                       check_orientation, (int32_t*)(d + oAs), (int32_t*)(d + oN));
-    if (hipGetLastError() != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "k_search_by_projection launch failed");
+    rc = pg_search_by_projection_batch(c, mode, (pgorb_keypoint*)(d + oK), d + oD, (int32_t*)(d + oN), n, (int32_t*)(d + oGS), (int32_t*)(d + oGI),
+                                       nullptr, 1, min_x, max_x, min_y, max_y, kp_has_point ? d + oH : nullptr, nq, (int32_t*)(d + oN) + 1, d + oV,
+                                       (float*)(d + oX), (float*)(d + oY), (int32_t*)(d + oL), (float*)(d + oA), d + oQD, d + oO, th, nnratio,
+                                       check_orientation, (int32_t*)(d + oAs), (int32_t*)(d + oN) + 2, 0);
+    if (rc) return rc;
     int32_t nm = 0;
     ok = hipMemcpy(assigned, d + oAs, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess &&
-         hipMemcpy(&nm, d + oN, 4, hipMemcpyDeviceToHost) == hipSuccess;
+         hipMemcpy(&nm, d + oN + 8, 4, hipMemcpyDeviceToHost) == hipSuccess;
     if (!ok) return pg_ctx_fail(c, PGORB_E_HIP, "hipMemcpy D2H failed");
     return nm;
 }
@@ -981,23 +1149,8 @@ int pgorb_search_by_projection_points(pgorb_ctx* c, const pgorb_keypoint* kps, c
                                       float th, float nnratio, int32_t* assigned)
 {
     if (!c) return PGORB_E_ARG;
-    if (npoints < 0 || (npoints && (!level || !view_cos))) return pg_ctx_fail(c, PGORB_E_ARG, "bad argument");
-    const int L = pgorb_levels(c);
-    std::vector<float> sf(L + 1), radius(npoints > 0 ? npoints : 1);
-    std::vector<int32_t> lo(npoints > 0 ? npoints : 1), hi(npoints > 0 ? npoints : 1);
-    std::vector<uint8_t> ok(npoints > 0 ? npoints : 1);
-    pgorb_scale_tables(c, sf.data(), nullptr, nullptr, nullptr);
-    const bool bFactor = th != 1.0;                                      // :50
-    for (int i = 0; i < npoints; i++) {
-        ok[i] = valid[i] && level[i] >= 0 && level[i] < L;
-        float r = ((double)view_cos[i] > 0.998) ? 2.5f : 4.0f;           // RadiusByViewingCos (:133-139)
-        if (bFactor) r *= th;                                            // :65-66
-        radius[i] = r * sf[ok[i] ? level[i] : 0];                        // r*F.mvScaleFactors[nPredictedLevel] (:69)
-        lo[i] = level[i] - 1; hi[i] = level[i];
-    }
-    return pg_search_by_projection_host(c, 0, kps, desc, n, min_x, max_x, min_y, max_y, kp_has_point, npoints, ok.data(),
-                                        proj_x, proj_y, radius.data(), lo.data(), hi.data(), nullptr, point_desc,
-                                        point_has_obs, nnratio, 0, assigned);
+    return pg_search_by_projection_host(c, 0, kps, desc, n, min_x, max_x, min_y, max_y, kp_has_point, npoints, valid, proj_x, proj_y,
+                                        level, view_cos, point_desc, point_has_obs, th, nnratio, 0, assigned);
 }
 
 int pgorb_search_by_projection_frame(pgorb_ctx* c, const pgorb_keypoint* kps, const uint8_t* desc, int n, float min_x,
@@ -1007,20 +1160,8 @@ int pgorb_search_by_projection_frame(pgorb_ctx* c, const pgorb_keypoint* kps, co
                                      float th, int check_orientation, int32_t* assigned)
 {
     if (!c) return PGORB_E_ARG;
-    if (nlast < 0 || (nlast && (!last_octave || !last_angle))) return pg_ctx_fail(c, PGORB_E_ARG, "bad argument");
-    const int L = pgorb_levels(c);
-    std::vector<float> sf(L + 1), radius(nlast > 0 ? nlast : 1);
-    std::vector<int32_t> lo(nlast > 0 ? nlast : 1), hi(nlast > 0 ? nlast : 1);
-    std::vector<uint8_t> ok(nlast > 0 ? nlast : 1);
-    pgorb_scale_tables(c, sf.data(), nullptr, nullptr, nullptr);
-    for (int i = 0; i < nlast; i++) {
-        ok[i] = valid[i] && last_octave[i] >= 0 && last_octave[i] < L;
-        radius[i] = th * sf[ok[i] ? last_octave[i] : 0];                 // :1383
-        lo[i] = last_octave[i] - 1; hi[i] = last_octave[i] + 1;          // :1392 (neither forward nor backward: mono)
-    }
-    return pg_search_by_projection_host(c, 1, kps, desc, n, min_x, max_x, min_y, max_y, kp_has_point, nlast, ok.data(), u, v,
-                                        radius.data(), lo.data(), hi.data(), last_angle, point_desc, point_has_obs, 0.f,
-                                        check_orientation, assigned);
+    return pg_search_by_projection_host(c, 1, kps, desc, n, min_x, max_x, min_y, max_y, kp_has_point, nlast, valid, u, v,
+                                        last_octave, last_angle, point_desc, point_has_obs, th, 0.f, check_orientation, assigned);
 }
 
 int pgorb_frame_grid(pgorb_ctx* c, const pgorb_keypoint* kps, int n, float min_x, float max_x, float min_y,

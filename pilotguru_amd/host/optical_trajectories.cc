@@ -50,6 +50,7 @@ namespace {
 struct Flags {
     std::string vocabulary_file, camera_settings, out_dir, in_video, trajectory_in, poses_in, dump_features;
     bool visualize = true, vertical_flip = false, horizontal_flip = false, output_per_segment_videos = false;
+    bool init_extractor = false;       // front-end mode has no map: --init_extractor treats the ride as "not initialised yet"
     long long rotation_smooth_sigma = -1;
     int device = 0, batch = 32, max_frames = -1, segment_id = 0, rotation = 0, copy_threads = 8;
     int shard_rank = 0, shard_world = 1;          // --shard=rank/world: this process takes its chunk of the ride
@@ -66,7 +67,8 @@ bool parse_flags(int argc, char** argv, Flags& F)
     std::map<std::string, std::string*> str = {{"vocabulary_file", &F.vocabulary_file}, {"camera_settings", &F.camera_settings},
         {"out_dir", &F.out_dir}, {"in_video", &F.in_video}, {"trajectory_in", &F.trajectory_in}, {"poses_in", &F.poses_in}, {"dump_features", &F.dump_features}};
     std::map<std::string, bool*> bl = {{"visualize", &F.visualize}, {"vertical_flip", &F.vertical_flip},
-        {"horizontal_flip", &F.horizontal_flip}, {"output_per_segment_videos", &F.output_per_segment_videos}};
+        {"horizontal_flip", &F.horizontal_flip}, {"output_per_segment_videos", &F.output_per_segment_videos},
+        {"init_extractor", &F.init_extractor}};
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         if (a.rfind("--", 0) == 0) a = a.substr(2); else if (a.rfind("-", 0) == 0) a = a.substr(1); else return false;
@@ -329,7 +331,9 @@ int main(int argc, char** argv)
     std::map<std::string, double> S = read_settings(F.camera_settings);
     auto get = [&](const char* k, double d) { return S.count(k) ? S[k] : d; };
     // underscore keys of this fork (Tracking.cc:131-135); defaults as written by calibrate.cc:518-532
-    const int nFeatures = (int)get("ORBextractor_nFeatures", 2000), nLevels = (int)get("ORBextractor_nLevels", 8);
+    // mpIniORBextractor: 2 * nFeatures while the tracker is NOT_INITIALIZED / NO_IMAGES_YET (Tracking.cc:137-143, :262-264) --
+    // the frames MonocularInitialization runs SearchForInitialization on (:596-597)
+    const int nFeatures = (int)get("ORBextractor_nFeatures", 2000) * (F.init_extractor ? 2 : 1), nLevels = (int)get("ORBextractor_nLevels", 8);
     const float scaleFactor = (float)get("ORBextractor_scaleFactor", 1.2);
     const int iniTh = (int)get("ORBextractor_iniThFAST", 20), minTh = (int)get("ORBextractor_minThFAST", 7);
 

@@ -253,7 +253,11 @@ def test_destroying_the_context_takes_its_streams_along():
     L.pgorb_destroy(h)                             # waits for the batch in flight, frees the stream, then the context
 
 
-@pytest.mark.parametrize("w,h,nf,total,batch,depth,bow", [(640, 480, 1000, 11, 4, 3, True), (1280, 720, 1500, 7, 3, 2, False)])
+@pytest.mark.parametrize("w,h,nf,total,batch,depth,bow", [
+    (640, 480, 1000, 11, 4, 3, True), (1280, 720, 1500, 7, 3, 2, False),
+    # the INITIALISATION workload: until the map is initialised the reference extracts with 2 * nFeatures
+    # (Tracking.cc:137-143, :262-264) and runs SearchForInitialization(window 100, ratio 0.9) on those frames (:596-597)
+    (1920, 1080, 4000, 5, 2, 2, False)])
 def test_streamed_front_end_stage_against_the_oracle(w, h, nf, total, batch, depth, bow, tmp_path):
     """pgorb_stream_frontend: what the tracking thread does with every fresh Frame, on the device per batch -- the
     SearchForInitialization of (previous frame, frame) as MonocularInitialization calls it (Tracking.cc:583-597,

@@ -275,3 +275,102 @@ def test_gpu_undistort_and_distorted_frame_pipeline(oracle):
                                                         F2.mDescriptors, F2.bounds, prev, 100, 0.9, True)
     nm, m12 = pg.ORBmatcher(0.9, True).SearchForInitialization(F1, F2, prev, 100)
     assert nm == onm and np.array_equal(m12, om12) and prev.tobytes() == oprev.tobytes() and nm > 100
+
+
+@pytest.mark.gpu
+def test_gpu_batched_resident_forms_of_the_slam_state_matchers(tmp_path, oracle):
+    """pgorb_search_by_projection_{points,frame}_batch_device, pgorb_feature_vectors_batch_device and
+    pgorb_search_by_bow_batch_device: a ride extracted on the device, every frame matched against map points 'seen' in
+    its predecessor (ORBmatcher.cc:46-131, :1355-1474) and BoW-matched against its predecessor as the key frame
+    (:161-290), all pairs in ONE launch each -- assignment arrays and counts of every pair against the oracle."""
+    import ctypes as C
+    import os
+    import torch
+    import pilotguru_amd as pg
+    from pilotguru_amd import vocab as V
+    w, h, nf, B = 640, 480, 1200, 6
+    shift = (5, 2)
+    ride = synth_ride(9, w, h, B, dx=shift[0], dy=shift[1])
+    ext = pg.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B)
+    L, hdl = ext._L, ext._h
+    p = lambda t: C.c_void_p(t.data_ptr())
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    kps, desc, n = ext.extract_batch_device(torch.from_numpy(ride).cuda())
+    ext.check_async()
+    cap = kps.shape[1]
+    nh = n.cpu().numpy()
+    kh = kps.cpu().numpy().view(np.uint8).reshape(B, cap, 28)
+    dh = desc.cpu().numpy()
+    K = [kh[f, :nh[f]].copy().view(oracle.KEYPOINT_DTYPE).reshape(-1) for f in range(B)]
+    D = [dh[f, :nh[f]].copy() for f in range(B)]
+    bounds = (0.0, float(w), 0.0, float(h))
+    gs = torch.empty((B, 64 * 48 + 1), dtype=torch.int32, device="cuda"); gi = torch.empty((B, cap), dtype=torch.int32, device="cuda")
+    ext._check(L.pgorb_frame_grid_batch_device(hdl, p(kps), p(n), B, cap, *bounds, p(gs), p(gi), s))
+    # pair j: queries built from frame j, matched against frame j + 1
+    npairs = B - 1
+    rng = np.random.RandomState(11)
+    Q = [_synthetic_map_points(K[j], D[j], shift, rng) for j in range(npairs)]
+    qcap = max(len(q[0]) for q in Q) + 3
+    def pack(idx, dtype, width=None):
+        a = np.zeros((npairs, qcap) + ((width,) if width else ()), dtype)
+        for j, q in enumerate(Q):
+            a[j, :len(q[idx])] = q[idx]
+        return torch.from_numpy(a).cuda()
+    valid, px, py, lvl, vc, pd, obs = pack(1, np.uint8), pack(2, np.float32), pack(3, np.float32), pack(4, np.int32), pack(5, np.float32), pack(6, np.uint8, 32), pack(7, np.uint8)
+    ang_np = np.zeros((npairs, qcap), np.float32)
+    for j, q in enumerate(Q):
+        a = K[j]["angle"][q[0]].copy(); a[::7] = (a[::7] + 100.0) % 360.0
+        ang_np[j, :len(a)] = a
+    ang = torch.from_numpy(ang_np).cuda()
+    nq = torch.tensor([len(q[0]) for q in Q], dtype=torch.int32, device="cuda")
+    has_np = (rng.uniform(size=(npairs, cap)) > 0.9).astype(np.uint8)
+    has = torch.from_numpy(has_np).cuda()
+    pair_frame = torch.arange(1, B, dtype=torch.int32, device="cuda")
+    asg = torch.empty((npairs, cap), dtype=torch.int32, device="cuda"); nm = torch.empty(npairs, dtype=torch.int32, device="cuda")
+    sf = ext.GetScaleFactors()
+    for th, ratio in ((3.0, 0.8), (1.0, 0.8)):
+        ext._check(L.pgorb_search_by_projection_points_batch_device(hdl, p(kps), p(desc), p(n), cap, p(gs), p(gi), p(pair_frame), npairs, *bounds,
+                   p(has), qcap, p(nq), p(valid), p(px), p(py), p(lvl), p(vc), p(pd), p(obs), th, ratio, p(asg), p(nm), s))
+        torch.cuda.synchronize()
+        for j, q in enumerate(Q):
+            onm, oasg = oracle.search_by_projection_points(K[j + 1], D[j + 1], bounds, sf, has_np[j, :nh[j + 1]], q[1], q[2], q[3], q[4], q[5], q[6], q[7], th, ratio)
+            assert int(nm[j]) == onm > 100 and np.array_equal(asg[j, :nh[j + 1]].cpu().numpy(), oasg), "points pair %d" % j
+            assert bool((asg[j, nh[j + 1]:] == -1).all())
+    for th, ori in ((15.0, True), (7.0, False)):
+        ext._check(L.pgorb_search_by_projection_frame_batch_device(hdl, p(kps), p(desc), p(n), cap, p(gs), p(gi), p(pair_frame), npairs, *bounds,
+                   None, qcap, p(nq), p(valid), p(px), p(py), p(lvl), p(ang), p(pd), p(obs), th, int(ori), p(asg), p(nm), s))
+        torch.cuda.synchronize()
+        for j, q in enumerate(Q):
+            onm, oasg = oracle.search_by_projection_frame(K[j + 1], D[j + 1], bounds, sf, None, q[1], q[2], q[3], q[4], ang_np[j, :len(q[0])], q[6], q[7], th, ori)
+            assert int(nm[j]) == onm > 100 and np.array_equal(asg[j, :nh[j + 1]].cpu().numpy(), oasg), "frame pair %d" % j
+    # BoW: transform on the device, FeatureVectors on the device, key frame j vs frame j + 1
+    vdesc, weight, parent = V.synth_vocabulary(6, 4, seed=4)
+    path = os.path.join(str(tmp_path), "voc.txt")
+    V.write_vocabulary_text(path, 6, 4, vdesc, weight, parent)
+    voc = V.ORBVocabulary(text_file=path)
+    voc.upload(ext)
+    word = torch.empty((B, cap), dtype=torch.int32, device="cuda"); wt = torch.empty((B, cap), dtype=torch.float64, device="cuda")
+    node = torch.empty((B, cap), dtype=torch.int32, device="cuda")
+    ext._check(L.pgorb_bow_transform_device(hdl, p(desc), B * cap, 2, p(word), p(wt), p(node), s))
+    fvn = torch.empty((B, cap), dtype=torch.int32, device="cuda"); fvs = torch.empty((B, cap + 1), dtype=torch.int32, device="cuda")
+    fvf = torch.empty((B, cap), dtype=torch.int32, device="cuda"); nfv = torch.empty(B, dtype=torch.int32, device="cuda")
+    ext._check(L.pgorb_feature_vectors_batch_device(hdl, p(node), p(n), B, cap, p(fvn), p(fvs), p(fvf), p(nfv), s))
+    torch.cuda.synchronize()
+    FV = []
+    for f in range(B):
+        _, fv = voc.transform(D[f], 2)                                   # host accumulation (pinned to the reference's FeatureVector.cpp)
+        k = int(nfv[f])
+        assert k == len(fv[0]) and np.array_equal(fvn[f, :k].cpu().numpy().astype(np.uint32), fv[0])
+        assert np.array_equal(fvs[f, :k + 1].cpu().numpy(), fv[1]) and np.array_equal(fvf[f, :nh[f]].cpu().numpy().astype(np.uint32), fv[2])
+        FV.append(fv)
+    kfv_np = (rng.uniform(size=(npairs, cap)) > 0.3).astype(np.uint8)
+    kfv = torch.from_numpy(kfv_np).cuda()
+    pkf = torch.arange(0, B - 1, dtype=torch.int32, device="cuda")
+    mt = torch.empty((npairs, cap), dtype=torch.int32, device="cuda")
+    for ratio, ori in ((0.7, True), (0.9, False)):
+        ext._check(L.pgorb_search_by_bow_batch_device(hdl, p(kps), p(desc), p(n), cap, p(fvn), p(fvs), p(fvf), p(nfv), p(pkf), p(pair_frame), npairs,
+                   p(kfv), ratio, int(ori), p(mt), p(nm), s))
+        torch.cuda.synchronize()
+        for j in range(npairs):
+            onm, om = oracle.search_by_bow(D[j], K[j]["angle"], kfv_np[j, :nh[j]], FV[j], D[j + 1], K[j + 1]["angle"], FV[j + 1], ratio, ori)
+            assert int(nm[j]) == onm > 50 and np.array_equal(mt[j, :nh[j + 1]].cpu().numpy(), om), "bow pair %d" % j

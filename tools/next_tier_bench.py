@@ -22,8 +22,9 @@ from oracle import orb_oracle
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=128)
 ap.add_argument("--out", default="")
+ap.add_argument("--features", type=int, default=2000, help="4000 = the initialisation extractor (2 * nFeatures, Tracking.cc:143)")
 a = ap.parse_args()
-w, h, nf, B = 1920, 1080, 2000, a.batch
+w, h, nf, B = 1920, 1080, a.features, a.batch
 ride = synth_ride(0, w, h, B)
 ext = pg.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B)
 fr = torch.from_numpy(ride).cuda()
@@ -136,7 +137,48 @@ prevm = np.stack([F1.mvKeys["x"], F1.mvKeys["y"]], 1).astype(np.float32)
 g_ms = wall(lambda: sm.SearchForInitialization(F1, F2, prevm.copy(), 100))
 host_rows.append(("SearchForInitialization(F1, F2, 100), one pair through the host API", g_ms, c_sfi / (B - 1)))
 
-lines = ["# python tools/next_tier_bench.py --batch %d   (MI355X; ms per %d-frame 1080p batch; CPU = oracle, 1 thread, one frame or pair scaled to the batch)" % (B, B),
+# ---- round 3: the same three matchers as BATCHED, RESIDENT calls: every frame against its predecessor, all pairs in one launch ----
+npairs = B - 1
+qn = min(int(nk * 0.8), 2000)
+qcap = qn
+def rep(a, dt):                                      # the same query set for every pair (frame f's keypoints projected into f + 1)
+    return torch.from_numpy(np.ascontiguousarray(np.broadcast_to(np.asarray(a[:qn], dt), (npairs,) + np.asarray(a[:qn]).shape))).cuda()
+qsel = []
+vq, xq, yq, lq, cq, aq, dq, oq = [], [], [], [], [], [], [], []
+for f in range(npairs):
+    kf = kh[f, :nh[f]].copy().view(orb_oracle.KEYPOINT_DTYPE).reshape(-1)
+    ss = rng.permutation(nh[f])[:qn]
+    m = len(ss)
+    pad = lambda a, dt: np.concatenate([np.asarray(a, dt), np.zeros((qcap - m,) + np.asarray(a).shape[1:], dt)])
+    vq.append(pad((rng.uniform(size=m) > 0.05), np.uint8)); xq.append(pad(kf["x"][ss] - 2 + rng.uniform(-1.5, 1.5, m), np.float32))
+    yq.append(pad(kf["y"][ss] - 1 + rng.uniform(-1.5, 1.5, m), np.float32)); lq.append(pad(kf["octave"][ss], np.int32))
+    cq.append(pad(np.full(m, 0.9995), np.float32)); aq.append(pad(kf["angle"][ss], np.float32)); dq.append(pad(dh[f, ss], np.uint8))
+    oq.append(pad((rng.uniform(size=m) > 0.1), np.uint8)); qsel.append(m)
+T = lambda L_: torch.from_numpy(np.stack(L_)).cuda()
+vq, xq, yq, lq, cq, aq, dq, oq = T(vq), T(xq), T(yq), T(lq), T(cq), T(aq), T(dq), T(oq)
+nqd = torch.tensor(qsel, dtype=torch.int32, device="cuda")
+pairF = torch.arange(1, B, dtype=torch.int32, device="cuda"); pairK = torch.arange(0, B - 1, dtype=torch.int32, device="cuda")
+asg = torch.empty((npairs, cap), dtype=torch.int32, device="cuda"); nmb = torch.empty(npairs, dtype=torch.int32, device="cuda")
+bnd = (0.0, float(w), 0.0, float(h))
+batch_rows = []
+t_pp = timed(lambda: ext._check(ext._L.pgorb_search_by_projection_points_batch_device(ext._h, p(kps), p(desc), p(n), cap, p(gs), p(gi), p(pairF), npairs, *bnd,
+             None, qcap, p(nqd), p(vq), p(xq), p(yq), p(lq), p(cq), p(dq), p(oq), 3.0, 0.8, p(asg), p(nmb), s)))
+batch_rows.append(("SearchByProjection(Frame, MapPoints, th 3): %d pairs x %d points -> %d" % (npairs, qn, int(nmb.float().mean())), t_pp, host_rows[0][2]))
+t_pf = timed(lambda: ext._check(ext._L.pgorb_search_by_projection_frame_batch_device(ext._h, p(kps), p(desc), p(n), cap, p(gs), p(gi), p(pairF), npairs, *bnd,
+             None, qcap, p(nqd), p(vq), p(xq), p(yq), p(lq), p(aq), p(dq), p(oq), 15.0, 1, p(asg), p(nmb), s)))
+batch_rows.append(("SearchByProjection(Frame, LastFrame, th 15): %d pairs x %d points -> %d" % (npairs, qn, int(nmb.float().mean())), t_pf, host_rows[1][2]))
+wordb = torch.empty((B, cap), dtype=torch.int32, device="cuda"); wtb = torch.empty((B, cap), dtype=torch.float64, device="cuda"); nodeb = torch.empty((B, cap), dtype=torch.int32, device="cuda")
+ext._check(ext._L.pgorb_bow_transform_device(ext._h, p(desc), B * cap, 4, p(wordb), p(wtb), p(nodeb), s))
+fvn = torch.empty((B, cap), dtype=torch.int32, device="cuda"); fvs = torch.empty((B, cap + 1), dtype=torch.int32, device="cuda")
+fvf = torch.empty((B, cap), dtype=torch.int32, device="cuda"); nfvd = torch.empty(B, dtype=torch.int32, device="cuda")
+t_fv = timed(lambda: ext._check(ext._L.pgorb_feature_vectors_batch_device(ext._h, p(nodeb), p(n), B, cap, p(fvn), p(fvs), p(fvf), p(nfvd), s)))
+batch_rows.append(("FeatureVector of %d frames (CSR by node, on the device)" % B, t_fv, float("nan")))
+kfvd = torch.from_numpy((rng.uniform(size=(npairs, cap)) > 0.3).astype(np.uint8)).cuda()
+t_bw = timed(lambda: ext._check(ext._L.pgorb_search_by_bow_batch_device(ext._h, p(kps), p(desc), p(n), cap, p(fvn), p(fvs), p(fvf), p(nfvd), p(pairK), p(pairF), npairs,
+             p(kfvd), 0.7, 1, p(asg), p(nmb), s)))
+batch_rows.append(("SearchByBoW(KeyFrame, Frame): %d pairs -> %d" % (npairs, int(nmb.float().mean())), t_bw, host_rows[2][2]))
+
+lines = ["# python tools/next_tier_bench.py --batch %d --features %d   (MI355X; ms per %d-frame 1080p batch; CPU = oracle, 1 thread, one frame or pair scaled to the batch)" % (B, nf, B),
          "# extraction alone (K1-K6): %.3f ms" % t_plain,
          "%-58s %10s %12s %12s %10s" % ("kernel", "GPU ms", "us / frame", "GB/s (alg.)", "CPU ms")]
 for name, ms, byts, cpu in rows:
@@ -145,6 +187,10 @@ lines.append("# single host calls on one 1080p frame pair (upload + kernel + dow
 lines.append("%-72s %10s %10s" % ("call", "GPU ms", "CPU ms"))
 for name, g, cc in host_rows:
     lines.append("%-72s %10.3f %10.2f" % (name, g, cc))
+lines.append("# round 3: batched, resident forms (every frame vs its predecessor, one launch for all pairs; GPU ms per batch and per pair) next to the oracle's one-core ms per pair")
+lines.append("%-86s %10s %12s %12s" % ("call", "GPU ms", "GPU ms/pair", "CPU ms/pair"))
+for name, g, cc in batch_rows:
+    lines.append("%-86s %10.3f %12.4f %12.2f" % (name, g, g / npairs, cc))
 print("\n".join(lines))
 if a.out:
     open(a.out, "w").write("\n".join(lines) + "\n")
