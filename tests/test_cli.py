@@ -49,6 +49,25 @@ def test_trajectory_json_writer_matches_fixture(tmp_path):
     assert abs(p["angular_velocity"] - 0.01 / (0.033333 + 1e-10)) < 1e-12
 
 
+def test_trajectory_json_layout_against_a_real_nlohmann_dump(tmp_path):
+    """The writer's STRUCTURE (key order, indentation, one array element per line, integer 0, null) against a file a real
+    nlohmann::json produced: tests/golden/make_trajectory_layout.cc assembles the object as src/io/json_converters.cc:6-96
+    does and dumps it with the 3.1.1 header of the build image; the values are ones 2.1.1 (the reference's version) and
+    3.x print identically.  When the header is present (this container) the generator is re-run and must reproduce the fixture."""
+    import shutil
+    src = os.path.join(HERE, "golden", "trajectory_layout_in.txt")
+    want = open(os.path.join(HERE, "golden", "trajectory_layout_expected.json")).read()
+    r = _cli("--trajectory_in=" + src, "--out_dir=" + str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    assert open(os.path.join(str(tmp_path), "trajectory-0.json")).read() == want
+    assert '"x": null' not in want and "null" in want and '"angular_velocity": 0,' in want
+    if os.path.exists("/opt/conda/include/json.hpp") and shutil.which("g++"):
+        exe = os.path.join(str(tmp_path), "mtl")
+        subprocess.run(["g++", "-std=c++11", "-I/opt/conda/include", os.path.join(HERE, "golden", "make_trajectory_layout.cc"), "-o", exe], check=True)
+        got = subprocess.run([exe, src], stdout=subprocess.PIPE, universal_newlines=True, check=True).stdout
+        assert got == want
+
+
 def test_trajectory_json_non_finite_numbers_become_null(tmp_path):
     """nlohmann 2.1.1 stores a non-finite float as null, so the reference's files stay valid JSON."""
     src = open(os.path.join(HERE, "golden", "trajectory_in.txt")).read().split("\n")
