@@ -62,7 +62,9 @@ def _ride_vs_oracle(ride, nf, batch):
     return nh
 
 
-@pytest.mark.parametrize("w,h,nf,B,batch", [(1920, 1080, 2000, 32, 16), (3840, 2160, 4000, 8, 4)])
+@pytest.mark.parametrize("w,h,nf,B,batch", [
+    (1920, 1080, 2000, 32, 16), (3840, 2160, 4000, 8, 4),
+    (1920, 1080, 2000, 128, 128)])      # the bench's own plan: batch 128 (the XCD-balanced cell order and K4-6's tile order depend on it)
 def test_every_frame_of_a_ride_at_bench_shapes(w, h, nf, B, batch):
     nh = _ride_vs_oracle(synth_ride(0, w, h, B), nf, batch)
     assert nh.min() >= nf - 1                      # acceptance of the scene: every level fills its quota
