@@ -575,7 +575,7 @@ def main():
         ach = (abytes[rk] * B / launches) / (stage_ms[rk] / launches * 1e-3) / 1e9
         kname = {"pyramid": "k_pyr_resize_rows4_lds", "fast": ext.fast_kernel_name(), "describe": "k_describe",
                  "match": "k_match_mfma"}[rk]
-        traffic, traffic_src = None, None               # HBM bytes per launch from the committed PMC passes
+        traffic, traffic_src, valu_insts = None, None, None   # HBM bytes / VALU instructions per launch from the committed PMC passes
         try:
             import glob
             for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):   # newest round first
@@ -585,6 +585,7 @@ def main():
                     k = tr["kernels"][kname]
                     traffic = (2.0 * k["fetch_kb"] + k["write_kb"]) * 1024.0
                     traffic_src = "profiles/" + os.path.basename(path)
+                    valu_insts = k.get("sq_insts_valu")
                     break
         except (OSError, KeyError, ValueError):
             pass
@@ -608,6 +609,13 @@ def main():
                                             "not re-measured by this process)") if traffic_src else None,
                          "algorithmic_bytes_per_launch": abytes[rk] * B / launches,
                          "launch_ms": stage_ms[rk] / launches},
+            # the resource that actually binds this path: wave-level VALU instructions of the same kernel
+            # against what the chip's 1024 SIMDs can issue at the guide's 2 cycles per wave64 instruction
+            "roofline_valu": None if not valu_insts else {
+                "kernel": kname, "insts": valu_insts, "insts_source": traffic_src + " (SQ_INSTS_VALU of an earlier profiled run, per launch)",
+                "cycles_per_inst_peak": 2, "simds": 1024, "clock_ghz": 2.4,
+                "min_ms_at_peak": valu_insts * 2 / 1024 / 2.4e9 * 1e3, "launch_ms": stage_ms[rk] / launches,
+                "frac": (valu_insts * 2 / 1024 / 2.4e9 * 1e3) / (stage_ms[rk] / launches)},
             "stage_ms_per_step": stage_ms, "dominant_stage": dom,
             "whole_path_algorithmic_GBps": sum(abytes.values()) * fps / world / 1e9,
             "verified": verified,

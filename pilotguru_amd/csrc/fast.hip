@@ -563,6 +563,47 @@ extern "C" int pgorb_debug_fast_times(unsigned int* out, int nwaves)
 #define FT_TS(k) do {} while (0)
 #endif
 
+// One detector pass at threshold t over the staged window == cv::FAST(window, t, true): necessary test + compaction,
+// exact scores, NMS, survivors into the cell's slots.  Returns the number of survivors.  STRONG: the four-pair test
+// (the minThFAST retry).
+template <int TPC, int MPC, bool NARROW, bool STRONG>
+__device__ __forceinline__ int fast_pass(const PgPlan& P, const uint8_t* tile, int TP, uint8_t* smap, int mapPitch, int mapRows,
+                                         int IW, int IH, int t, uint16_t* list, uint32_t* out, int cellCap, int xoff, int yoff, int lane)
+{
+    // (2) necessary test + compaction
+    const int nlist = NARROW ? quick_pass_b<STRONG>(tile, IW, IH, t, list, lane)
+                    : (IW <= 32) ? quick_pass<8, STRONG>(tile, TP, IW, 0, IH, t, list, lane)
+                                 : quick_pass<16, STRONG>(tile, TP, IW, 0, IH, t, list, lane);
+    if (nlist < 0)                                         // list would overflow: chunked slow path
+        return fast_pass_chunked(tile, TP, smap, mapPitch, mapRows, IW, IH, t, list, out, cellCap, xoff, yoff, lane);
+    PG_WAVE_SYNC();
+    // (3) exact scores for the compacted pixels
+    score_list<NARROW>(tile, TP, smap, mapPitch, list, nlist, t, lane);
+    PG_WAVE_SYNC();
+    // (4) NMS (strictly greater than all 8 neighbours; outside the interior = 0); survivors go
+    // straight into this cell's slots
+    int total = 0;
+    for (int base = 0; base < nlist; base += 64) {
+        const int i = base + lane;
+        int sc = 0, p = 0;
+        if (i < nlist) {
+            p = list[i];
+            if (p != (int)FAST_DEAD) sc = nms_score(smap, mapPitch, (p >> 8) & 0x7F, p & 0xFF);   // (dead: not a corner at t)
+        }
+        const unsigned long long m = __ballot(sc != 0);
+        if (sc) {
+            const int pos = total + wave_prefix(m);
+            const int iy = (p >> 8) & 0x7F, ix = p & 0xFF;
+            if (pos < cellCap)
+                out[pos] = (uint32_t)(ix + xoff) | ((uint32_t)(iy + yoff) << 12) | ((uint32_t)sc << 24);
+            else
+                atomicExch(P.status, PGORB_E_OVERFLOW);          // cannot happen (see header)
+        }
+        total += __popcll(m);
+    }
+    return total;
+}
+
 // TPC / MPC: compile-time tile and score-map pitches of the common geometry (cells up to 36 px:
 // TP = 48, map pitch 40), so that ring / neighbour offsets are instruction immediates; 0 = use the
 // run-time values (larger cells).
@@ -690,72 +731,22 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgPlan P, int 
     uint32_t* out = cellCandBase + (int64_t)frame * cellCandFrame + rec[7];
     const int xoff = 3 + iniX - PG_EDGE, yoff = 3 + iniY - PG_EDGE;   // window-local -> region-relative (:822-823)
 
-    for (int pass = 0; pass < 2; pass++) {
-        const int t = pass == 0 ? iniTh : minTh;
-        // (2) necessary test + compaction
-        int nlist;
-        if (pass == 0)
-            nlist = NARROW ? quick_pass_b<false>(tile, IW, IH, t, list, lane)
-                  : (IW <= 32) ? quick_pass<8, false>(tile, TP, IW, 0, IH, t, list, lane)
-                               : quick_pass<16, false>(tile, TP, IW, 0, IH, t, list, lane);
-        else
-            nlist = NARROW ? quick_pass_b<true>(tile, IW, IH, t, list, lane)
-                  : (IW <= 32) ? quick_pass<8, true>(tile, TP, IW, 0, IH, t, list, lane)
-                               : quick_pass<16, true>(tile, TP, IW, 0, IH, t, list, lane);
-#if defined(PGORB_FAST_SKIP) && PGORB_FAST_SKIP == 1       // timing experiment: staging + the iniTh quick test only
-        if (lane == 0) *cellCnt = 0;
-        return;
+    // The two detector passes written out (round 3): as a `for (pass)` loop the compiler merged the two bodies and paid for it
+    // with scalar flag juggling around every phase.
+    int total = fast_pass<TPC, MPC, NARROW, false>(P, tile, TP, smap, mapPitch, mapRows, IW, IH, iniTh, list, out, cellCap, xoff, yoff, lane);
+#if defined(PGORB_FAST_SKIP)                               // timing experiments: no minTh retry
+    if (lane == 0) *cellCnt = min(total, cellCap);
+    return;
 #endif
-        if (nlist < 0) {                                   // list would overflow: chunked slow path
-            const int total = fast_pass_chunked(tile, TP, smap, mapPitch, mapRows, IW, IH, t, list, out,
-                                                cellCap, xoff, yoff, lane);
-            if (total > 0 || pass == 1) {
-                if (lane == 0) *cellCnt = min(total, cellCap);
-                return;
-            }
-            continue;
-        }
-        PG_WAVE_SYNC();
-        if (pass == 0) FT_TS(5);
-        // (3) exact scores for the compacted pixels
-        score_list<NARROW>(tile, TP, smap, mapPitch, list, nlist, t, lane);
-        PG_WAVE_SYNC();
-        if (pass == 0) FT_TS(6);
-        // (4) NMS (strictly greater than all 8 neighbours; outside the interior = 0); survivors go
-        // straight into this cell's slots
-        int total = 0;
-        for (int base = 0; base < nlist; base += 64) {
-            const int i = base + lane;
-            int sc = 0, p = 0;
-            if (i < nlist) {
-                p = list[i];
-                if (p != (int)FAST_DEAD) sc = nms_score(smap, mapPitch, (p >> 8) & 0x7F, p & 0xFF);   // (dead: not a corner at t)
-            }
-            const unsigned long long m = __ballot(sc != 0);
-            if (sc) {
-                const int pos = total + wave_prefix(m);
-                const int iy = (p >> 8) & 0x7F, ix = p & 0xFF;
-                if (pos < cellCap)
-                    out[pos] = (uint32_t)(ix + xoff) | ((uint32_t)(iy + yoff) << 12) | ((uint32_t)sc << 24);
-                else
-                    atomicExch(P.status, PGORB_E_OVERFLOW);          // cannot happen (see header)
-            }
-            total += __popcll(m);
-        }
-#if defined(PGORB_FAST_SKIP) && PGORB_FAST_SKIP == 2       // timing experiment: no minTh retry
-        if (lane == 0) *cellCnt = total;
-        return;
-#endif
-        if (total > 0 || pass == 1) {
-            if (lane == 0) *cellCnt = total;
-            FT_TS(3);
-            return;
-        }
-        // vKeysCell.empty() -> retry at minThFAST (:812-816).  The score map keeps what this pass wrote: a FAST score does
+    if (total == 0) {
+        // vKeysCell.empty() -> retry at minThFAST (:812-816).  The score map keeps what the first pass wrote: a FAST score does
         // not depend on the threshold and every corner at iniThFAST is a candidate of the retry again (an "empty" cell
         // can hold corners -- equal neighbouring maxima that strict NMS removed)
         PG_WAVE_SYNC();
+        total = fast_pass<TPC, MPC, NARROW, true>(P, tile, TP, smap, mapPitch, mapRows, IW, IH, minTh, list, out, cellCap, xoff, yoff, lane);
     }
+    if (lane == 0) *cellCnt = min(total, cellCap);
+    FT_TS(3);
 }
 
 #ifdef PGORB_FAST_BLOCKS   // developer build (make EXTRA=-DPGORB_FAST_BLOCKS): the tile-shape sweep of BASELINE.json configs[2]; it lost on every shape and is not part of the product library

@@ -38,11 +38,24 @@ def table(counter):
             if len(p) >= 3: d[p[0]] = float(p[2])
     return d
 f, w = table("FETCH_SIZE"), table("WRITE_SIZE")
+def counters(group_first):
+    """per-kernel dict of every counter of the PMC group whose header line starts with `group_first`"""
+    m = re.search(r"## --pmc %s[^\n]*\n(.*?)(\n\n|\Z)" % group_first, txt, re.S)
+    d = {}
+    if m:
+        rows = m.group(1).splitlines()
+        names = rows[0].split()[2:]
+        for line in rows[1:]:
+            p = line.split()
+            if len(p) >= 2 + len(names): d[p[0]] = dict(zip(names, [float(x) for x in p[2:2 + len(names)]]))
+    return d
+inst = counters("SQ_INSTS_VALU")
 line = json.loads(open("%s/%s_bench_line.json" % (out, tag)).read())
 cfg = line["config"]
 res = {"_comment": "HBM traffic per dispatch from the rocprofv3 PMC passes of %s_pmc.txt: bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md HBM section; WRITE_SIZE uncalibrated). bench.py reports it as roofline.traffic only when its workload matches." % tag,
        "workload": {"width": 1920, "height": 1080, "features": 2000, "batch": cfg["batch"]},
-       "kernels": {k: {"fetch_kb": f[k], "write_kb": w.get(k, 0.0)} for k in f}}
+       "kernels": {k: dict({"fetch_kb": f[k], "write_kb": w.get(k, 0.0)},
+                           **{n.lower(): v for n, v in inst.get(k, {}).items() if n in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES")}) for k in f}}
 json.dump(res, open("%s/%s_traffic.json" % (out, tag), "w"), indent=2)
 PY
 cat "$OUT/${TAG}_kernel_stats.txt"; cat "$OUT/${TAG}_pmc.txt"; cat "$OUT/${TAG}_bench_line.json"
