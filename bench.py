@@ -598,7 +598,7 @@ def main():
             "config": {"workload": "%dx%d grayscale, %d kp/frame, 8-level pyramid, batch %d frames/GPU "
                                    "resident in HBM, extract + best-2 Hamming match vs previous frame"
                                    % (W, H, NF, B),
-                       "scene": args.scene,
+                       "scene": args.scene, "width": W, "height": H, "features": NF,
                        "batch": B, "keypoints_per_frame": nkp, "parallelism": "frames-sharded x%d" % world,
                        "vocab_broadcast_bytes": vocab_bytes, "vocab_broadcast_s": vocab_bcast_s,
                        "matcher": matcher, "matcher_popcount_ms_per_step": popcount_ms},

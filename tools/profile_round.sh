@@ -53,7 +53,8 @@ inst = counters("SQ_INSTS_VALU")
 line = json.loads(open("%s/%s_bench_line.json" % (out, tag)).read())
 cfg = line["config"]
 res = {"_comment": "HBM traffic per dispatch from the rocprofv3 PMC passes of %s_pmc.txt: bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md HBM section; WRITE_SIZE uncalibrated). bench.py reports it as roofline.traffic only when its workload matches." % tag,
-       "workload": {"width": 1920, "height": 1080, "features": 2000, "batch": cfg["batch"]},
+       "workload": {"width": cfg.get("width", 1920), "height": cfg.get("height", 1080), "features": cfg.get("features", 2000), "batch": cfg["batch"]},
+       "scene": cfg.get("scene", "textured"),
        "kernels": {k: dict({"fetch_kb": f[k], "write_kb": w.get(k, 0.0)},
                            **{n.lower(): v for n, v in inst.get(k, {}).items() if n in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES")}) for k in f}}
 json.dump(res, open("%s/%s_traffic.json" % (out, tag), "w"), indent=2)
