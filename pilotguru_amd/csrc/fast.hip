@@ -359,15 +359,19 @@ __device__ __forceinline__ int quick_pass_u(const uint8_t* tile, int IW, int IH,
 // Result bits: byte p of the accumulator = pixel p of the quad, bit 4 + s = darker-ring outcome of step s, bit s =
 // brighter-ring outcome (s = 0..3; a fifth step, interiors taller than 32 rows, fills a second word).  ONE 32-bit word
 // holds a lane's 16 pixels x 2 polarities, so the compaction loop runs max-over-lanes(count) times instead of once per
-// polarity, and a list entry is just (lane << 6) | (word << 5) | bit position: the (row, column) arithmetic is done
+// polarity, and a list entry is just (a per-lane constant) | bit position: the (row, column) arithmetic is done
 // by the scoring round, for 64 entries at once, not per entry by the lane that found it.
-#define FAST_BFMT_ENTRY(lane, word, bpos) (uint16_t)(((lane) << 6) | ((word) << 5) | (bpos))
+// entry = row bits of the lane (8-10) | quad of the lane (5-7) | bit position (0-4: pixel, polarity, step) | fifth-step flag (11):
+// the column 4 * quad + pixel is ONE bit field of the entry, the row 8 * step + lane row two
+__device__ __forceinline__ int bfmt_lane_base(int lane)
+{
+    const int lr = ((lane >> 3) & 3) * 2 + (lane >> 5);              // the lane -> row map of the test (see quick_pass)
+    return (lr << 8) | ((lane & 7) << 5);
+}
 __device__ __forceinline__ void bfmt_decode(int e, int& iy, int& ix, int& bright)
 {
-    const int ln = e >> 6;
-    const int lr = ((ln >> 3) & 3) * 2 + (ln >> 5);                  // the lane -> row map of the test (see quick_pass)
-    iy = 8 * ((e & 3) + ((e >> 3) & 4)) + lr;
-    ix = 4 * (ln & 7) + ((e >> 3) & 3);
+    ix = (e >> 3) & 31;                                              // 4 * quad + pixel
+    iy = ((e & 3) << 3) + ((e >> 8) & 7) + ((e >> 11) << 5);         // 8 * step + lane row (+ 32: fifth step)
     bright = ((e >> 2) & 1) ^ 1;
 }
 
@@ -428,7 +432,7 @@ __device__ __forceinline__ int quick_pass_b(const uint8_t* tile, int IW, int IH,
     const int nlist = __builtin_amdgcn_readlane(incl, 63);
     if (nlist > FAST_LIST_CAP) return -1;
     uint16_t* lp = list + (incl - cnt);
-    const int base = lane << 6;
+    const int base = bfmt_lane_base(lane);
     uint32_t bits = acc;
     while (bits) {
         const int bpos = __ffs((int)bits) - 1;
@@ -440,7 +444,7 @@ __device__ __forceinline__ int quick_pass_b(const uint8_t* tile, int IW, int IH,
         while (bits) {
             const int bpos = __ffs((int)bits) - 1;
             bits &= bits - 1;
-            *lp++ = (uint16_t)(base | 32 | bpos);
+            *lp++ = (uint16_t)(base | 0x800 | bpos);
         }
     }
     return nlist;
