@@ -316,7 +316,7 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
         V.cellCap = ((V.wCell + 1) / 2) * ((V.hCell + 1) / 2);
         V.cellCandOff = (int64_t)cellCandFrame;
         cellCandFrame += align_up((size_t)V.cellCap * V.nCols * V.nRows, 64);
-        V.selOff = (int64_t)selFrame; selFrame += align_up(V.selCap, 16);
+        V.selOff = (int64_t)selFrame; selFrame += V.selCap;          // slab offset == capacity prefix: K4-6's slot s of a frame IS entry s
         // node arrays of the quadtree: LDS when 30 ints per node fit its 140 KB, else a global slab
         // (quotas above ~1180 keypoints on one level: slower, but no configuration is refused)
         V.nodeOff = -1;
@@ -341,7 +341,9 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
     if ((rc = ensure(c, c->cand, candFrame * 8 * B))) return rc;          // uint2 key records
     if ((rc = ensure(c, c->cellCand, cellCandFrame * 4 * B))) return rc;
     if ((rc = ensure(c, c->cellCount, (size_t)cells * 4 * B + 64))) return rc;
-    if ((rc = ensure(c, c->sel, selFrame * 8 * B))) return rc;            // uint2 {record, list position} per keypoint
+    selFrame = align_up(selFrame, 16);
+    P.selFrame = (int64_t)selFrame;
+    if ((rc = ensure(c, c->sel, selFrame * 32 * B))) return rc;           // one 32-byte selection record per keypoint (quadtree.hip, PgSelRec)
     if ((rc = ensure(c, c->nodes, nodeFrame * 4 * B + 64))) return rc;
     if ((rc = ensure(c, c->counters, (size_t)B * PG_MAXL * 4 * 2 + 64))) return rc;
     for (int l = 0; l < L; l++) {

@@ -217,8 +217,8 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
     // XCD-contiguous keypoint ranges: consecutive workgroups go to consecutive XCDs, so give XCD x
     // the x-th eighth of the frame's keypoint list (neighbours in the list are neighbours in the
     // image: their 43x43 windows share L2 lines)
-    int idx = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    // The wave is one long dependent chain and lives ~10 us; every load that does not depend on
+    const int slot = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    // The wave is one long dependent chain and lives ~8 us; every load that does not depend on
     // the keypoint is issued here, before the chain starts: the lane's entries of the moment
     // table, the Toeplitz operands of the row pass and its four test-point pairs.
     uint32_t mtU[5], mtM[5];
@@ -233,54 +233,44 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
     float4 pat[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) pat[r] = *reinterpret_cast<const float4*>(pg_pattern31f.v + 4 * (64 * r + lane));
-    // locate (level, index in level) from the per-level keypoint counts: ONE scalar load of the
-    // frame's 16 counters (a loop over kpc[q] was eight dependent round trips, 4 us of the wave)
+    // Slot s of a frame IS entry s of the frame's selection slab (the levels' slabs lie back to back, K3 writes them in
+    // dispatch order), and the 32-byte record holds the keypoint AND what the wave needs of its level (PgSelRec): the
+    // record and the frame's per-level counts load in ONE scalar trip behind the arguments.  (The first version searched
+    // the counts for the slot's level, loaded the record, then the level's fields: three dependent round trips were
+    // 2.6 of the wave's 8.1 us.)  A level that kept fewer keypoints than its capacity (~1 % of the slots) leaves marked
+    // records behind; their waves return after the loads.
     const int32_t* kpc = P.kpCount + frame * PG_MAXL;
-    // kernel arguments the chain needs, incl. every level's selection offset, in the first batch
     const int nlevels = P.nlevels;
-    const uint32_t* selp = P.sel + 2 * (int64_t)frame * P.selFrame;      // uint2 {record, list position} in dispatch order (K3)
-    int selOffs[PG_MAXL];                                   // (a frame's selection slab is a few thousand entries)
-#pragma unroll
-    for (int q = 0; q < PG_MAXL; q++) selOffs[q] = (int)P.lvl[q].selOff;
-    static_assert(PG_MAXL == 16, "the pin below names 16 levels");
-    asm volatile("" :: "s"(kpc), "s"(nlevels), "s"(selp), "s"(n_out), "s"(kps), "s"(desc), "s"(cap_per_frame),
-                 "s"(selOffs[0]), "s"(selOffs[1]), "s"(selOffs[2]), "s"(selOffs[3]), "s"(selOffs[4]), "s"(selOffs[5]),
-                 "s"(selOffs[6]), "s"(selOffs[7]), "s"(selOffs[8]), "s"(selOffs[9]), "s"(selOffs[10]), "s"(selOffs[11]),
-                 "s"(selOffs[12]), "s"(selOffs[13]), "s"(selOffs[14]), "s"(selOffs[15]));
+    const PgSelRec* recp = reinterpret_cast<const PgSelRec*>(P.sel) + ((int64_t)frame * P.selFrame + slot);
+    const int tieMode = P.tieMode;
+    asm volatile("" :: "s"(kpc), "s"(nlevels), "s"(recp), "s"(n_out), "s"(kps), "s"(desc), "s"(cap_per_frame), "s"(tieMode));
     typedef int32_t pg_i32x16 __attribute__((ext_vector_type(16)));
+    typedef uint32_t pg_u32x8 __attribute__((ext_vector_type(8)));
     pg_i32x16 kc;
-    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(kc) : "s"(kpc) : "memory");
-    int l = 0, total = 0, before = 0, found = -1, j = 0;
-    int selOff = 0;
+    pg_u32x8 rec;
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx8 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(kc), "=&s"(rec) : "s"(kpc), "s"(recp) : "memory");
+    if (slot >= P.selTotal) { if (blockIdx.x == 0 && lane == 0) n_out[frame] = 0; return; }     // (grid padding; never slot 0)
+    const int l = (int)(rec[1] >> 16) & 15;                 // (an unused slot's level is masked here and refused below)
+    int total = 0, before = 0;                              // keypoints of the frame / of the levels below l
 #pragma unroll
     for (int q = 0; q < PG_MAXL; q++) {
         const int c = (q < nlevels) ? kc[q] : 0;
-        if (found < 0 && idx < total + c) { found = q; before = total; selOff = selOffs[q]; }
+        if (q < l) before += c;
         total += c;
     }
-    if (blockIdx.x == 0 && lane == 0) n_out[frame] = total;      // (idx == 0 as well)
-    if (found < 0) return;
-    l = found; j = idx - before;
-    // the selection record and the level's fields travel together
-    const uint32_t* cvp = selp + 2 * (selOff + j);
-    const PgLevel& L = P.lvl[l];
-    const uint8_t* Limg = L.img; const int64_t Lfstride = L.fstride; const int Lpitch = L.pitch, Lw = L.w, Lh = L.h;
-    const float Lscale = L.scale, LpatchSize = L.patchSize;
-    uint32_t cv;
-    typedef uint32_t pg_u32x2 __attribute__((ext_vector_type(2)));
-    pg_u32x2 cvj;
-    asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=s"(cvj) : "s"(cvp) : "memory");
-    asm volatile("" :: "s"(Limg), "s"(Lfstride), "s"(Lpitch), "s"(Lw), "s"(Lh), "s"(Lscale), "s"(LpatchSize));
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(cvj));
-    cv = cvj[0];
-    idx = before + (int)cvj[1];                             // the OUTPUT slot is the keypoint's position in the reference's list
+    if (blockIdx.x == 0 && lane == 0) n_out[frame] = total;      // (slot 0)
+    if (rec[1] == 0xFFFFFFFFu || l >= nlevels) return;      // an unused slot of a level's slab (K3 marks them)
+    const uint32_t cv = rec[0];
+    const int idx = before + (int)(rec[1] & 0xFFFFu);       // the OUTPUT slot is the keypoint's position in the reference's list
+    const int Lpitch = (int)rec[2], Lw = (int)(rec[3] & 0xFFFFu), Lh = (int)(rec[3] >> 16);
+    const uint8_t* img = reinterpret_cast<const uint8_t*>((uintptr_t)(((uint64_t)rec[5] << 32) | rec[4]));
+    const float Lscale = __uint_as_float(rec[6]), LpatchSize = __uint_as_float(rec[7]);
     const int x = (int)(cv & 0xFFF) + PG_EDGE, y = (int)((cv >> 12) & 0xFFF) + PG_EDGE;   // :842-843
     const int resp = (int)(cv >> 24);
 #ifdef PGORB_DESC_TIMING
     asm volatile("" :: "s"(cv));
     DT_TS(0);
 #endif
-    const uint8_t* img = Limg + (int64_t)frame * Lfstride;
     const int w = Lw, h = Lh;
 
     // ---- stage the raw 43x43 window: window column 0 lands on an LDS dword boundary --------
@@ -392,8 +382,8 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
         const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(px0, a), __fmul_rn(py0, b)));
         const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1, b), __fmul_rn(py1, a)));
         const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(px1, a), __fmul_rn(py1, b)));
-        const int t0 = pg_blur_at(hT, 18 + r0, 18 + c0, G, K01, K23, K45, P.tieMode == 0 && x + c0 < wvec);
-        const int t1 = pg_blur_at(hT, 18 + r1, 18 + c1, G, K01, K23, K45, P.tieMode == 0 && x + c1 < wvec);
+        const int t0 = pg_blur_at(hT, 18 + r0, 18 + c0, G, K01, K23, K45, tieMode == 0 && x + c0 < wvec);
+        const int t1 = pg_blur_at(hT, 18 + r1, 18 + c1, G, K01, K23, K45, tieMode == 0 && x + c1 < wvec);
         bits[r] = __ballot(t0 < t1);
     }
 

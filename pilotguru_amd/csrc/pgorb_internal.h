@@ -77,12 +77,24 @@ struct PgLevel {
     float    patchSize;       // (float)(int)(31*scale)  ORBextractor.cc:836
 };
 
+// K3 -> K4-6: one record per selected keypoint, in K4-6's dispatch order; everything the descriptor wave needs about
+// its keypoint AND its level, so that its prologue is two scalar round trips (arguments; record + the frame's counts)
+struct PgSelRec {
+    uint32_t cv;              // x | y << 12 | response << 24 (region-relative, like the candidate records)
+    uint32_t posLevel;        // position in the reference's output list of the level | level << 16
+    int32_t  pitch;           // level plane: row pitch
+    uint32_t wh;              // w | h << 16
+    uint64_t plane;           // address of THIS frame's plane of the level
+    float    scale, patchSize;
+};
+static_assert(sizeof(PgSelRec) == 32, "one s_load_dwordx8");
+
 struct PgPlan {
     PgLevel  lvl[PG_MAXL];
     int32_t  nlevels, totalCells, iniTh, minTh, tieMode;
     int32_t  selTotal;        // sum of selCap over levels (= per-frame keypoint bound)
     int64_t  candFrame;       // key records per frame in the cand arena
-    int64_t  selFrame;        // u32 per frame in sel arena
+    int64_t  selFrame;        // selection records (PgSelRec, 32 B) per frame in the sel arena
     int64_t  nodeFrame;       // int per frame in node scratch
     int64_t  cellCandFrame;   // u32 per frame in the per-cell slot slab
     uint32_t* cellCand;       // K2 output: [frame][level][cell][cellCap]

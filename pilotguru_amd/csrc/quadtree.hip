@@ -256,9 +256,12 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P)
         ncand = qt_scan_excl(cellOff, ncells, sh);
         if (tid == 0) { cellOff[ncells] = ncand; P.candCount[frame * PG_MAXL + l] = ncand; }
         __syncthreads();
-        if (ncand <= 0) { if (tid == 0) *kpc = 0; return; }
-        if (nIni < 1) {                                      // see api.hip level_geometry: reference UB, reported
-            if (tid == 0) { atomicExch(P.status, PGORB_E_TOOSMALL); *kpc = 0; }
+        if (ncand <= 0 || nIni < 1) {
+            // no keypoint on this level: every slot of its selection slab is marked unused for K4-6
+            PgSelRec* selE = reinterpret_cast<PgSelRec*>(P.sel) + ((int64_t)frame * P.selFrame + L.selOff);
+            for (int p = tid; p < L.selCap; p += QT_T) selE[p].posLevel = 0xFFFFFFFFu;
+            if (tid == 0) *kpc = 0;
+            if (ncand > 0 && tid == 0) atomicExch(P.status, PGORB_E_TOOSMALL);      // see api.hip level_geometry: reference UB, reported
             return;
         }
         QT_TS(8);
@@ -630,7 +633,10 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P)
     // {record, position in the reference's output list}: K4-6 gives XCD x the x-th eighth of this order, so the
     // 43 x 43 windows one XCD's L2 sees overlap (in list order every window line was fetched from HBM about twice).
     // The keypoint's OUTPUT slot stays its list position.  Counting sort on the tile index, in the pyramid's LDS.
-    uint2* sel = reinterpret_cast<uint2*>(P.sel) + ((int64_t)frame * P.selFrame + L.selOff);
+    PgSelRec* sel = reinterpret_cast<PgSelRec*>(P.sel) + ((int64_t)frame * P.selFrame + L.selOff);
+    PgSelRec proto;
+    proto.cv = 0; proto.posLevel = (uint32_t)l << 16; proto.pitch = L.pitch; proto.wh = (uint32_t)L.w | ((uint32_t)L.h << 16);
+    proto.plane = (uint64_t)(uintptr_t)(L.img + (int64_t)frame * L.fstride); proto.scale = L.scale; proto.patchSize = L.patchSize;
     const int nsel = min(size, L.selCap);
     if (size > L.selCap && tid == 0) atomicExch(P.status, PGORB_E_OVERFLOW);
     const int tileCap = min(1024, 4 * NC - 2);              // the histogram lives in cnt4 [4 * NC]
@@ -667,8 +673,11 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P)
     qt_scan_excl(hist, tileCap + 1, sh);
     for (int p = tid; p < nsel; p += QT_T) {
         const int wk = wKey[p];
-        sel[hist[wk >> 16] + (wk & 0xFFFF)] = make_uint2((uint32_t)wRec[p], (uint32_t)p);
+        PgSelRec r = proto;
+        r.cv = (uint32_t)wRec[p]; r.posLevel |= (uint32_t)p;
+        sel[hist[wk >> 16] + (wk & 0xFFFF)] = r;
     }
+    for (int p = nsel + tid; p < L.selCap; p += QT_T) sel[p].posLevel = 0xFFFFFFFFu;       // unused slots of the slab: K4-6 returns on them
     if (tid == 0) *kpc = nsel;
     QT_TS(7);
 }
@@ -681,7 +690,10 @@ void pg_launch_quadtree(const PgPlan& P, int nframes, hipStream_t s)
         if (P.lvl[l].nodeOff >= 0) need[1] = max(need[1], cells);
         else need[0] = max(need[0], max(P.lvl[l].nodeCap * 30, cells));
     }
-    static size_t configured[2] = {0, 0};
+    static size_t configuredDev[64][2] = {{0, 0}};            // (the attribute is per device)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    size_t* configured = configuredDev[dev & 63];
     dim3 grid(nframes, P.nlevels), block(QT_T);
     for (int big = 0; big < 2; big++) {
         if (!need[big]) continue;
