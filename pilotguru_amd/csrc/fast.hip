@@ -21,7 +21,9 @@
 //      prefetch 2x, with LDS-DMA double buffering 1.5x: the kernel is VALU-issue bound and
 //      needs its 8 waves per SIMD more than it needs the load latency hidden)
 //  (2) each lane tests a QUAD of 4 horizontally adjacent pixels per step from 5 aligned LDS
-//      dwords (centre, left, right, 3 rows up, 3 rows down), two pixels per 32-bit operation:
+//      dwords (centre, left, right, 3 rows up, 3 rows down), FOUR pixels per 32-bit operation
+//      (quick_pass_b: v_lerp_u8 half-differences, bytes in place; the 16-bit-field form quick_pass
+//      serves cells wider than 32 px):
 //      a pixel can only be a corner if both opposite ring pairs (0,8) and (4,12) contain a
 //      darker (or a brighter) pixel (minThFAST pass: all four pairs incl. the diagonals); the
 //      few percent that pass are compacted into an LDS list with ONE DPP prefix sum per pass;
@@ -255,89 +257,6 @@ __device__ __forceinline__ int quick_pass(const uint8_t* tile, int TP, int IW, i
                 list[off++] = (uint16_t)((pol << 15) | (iy << 8) | (4 * lq + ((bpos >> 4) << 1) + (bpos & 1)));
             }
         }
-    return nlist;
-}
-
-// (2u) the same test for a whole cell of the NARROW geometry (interior <= 32 x 40, tile pitch 48), steps unrolled:
-// every row offset is an instruction immediate, the shift that files a step's result bits is a constant, and the
-// per-step bookkeeping of the loop form (row compare, exec masking, pointer increments: ~35 of its 175 cycles per
-// step) is gone -- rows past the interior are computed on whatever lies behind the tile in LDS and masked ONCE at the
-// end together with the columns.  Bit selection and accumulation use v_bitop3_b32 (fast issue class).
-template <bool STRONG>
-__device__ __forceinline__ int quick_pass_u(const uint8_t* tile, int IW, int IH, int t, uint16_t* list, int lane)
-{
-    constexpr int TP = 48;
-    const int lq = lane & 7;
-    const int lr = ((lane >> 3) & 3) * 2 + (lane >> 5);              // bank-conflict-free row order, see quick_pass
-    const uint32_t K15 = 0x80008000u;
-    const uint32_t Kd = (uint32_t)(0x8000 - t - 1) * 0x00010001u;
-    const uint32_t OD = 0x0c030c01u, X20 = 0x0c040c02u, X31 = 0x0c050c03u, M02 = 0x00FF00FFu;
-    const uint32_t* b0 = reinterpret_cast<const uint32_t*>(tile + lr * TP) + 1 + lq;   // (row lr, interior quad lq)
-    uint32_t accD = 0u, accB = 0u;
-#pragma unroll
-    for (int s = 0; s < 5; s++) {
-        if (8 * s >= IH) break;                                       // wave-uniform
-        const uint32_t* ru = b0 + (8 * s) * (TP / 4);
-        const uint32_t* rc = b0 + (8 * s + 3) * (TP / 4);
-        const uint32_t* rd = b0 + (8 * s + 6) * (TP / 4);
-        const uint32_t C = rc[0], Lw = rc[-1], Rw = rc[1], U = ru[0], D = rd[0];
-        const uint32_t Ce = C & M02, Co = __builtin_amdgcn_perm(C, C, OD);
-        const uint32_t Ue = U & M02, Uo = __builtin_amdgcn_perm(U, U, OD);
-        const uint32_t De = D & M02, Do = __builtin_amdgcn_perm(D, D, OD);
-        const uint32_t W12e = __builtin_amdgcn_perm(Lw, Lw, OD);
-        const uint32_t W4o = Rw & M02;
-        const uint32_t W12o = __builtin_amdgcn_perm(C, Lw, X20);
-        const uint32_t W4e = __builtin_amdgcn_perm(Rw, C, X31);
-        uint32_t dkE = pg_pkmax(pg_pkmin(De, Ue), pg_pkmin(W4e, W12e)), brE = pg_pkmin(pg_pkmax(De, Ue), pg_pkmax(W4e, W12e));
-        uint32_t dkO = pg_pkmax(pg_pkmin(Do, Uo), pg_pkmin(W4o, W12o)), brO = pg_pkmin(pg_pkmax(Do, Uo), pg_pkmax(W4o, W12o));
-        if (STRONG) {
-            const uint32_t* rp = b0 + (8 * s + 5) * (TP / 4);
-            const uint32_t* rm = b0 + (8 * s + 1) * (TP / 4);
-            const uint32_t Pc = rp[0], Pl = rp[-1], Pr = rp[1], Mc = rm[0], Ml = rm[-1], Mr = rm[1];
-            const uint32_t r2e = __builtin_amdgcn_perm(Pr, Pc, X20), r14e = __builtin_amdgcn_perm(Pc, Pl, X20);
-            const uint32_t r6e = __builtin_amdgcn_perm(Mr, Mc, X20), r10e = __builtin_amdgcn_perm(Mc, Ml, X20);
-            const uint32_t r2o = __builtin_amdgcn_perm(Pr, Pc, X31), r14o = __builtin_amdgcn_perm(Pc, Pl, X31);
-            const uint32_t r6o = __builtin_amdgcn_perm(Mr, Mc, X31), r10o = __builtin_amdgcn_perm(Mc, Ml, X31);
-            dkE = pg_pkmax(dkE, pg_pkmax(pg_pkmin(r2e, r10e), pg_pkmin(r6e, r14e)));
-            brE = pg_pkmin(brE, pg_pkmin(pg_pkmax(r2e, r10e), pg_pkmax(r6e, r14e)));
-            dkO = pg_pkmax(dkO, pg_pkmax(pg_pkmin(r2o, r10o), pg_pkmin(r6o, r14o)));
-            brO = pg_pkmin(brO, pg_pkmin(pg_pkmax(r2o, r10o), pg_pkmax(r6o, r14o)));
-        }
-        const uint32_t darkE = (Ce + Kd) - dkE, brightE = brE + (Kd - Ce);
-        const uint32_t darkO = (Co + Kd) - dkO, brightO = brO + (Kd - Co);
-        // bit 15 of the odd field, bit 14 := bit 15 of the even field; then filed at the step's position:
-        // sel = K15 ? odd : even >> 1  (0xCA = a ? b : c),  acc |= (sel >> 2s) & (0xC000C000 >> 2s)  (0xF8 = a | b & c)
-        const uint32_t selD = __builtin_amdgcn_bitop3_b32(K15, darkO, darkE >> 1, 0xCA);
-        const uint32_t selB = __builtin_amdgcn_bitop3_b32(K15, brightO, brightE >> 1, 0xCA);
-        accD = __builtin_amdgcn_bitop3_b32(accD, selD >> (2 * s), 0xC000C000u >> (2 * s), 0xF8);
-        accB = __builtin_amdgcn_bitop3_b32(accB, selB >> (2 * s), 0xC000C000u >> (2 * s), 0xF8);
-    }
-    // validity, once: columns of this quad inside the interior x rows 8 s + lr < IH
-    uint32_t colMask = 0;
-    if (4 * lq + 0 < IW) colMask |= 1u << 14;
-    if (4 * lq + 1 < IW) colMask |= 1u << 15;
-    if (4 * lq + 2 < IW) colMask |= 1u << 30;
-    if (4 * lq + 3 < IW) colMask |= 1u << 31;
-    const int ns = min(max((IH - lr + 7) >> 3, 0), 5);               // steps whose row of this lane lies inside the interior
-    const uint32_t half = (0xFFFFu << (16 - 2 * ns)) & 0xFFFFu;      // bit pairs of steps 0 .. ns-1 (15,14 | 13,12 | ...)
-    const uint32_t rep = colMask | (colMask >> 2) | (colMask >> 4) | (colMask >> 6) | (colMask >> 8);
-    const uint32_t valid = rep & (half | (half << 16));
-    accD &= valid; accB &= valid;
-    const int cnt = __popc(accD) + __popc(accB);
-    const int incl = wave_incl_scan(cnt);
-    const int nlist = __builtin_amdgcn_readlane(incl, 63);
-    if (nlist > FAST_LIST_CAP) return -1;
-    int off = incl - cnt;
-#pragma unroll
-    for (int pol = 0; pol < 2; pol++) {
-        uint32_t bits = pol ? accB : accD;
-        while (bits) {
-            const int bpos = __ffs((int)bits) - 1;
-            bits &= bits - 1;
-            const int iy = (7 - ((bpos & 15) >> 1)) * 8 + lr;
-            list[off++] = (uint16_t)((pol << 15) | (iy << 8) | (4 * lq + ((bpos >> 4) << 1) + (bpos & 1)));
-        }
-    }
     return nlist;
 }
 
@@ -1208,7 +1127,7 @@ void pg_launch_fast_cells(const PgPlan& P, int nframes, hipStream_t s, int level
     const int cell0 = all ? 0 : P.lvl[levelBeg].cellBase;
     const int cellEnd = all ? 8 * P.cellsPerXcdBal : (levelEnd < P.nlevels) ? P.lvl[levelEnd].cellBase : P.totalCells;
     const int cellsPerXcd = all ? P.cellsPerXcdBal : (cellEnd - cell0 + 7) / 8;
-    const bool narrow = maxW - 6 <= 32 && maxH - 6 <= 40;      // 8 quads per row, at most 5 steps of 8 rows (quick_pass_u)
+    const bool narrow = maxW - 6 <= 32 && maxH - 6 <= 40;      // 8 quads per row, at most 5 steps of 8 rows (quick_pass_b)
     static const int wpbEnv = getenv("PGORB_FAST_WPB") ? atoi(getenv("PGORB_FAST_WPB")) : 1;     // 4 independent waves per workgroup measured 13 % slower
     const int wpb = (wpbEnv == 4) ? 4 : 1;
     const int waveLds = (int)((smem + 15) & ~(size_t)15);
