@@ -542,7 +542,7 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgPlan P, int 
     const int TP = TPC ? TPC : TPr, mapPitch = MPC ? MPC : MPr;
     const int lane = threadIdx.x & 63;
     const int wv = (WPB > 1) ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
-    const uint32_t frame = blockIdx.y;                             // (unsigned: 32 x 32 -> 64-bit scalar multiplies, two instructions each)
+    const int frame = blockIdx.y;
     // Records [cell0, cellEnd) of `tab`.  The default table is in a BALANCED dispatch order (api.hip): XCD x -- the
     // dispatcher deals consecutive workgroups to consecutive XCDs -- gets the x-th eighth of EVERY level's cells, a
     // contiguous band per level, so neighbours still share L2 lines and every XCD sees the same mix of cheap cells
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgPlan P, int 
     const int cell = cell0 + (blockIdx.x & 7) * cellsPerXcd + (blockIdx.x >> 3) * WPB + wv;      // position in the table
 #ifdef PGORB_FAST_TIMING
     unsigned long long ft_t0 = wall_clock64();
-    const int ft_id = (int)frame * P.totalCells + cell;
+    const int ft_id = frame * P.totalCells + cell;
 #endif
     // Two scalar round trips to the window address: (1) the kernel arguments, including what level
     // 0 needs when it aliases the caller's buffer, (2) ONE s_load_dwordx8 of the cell's record
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgPlan P, int 
     //  fetched where it is first used costs the wave one more trip to the scalar cache in the middle of its prologue)
     int32_t* const cellCountBase = P.cellCount;
     uint32_t* const cellCandBase = P.cellCand;
-    const uint32_t cellCandFrame = (uint32_t)P.cellCandFrame;     // u32 slots per frame: < 2^32 (make_plan)
+    const int64_t cellCandFrame = P.cellCandFrame;
     const int iniTh = P.iniTh, minTh = P.minTh;
     asm volatile("" :: "s"(l0img), "s"(l0pitch), "s"(l0fstride), "s"(pyrBase), "s"(totalCells), "s"(cellCountBase),
                  "s"(cellCandBase), "s"(cellCandFrame), "s"(iniTh), "s"(minTh), "s"(TPr), "s"(tileRows), "s"(MPr), "s"(mapRows),
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgPlan P, int 
     if (cell >= cellEnd || (int)(blockIdx.x >> 3) * WPB + wv >= cellsPerXcd) return;
     const int iniX = rec[1] & 0xFFFF, iniY = rec[1] >> 16;
     const int W = rec[2] & 0xFF, H = (rec[2] >> 8) & 0xFF, cellCap = rec[2] >> 17;
-    int32_t* cellCnt = cellCountBase + ((uint64_t)frame * (uint32_t)totalCells + (rec[0] >> 4));     // the record names its cell
+    int32_t* cellCnt = cellCountBase + (int64_t)frame * totalCells + (rec[0] >> 4);     // the record names its cell
     FT_TS(0);
     if (rec[2] & 0x10000u) {                             // skipped cell (or a padding position of the balanced table)
         if (lane == 0 && (rec[0] >> 4) != 0x0FFFFFFFu) *cellCnt = 0;
@@ -651,7 +651,7 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgPlan P, int 
     PG_WAVE_SYNC();
     FT_TS(2);
 
-    uint32_t* out = cellCandBase + ((uint64_t)frame * cellCandFrame + rec[7]);
+    uint32_t* out = cellCandBase + (int64_t)frame * cellCandFrame + rec[7];
     const int xoff = 3 + iniX - PG_EDGE, yoff = 3 + iniY - PG_EDGE;   // window-local -> region-relative (:822-823)
 
     // The two detector passes written out (round 3): as a `for (pass)` loop the compiler merged the two bodies and paid for it
