@@ -268,9 +268,10 @@ int  pgorb_search_by_bow(pgorb_ctx* ctx,
  * Frames live in the layout of pgorb_extract_batch_device (keypoints / descriptors `cap_per_frame` apart, counts d_n),
  * grids as pgorb_frame_grid_batch_device writes them; pair p matches its queries against frame d_pair_frame[p]
  * (NULL: frame p).  Query arrays are [npairs][qcap] with d_nq[p] entries in use; d_kp_has_point (NULL = none) and
- * d_assigned are [npairs][cap_per_frame], d_nmatches [npairs].  One wave per pair, all pairs concurrently: the
- * reference's order dependence (an assignment is seen by every later query, ORBmatcher.cc:75-79, :1398-1402, :236-240)
- * stays inside a pair.  Call sites: Tracking::SearchLocalPoints (Tracking.cc:1175), TrackWithMotionModel (:876, :882),
+ * d_assigned are [npairs][cap_per_frame], d_nmatches [npairs].  The reference's order dependence (an assignment is seen
+ * by every later query, ORBmatcher.cc:75-79, :1398-1402, :236-240) stays inside a pair; pairs run concurrently.  SearchByProjection:
+ * two passes (candidates and distances of every query in parallel, then one wave per pair in the reference's order);
+ * SearchByBoW: one wave per common vocabulary node (a frame feature belongs to one node, so nodes are independent).  Call sites: Tracking::SearchLocalPoints (Tracking.cc:1175), TrackWithMotionModel (:876, :882),
  * TrackReferenceKeyFrame (:758). */
 int  pgorb_search_by_projection_points_batch_device(pgorb_ctx* ctx,
         const pgorb_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, int cap_per_frame,

@@ -617,7 +617,7 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgPlan P, int 
         // behind it absorbs the last partial step): behind the window loads the compiler waits for the DMA before every
         // ds_write (it cannot tell the two LDS targets apart), which put the clearing after the landing instead of under it
         const int nz = (mapRows * mapPitch + 15) >> 4;
-        if (MPC == 40) {                                           // <= 42 rows of 40 bytes: at most two steps
+        if (MPC == 40 && NARROW) {                                 // <= 42 rows of 40 bytes: at most two steps
             if (lane < nz) reinterpret_cast<uint4*>(smap)[lane] = make_uint4(0u, 0u, 0u, 0u);
             if (lane + 64 < nz) reinterpret_cast<uint4*>(smap)[lane + 64] = make_uint4(0u, 0u, 0u, 0u);
         } else {
@@ -625,12 +625,16 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgPlan P, int 
         }
         const bool laneOn = r0 < rowsPer;
         if (TPC == 48) {
-            // 3 chunks per row, 21 rows per instruction, windows of at most 46 rows: at most three instructions, straight
-            // line (the loop form compiled into a 4 x unrolled loop with a remainder loop and a division for the trip count),
-            // written out so that the address is SGPR base + 32-bit VGPR offset (the builtin takes a flat 64-bit VGPR address)
+            // 3 chunks per row, 21 rows per instruction; the narrow geometry's windows have at most 46 rows: at most three
+            // instructions, straight line (the loop form compiled into a 4 x unrolled loop with a remainder loop and a division
+            // for the trip count), written out so that the address is SGPR base + 32-bit VGPR offset (the builtin takes a flat
+            // 64-bit VGPR address).  A 36-px-wide cell of a level with ONE cell row can be up to 59 px tall (65 window rows):
+            // the wide instantiation unrolls six guarded steps (126 rows).  (Round 3's first version stopped at three for
+            // both and lost the bottom rows of such cells -- found by the fuzz soak, tests/test_gpu_parity.py has the case now.)
             const uint32_t ldsTile = (uint32_t)(uintptr_t)(pg_lptr_t)tile;
+            constexpr int KMAX = NARROW ? 3 : 6;
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
+            for (int k = 0; k < KMAX; k++) {
                 if (k * 21 < H) {                                          // wave-uniform
                     const uint8_t* gk = win + (int64_t)(k * 21) * pitch;   // scalar
                     if (laneOn && r0 + k * 21 < H)
@@ -1115,7 +1119,7 @@ void pg_launch_fast_cells(const PgPlan& P, int nframes, hipStream_t s, int level
     int TP = (maxW + 6 + 15) & ~15;                        // byte 0 pad + window + quick-test over-read, 16-B chunks
     const int tileRows = maxH;
     int mapPitch = ((maxW - 6 + 2) + 3) & ~3;
-    const bool common = TP <= 48 && mapPitch <= 40;        // the instantiation with immediate offsets
+    const bool common = TP <= 48 && mapPitch <= 40 && maxH <= 126;        // the instantiation with immediate offsets (six window loads of 21 rows)
     if (common) { TP = 48; mapPitch = 40; }
     const int chunkInv = 65536 / (TP >> 4) + 1;            // lane / (TP/16) == (lane * chunkInv) >> 16 for lane < 64
     const int mapRows = maxH - 6 + 2;

@@ -479,127 +479,255 @@ struct PgProjBatch {
 
 #define TH_HIGH 100
 
-__global__ __launch_bounds__(64) void k_search_by_projection(
-    PgProjBatch B, float minX, float minY, float invW, float invH, int mode, float nnratio, int checkOrientation,
-    int32_t* __restrict__ assignedOut, int32_t* __restrict__ nmatchesOut)
+// Round 3, two passes like SearchForInitialization: the candidates of a query and their distances do not depend on the
+// assignments made so far (only `taken` does), so pass A computes them for every query of every pair in parallel and
+// pass B -- one wave per pair, the reference's order -- only filters the stored candidates by `taken` and picks.
+#define PROJ_K 64                // stored candidates per query (one per lane of pass B)
+#define PROJ_OVER 255            // count value: more than PROJ_K survivors, pass B evaluates the query in place
+
+// GetFeaturesInArea's window and the level range of query q; false = the reference skips the query
+__device__ __forceinline__ bool proj_query(const PgProjBatch& B, int64_t qi, int mode, float minX, float minY, float invW, float invH,
+                                           float& x, float& y, float& r, int& minLevel, int& maxLevel, int& cx0, int& cx1, int& cy0, int& cy1)
 {
-    const int p = blockIdx.x, frame = B.pairFrame ? B.pairFrame[p] : p;
-    const int cap = B.cap, n = min(B.n[frame], cap), nq = min(B.nq[p], B.qcap);
+    const int lvl = B.level[qi];
+    if (!B.valid[qi] || lvl < 0 || lvl >= B.nlevels) return false;
+    x = B.x[qi]; y = B.y[qi];
+    if (mode == 0) {
+        r = ((double)B.aux[qi] > 0.998) ? 2.5f : 4.0f;                // RadiusByViewingCos (:133-139)
+        if (B.th != 1.0f) r = __fmul_rn(r, B.th);                     // bFactor (:50, :65-66)
+        r = __fmul_rn(r, B.sf[lvl]);                                  // r * F.mvScaleFactors[nPredictedLevel] (:69)
+        minLevel = lvl - 1; maxLevel = lvl;                           // :69-70
+    } else {
+        r = __fmul_rn(B.th, B.sf[lvl]);                               // th * CurrentFrame.mvScaleFactors[nLastOctave] (:1383)
+        minLevel = lvl - 1; maxLevel = lvl + 1;                       // :1392 (mono: neither forward nor backward)
+    }
+    return sfi_window(x, y, r, minX, minY, invW, invH, cx0, cx1, cy0, cy1);   // Frame.cc:336-350
+}
+
+// entry of a stored candidate: distance << 23 | rotation bin << 18 | octave << 14 | keypoint index
+__device__ __forceinline__ uint32_t proj_entry(int dist, int bin, int octave, int i2)
+{
+    return ((uint32_t)dist << 23) | ((uint32_t)(bin & 31) << 18) | ((uint32_t)(octave & 15) << 14) | (uint32_t)i2;
+}
+__device__ __forceinline__ int proj_bin(float qangle, float kangle)
+{
+    float rot = __fsub_rn(qangle, kangle);                            // :1428-1434
+    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+    int bin = (int)roundf(__fmul_rn(rot, 1.0f / HISTO_LENGTH));
+    if (bin == HISTO_LENGTH) bin = 0;
+    return bin;
+}
+
+// Pass A: workgroup = 4 waves = 4 consecutive queries of pair blockIdx.y
+__global__ __launch_bounds__(256) void k_proj_candidates(PgProjBatch B, float minX, float minY, float invW, float invH, int mode,
+                                                         uint32_t* __restrict__ lists, uint8_t* __restrict__ listCnt)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, p = blockIdx.y;
+    const int q = blockIdx.x * 4 + wv;
+    const int nq = min(B.nq[p], B.qcap);
+    if (q >= nq) return;
+    const int frame = B.pairFrame ? B.pairFrame[p] : p, cap = B.cap;
+    const int64_t qi = (int64_t)p * B.qcap + q;
+    uint8_t* cntOut = listCnt + qi;
+    float x, y, r; int minLevel, maxLevel, cx0, cx1, cy0, cy1;
+    if (!proj_query(B, qi, mode, minX, minY, invW, invH, x, y, r, minLevel, maxLevel, cx0, cx1, cy0, cy1)) {
+        if (lane == 0) *cntOut = 0;
+        return;
+    }
     const pgorb_keypoint* __restrict__ K = B.K + (int64_t)frame * cap;
     const uint8_t* __restrict__ D = B.D + (int64_t)frame * cap * 32;
     const int32_t* __restrict__ gstart = B.gstart + (int64_t)frame * (GRID_CELLS + 1);
     const int32_t* __restrict__ gidx = B.gidx + (int64_t)frame * cap;
+    uint16_t* candList = reinterpret_cast<uint16_t*>(pg_sfi_smem) + (size_t)wv * cap;
+    const int ncy = cy1 - cy0 + 1, T = (cx1 - cx0 + 1) * ncy;
+    int M = 0;
+    for (int base = 0; base < T; base += 64) {                  // window cells in (ix, iy) order, entries in insertion order
+        const int t = base + lane;
+        int s0 = 0, cnt = 0;
+        if (t < T) {
+            const int c = (cx0 + t / ncy) * GRID_ROWS + cy0 + t % ncy;
+            s0 = gstart[c]; cnt = gstart[c + 1] - s0;
+        }
+        const int incl = wave_incl_scan(cnt, lane);
+        const int off = M + incl - cnt;
+        for (int j = 0; j < cnt; j++) candList[off + j] = (uint16_t)gidx[s0 + j];
+        M += __builtin_amdgcn_readlane(incl, 63);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    const uint4 q0 = reinterpret_cast<const uint4*>(B.desc + qi * 32)[0];
+    const uint4 q1 = reinterpret_cast<const uint4*>(B.desc + qi * 32)[1];
+    const float qangle = mode == 1 ? B.aux[qi] : 0.f;
+    uint32_t* out = lists + qi * PROJ_K;
+    int total = 0;
+    for (int base = 0; base < M; base += 64) {
+        const int k = base + lane;
+        bool ok = false; uint32_t e = 0;
+        if (k < M) {
+            const int i2 = candList[k];
+            const pgorb_keypoint kp2 = K[i2];
+            ok = true;
+            if (bCheckLevels && (kp2.octave < minLevel || (maxLevel >= 0 && kp2.octave > maxLevel))) ok = false;
+            if (!(fabsf(__fsub_rn(kp2.x, x)) < r && fabsf(__fsub_rn(kp2.y, y)) < r)) ok = false;
+            if (ok) e = proj_entry(sfi_distance(q0, q1, D + (int64_t)i2 * 32), mode == 1 ? proj_bin(qangle, kp2.angle) : 0, kp2.octave, i2);
+        }
+        const unsigned long long m = __ballot(ok);
+        const int pos = total + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+        if (ok && pos < PROJ_K) out[pos] = e;
+        total += __popcll(m);
+    }
+    if (lane == 0) *cntOut = (uint8_t)(total > PROJ_K ? PROJ_OVER : total);
+}
+
+// a query with more than PROJ_K candidates: the whole evaluation in place, in the reference's order (the round-2 form of the
+// kernel); returns the best two entries, their keys' distances in the entry's distance field
+__device__ __noinline__ uint2 proj_eval_in_place(const PgProjBatch B, int64_t qi, int frame, int mode, float minX, float minY, float invW,
+                                                 float invH, const uint8_t* taken, int lane)
+{
+    float x, y, r; int minLevel, maxLevel, cx0, cx1, cy0, cy1;
+    proj_query(B, qi, mode, minX, minY, invW, invH, x, y, r, minLevel, maxLevel, cx0, cx1, cy0, cy1);      // (true: pass A got here)
+    const int cap = B.cap;
+    const pgorb_keypoint* K = B.K + (int64_t)frame * cap;
+    const uint8_t* D = B.D + (int64_t)frame * cap * 32;
+    const int32_t* gstart = B.gstart + (int64_t)frame * (GRID_CELLS + 1);
+    const int32_t* gidx = B.gidx + (int64_t)frame * cap;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    const uint4 q0 = reinterpret_cast<const uint4*>(B.desc + qi * 32)[0];
+    const uint4 q1 = reinterpret_cast<const uint4*>(B.desc + qi * 32)[1];
+    const float qangle = mode == 1 ? B.aux[qi] : 0.f;
+    unsigned long long b1 = ~0ull, b2 = ~0ull;              // (distance << 48 | scan position << 32 | entry): the lane's two smallest
+    int posBase = 0;
+    for (int ix = cx0; ix <= cx1; ix++)
+        for (int iy = cy0; iy <= cy1; iy++) {
+            const int c = ix * GRID_ROWS + iy, s0 = gstart[c], cnt = gstart[c + 1] - s0;
+            for (int k = lane; k < cnt; k += 64) {
+                const int i2 = gidx[s0 + k];
+                const pgorb_keypoint kp2 = K[i2];
+                if (bCheckLevels && (kp2.octave < minLevel || (maxLevel >= 0 && kp2.octave > maxLevel))) continue;
+                if (!(fabsf(__fsub_rn(kp2.x, x)) < r && fabsf(__fsub_rn(kp2.y, y)) < r)) continue;
+                if (taken[i2]) continue;
+                const int dist = sfi_distance(q0, q1, D + (int64_t)i2 * 32);
+                const unsigned long long key = ((unsigned long long)dist << 48) | ((unsigned long long)(posBase + k) << 32) |
+                                               proj_entry(dist, mode == 1 ? proj_bin(qangle, kp2.angle) : 0, kp2.octave, i2);
+                if (key < b1) { b2 = b1; b1 = key; } else if (key < b2) b2 = key;
+            }
+            posBase += cnt;
+        }
+    // the wave's two smallest keys
+    unsigned long long w1 = b1;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(w1, d); w1 = o < w1 ? o : w1; }
+    unsigned long long mine = (b1 == w1) ? b2 : b1, w2 = mine;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(w2, d); w2 = o < w2 ? o : w2; }
+    return make_uint2(w1 == ~0ull ? 0xFFFFFFFFu : (uint32_t)w1, w2 == ~0ull ? 0xFFFFFFFFu : (uint32_t)w2);
+}
+
+#define PROJ_G 8                 // queries per prefetch group of pass B
+
+// Pass B: one wave per pair, queries in order
+__global__ __launch_bounds__(64) void k_search_by_projection(
+    PgProjBatch B, float minX, float minY, float invW, float invH, int mode, float nnratio, int checkOrientation,
+    const uint32_t* __restrict__ lists, const uint8_t* __restrict__ listCnt,
+    int32_t* __restrict__ assignedOut, int32_t* __restrict__ nmatchesOut)
+{
+    const int p = blockIdx.x, frame = B.pairFrame ? B.pairFrame[p] : p;
+    const int cap = B.cap, n = min(B.n[frame], cap), nq = min(B.nq[p], B.qcap);
     const uint8_t* kpHasPoint = B.kpHasPoint ? B.kpHasPoint + (int64_t)p * cap : nullptr;
     const int64_t qo = (int64_t)p * B.qcap;
+    const uint32_t* L = lists + qo * PROJ_K;
+    const uint8_t* LC = listCnt + qo;
     assignedOut += (int64_t)p * cap; nmatchesOut += p;
     const int lane = threadIdx.x;
-    // state in LDS: taken[i] = keypoint i holds a point with observations (before or by this
-    // call); asg[i] = query assigned to keypoint i by this call; candList = vIndices;
-    // rotBin[q] / qBest[q] = histogram bin and keypoint of accepted query q (mode 1)
+    // state in LDS: taken[i] = keypoint i holds a point with observations (before or by this call); asg[i] = query assigned
+    // to keypoint i by this call; rotBin[q] / qBest[q] = histogram bin and keypoint of accepted query q (mode 1);
+    // active = the queries that have candidates, in order
     uint8_t* taken = pg_sfi_smem;                                         // [cap]
     int32_t* asg = reinterpret_cast<int32_t*>(pg_sfi_smem + ((cap + 15) & ~15));    // [cap]
-    uint16_t* candList = reinterpret_cast<uint16_t*>(asg + cap);          // [cap]
-    uint16_t* qBest = candList + cap;                                     // [qcap]
+    uint16_t* active = reinterpret_cast<uint16_t*>(asg + cap);            // [qcap]
+    uint16_t* qBest = active + B.qcap;                                    // [qcap]
     int8_t* rotBin = reinterpret_cast<int8_t*>(qBest + B.qcap);           // [qcap]
     for (int i = lane; i < n; i += 64) { taken[i] = kpHasPoint ? (kpHasPoint[i] != 0) : 0; asg[i] = -1; }
     if (mode == 1) for (int i = lane; i < nq; i += 64) rotBin[i] = -1;
+    int nact = 0;
+    for (int base = 0; base < nq; base += 512) {
+        uint8_t cv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = base + 64 * u + lane; cv[u] = i < nq ? LC[i] : (uint8_t)0; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const bool on = cv[u] != 0;
+            const unsigned long long m = __ballot(on);
+            if (on) active[nact + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] = (uint16_t)(base + 64 * u + lane);
+            nact += __popcll(m);
+        }
+    }
     __syncthreads();
-    const float factor = 1.0f / HISTO_LENGTH;
     int nmatches = 0;
-    for (int q = 0; q < nq; q++) {
-        const int lvl = B.level[qo + q];
-        if (!B.valid[qo + q] || lvl < 0 || lvl >= B.nlevels) continue;
-        const float x = B.x[qo + q], y = B.y[qo + q];
-        float r; int minLevel, maxLevel;
-        if (mode == 0) {
-            r = ((double)B.aux[qo + q] > 0.998) ? 2.5f : 4.0f;            // RadiusByViewingCos (:133-139)
-            if (B.th != 1.0f) r = __fmul_rn(r, B.th);                     // bFactor (:50, :65-66)
-            r = __fmul_rn(r, B.sf[lvl]);                                  // r * F.mvScaleFactors[nPredictedLevel] (:69)
-            minLevel = lvl - 1; maxLevel = lvl;                           // :69-70
-        } else {
-            r = __fmul_rn(B.th, B.sf[lvl]);                               // th * CurrentFrame.mvScaleFactors[nLastOctave] (:1383)
-            minLevel = lvl - 1; maxLevel = lvl + 1;                       // :1392 (mono: neither forward nor backward)
-        }
-        // GetFeaturesInArea(x, y, r, minLevel, maxLevel)  (Frame.cc:336-350)
-        const int nMinCellX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, minX), r), invW)));
-        if (nMinCellX >= GRID_COLS) continue;
-        const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, minX), r), invW)));
-        if (nMaxCellX < 0) continue;
-        const int nMinCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, minY), r), invH)));
-        if (nMinCellY >= GRID_ROWS) continue;
-        const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, minY), r), invH)));
-        if (nMaxCellY < 0) continue;
-        const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
-        const int ncy = nMaxCellY - nMinCellY + 1;
-        const int T = max(0, (nMaxCellX - nMinCellX + 1)) * max(0, ncy);
-        int M = 0;
-        for (int base = 0; base < T; base += 64) {
-            const int t = base + lane;
-            int s = 0, cnt = 0;
-            if (t < T) {
-                const int c = (nMinCellX + t / ncy) * GRID_ROWS + nMinCellY + t % ncy;
-                s = gstart[c]; cnt = gstart[c + 1] - s;
+    uint32_t curE[PROJ_G], nxtE[PROJ_G]; int curC[PROJ_G], nxtC[PROJ_G], curQ[PROJ_G], nxtQ[PROJ_G], curO[PROJ_G], nxtO[PROJ_G];
+    auto load_group = [&](int g, uint32_t (&E)[PROJ_G], int (&Cn)[PROJ_G], int (&Q)[PROJ_G], int (&O)[PROJ_G]) {
+#pragma unroll
+        for (int j = 0; j < PROJ_G; j++) {
+            const int a = g * PROJ_G + j;
+            Q[j] = -1; Cn[j] = 0; E[j] = 0; O[j] = 0;
+            if (a < nact) {
+                const int q = active[a];
+                Q[j] = q; Cn[j] = LC[q]; O[j] = B.hasObs[qo + q];
+                E[j] = L[(int64_t)q * PROJ_K + lane];                        // (all 64 slots; slots past the count are masked below)
             }
-            const int incl = wave_incl_scan(cnt, lane);
-            const int off = M + incl - cnt;
-            for (int j = 0; j < cnt; j++) candList[off + j] = (uint16_t)gidx[s + j];
-            M += __shfl(incl, 63);
         }
-        __syncthreads();
-        if (M == 0) continue;
-        const uint4 q0 = reinterpret_cast<const uint4*>(B.desc + (qo + q) * 32)[0];
-        const uint4 q1 = reinterpret_cast<const uint4*>(B.desc + (qo + q) * 32)[1];
-        unsigned b1key = 0xFFFFFFFFu, b2key = 0xFFFFFFFFu;     // (dist << 16 | list position): two smallest of this lane
-        for (int k = lane; k < M; k += 64) {
-            const int i2 = candList[k];
-            const pgorb_keypoint kp2 = K[i2];
-            if (bCheckLevels) {
-                if (kp2.octave < minLevel) continue;
-                if (maxLevel >= 0 && kp2.octave > maxLevel) continue;
+    };
+    const int ngroups = (nact + PROJ_G - 1) / PROJ_G;
+    if (ngroups) load_group(0, curE, curC, curQ, curO);
+    for (int g = 0; g < ngroups; g++) {
+        if (g + 1 < ngroups) load_group(g + 1, nxtE, nxtC, nxtQ, nxtO);
+#pragma unroll
+        for (int j = 0; j < PROJ_G; j++) {
+            const int q = curQ[j];
+            if (q < 0) break;                                               // (wave-uniform)
+            uint32_t e1, e2;                                                // entries of the best and the second candidate
+            if (curC[j] != PROJ_OVER) {
+                const uint32_t e = curE[j];
+                const bool keep = lane < curC[j] && !taken[e & 0x3FFFu];    // mvpMapPoints[idx] with Observations() > 0 (:79-81 / :1397-1399)
+                const unsigned key = keep ? (((e >> 23) << 16) | (unsigned)lane) : 0xFFFFFFFFu;
+                unsigned k1, k2;
+                wave_min2_u32(key, k1, k2);
+                if (k1 == 0xFFFFFFFFu) continue;
+                e1 = (uint32_t)__builtin_amdgcn_readlane((int)e, (int)(k1 & 63u));
+                e2 = (k2 == 0xFFFFFFFFu) ? 0xFFFFFFFFu : (uint32_t)__builtin_amdgcn_readlane((int)e, (int)(k2 & 63u));
+            } else {
+                const uint2 ev = proj_eval_in_place(B, qo + q, frame, mode, minX, minY, invW, invH, taken, lane);
+                e1 = ev.x; e2 = ev.y;
+                if (e1 == 0xFFFFFFFFu) continue;
             }
-            if (!(fabsf(__fsub_rn(kp2.x, x)) < r && fabsf(__fsub_rn(kp2.y, y)) < r)) continue;
-            if (taken[i2]) continue;                           // mvpMapPoints[idx] with Observations() > 0
-            const uint4 d0 = reinterpret_cast<const uint4*>(D + (int64_t)i2 * 32)[0];
-            const uint4 d1 = reinterpret_cast<const uint4*>(D + (int64_t)i2 * 32)[1];
-            const int dist = __popc(q0.x ^ d0.x) + __popc(q0.y ^ d0.y) + __popc(q0.z ^ d0.z) + __popc(q0.w ^ d0.w) +
-                             __popc(q1.x ^ d1.x) + __popc(q1.y ^ d1.y) + __popc(q1.z ^ d1.z) + __popc(q1.w ^ d1.w);
-            const unsigned key = ((unsigned)dist << 16) | (unsigned)k;
-            if (key < b1key) { b2key = b1key; b1key = key; } else if (key < b2key) b2key = key;
-        }
-        // the two smallest keys of the wave = best and second in (distance, scan order)
-        const unsigned w1 = wave_min_u32(b1key);
-        if (w1 != 0xFFFFFFFFu && (int)(w1 >> 16) < 256) {      // bestDist starts at 256 (:74 / :1390)
-            const unsigned w2 = wave_min_u32(b1key == w1 ? b2key : b1key);
-            const int bestDist = (int)(w1 >> 16), bestIdx = candList[w1 & 0xFFFF];
+            const int bestDist = (int)(e1 >> 23), bestIdx = (int)(e1 & 0x3FFFu);
+            if (bestDist >= 256) continue;                                  // bestDist starts at 256 (:74 / :1390)
             bool accept = false;
             int bin = -1;
             if (mode == 0) {
-                const bool has2 = (w2 != 0xFFFFFFFFu) && (int)(w2 >> 16) < 256;
-                const int bestDist2 = has2 ? (int)(w2 >> 16) : 256;
-                const int bestLevel = K[bestIdx].octave;
-                const int bestLevel2 = has2 ? K[candList[w2 & 0xFFFF]].octave : -1;
-                if (bestDist <= TH_HIGH)                       // :113-123
+                const bool has2 = e2 != 0xFFFFFFFFu && (int)(e2 >> 23) < 256;
+                const int bestDist2 = has2 ? (int)(e2 >> 23) : 256;
+                const int bestLevel = (int)((e1 >> 14) & 15u), bestLevel2 = has2 ? (int)((e2 >> 14) & 15u) : -1;
+                if (bestDist <= TH_HIGH)                                    // :113-123
                     accept = !(bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(nnratio, (float)bestDist2));
             } else {
-                accept = bestDist <= TH_HIGH;                  // :1421
-                if (accept && checkOrientation) {              // :1426-1436
-                    float rot = __fsub_rn(B.aux[qo + q], K[bestIdx].angle);
-                    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
-                    bin = (int)roundf(__fmul_rn(rot, factor));
-                    if (bin == HISTO_LENGTH) bin = 0;
-                }
+                accept = bestDist <= TH_HIGH;                               // :1421
+                if (accept && checkOrientation) bin = (int)((e1 >> 18) & 31u);     // :1426-1436 (computed in pass A)
             }
             if (accept) {
                 nmatches++;
                 if (lane == 0) {
-                    asg[bestIdx] = q;                          // F.mvpMapPoints[bestIdx] = pMP
-                    taken[bestIdx] = B.hasObs[qo + q] != 0;
+                    asg[bestIdx] = q;                                       // F.mvpMapPoints[bestIdx] = pMP
+                    taken[bestIdx] = curO[j] != 0;
                     if (mode == 1) { rotBin[q] = (int8_t)bin; qBest[q] = (uint16_t)bestIdx; }
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
         }
-        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PROJ_G; j++) { curE[j] = nxtE[j]; curC[j] = nxtC[j]; curQ[j] = nxtQ[j]; curO[j] = nxtO[j]; }
     }
+    __syncthreads();
     if (mode == 1 && checkOrientation) {                       // :1443-1469
         int h = 0;
         for (int i = 0; i < nq; i++) h += (rotBin[i] == lane);
@@ -641,10 +769,20 @@ struct PgBowBatch {
     const int32_t* pairKF; const int32_t* pairF; const uint8_t* kfValid;
 };
 
+// Round 3: NODES in parallel.  A frame feature belongs to exactly one vocabulary node, so the reference's order dependence
+// ("vpMapPointMatches[realIdxF] already set", :219-220) never crosses a node: one wave walks ONE common node -- its key-frame
+// features in order, the frame's features of the node one per lane and held in registers (descriptor, angle, "already
+// matched" bit) for the whole walk -- and all nodes of all pairs run side by side.  A finishing wave per pair counts the
+// matches and applies the rotation histogram (:256-277).  (The one-wave-per-pair form walked all ~2000 key-frame features of a
+// pair in a row with the descriptor reads inside the chain: 1.34 ms per 127 pairs; a two-pass form like SearchByProjection's
+// did not help because most features sit in nodes with more than 64 frame features.)
+#define BOW_R 4                  // frame features per lane held in registers: nodes of up to 256 frame features
+#define BOW_WAVES 64             // waves per pair, each takes the nodes a = wave, wave + 64, ...
+
 __global__ __launch_bounds__(64) void k_search_by_bow(PgBowBatch B, float nnratio, int checkOrientation,
-                                                       int32_t* __restrict__ matchesOut, int32_t* __restrict__ nmatchesOut)
+                                                       int32_t* __restrict__ matchesOut, int8_t* __restrict__ binOut)
 {
-    const int p = blockIdx.x, fa = B.pairKF[p], fb = B.pairF[p], cap = B.cap;
+    const int p = blockIdx.y, fa = B.pairKF[p], fb = B.pairF[p], cap = B.cap;
     const uint8_t* __restrict__ kfDesc = B.D + (int64_t)fa * cap * 32;
     const uint8_t* __restrict__ fDesc = B.D + (int64_t)fb * cap * 32;
     const pgorb_keypoint* __restrict__ kfK = B.K + (int64_t)fa * cap;
@@ -654,81 +792,113 @@ __global__ __launch_bounds__(64) void k_search_by_bow(PgBowBatch B, float nnrati
     const uint32_t* __restrict__ aFeat = B.fvFeat + (int64_t)fa * cap;
     const uint32_t* __restrict__ bNode = B.fvNode + (int64_t)fb * cap; const int32_t* __restrict__ bStart = B.fvStart + (int64_t)fb * (cap + 1);
     const uint32_t* __restrict__ bFeat = B.fvFeat + (int64_t)fb * cap;
-    const int nA = B.nfv[fa], nB = B.nfv[fb], nf = min(B.n[fb], cap);
-    matchesOut += (int64_t)p * cap; nmatchesOut += p;
+    const int nA = B.nfv[fa], nB = B.nfv[fb];
+    matchesOut += (int64_t)p * cap; binOut += (int64_t)p * cap;
     const int lane = threadIdx.x;
-    int32_t* asg = reinterpret_cast<int32_t*>(pg_sfi_smem);               // [nf] vpMapPointMatches (as KF index)
-    int8_t* rotBin = reinterpret_cast<int8_t*>(asg + nf);                 // [nf]
-    for (int i = lane; i < nf; i += 64) { asg[i] = -1; rotBin[i] = -1; }
-    __syncthreads();
-    const float factor = 1.0f / HISTO_LENGTH;
-    int nmatches = 0, a = 0, b = 0;
-    while (a < nA && b < nB) {                                            // :185-252
-        const uint32_t na = aNode[a], nb = bNode[b];
-        if (na < nb) { a++; continue; }                                   // lower_bound on a sorted list
-        if (nb < na) { b++; continue; }
-        const int a0 = aStart[a], a1 = aStart[a + 1], b0 = bStart[b], b1 = bStart[b + 1];
+    for (int a = blockIdx.x; a < nA; a += BOW_WAVES) {
+        const uint32_t node = aNode[a];
+        int lo = 0, hi = nB;                                              // the frame's entry of the same node (both lists ascend)
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (bNode[mid] < node) lo = mid + 1; else hi = mid; }
+        if (lo >= nB || bNode[lo] != node) continue;
+        const int a0 = aStart[a], a1 = aStart[a + 1], b0 = bStart[lo], b1 = bStart[lo + 1], nb = b1 - b0;
+        const bool inRegs = nb <= 64 * BOW_R;
+        // the frame's features of the node: lane holds candidates k = lane, lane + 64, ... (k = position in the node's list)
+        uint4 d0[BOW_R], d1[BOW_R]; float ang[BOW_R]; int idxF[BOW_R];
+        unsigned takenBits = 0;
+#pragma unroll
+        for (int r = 0; r < BOW_R; r++) {
+            const int k = 64 * r + lane;
+            idxF[r] = -1; ang[r] = 0.f; d0[r] = make_uint4(0, 0, 0, 0); d1[r] = d0[r];
+            if (inRegs && k < nb) {
+                idxF[r] = (int)bFeat[b0 + k];
+                d0[r] = reinterpret_cast<const uint4*>(fDesc + (int64_t)idxF[r] * 32)[0];
+                d1[r] = reinterpret_cast<const uint4*>(fDesc + (int64_t)idxF[r] * 32)[1];
+                ang[r] = fK[idxF[r]].angle;
+            }
+        }
         for (int ia = a0; ia < a1; ia++) {
-            const int realIdxKF = (int)aFeat[ia];
-            if (!kfValid[realIdxKF]) continue;                            // !pMP || pMP->isBad()
+            const int realIdxKF = __builtin_amdgcn_readfirstlane((int)aFeat[ia]);
+            if (!kfValid[realIdxKF]) continue;                            // !pMP || pMP->isBad() (:208-213)
             const uint4 q0 = reinterpret_cast<const uint4*>(kfDesc + (int64_t)realIdxKF * 32)[0];
             const uint4 q1 = reinterpret_cast<const uint4*>(kfDesc + (int64_t)realIdxKF * 32)[1];
             unsigned b1key = 0xFFFFFFFFu, b2key = 0xFFFFFFFFu;
-            for (int k = b0 + lane; k < b1; k += 64) {
-                const int realIdxF = (int)bFeat[k];
-                if (asg[realIdxF] >= 0) continue;                         // vpMapPointMatches[realIdxF]
-                const uint4 d0 = reinterpret_cast<const uint4*>(fDesc + (int64_t)realIdxF * 32)[0];
-                const uint4 d1 = reinterpret_cast<const uint4*>(fDesc + (int64_t)realIdxF * 32)[1];
-                const int dist = __popc(q0.x ^ d0.x) + __popc(q0.y ^ d0.y) + __popc(q0.z ^ d0.z) + __popc(q0.w ^ d0.w) +
-                                 __popc(q1.x ^ d1.x) + __popc(q1.y ^ d1.y) + __popc(q1.z ^ d1.z) + __popc(q1.w ^ d1.w);
-                const unsigned key = ((unsigned)dist << 16) | (unsigned)(k - b0);
-                if (key < b1key) { b2key = b1key; b1key = key; } else if (key < b2key) b2key = key;
-            }
-            const unsigned w1 = wave_min_u32(b1key);
-            if (w1 != 0xFFFFFFFFu && (int)(w1 >> 16) < 256) {             // bestDist1 starts at 256
-                const unsigned w2 = wave_min_u32(b1key == w1 ? b2key : b1key);
-                const int bestDist1 = (int)(w1 >> 16);
-                const int bestDist2 = (w2 != 0xFFFFFFFFu && (int)(w2 >> 16) < 256) ? (int)(w2 >> 16) : 256;
-                const int bestIdxF = (int)bFeat[b0 + (int)(w1 & 0xFFFF)];
-                if (bestDist1 <= TH_LOW && (float)bestDist1 < __fmul_rn(nnratio, (float)bestDist2)) {   // :233-235
-                    int bin = -1;
-                    if (checkOrientation) {                               // :241-250
-                        float rot = __fsub_rn(kfK[realIdxKF].angle, fK[bestIdxF].angle);
-                        if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
-                        bin = (int)roundf(__fmul_rn(rot, factor));
-                        if (bin == HISTO_LENGTH) bin = 0;
-                    }
-                    nmatches++;
-                    if (lane == 0) { asg[bestIdxF] = realIdxKF; rotBin[bestIdxF] = (int8_t)bin; }
+            if (inRegs) {
+#pragma unroll
+                for (int r = 0; r < BOW_R; r++) {
+                    if (idxF[r] < 0 || (takenBits >> r) & 1u) continue;   // vpMapPointMatches[realIdxF] (:219-220)
+                    const int dist = __popc(q0.x ^ d0[r].x) + __popc(q0.y ^ d0[r].y) + __popc(q0.z ^ d0[r].z) + __popc(q0.w ^ d0[r].w) +
+                                     __popc(q1.x ^ d1[r].x) + __popc(q1.y ^ d1[r].y) + __popc(q1.z ^ d1[r].z) + __popc(q1.w ^ d1[r].w);
+                    const unsigned key = ((unsigned)dist << 16) | (unsigned)(64 * r + lane);
+                    if (key < b1key) { b2key = b1key; b1key = key; } else if (key < b2key) b2key = key;
+                }
+            } else {                                                      // a node with more frame features than the registers hold
+                for (int k = lane; k < nb; k += 64) {
+                    const int realIdxF = (int)bFeat[b0 + k];
+                    if (matchesOut[realIdxF] >= 0) continue;              // (this wave's own earlier writes: same lane, program order)
+                    const unsigned key = ((unsigned)sfi_distance(q0, q1, fDesc + (int64_t)realIdxF * 32) << 16) | (unsigned)k;
+                    if (key < b1key) { b2key = b1key; b1key = key; } else if (key < b2key) b2key = key;
                 }
             }
-            __syncthreads();
+            const unsigned w1 = wave_min_u32(b1key);
+            if (w1 == 0xFFFFFFFFu || (int)(w1 >> 16) >= 256) continue;     // bestDist1 starts at 256
+            const unsigned w2 = wave_min_u32(b1key == w1 ? b2key : b1key);
+            const int bestDist1 = (int)(w1 >> 16);
+            const int bestDist2 = (w2 != 0xFFFFFFFFu && (int)(w2 >> 16) < 256) ? (int)(w2 >> 16) : 256;
+            if (bestDist1 <= TH_LOW && (float)bestDist1 < __fmul_rn(nnratio, (float)bestDist2)) {   // :233-235
+                const int kbest = (int)(w1 & 0xFFFFu);
+                if ((kbest & 63) == lane) {                              // the lane that holds the winner files it
+                    int bestIdxF; float fang;
+                    if (inRegs) {
+                        const int r = kbest >> 6;
+                        bestIdxF = idxF[0]; fang = ang[0];
+#pragma unroll
+                        for (int rr = 1; rr < BOW_R; rr++) if (r == rr) { bestIdxF = idxF[rr]; fang = ang[rr]; }
+                        takenBits |= 1u << r;
+                    } else {
+                        bestIdxF = (int)bFeat[b0 + kbest]; fang = fK[bestIdxF].angle;
+                    }
+                    matchesOut[bestIdxF] = realIdxKF;
+                    binOut[bestIdxF] = (int8_t)(checkOrientation ? proj_bin(kfK[realIdxKF].angle, fang) : -1);    // :241-250
+                }
+                if (!inRegs) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the next feature's scan reads matchesOut from other lanes
+            }
         }
-        a++; b++;
     }
+}
+
+// after the nodes: count the matches of a pair and apply the rotation histogram
+__global__ __launch_bounds__(64) void k_bow_finish(PgBowBatch B, int checkOrientation, int32_t* __restrict__ matchesOut,
+                                                    const int8_t* __restrict__ binIn, int32_t* __restrict__ nmatchesOut)
+{
+    const int p = blockIdx.x, fb = B.pairF[p], cap = B.cap, nf = min(B.n[fb], cap), lane = threadIdx.x;
+    matchesOut += (int64_t)p * cap; binIn += (int64_t)p * cap; nmatchesOut += p;
+    int nmatches = 0;
+    for (int i = lane; i < nf; i += 64) nmatches += matchesOut[i] >= 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) nmatches += __shfl_xor(nmatches, d);
+    const int8_t* rotBin = binIn;
+    int32_t* asg = matchesOut;
     if (checkOrientation) {                                               // :256-277
         int h = 0;
         for (int i = 0; i < nf; i++) h += (rotBin[i] == lane);
         int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
         for (int i = 0; i < HISTO_LENGTH; i++) {
-            const int s = __shfl(h, i);
-            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
-            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
-            else if (s > max3) { max3 = s; ind3 = i; }
+            const int sc = __shfl(h, i);
+            if (sc > max1) { max3 = max2; max2 = max1; max1 = sc; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (sc > max2) { max3 = max2; max2 = sc; ind3 = ind2; ind2 = i; }
+            else if (sc > max3) { max3 = sc; ind3 = i; }
         }
         if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
         else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
         int removed = 0;
         for (int i = lane; i < nf; i += 64) {
             const int bb = rotBin[i];
-            if (bb >= 0 && bb != ind1 && bb != ind2 && bb != ind3) { asg[i] = -1; removed++; }
+            if (bb >= 0 && bb != ind1 && bb != ind2 && bb != ind3 && asg[i] >= 0) { asg[i] = -1; removed++; }
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) removed += __shfl_xor(removed, d);
         nmatches -= removed;
-        __syncthreads();
     }
-    for (int i = lane; i < cap; i += 64) matchesOut[i] = i < nf ? asg[i] : -1;
     if (lane == 0) *nmatchesOut = nmatches;
 }
 
@@ -884,7 +1054,7 @@ int pgorb_image_bounds(int cols, int rows, const float camera[4], const float di
 // per-device "dynamic LDS limit already raised to" bookkeeping of the three latency kernels below
 static bool pg_raise_lds(pgorb_ctx* c, const void* fn, int which, size_t lds)
 {
-    static size_t configured[3][64] = {{0}};
+    static size_t configured[4][64] = {{0}};
     const int dv = pg_ctx_device(c) & 63;
     if (lds > 160 * 1024) return false;
     if (lds > configured[which][dv]) {
@@ -921,10 +1091,16 @@ int pgorb_search_by_bow_batch_device(pgorb_ctx* c, const pgorb_keypoint* d_kps, 
     if (cap > 16000) return pg_ctx_fail(c, PGORB_E_LIMIT, "more than 16000 keypoints per frame");
     if (!npairs) return 0;
     if (hipSetDevice(pg_ctx_device(c)) != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "hipSetDevice failed");
-    const size_t lds = (size_t)cap * 5 + 64;
-    if (!pg_raise_lds(c, reinterpret_cast<const void*>(k_search_by_bow), 1, lds)) return pg_ctx_fail(c, PGORB_E_LIMIT, "SearchByBoW state exceeds the LDS");
+    // scratch: the rotation bin of every matched frame feature [npairs][cap] i8
+    void* scratch;
+    int rcs = pg_ctx_stage(c, 3, (size_t)npairs * cap + 256, &scratch);
+    if (rcs) return rcs;
+    int8_t* bins = (int8_t*)scratch;
+    if (hipMemsetAsync(d_matches, 0xFF, (size_t)npairs * cap * 4, (hipStream_t)stream) != hipSuccess ||
+        hipMemsetAsync(bins, 0xFF, (size_t)npairs * cap, (hipStream_t)stream) != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "hipMemsetAsync failed");
     PgBowBatch B = {d_kps, d_desc, d_n, cap, d_fv_node, d_fv_start, d_fv_feat, d_nfv, d_pair_kf, d_pair_f, d_kf_point_valid};
-    hipLaunchKernelGGL(k_search_by_bow, dim3(npairs), dim3(64), lds, (hipStream_t)stream, B, nnratio, check_orientation, d_matches, d_nmatches);
+    hipLaunchKernelGGL(k_search_by_bow, dim3(BOW_WAVES, npairs), dim3(64), 0, (hipStream_t)stream, B, nnratio, check_orientation, d_matches, bins);
+    hipLaunchKernelGGL(k_bow_finish, dim3(npairs), dim3(64), 0, (hipStream_t)stream, B, check_orientation, d_matches, bins, d_nmatches);
     if (hipGetLastError() != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "k_search_by_bow launch failed");
     return 0;
 }
@@ -1058,10 +1234,20 @@ static int pg_search_by_projection_batch(pgorb_ctx* c, int mode, const pgorb_key
     B.desc = d_qdesc; B.hasObs = d_qobs; B.nlevels = pgorb_levels(c); B.th = th;
     pgorb_scale_tables(c, B.sf, nullptr, nullptr, nullptr);
     const float invW = (float)GRID_COLS / (max_x - min_x), invH = (float)GRID_ROWS / (max_y - min_y);
-    const size_t lds = (size_t)((cap + 15) & ~15) + (size_t)cap * 6 + (size_t)qcap * 3 + 64;
-    if (!pg_raise_lds(c, reinterpret_cast<const void*>(k_search_by_projection), 0, lds)) return pg_ctx_fail(c, PGORB_E_LIMIT, "SearchByProjection state exceeds the LDS");
+    // scratch of the two passes: lists[npairs][qcap][PROJ_K] u32 | count[npairs][qcap] u8
+    const size_t szL = (size_t)npairs * qcap * PROJ_K * 4;
+    void* scratch;
+    int rcs = pg_ctx_stage(c, 3, szL + (size_t)npairs * qcap + 256, &scratch);
+    if (rcs) return rcs;
+    uint32_t* lists = (uint32_t*)scratch;
+    uint8_t* listCnt = (uint8_t*)scratch + szL;
+    const size_t ldsA = (size_t)4 * cap * 2;
+    const size_t lds = (size_t)((cap + 15) & ~15) + (size_t)cap * 4 + (size_t)qcap * 5 + 64;
+    if (!pg_raise_lds(c, reinterpret_cast<const void*>(k_search_by_projection), 0, lds) ||
+        !pg_raise_lds(c, reinterpret_cast<const void*>(k_proj_candidates), 3, ldsA)) return pg_ctx_fail(c, PGORB_E_LIMIT, "SearchByProjection state exceeds the LDS");
+    if (qcap) hipLaunchKernelGGL(k_proj_candidates, dim3((qcap + 3) / 4, npairs), dim3(256), ldsA, stream, B, min_x, min_y, invW, invH, mode, lists, listCnt);
     hipLaunchKernelGGL(k_search_by_projection, dim3(npairs), dim3(64), lds, stream, B, min_x, min_y, invW, invH, mode, nnratio,
-                       check_orientation, d_assigned, d_nmatches);
+                       check_orientation, lists, listCnt, d_assigned, d_nmatches);
     if (hipGetLastError() != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "k_search_by_projection launch failed");
     return 0;
 }

@@ -582,6 +582,28 @@ def test_popcount_matcher_switch_gives_the_same_matches(tmp_path):
     assert np.all(outs[0]["d1"][:200] == 0)
 
 
+@pytest.mark.parametrize("w,h,scale,nlev,nf", [(884, 212, 1.33, 4, 1438), (565, 129, 1.2, 4, 2394), (963, 352, 2.0, 3, 1828), (662, 120, 1.33, 2, 1116)])
+def test_levels_with_one_tall_cell_row(oracle, w, h, scale, nlev, nf):
+    """Wide, low frames: a level whose region is 30..59 px high has ONE cell row of up to 59-px cells (65 window rows) at
+    the common cell width -- K2's instantiation with immediate offsets but not the narrow one.  Round 3's straight-line
+    window staging first covered 63 rows only and its two-step map clearing 51 (found by tools/experiments/fuzz_parity.py)."""
+    import pilotguru_amd as pg
+    img = synth_scene(1000 + w, w, h)
+    ora = oracle.OrbOracle(nf, scale, nlev, 20, 7)
+    okp, odesc = ora.extract(img)
+    ext = pg.ORBextractor(nf, scale, nlev, 20, 7, max_width=w, max_height=h)
+    kp, desc = ext(img)
+    tall = 0
+    for l in range(nlev):
+        x, y, r = ext.debug_level_candidates(0, l)
+        oc = ora.level_candidates(l)
+        assert sorted(zip(y.tolist(), x.tolist(), r.tolist())) == sorted(zip(oc["y"].tolist(), oc["x"].tolist(), oc["response"].tolist())), "level %d" % l
+        lw, lh = ora.level_size(l)
+        tall += 30 <= lh - 32 < 60 and (lh - 32) > 40
+    assert tall >= 1                                    # the case is in the frame
+    assert len(kp) == len(okp) > 0 and kp.tobytes() == okp.tobytes() and np.array_equal(desc, odesc)
+
+
 def _block_form_available():
     import pilotguru_amd as pg
     ext = pg.ORBextractor(100, 1.2, 2, 20, 7, max_width=320, max_height=240)

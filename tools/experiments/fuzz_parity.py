@@ -29,8 +29,11 @@ for it in range(N):
     err = ""
     try:
         ext = pg.ORBextractor(nf, scale, nlev, ini, mn, max_width=w, max_height=h)
-        form = int(rng.randint(0, 3))                    # K2: cell form, or the block form with a random tile shape
-        ext.set_option("fast_kernel", 1 if form else 0)
+        form = int(rng.randint(0, 3))                    # K2: cell form, or (developer builds) the block form with a random tile shape
+        try:
+            ext.set_option("fast_kernel", 1 if form else 0)
+        except Exception:
+            form = 0                                     # the product library has the cell form only
         if form:
             ext.set_option("fast_block_cx", int(rng.randint(1, 5))); ext.set_option("fast_block_cy", int(rng.randint(1, 5)))
         kp, d = ext(img)

@@ -1,0 +1,5 @@
+#!/bin/bash
+export TMPDIR=/tmp
+touch pilotguru_amd/csrc/quadtree.hip
+make -C pilotguru_amd/csrc -j8 EXTRA=-DPGORB_QT_TIMING > /dev/null 2>&1
+python tools/experiments/qt_timing.py 2>&1 | grep -v amdgpu.ids
