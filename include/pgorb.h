@@ -483,7 +483,11 @@ int      pgorb_stream_frontend_results(pgorb_stream* s, int slot, const int32_t*
  * key "fast_kernel": 0 = K2 as one wave per 30-px cell (default), 1 (developer builds with -DPGORB_FAST_BLOCKS only; the
  * product library answers PGORB_E_ARG) = K2 as one workgroup per block of
  * "fast_block_cx" x "fast_block_cy" cells (1..4 each, default 4 x 2; changing them rebuilds the plan) -- the tile
- * shapes of BASELINE.json configs[2]'s sweep. */
+ * shapes of BASELINE.json configs[2]'s sweep.
+ * key "pipeline_pyramid": 1 = the resize chain on a side stream beside K2, level by level (slower).
+ * key "pipeline_levels": bit l set = a group of levels starts at level l; K3 / K4-6 of one group run on side streams beside K2
+ * of the next (slower for every grouping measured).  0 = one launch per kernel (default).
+ * key "pipeline_levels_priority": 1 = the K3 side stream is created with the highest priority (read when it is first used). */
 int  pgorb_set_option(pgorb_ctx* ctx, const char* key, int value);
 int  pgorb_get_option(const pgorb_ctx* ctx, const char* key);
 /* 1 when a match of `cap_per_frame` descriptors per frame takes the popcount kernels, else 0 */

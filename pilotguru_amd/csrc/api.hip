@@ -47,6 +47,11 @@ struct pgorb_ctx {
     int pipePyr = 0;
     hipStream_t sPyr = nullptr, sFast = nullptr;
     hipEvent_t evFork = nullptr, evLevel[PG_MAXL] = {}, evPyrDone = nullptr, evFastDone = nullptr;
+    // K3 / K4-6 of a group of levels beside K2 of the next group (pgorb_set_option "pipeline_levels", bit l = a group
+    // starts at level l): K3 is one workgroup's critical path per (frame, level) and leaves the chip mostly idle
+    int pipeLev = 0, pipeLevPrio = 0;
+    hipStream_t sQt = nullptr, sDesc = nullptr;
+    hipEvent_t evGrpFast[PG_MAXL] = {}, evGrpQt[PG_MAXL] = {}, evDescDone = nullptr;
     Arena stageKps, stageDesc, stageN, stageA, stageB, stageOut, stageSfi, vocab;
     Arena xdesc;                              // matcher scratch: train descriptors as +-1 bytes (match.hip)
     void* pinned = nullptr;                   // page-locked bounce buffer for bulk result download
@@ -520,6 +525,42 @@ int run_batch(pgorb_ctx* c, const uint8_t* d_gray, bool resident_in_level0, int 
         if (ev) PG_HIP(c, hipEventRecord(ev[1], s));
         PG_HIP(c, hipStreamWaitEvent(s, c->evFastDone, 0));
         if (ev) PG_HIP(c, hipEventRecord(ev[2], s));
+    } else if (c->pipeLev && P.nlevels > 1 && pg_fast_is_cell_form(P)) {
+        // K2 group by group on the caller's stream; K3 of a group on a second stream as soon as its K2 is done, K4-6 of a
+        // group on a third as soon as its K3 is done: the latency-bound quadtree of one group runs under the issue-bound
+        // kernels of the others.  (Stage events: "fast" = K2 of all groups, "quadtree" = the wait for the side streams.)
+        if (!c->sQt) {
+            int lo = 0, hi = 0;
+            PG_HIP(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+            PG_HIP(c, hipStreamCreateWithPriority(&c->sQt, hipStreamNonBlocking, c->pipeLevPrio ? hi : lo));
+            PG_HIP(c, hipStreamCreateWithPriority(&c->sDesc, hipStreamNonBlocking, lo));
+            PG_HIP(c, hipEventCreateWithFlags(&c->evDescDone, hipEventDisableTiming));
+            for (int l = 0; l < PG_MAXL; l++) {
+                PG_HIP(c, hipEventCreateWithFlags(&c->evGrpFast[l], hipEventDisableTiming));
+                PG_HIP(c, hipEventCreateWithFlags(&c->evGrpQt[l], hipEventDisableTiming));
+            }
+        }
+        for (int l = 1; l < P.nlevels; l++) pg_launch_pyramid_level(P, l, nframes, s);
+        if (ev) PG_HIP(c, hipEventRecord(ev[1], s));
+        for (int beg = 0; beg < P.nlevels;) {
+            int end = beg + 1;
+            while (end < P.nlevels && !((c->pipeLev >> end) & 1)) end++;
+            pg_launch_fast_levels(P, nframes, beg, end, s);
+            PG_HIP(c, hipEventRecord(c->evGrpFast[beg], s));
+            PG_HIP(c, hipStreamWaitEvent(c->sQt, c->evGrpFast[beg], 0));
+            pg_launch_quadtree_levels(P, nframes, beg, end, c->sQt);
+            PG_HIP(c, hipEventRecord(c->evGrpQt[beg], c->sQt));
+            PG_HIP(c, hipStreamWaitEvent(c->sDesc, c->evGrpQt[beg], 0));
+            pg_launch_describe_levels(P, nframes, d_kps, d_desc, cap_per_frame, d_n, beg, end, c->sDesc);
+            beg = end;
+        }
+        if (ev) PG_HIP(c, hipEventRecord(ev[2], s));
+        PG_HIP(c, hipEventRecord(c->evDescDone, c->sDesc));
+        PG_HIP(c, hipStreamWaitEvent(s, c->evDescDone, 0));
+        if (ev) { PG_HIP(c, hipEventRecord(ev[3], s)); PG_HIP(c, hipEventRecord(ev[4], s)); c->profExtract++; }
+        PG_HIP(c, hipGetLastError());
+        c->lastFrames = nframes;
+        return 0;
     } else {
         for (int l = 1; l < P.nlevels; l++) pg_launch_pyramid_level(P, l, nframes, s);
         if (ev) PG_HIP(c, hipEventRecord(ev[1], s));
@@ -651,6 +692,12 @@ void pgorb_destroy(pgorb_ctx* c)
         (void)hipStreamDestroy(c->sPyr); (void)hipStreamDestroy(c->sFast);
         (void)hipEventDestroy(c->evFork); (void)hipEventDestroy(c->evPyrDone); (void)hipEventDestroy(c->evFastDone);
         for (int l = 0; l < PG_MAXL; l++) (void)hipEventDestroy(c->evLevel[l]);
+    }
+    if (c->sQt) {
+        (void)hipStreamSynchronize(c->sQt); (void)hipStreamSynchronize(c->sDesc);
+        (void)hipStreamDestroy(c->sQt); (void)hipStreamDestroy(c->sDesc);
+        (void)hipEventDestroy(c->evDescDone);
+        for (int l = 0; l < PG_MAXL; l++) { (void)hipEventDestroy(c->evGrpFast[l]); (void)hipEventDestroy(c->evGrpQt[l]); }
     }
     if (c->pinned) (void)hipHostFree(c->pinned);
     for (hipEvent_t e : c->evExtract) (void)hipEventDestroy(e);
@@ -928,6 +975,8 @@ int pgorb_set_option(pgorb_ctx* c, const char* key, int value)
         return 0;
     }
     if (c && !strcmp(key, "pipeline_pyramid")) { c->pipePyr = value ? 1 : 0; return 0; }
+    if (c && !strcmp(key, "pipeline_levels")) { c->pipeLev = value & ((1 << PG_MAXL) - 2); return 0; }
+    if (c && !strcmp(key, "pipeline_levels_priority")) { c->pipeLevPrio = value ? 1 : 0; return 0; }
     if (c && (!strcmp(key, "fast_block_cx") || !strcmp(key, "fast_block_cy"))) {
         if (value < 1 || value > 4) return fail(c, PGORB_E_ARG, "%s must be 1..4", key);
         (key[12] == 'x' ? c->fastBlockCX : c->fastBlockCY) = value;
@@ -942,6 +991,7 @@ int pgorb_get_option(const pgorb_ctx* c, const char* key)
     if (!key) return PGORB_E_ARG;
     if (!strcmp(key, "fast_kernel")) return pg_fast_get_kernel();
     if (c && !strcmp(key, "pipeline_pyramid")) return c->pipePyr;
+    if (c && !strcmp(key, "pipeline_levels")) return c->pipeLev;
     if (c && !strcmp(key, "fast_block_cx")) return c->fastBlockCX;
     if (c && !strcmp(key, "fast_block_cy")) return c->fastBlockCY;
     return PGORB_E_ARG;

@@ -200,7 +200,7 @@ __device__ __forceinline__ int pg_blur_at(const uint32_t* hT, int Y, int X, cons
 __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 G,
                                                   pgorb_keypoint* __restrict__ kps,
                                                   uint8_t* __restrict__ desc, int cap_per_frame,
-                                                  int32_t* __restrict__ n_out)
+                                                  int32_t* __restrict__ n_out, int slotBeg, int slotEnd, int writeTotal)
 {
     // one 3520-byte LDS buffer per wave: first the raw window (43 rows x 48 B), then -- once the
     // moments and the row-pass operands have been read from it -- the row sums [row pair][column]
@@ -217,7 +217,9 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
     // XCD-contiguous keypoint ranges: consecutive workgroups go to consecutive XCDs, so give XCD x
     // the x-th eighth of the frame's keypoint list (neighbours in the list are neighbours in the
     // image: their 43x43 windows share L2 lines)
-    const int slot = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    // (the launch covers slots [slotBeg, slotEnd) -- the slabs of a range of levels; writeTotal: this launch reports the
+    //  frame's keypoint count, i.e. K3 has finished for every level)
+    const int slot = slotBeg + (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     // The wave is one long dependent chain and lives ~8 us; every load that does not depend on
     // the keypoint is issued here, before the chain starts: the lane's entries of the moment
     // table, the Toeplitz operands of the row pass and its four test-point pairs.
@@ -243,13 +245,14 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
     const int nlevels = P.nlevels;
     const PgSelRec* recp = reinterpret_cast<const PgSelRec*>(P.sel) + ((int64_t)frame * P.selFrame + slot);
     const int tieMode = P.tieMode;
-    asm volatile("" :: "s"(kpc), "s"(nlevels), "s"(recp), "s"(n_out), "s"(kps), "s"(desc), "s"(cap_per_frame), "s"(tieMode));
+    asm volatile("" :: "s"(kpc), "s"(nlevels), "s"(recp), "s"(n_out), "s"(kps), "s"(desc), "s"(cap_per_frame), "s"(tieMode),
+                 "s"(slotEnd), "s"(writeTotal));
     typedef int32_t pg_i32x16 __attribute__((ext_vector_type(16)));
     typedef uint32_t pg_u32x8 __attribute__((ext_vector_type(8)));
     pg_i32x16 kc;
     pg_u32x8 rec;
     asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx8 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(kc), "=&s"(rec) : "s"(kpc), "s"(recp) : "memory");
-    if (slot >= P.selTotal) { if (blockIdx.x == 0 && lane == 0) n_out[frame] = 0; return; }     // (grid padding; never slot 0)
+    if (slot >= slotEnd) return;                            // (grid padding; never the launch's first slot)
     const int l = (int)(rec[1] >> 16) & 15;                 // (an unused slot's level is masked here and refused below)
     int total = 0, before = 0;                              // keypoints of the frame / of the levels below l
 #pragma unroll
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
         if (q < l) before += c;
         total += c;
     }
-    if (blockIdx.x == 0 && lane == 0) n_out[frame] = total;      // (slot 0)
+    if (writeTotal && blockIdx.x == 0 && lane == 0) n_out[frame] = total;      // (the launch's first slot)
     if (rec[1] == 0xFFFFFFFFu || l >= nlevels) return;      // an unused slot of a level's slab (K3 marks them)
     const uint32_t cv = rec[0];
     const int idx = before + (int)(rec[1] & 0xFFFFu);       // the OUTPUT slot is the keypoint's position in the reference's list
@@ -431,6 +434,15 @@ static PgGauss7 pg_gauss7()
 void pg_launch_describe(const PgPlan& P, int nframes, pgorb_keypoint* d_kps, uint8_t* d_desc,
                         int cap_per_frame, int32_t* d_n, hipStream_t s)
 {
+    pg_launch_describe_levels(P, nframes, d_kps, d_desc, cap_per_frame, d_n, 0, P.nlevels, s);
+}
+
+// K4-6 for the keypoints of levels [levelBeg, levelEnd): their slots are one contiguous range of a frame's selection slab,
+// and a keypoint's output position needs the counts of the levels BELOW its own only.  The launch that contains the last
+// level also writes the frame's keypoint count (K3 must have finished for all levels by then).
+void pg_launch_describe_levels(const PgPlan& P, int nframes, pgorb_keypoint* d_kps, uint8_t* d_desc,
+                               int cap_per_frame, int32_t* d_n, int levelBeg, int levelEnd, hipStream_t s)
+{
     static const PgGauss7 G = pg_gauss7();
     static bool tabReady[64] = {};
     int dev = 0;
@@ -449,8 +461,11 @@ void pg_launch_describe(const PgPlan& P, int nframes, pgorb_keypoint* d_kps, uin
         (void)hipStreamSynchronize(s);                           // tab is a stack array
         tabReady[dev] = true;
     }
-    dim3 grid((P.selTotal + 7) & ~7, nframes), block(64);
-    hipLaunchKernelGGL(k_describe, grid, block, 0, s, P, G, d_kps, d_desc, cap_per_frame, d_n);
+    const int slotBeg = (int)P.lvl[levelBeg].selOff;
+    const int slotEnd = (levelEnd < P.nlevels) ? (int)P.lvl[levelEnd].selOff : P.selTotal;
+    dim3 grid((slotEnd - slotBeg + 7) & ~7, nframes), block(64);
+    hipLaunchKernelGGL(k_describe, grid, block, 0, s, P, G, d_kps, d_desc, cap_per_frame, d_n, slotBeg, slotEnd,
+                       levelEnd == P.nlevels ? 1 : 0);
 }
 
 // ---- exhaustive check of the sin/cos contract (tests/test_gpu_parity.py, SURVEY.md hard part 4) --------

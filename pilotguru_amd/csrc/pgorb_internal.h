@@ -136,8 +136,11 @@ void pg_launch_fast(const PgPlan& P, int nframes, hipStream_t s);
 void pg_launch_fast_levels(const PgPlan& P, int nframes, int levelBeg, int levelEnd, hipStream_t s);   // cell form only
 bool pg_fast_is_cell_form(const PgPlan& P);
 void pg_launch_quadtree(const PgPlan& P, int nframes, hipStream_t s);
+void pg_launch_quadtree_levels(const PgPlan& P, int nframes, int levelBeg, int levelEnd, hipStream_t s);
 void pg_launch_describe(const PgPlan& P, int nframes, pgorb_keypoint* d_kps, uint8_t* d_desc,
                         int cap_per_frame, int32_t* d_n, hipStream_t s);
+void pg_launch_describe_levels(const PgPlan& P, int nframes, pgorb_keypoint* d_kps, uint8_t* d_desc,
+                               int cap_per_frame, int32_t* d_n, int levelBeg, int levelEnd, hipStream_t s);
 void pg_launch_hamming_matrix(const uint8_t* d_a, int na, const uint8_t* d_b, int nb,
                               uint16_t* d_out, hipStream_t s);
 void pg_launch_prev_matched_init(const pgorb_keypoint* d_kps, int64_t rows, float* d_out, hipStream_t s);   // frame.hip

@@ -203,7 +203,7 @@ __device__ __forceinline__ int qt_walk(const int* map, int leaf, int nIni, int D
 // BIG: the level's node arrays do not fit LDS (quota above ~1180) and live in a global slab;
 // the same code, just slower.  Each instantiation skips the levels of the other kind.
 template <bool BIG>
-__global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P)
+__global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P, int level0)
 {
     __shared__ int sh[3 * QT_W + 8];
     __shared__ int pyr[QT_PYR_CAP];                       // count pyramid, later the node map
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P)
     // grid = (frames, levels): the heavy level-0 problems of all frames are dispatched first and
     // spread over all CUs (with level as the fast index every 8th workgroup -- always the same
     // 32 CUs under round-robin dispatch -- got all the level-0 work)
-    const int l = blockIdx.y, frame = blockIdx.x;
+    const int l = level0 + blockIdx.y, frame = blockIdx.x;        // (level0: the launch covers levels [level0, level0 + gridDim.y))
     const PgLevel& L = P.lvl[l];
     int* kpc = &P.kpCount[frame * PG_MAXL + l];
     uint2* keys = reinterpret_cast<uint2*>(P.cand) + ((int64_t)frame * P.candFrame + L.candOff);
@@ -686,10 +686,13 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P)
     QT_TS(7);
 }
 
-void pg_launch_quadtree(const PgPlan& P, int nframes, hipStream_t s)
+void pg_launch_quadtree(const PgPlan& P, int nframes, hipStream_t s) { pg_launch_quadtree_levels(P, nframes, 0, P.nlevels, s); }
+
+// K3 for the levels [levelBeg, levelEnd) only: a (frame, level) problem depends on nothing but K2's slots of that level
+void pg_launch_quadtree_levels(const PgPlan& P, int nframes, int levelBeg, int levelEnd, hipStream_t s)
 {
     int need[2] = {0, 0};                                 // dynamic LDS ints: [LDS-node levels], [global-node levels]
-    for (int l = 0; l < P.nlevels; l++) {
+    for (int l = levelBeg; l < levelEnd; l++) {
         const int cells = P.lvl[l].nCols * P.lvl[l].nRows + 1;
         if (P.lvl[l].nodeOff >= 0) need[1] = max(need[1], cells);
         else need[0] = max(need[0], max(P.lvl[l].nodeCap * 30, cells));
@@ -698,7 +701,7 @@ void pg_launch_quadtree(const PgPlan& P, int nframes, hipStream_t s)
     int dev = 0;
     (void)hipGetDevice(&dev);
     size_t* configured = configuredDev[dev & 63];
-    dim3 grid(nframes, P.nlevels), block(QT_T);
+    dim3 grid(nframes, levelEnd - levelBeg), block(QT_T);
     for (int big = 0; big < 2; big++) {
         if (!need[big]) continue;
         const size_t lds = (size_t)need[big] * sizeof(int);
@@ -707,7 +710,7 @@ void pg_launch_quadtree(const PgPlan& P, int nframes, hipStream_t s)
             (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             configured[big] = lds;
         }
-        if (big) hipLaunchKernelGGL(k_quadtree<true>, grid, block, lds, s, P);
-        else hipLaunchKernelGGL(k_quadtree<false>, grid, block, lds, s, P);
+        if (big) hipLaunchKernelGGL(k_quadtree<true>, grid, block, lds, s, P, levelBeg);
+        else hipLaunchKernelGGL(k_quadtree<false>, grid, block, lds, s, P, levelBeg);
     }
 }

@@ -721,3 +721,28 @@ def test_pyramid_beside_fast_pipeline_is_bit_exact(oracle):
         x, y, r = ext.debug_level_candidates(B - 1, l)
         oc = ora.level_candidates(l)
         assert sorted(zip(y.tolist(), x.tolist(), r.tolist())) == sorted(zip(oc["y"].tolist(), oc["x"].tolist(), oc["response"].tolist()))
+
+
+@pytest.mark.parametrize("mask", [0b10, 0b1010, 0b11111110])
+def test_level_groups_beside_each_other_are_bit_exact(oracle, mask):
+    """pgorb_set_option("pipeline_levels", mask): K2 group of levels by group of levels on the caller's stream, K3 and
+    K4-6 of each group on side streams behind it (k_quadtree / k_describe launched for a RANGE of levels: a keypoint's
+    output position needs the counts of the levels below its own only, the frame's count comes from the last launch).
+    Same keypoints and descriptors, batch of frames, repeated calls, and the serial order again afterwards."""
+    import torch
+    w, h, nf, B = 640, 480, 1000, 5
+    ride = synth_ride(19, w, h, B)
+    ext = _make(nf, w, h, batch=B)
+    frames = torch.from_numpy(ride).cuda()
+    ora = oracle.OrbOracle(nf, 1.2, 8, 20, 7)
+    want = [ora.extract(ride[f]) for f in range(B)]
+    for m in (mask, mask, 0):
+        ext.set_option("pipeline_levels", m)
+        kps, desc, n = ext.extract_batch_device(frames)
+        ext.check_async()
+        torch.cuda.synchronize()
+        nh = n.cpu().numpy()
+        for f in range(B):
+            okp, odesc = want[f]
+            assert nh[f] == len(okp) and kps[f, :nh[f]].cpu().numpy().tobytes() == okp.tobytes()
+            assert np.array_equal(desc[f, :nh[f]].cpu().numpy(), odesc)
