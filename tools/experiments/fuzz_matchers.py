@@ -39,9 +39,11 @@ for it in range(N):
     w = int(rng.randint(160, 900)); h = int(rng.randint(120, 700))
     nf = int(rng.randint(150, 3000)); nlev = int(rng.randint(1, 9))
     scale = float(rng.choice([1.2, 1.2, 1.2, 1.1, 1.5]))
-    dx, dy = int(rng.randint(-12, 13)), int(rng.randint(-8, 9))
-    cfg = dict(w=w, h=h, nf=nf, nlev=nlev, scale=scale, dx=dx, dy=dy)
+    dx, dy = int(rng.randint(0, 13)), int(rng.randint(0, 9))
     ride = synth_ride(5000 + it, w, h, 2, dx=dx, dy=dy)
+    if rng.randint(0, 2):                                        # the camera moves the other way
+        ride = np.ascontiguousarray(ride[::-1]); dx, dy = -dx, -dy
+    cfg = dict(w=w, h=h, nf=nf, nlev=nlev, scale=scale, dx=dx, dy=dy)
     if rng.randint(0, 5) == 0:                                   # low contrast: few keypoints, empty windows
         ride = (100 + (ride.astype(np.int32) - 128) // 5).clip(0, 255).astype(np.uint8)
     try:
