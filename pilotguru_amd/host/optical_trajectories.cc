@@ -52,7 +52,8 @@ struct Flags {
     bool visualize = true, vertical_flip = false, horizontal_flip = false, output_per_segment_videos = false;
     bool init_extractor = false;       // front-end mode has no map: --init_extractor treats the ride as "not initialised yet"
     long long rotation_smooth_sigma = -1;
-    int device = 0, batch = 32, max_frames = -1, segment_id = 0, rotation = 0, copy_threads = 8;
+    int device = 0, batch = 64, max_frames = -1, segment_id = 0, rotation = 0;
+    int copy_threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));     // slot filling and the per-frame BoW maps
     int shard_rank = 0, shard_world = 1;          // --shard=rank/world: this process takes its chunk of the ride
 };
 
@@ -394,7 +395,7 @@ int main(int argc, char** argv)
     long total = 0, read = 0; bool first = true, firstOfRide = true;
     int submitted = 0, collected = 0; bool more = !frame0.empty();
     const auto loopStart = std::chrono::steady_clock::now();
-    std::vector<uint32_t> bid, fnode, ffeat; std::vector<double> bval; std::vector<int32_t> fstart;
+    std::vector<int> nbowB, nfvB;
     while (more || collected < submitted) {
         // keep DEPTH batches in flight: fill and submit the next slot while there are frames
         while (more && submitted - collected < DEPTH) {
@@ -437,18 +438,33 @@ int main(int argc, char** argv)
         if (pgorb_stream_frontend_results(st, slot, nullptr, &nmatch, &word, &wt, &node) != PGORB_OK) check_failed(pgorb_last_error(ext->context()));
         collected++;
         const std::vector<long long>&tus = tusS[slot], &ids = idsS[slot];
+        // Frame::ComputeBoW: BowVector / FeatureVector of transform(descriptors, ..., 4)  (Frame.cc:399-406): the per-feature words
+        // come from the device, the two ordered maps are built on the host -- ~0.1 ms per frame, so the frames of a batch are
+        // shared out over the copy threads (one thread held the whole loop to ~5 000 frames/s)
+        nbowB.assign(nb, 0); nfvB.assign(nb, 0);
+        {
+            const int nthreads = std::max(1, std::min(nb, F.copy_threads));
+            auto work = [&](int t) {
+                std::vector<uint32_t> bid, fnode, ffeat; std::vector<double> bval; std::vector<int32_t> fstart;
+                for (int i = t; i < nb; i += nthreads) {
+                    if (ids[i] < firstOwned || !n[i]) continue;
+                    const size_t o = (size_t)i * cap;
+                    bid.resize(n[i] + 1); bval.resize(n[i] + 1); fnode.resize(n[i] + 1); ffeat.resize(n[i] + 1); fstart.resize(n[i] + 2);
+                    pgorb_bow_vectors(n[i], word + o, wt + o, node + o, vs, vwt, bid.data(), bval.data(), &nbowB[i],
+                                      fnode.data(), fstart.data(), ffeat.data(), &nfvB[i]);
+                }
+            };
+            std::vector<std::thread> pool;
+            for (int t = 1; t < nthreads; t++) pool.emplace_back(work, t);
+            work(0);
+            for (auto& th : pool) th.join();
+        }
         for (int i = 0; i < nb; i++) {
             const bool hadPrev = !firstOfRide;
             firstOfRide = false;
             if (ids[i] < firstOwned) continue;               // the overlap frame of a shard: only a predecessor
-            // Frame::ComputeBoW: BowVector / FeatureVector of transform(descriptors, ..., 4)  (Frame.cc:399-406)
             const size_t o = (size_t)i * cap;
-            int nbow = 0, nfv = 0;
-            if (n[i]) {
-                bid.resize(n[i] + 1); bval.resize(n[i] + 1); fnode.resize(n[i] + 1); ffeat.resize(n[i] + 1); fstart.resize(n[i] + 2);
-                pgorb_bow_vectors(n[i], word + o, wt + o, node + o, vs, vwt, bid.data(), bval.data(), &nbow,
-                                  fnode.data(), fstart.data(), ffeat.data(), &nfv);
-            }
+            const int nbow = nbowB[i], nfv = nfvB[i];
             const int nmatches = hadPrev ? nmatch[i] : -1;   // MonocularInitialization's matcher call (Tracking.cc:596-597)
             js << (first ? "\n" : ",\n") << "    {\"frame_id\": " << ids[i] << ", \"time_usec\": " << tus[i] << ", \"n_keypoints\": " << n[i]
                << ", \"n_bow_words\": " << nbow << ", \"n_feature_nodes\": " << nfv << ", \"n_matches_prev\": " << nmatches << "}";
