@@ -490,7 +490,7 @@ extern "C" int pgorb_debug_fast_times(unsigned int* out, int nwaves)
 // exact scores, NMS, survivors into the cell's slots.  Returns the number of survivors.  STRONG: the four-pair test
 // (the minThFAST retry).
 template <int TPC, int MPC, bool NARROW, bool STRONG>
-__device__ __forceinline__ int fast_pass(const PgPlan& P, const uint8_t* tile, int TP, uint8_t* smap, int mapPitch, int mapRows,
+__device__ __forceinline__ int fast_pass(int32_t* status, const uint8_t* tile, int TP, uint8_t* smap, int mapPitch, int mapRows,
                                          int IW, int IH, int t, uint16_t* list, uint32_t* out, int cellCap, int xoff, int yoff, int lane)
 {
     // (2) necessary test + compaction
@@ -520,7 +520,7 @@ __device__ __forceinline__ int fast_pass(const PgPlan& P, const uint8_t* tile, i
             if (pos < cellCap)
                 out[pos] = (uint32_t)(ix + xoff) | ((uint32_t)(iy + yoff) << 12) | ((uint32_t)sc << 24);
             else
-                atomicExch(P.status, PGORB_E_OVERFLOW);          // cannot happen (see header)
+                atomicExch(status, PGORB_E_OVERFLOW);            // cannot happen (see header)
         }
         total += __popcll(m);
     }
@@ -570,7 +570,8 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgPlan P, int 
     uint32_t* const cellCandBase = P.cellCand;
     const uint32_t cellCandFrame = (uint32_t)P.cellCandFrame;     // u32 slots per frame: < 2^32 (make_plan)
     const int iniTh = P.iniTh, minTh = P.minTh;
-    asm volatile("" :: "s"(l0img), "s"(l0pitch), "s"(l0fstride), "s"(pyrBase), "s"(totalCells), "s"(cellCountBase),
+    int32_t* const statusPtr = P.status;
+    asm volatile("" :: "s"(statusPtr), "s"(l0img), "s"(l0pitch), "s"(l0fstride), "s"(pyrBase), "s"(totalCells), "s"(cellCountBase),
                  "s"(cellCandBase), "s"(cellCandFrame), "s"(iniTh), "s"(minTh), "s"(TPr), "s"(tileRows), "s"(MPr), "s"(mapRows),
                  "s"(chunkInv), "s"(waveLds));
     typedef uint32_t pg_u32x8 __attribute__((ext_vector_type(8)));
@@ -617,9 +618,11 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgPlan P, int 
         // behind it absorbs the last partial step): behind the window loads the compiler waits for the DMA before every
         // ds_write (it cannot tell the two LDS targets apart), which put the clearing after the landing instead of under it
         const int nz = (mapRows * mapPitch + 15) >> 4;
-        if (MPC == 40 && NARROW) {                                 // <= 42 rows of 40 bytes: at most two steps
-            if (lane < nz) reinterpret_cast<uint4*>(smap)[lane] = make_uint4(0u, 0u, 0u, 0u);
-            if (lane + 64 < nz) reinterpret_cast<uint4*>(smap)[lane + 64] = make_uint4(0u, 0u, 0u, 0u);
+        if (MPC == 40 && NARROW) {                                 // <= 42 rows of 40 bytes: two unconditional steps of 1 KiB -- what
+            (void)nz;                                              // they clear past the map is the candidate list, written later (the
+            const uint4 z = make_uint4(0u, 0u, 0u, 0u);            // launcher keeps map + list >= 2 KiB)
+            reinterpret_cast<uint4*>(smap)[lane] = z;
+            reinterpret_cast<uint4*>(smap)[lane + 64] = z;
         } else {
             for (int i = lane; i < nz; i += 64) reinterpret_cast<uint4*>(smap)[i] = make_uint4(0u, 0u, 0u, 0u);
         }
@@ -660,7 +663,7 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgPlan P, int 
 
     // The two detector passes written out (round 3): as a `for (pass)` loop the compiler merged the two bodies and paid for it
     // with scalar flag juggling around every phase.
-    int total = fast_pass<TPC, MPC, NARROW, false>(P, tile, TP, smap, mapPitch, mapRows, IW, IH, iniTh, list, out, cellCap, xoff, yoff, lane);
+    int total = fast_pass<TPC, MPC, NARROW, false>(statusPtr, tile, TP, smap, mapPitch, mapRows, IW, IH, iniTh, list, out, cellCap, xoff, yoff, lane);
 #if defined(PGORB_FAST_SKIP)                               // timing experiments: no minTh retry
     if (lane == 0) *cellCnt = min(total, cellCap);
     return;
@@ -670,7 +673,7 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgPlan P, int 
         // not depend on the threshold and every corner at iniThFAST is a candidate of the retry again (an "empty" cell
         // can hold corners -- equal neighbouring maxima that strict NMS removed)
         PG_WAVE_SYNC();
-        total = fast_pass<TPC, MPC, NARROW, true>(P, tile, TP, smap, mapPitch, mapRows, IW, IH, minTh, list, out, cellCap, xoff, yoff, lane);
+        total = fast_pass<TPC, MPC, NARROW, true>(statusPtr, tile, TP, smap, mapPitch, mapRows, IW, IH, minTh, list, out, cellCap, xoff, yoff, lane);
     }
     if (lane == 0) *cellCnt = min(total, cellCap);
     FT_TS(3);
@@ -1123,7 +1126,7 @@ void pg_launch_fast_cells(const PgPlan& P, int nframes, hipStream_t s, int level
     if (common) { TP = 48; mapPitch = 40; }
     const int chunkInv = 65536 / (TP >> 4) + 1;            // lane / (TP/16) == (lane * chunkInv) >> 16 for lane < 64
     const int mapRows = maxH - 6 + 2;
-    size_t smem = (size_t)tileRows * TP + (size_t)mapRows * mapPitch + FAST_LIST_CAP * 2 + 16;
+    size_t smem = (size_t)tileRows * TP + max((size_t)mapRows * mapPitch + FAST_LIST_CAP * 2, (size_t)2048) + 16;      // (2 KiB: k_fast_cells clears the map in two whole steps)
     // profiling knob: extra LDS per wave lowers occupancy (occupancy sweep)
     if (const char* e = getenv("PGORB_FAST_EXTRA_LDS")) smem += (size_t)atoi(e);
     const bool all = levelBeg == 0 && levelEnd == P.nlevels && P.cellTabBal;
