@@ -200,7 +200,7 @@ __device__ __forceinline__ int pg_blur_at(const uint32_t* hT, int Y, int X, cons
 __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 G,
                                                   pgorb_keypoint* __restrict__ kps,
                                                   uint8_t* __restrict__ desc, int cap_per_frame,
-                                                  int32_t* __restrict__ n_out, int slotBeg, int slotEnd, int writeTotal)
+                                                  int32_t* __restrict__ n_out, int slotBeg, int slotEnd, int writeTotal, int argPad)
 {
     // one 3520-byte LDS buffer per wave: first the raw window (43 rows x 48 B), then -- once the
     // moments and the row-pass operands have been read from it -- the row sums [row pair][column]
@@ -246,7 +246,8 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
     const PgSelRec* recp = reinterpret_cast<const PgSelRec*>(P.sel) + ((int64_t)frame * P.selFrame + slot);
     const int tieMode = P.tieMode;
     asm volatile("" :: "s"(kpc), "s"(nlevels), "s"(recp), "s"(n_out), "s"(kps), "s"(desc), "s"(cap_per_frame), "s"(tieMode),
-                 "s"(slotEnd), "s"(writeTotal));
+                 "s"(slotBeg), "s"(slotEnd), "s"(writeTotal), "s"(argPad));     // (argPad completes the 16-byte group of the three ints: with
+                 // a dead fourth dword the allocator reused its register for another argument load and split the batch in two)
     typedef int32_t pg_i32x16 __attribute__((ext_vector_type(16)));
     typedef uint32_t pg_u32x8 __attribute__((ext_vector_type(8)));
     pg_i32x16 kc;
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
     int total = 0, before = 0;                              // keypoints of the frame / of the levels below l
 #pragma unroll
     for (int q = 0; q < PG_MAXL; q++) {
-        const int c = (q < nlevels) ? kc[q] : 0;
+        const int c = kc[q];                                // (levels the plan does not have: zero, run_batch clears the counters and K3 never writes them)
         if (q < l) before += c;
         total += c;
     }
@@ -465,7 +466,7 @@ void pg_launch_describe_levels(const PgPlan& P, int nframes, pgorb_keypoint* d_k
     const int slotEnd = (levelEnd < P.nlevels) ? (int)P.lvl[levelEnd].selOff : P.selTotal;
     dim3 grid((slotEnd - slotBeg + 7) & ~7, nframes), block(64);
     hipLaunchKernelGGL(k_describe, grid, block, 0, s, P, G, d_kps, d_desc, cap_per_frame, d_n, slotBeg, slotEnd,
-                       levelEnd == P.nlevels ? 1 : 0);
+                       levelEnd == P.nlevels ? 1 : 0, 0);
 }
 
 // ---- exhaustive check of the sin/cos contract (tests/test_gpu_parity.py, SURVEY.md hard part 4) --------
