@@ -280,8 +280,10 @@ __device__ __forceinline__ int quick_pass(const uint8_t* tile, int TP, int IW, i
 // holds a lane's 16 pixels x 2 polarities, so the compaction loop runs max-over-lanes(count) times instead of once per
 // polarity, and a list entry is just (a per-lane constant) | bit position: the (row, column) arithmetic is done
 // by the scoring round, for 64 entries at once, not per entry by the lane that found it.
-// entry = row bits of the lane (8-10) | quad of the lane (5-7) | bit position (0-4: pixel, polarity, step) | fifth-step flag (11):
-// the column 4 * quad + pixel is ONE bit field of the entry, the row 8 * step + lane row two
+// entry = fifth-step flag (13) | row of the lane (8-10) | quad of the lane (5-7) | bit position (0-4: pixel, polarity, step):
+// the column 4 * quad + pixel is ONE bit field of the entry, and entry >> 8 = lane row + 32 * (fifth step) is the row but for
+// the 8 * step of bits 0-1 -- three operations to decode a row
+#define BFMT_FIFTH 0x2000
 __device__ __forceinline__ int bfmt_lane_base(int lane)
 {
     const int lr = ((lane >> 3) & 3) * 2 + (lane >> 5);              // the lane -> row map of the test (see quick_pass)
@@ -290,7 +292,7 @@ __device__ __forceinline__ int bfmt_lane_base(int lane)
 __device__ __forceinline__ void bfmt_decode(int e, int& iy, int& ix, int& bright)
 {
     ix = (e >> 3) & 31;                                              // 4 * quad + pixel
-    iy = ((e & 3) << 3) + ((e >> 8) & 7) + ((e >> 11) << 5);         // 8 * step + lane row (+ 32: fifth step)
+    iy = ((e & 3) << 3) | (e >> 8);                                  // 8 * step + lane row (+ 32: fifth step)
     bright = ((e >> 2) & 1) ^ 1;
 }
 
@@ -363,7 +365,7 @@ __device__ __forceinline__ int quick_pass_b(const uint8_t* tile, int IW, int IH,
         while (bits) {
             const int bpos = __ffs((int)bits) - 1;
             bits &= bits - 1;
-            *lp++ = (uint16_t)(base | 0x800 | bpos);
+            *lp++ = (uint16_t)(base | BFMT_FIFTH | bpos);
         }
     }
     return nlist;
