@@ -372,14 +372,14 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
     }
     P.cellCand = (uint32_t*)c->cellCand.p; P.cellCount = (int32_t*)c->cellCount.p;
     {
-        std::vector<uint32_t> ct((size_t)cells * 8);
+        std::vector<uint32_t> ct((size_t)cells * 16, 0u);
         for (int l = 0; l < L; l++) {
             const PgLevel& V = P.lvl[l];
             const int maxBorderX = V.w - PG_EDGE, maxBorderY = V.h - PG_EDGE;
             for (int i = 0; i < V.nRows; i++)
                 for (int j = 0; j < V.nCols; j++) {
                     const int cidx = i * V.nCols + j;
-                    uint32_t* r = &ct[((size_t)V.cellBase + cidx) * 8];
+                    uint32_t* r = &ct[((size_t)V.cellBase + cidx) * 16];
                     const int iniY = PG_EDGE + i * V.hCell, iniX = PG_EDGE + j * V.wCell;      // :791-801
                     const int W = std::min(iniX + V.wCell + 6, maxBorderX) - iniX;
                     const int H = std::min(iniY + V.hCell + 6, maxBorderY) - iniY;
@@ -393,9 +393,25 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
                     r[4] = (uint32_t)off; r[5] = (uint32_t)(off >> 32);
                     r[6] = (uint32_t)V.fstride;
                     r[7] = (uint32_t)(V.cellCandOff + (int64_t)cidx * V.cellCap);
+                    // w8-w15: which lanes / result bits of the necessary test lie inside the interior, as LANE MASKS and bit
+                    // patterns (fast.hip, quick_pass_b: lane = quad (lane & 7) x row lr = 2 ((lane >> 3) & 3) + (lane >> 5), steps of 8
+                    // rows) -- a per-cell constant that used to cost every wave 17 vector instructions
+                    const int IW = W - 6, IH = H - 6;
+                    if (!skip && IW <= 32 && IH <= 40) {
+                        const int qFull = IW >> 2, rem = IW & 3, base = IH >> 3, rr = IH & 7;
+                        r[8] = ((1u << qFull) - 1u) * 0x01010101u;                     // lanes of whole quads (both 32-lane halves)
+                        r[9] = qFull < 8 ? (1u << qFull) * 0x01010101u : 0u;           // lanes of the partial quad
+                        r[10] = (1u << (8 * rem)) - 1u;                                // its pixels, one byte each
+                        const int kLo = (rr + 1) >> 1, kHi = rr >> 1;                  // lanes whose row takes one step more than IH / 8
+                        r[11] = kLo >= 4 ? 0xFFFFFFFFu : (1u << (8 * kLo)) - 1u;       //   lanes 0-31: lr = 2 (lane >> 3)
+                        r[12] = (1u << (8 * kHi)) - 1u;                                //   lanes 32-63: lr = 2 ((lane >> 3) & 3) + 1
+                        r[13] = ((1u << std::min(base, 4)) - 1u) * 0x11111111u;        // step bits every row has
+                        r[14] = base < 4 ? 0x11111111u << base : 0u;                   // the step more
+                        r[15] = base >= 5 ? 2u : (base == 4 ? 1u : 0u);                // fifth step: all rows / the rows of w11-w12 / none
+                    }
                 }
         }
-        if ((rc = ensure(c, c->cellTab, ct.size() * 4 + 8 * 32))) return rc;      // + 8 records of slack (fast.hip)
+        if ((rc = ensure(c, c->cellTab, ct.size() * 4 + 8 * 64))) return rc;      // + 8 records of slack (fast.hip)
         PG_HIP(c, hipMemcpy(c->cellTab.p, ct.data(), ct.size() * 4, hipMemcpyHostToDevice));
         P.cellTab = (const uint32_t*)c->cellTab.p;
         P.pyrBase = (const uint8_t*)c->pyr.p;
@@ -409,14 +425,14 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
             }
         size_t per = 0;
         for (auto& v : lists) per = std::max(per, v.size());
-        std::vector<uint32_t> cb(8 * per * 8, 0u);
+        std::vector<uint32_t> cb(8 * per * 16, 0u);
         for (int x = 0; x < 8; x++)
             for (size_t k = 0; k < per; k++) {
-                uint32_t* r = &cb[((size_t)x * per + k) * 8];
-                if (k < lists[x].size()) memcpy(r, &ct[(size_t)lists[x][k] * 8], 32);
+                uint32_t* r = &cb[((size_t)x * per + k) * 16];
+                if (k < lists[x].size()) memcpy(r, &ct[(size_t)lists[x][k] * 16], 64);
                 else { r[0] = 0xFFFFFFF0u; r[2] = 1u << 16; }                                // padding: the wave returns at once
             }
-        if ((rc = ensure(c, c->cellTabBal, cb.size() * 4 + 8 * 32))) return rc;
+        if ((rc = ensure(c, c->cellTabBal, cb.size() * 4 + 8 * 64))) return rc;
         PG_HIP(c, hipMemcpy(c->cellTabBal.p, cb.data(), cb.size() * 4, hipMemcpyHostToDevice));
         P.cellTabBal = (const uint32_t*)c->cellTabBal.p;
         P.cellsPerXcdBal = (int)per;

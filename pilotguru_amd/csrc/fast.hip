@@ -296,8 +296,32 @@ __device__ __forceinline__ void bfmt_decode(int e, int& iy, int& ix, int& bright
     bright = ((e >> 2) & 1) ^ 1;
 }
 
+// the cell record's validity words (PgPlan::cellTab w8-w15), as the scalars they are
+struct PgCellValid { uint32_t qLt, qEq, partial, rowLo, rowHi, stepBase, stepMore, fifth; };
+// 0 / ~0 per lane from a 64-bit LANE mask held in SGPRs: one v_cndmask_b32 (the mask is the instruction's condition operand)
+__device__ __forceinline__ uint32_t pg_lanes(unsigned long long m)
+{
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(r) : "s"(m));
+    return r;
+}
+
+// ... turned into this lane's words once per cell (both detector passes use them): pixels of the lane's quad inside the interior (whole
+// bytes) x steps whose row 8 s + lr lies inside it.  10 vector instructions instead of the 17 that derived them from IW, IH, lq, lr
+struct PgLaneValid { uint32_t acc, acc2; };
+__device__ __forceinline__ PgLaneValid pg_lane_valid(const PgCellValid& V)
+{
+    const unsigned long long mRow = ((unsigned long long)V.rowHi << 32) | V.rowLo;
+    const uint32_t colBytes = (pg_lanes(((unsigned long long)V.qEq << 32) | V.qEq) & V.partial) | pg_lanes(((unsigned long long)V.qLt << 32) | V.qLt);
+    const uint32_t stepBits = (pg_lanes(mRow) & V.stepMore) | V.stepBase;
+    PgLaneValid L;
+    L.acc = colBytes & stepBits;
+    L.acc2 = colBytes & pg_lanes(V.fifth == 2 ? ~0ull : (V.fifth == 1 ? mRow : 0ull));
+    return L;
+}
+
 template <bool STRONG>
-__device__ __forceinline__ int quick_pass_b(const uint8_t* tile, int IW, int IH, int t, uint16_t* list, int lane)
+__device__ __forceinline__ int quick_pass_b(const uint8_t* tile, int IW, int IH, int t, uint16_t* list, int lane, const PgLaneValid& V)
 {
     constexpr int TP = 48;
     const int lq = lane & 7;
@@ -342,12 +366,8 @@ __device__ __forceinline__ int quick_pass_b(const uint8_t* tile, int IW, int IH,
         else acc2 = (comb >> 3) & 0x11111111u;
     }
 #undef PG_RING
-    // validity, once: pixels of this quad inside the interior (whole bytes) x steps whose row 8 s + lr lies inside it
-    const int npx = min(max(IW - 4 * lq, 0), 4), ns = min(max((IH - lr + 7) >> 3, 0), 5);
-    const uint32_t colBytes = npx >= 4 ? 0xFFFFFFFFu : ((1u << (8 * npx)) - 1u);
-    const uint32_t stepBits = ((1u << min(ns, 4)) - 1u) * 0x11111111u;
-    acc &= colBytes & stepBits;
-    acc2 &= ns > 4 ? colBytes : 0u;
+    acc &= V.acc;                                                     // validity (pg_lane_valid)
+    acc2 &= V.acc2;
     const int cnt = __popc(acc) + __popc(acc2);
     const int incl = wave_incl_scan(cnt);
     const int nlist = __builtin_amdgcn_readlane(incl, 63);
@@ -493,10 +513,11 @@ extern "C" int pgorb_debug_fast_times(unsigned int* out, int nwaves)
 // (the minThFAST retry).
 template <int TPC, int MPC, bool NARROW, bool STRONG>
 __device__ __forceinline__ int fast_pass(int32_t* status, const uint8_t* tile, int TP, uint8_t* smap, int mapPitch, int mapRows,
-                                         int IW, int IH, int t, uint16_t* list, uint32_t* out, int cellCap, int xoff, int yoff, int lane)
+                                         int IW, int IH, int t, uint16_t* list, uint32_t* out, int cellCap, int xoff, int yoff, int lane,
+                                         const PgLaneValid& V)
 {
     // (2) necessary test + compaction
-    const int nlist = NARROW ? quick_pass_b<STRONG>(tile, IW, IH, t, list, lane)
+    const int nlist = NARROW ? quick_pass_b<STRONG>(tile, IW, IH, t, list, lane, V)
                     : (IW <= 32) ? quick_pass<8, STRONG>(tile, TP, IW, 0, IH, t, list, lane)
                                  : quick_pass<16, STRONG>(tile, TP, IW, 0, IH, t, list, lane);
     if (nlist < 0)                                         // list would overflow: chunked slow path
@@ -517,9 +538,9 @@ __device__ __forceinline__ int fast_pass(int32_t* status, const uint8_t* tile, i
         }
         const unsigned long long m = __ballot(sc != 0);
         if (sc) {
-            const int pos = total + wave_prefix(m);
+            const uint32_t pos = (uint32_t)(total + wave_prefix(m));      // (unsigned: scalar base + 32-bit lane offset, no 64-bit address arithmetic)
             const int iy = (p >> 8) & 0x7F, ix = p & 0xFF;
-            if (pos < cellCap)
+            if (pos < (uint32_t)cellCap)
                 out[pos] = (uint32_t)(ix + xoff) | ((uint32_t)(iy + yoff) << 12) | ((uint32_t)sc << 24);
             else
                 atomicExch(status, PGORB_E_OVERFLOW);            // cannot happen (see header)
@@ -564,7 +585,7 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgPlan P, int 
     const int l0pitch = P.lvl[0].pitch;
     const int64_t l0fstride = P.lvl[0].fstride;
     const uint8_t* pyrBase = P.pyrBase;
-    const uint32_t* recp = tab + 8 * (int64_t)cell;                // (the tables have 8 records of slack)
+    const uint32_t* recp = tab + 16 * (int64_t)cell;               // (the tables have 8 records of slack)
     const int totalCells = P.totalCells;
     // (everything else the wave will need from the argument block rides in the same batch of scalar loads: a field
     //  fetched where it is first used costs the wave one more trip to the scalar cache in the middle of its prologue)
@@ -576,9 +597,9 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgPlan P, int 
     asm volatile("" :: "s"(statusPtr), "s"(l0img), "s"(l0pitch), "s"(l0fstride), "s"(pyrBase), "s"(totalCells), "s"(cellCountBase),
                  "s"(cellCandBase), "s"(cellCandFrame), "s"(iniTh), "s"(minTh), "s"(TPr), "s"(tileRows), "s"(MPr), "s"(mapRows),
                  "s"(chunkInv), "s"(waveLds));
-    typedef uint32_t pg_u32x8 __attribute__((ext_vector_type(8)));
-    pg_u32x8 rec;
-    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rec) : "s"(recp) : "memory");
+    typedef uint32_t pg_u32x16 __attribute__((ext_vector_type(16)));
+    pg_u32x16 rec;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rec) : "s"(recp) : "memory");
     if (cell >= cellEnd || (int)(blockIdx.x >> 3) * WPB + wv >= cellsPerXcd) return;
     const int iniX = rec[1] & 0xFFFF, iniY = rec[1] >> 16;
     const int W = rec[2] & 0xFF, H = (rec[2] >> 8) & 0xFF, cellCap = rec[2] >> 17;
@@ -661,11 +682,13 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgPlan P, int 
     FT_TS(2);
 
     uint32_t* out = cellCandBase + ((uint64_t)frame * cellCandFrame + rec[7]);
+    const PgCellValid cv = {rec[8], rec[9], rec[10], rec[11], rec[12], rec[13], rec[14], rec[15]};
+    const PgLaneValid valid = NARROW ? pg_lane_valid(cv) : PgLaneValid{0u, 0u};
     const int xoff = 3 + iniX - PG_EDGE, yoff = 3 + iniY - PG_EDGE;   // window-local -> region-relative (:822-823)
 
     // The two detector passes written out (round 3): as a `for (pass)` loop the compiler merged the two bodies and paid for it
     // with scalar flag juggling around every phase.
-    int total = fast_pass<TPC, MPC, NARROW, false>(statusPtr, tile, TP, smap, mapPitch, mapRows, IW, IH, iniTh, list, out, cellCap, xoff, yoff, lane);
+    int total = fast_pass<TPC, MPC, NARROW, false>(statusPtr, tile, TP, smap, mapPitch, mapRows, IW, IH, iniTh, list, out, cellCap, xoff, yoff, lane, valid);
 #if defined(PGORB_FAST_SKIP)                               // timing experiments: no minTh retry
     if (lane == 0) *cellCnt = min(total, cellCap);
     return;
@@ -675,7 +698,7 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgPlan P, int 
         // not depend on the threshold and every corner at iniThFAST is a candidate of the retry again (an "empty" cell
         // can hold corners -- equal neighbouring maxima that strict NMS removed)
         PG_WAVE_SYNC();
-        total = fast_pass<TPC, MPC, NARROW, true>(statusPtr, tile, TP, smap, mapPitch, mapRows, IW, IH, minTh, list, out, cellCap, xoff, yoff, lane);
+        total = fast_pass<TPC, MPC, NARROW, true>(statusPtr, tile, TP, smap, mapPitch, mapRows, IW, IH, minTh, list, out, cellCap, xoff, yoff, lane, valid);
     }
     if (lane == 0) *cellCnt = min(total, cellCap);
     FT_TS(3);

@@ -99,13 +99,14 @@ struct PgPlan {
     int64_t  cellCandFrame;   // u32 per frame in the per-cell slot slab
     uint32_t* cellCand;       // K2 output: [frame][level][cell][cellCap]
     int32_t*  cellCount;      // K2 output: [frame][totalCells]
-    // [totalCells] 32-byte record per cell, built with the plan (api.hip): everything K2 needs to
+    // [totalCells] 64-byte record per cell, built with the plan (api.hip): everything K2 needs to
     // find its window in ONE scalar load -- the wave start used to be a chain of four dependent
     // scalar round trips (kernarg -> cell table -> level -> level fields).
     //   w0 level | cell index in the frame's cellCount array << 4      w1 iniX | iniY << 16
     //   w2 W | H << 8 | skip << 16 | cellCap << 17      w3 level pitch
     //   w4,w5 byte offset of (iniY, iniX - 1) in frame 0 of the level, relative to pyrBase
     //   w6 level frame stride                           w7 slot offset of the cell in the frame's slab
+    //   w8-w15 validity of the necessary test's lanes and result bits for this cell's interior (lane masks, bit patterns)
     // Level 0 may alias the caller's buffer: its base / pitch / frame stride come from lvl[0].
     const uint32_t* cellTab;
     // the same records in K2's balanced dispatch order: [8 XCDs][cellsPerXcdBal], XCD x = the x-th eighth of every
