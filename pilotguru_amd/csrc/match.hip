@@ -71,9 +71,10 @@ __global__ __launch_bounds__(MT_T) void k_hamming_matrix(const uint8_t* __restri
 // Operand layout ("x16 block", 2 KiB per 16 descriptors): [k-step s][lane l][16 B]; the entry of
 // lane l in k-step s holds bits 128 s + 32 (l >> 4) .. + 31 of descriptor l & 15, one fp4 per bit
 // (0x2 = +1.0, 0xA = -1.0), bit e in nibble e.  Rows/columns are l & 15 for A and B alike and both
-// sides use the same K order, which is all the dot product needs.  Train frames are expanded once
-// per pair by k_expand_trains into a scratch slab and staged through LDS with LDS-DMA (double
-// buffered); queries are expanded in registers.
+// sides use the same K order, which is all the dot product needs.  Queries are expanded in registers.  Train descriptors
+// come into LDS as they are, 128 at a time by LDS-DMA (double buffered), and the workgroup -- 16 waves, 1 024 queries --
+// expands the tile into this layout in LDS once for all its waves (round 3; rounds 1-2 expanded every train frame into a
+// scratch slab in HBM first, k_expand_trains: kept as PGORB_MATCH_MODE=0).
 typedef int pg_v4i __attribute__((ext_vector_type(4)));
 typedef int pg_v8i __attribute__((ext_vector_type(8)));
 typedef float pg_v4f __attribute__((ext_vector_type(4)));
@@ -168,20 +169,28 @@ __device__ __forceinline__ void mx_update(const pg_v4f (&acc)[4], bool valid, fl
 // linear id mod 8 -- the XCD it is dispatched to -- is pair mod 8 and all query blocks of one pair share one XCD's
 // L2: the pair's expanded trains (128 B per descriptor) come from HBM once instead of once per query block
 // (profiles/r01_i_pmc.txt: 264 MB per step fetched for 18 MB of descriptors).  nb < 8192
-__global__ __launch_bounds__(64 * MX_WAVES) void k_match_mfma(const uint8_t* __restrict__ qdesc, const uint8_t* __restrict__ xt,
-                                                              const int32_t* __restrict__ n, int cap,
-                                                              const int32_t* __restrict__ pq, const int32_t* __restrict__ pt,
-                                                              int na_single, int nb_single, int blocksPerPair, int npairs,
-                                                              int32_t* best_idx, uint16_t* best, uint16_t* second)
+// WAVES waves of 64 queries per workgroup.  RAW: `xt` is the train frame set itself (32-byte descriptors): a tile's 128
+// descriptors come into LDS as they are (4 KiB by LDS-DMA, double buffered) and the WORKGROUP expands them to the fp4 operand
+// layout in LDS -- each thread a share of the tile's 1 024 sixteen-byte entries -- before its waves consume them; no expanded
+// copy in HBM.  !RAW: `xt` is k_expand_trains' slab, tiles arrive expanded (16 KiB each, double buffered).
+template <int WAVES, bool RAW>
+__global__ __launch_bounds__(64 * WAVES) void k_match_mfma(const uint8_t* __restrict__ qdesc, const uint8_t* __restrict__ xt,
+                                                           const int32_t* __restrict__ n, int cap,
+                                                           const int32_t* __restrict__ pq, const int32_t* __restrict__ pt,
+                                                           int na_single, int nb_single, int blocksPerPair, int npairs,
+                                                           int32_t* best_idx, uint16_t* best, uint16_t* second)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t tile[(2 * MX_TILE_BLOCKS + 1) * MX_BLOCK_BYTES];    // + read-ahead slack
+    constexpr int TILE_BYTES = MX_TILE_BLOCKS * MX_BLOCK_BYTES, RAW_BYTES = MX_TILE_BLOCKS * 16 * 32;
+    // !RAW: two expanded tiles + read-ahead slack.  RAW: one expanded tile + slack, then two raw tiles
+    constexpr int EXP_BYTES = (RAW ? 1 : 2) * TILE_BYTES + MX_BLOCK_BYTES;
+    __shared__ __attribute__((aligned(16))) uint8_t tile[EXP_BYTES + (RAW ? 2 * RAW_BYTES : 0)];
     const int p = blockIdx.x, qblk = blockIdx.y;
     if (p >= npairs) return;
     const int fq = pq ? pq[p] : 0, ft = pt ? pt[p] : 0;
     const int na = pq ? min(n[fq], cap) : na_single, nb = pt ? min(n[ft], cap) : nb_single;
-    if (qblk * 64 * MX_WAVES >= na) return;
+    if (qblk * 64 * WAVES >= na) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int qbase = qblk * 64 * MX_WAVES + wv * 64;
+    const int qbase = qblk * 64 * WAVES + wv * 64;
     const bool active = qbase < na;                              // wave-uniform
     const uint8_t* qd = qdesc + (int64_t)fq * cap * 32;
     const int64_t o = (int64_t)p * cap;
@@ -205,24 +214,29 @@ __global__ __launch_bounds__(64 * MX_WAVES) void k_match_mfma(const uint8_t* __r
         for (int r = 0; r < 4; r++) { k1[a][r] = -1.f; k2[a][r] = -1.f; }      // -1 = none (valid keys are >= 0)
 
     const int nblocks = (nb + 15) >> 4;
-    const uint8_t* xp = xt + (int64_t)p * blocksPerPair * MX_BLOCK_BYTES;
+    const uint8_t* xp = RAW ? xt + (int64_t)ft * cap * 32 : xt + (int64_t)p * blocksPerPair * MX_BLOCK_BYTES;
+    uint8_t* rawBase = tile + EXP_BYTES;                         // (RAW)
     // double-buffered tiles: the LDS-DMA of tile t+1 is in flight while tile t is consumed
     auto stage = [&](int t0, int buf) {
-        const int cnt = min(MX_TILE_BLOCKS, nblocks - t0);
-        // 16 B per lane, wave w fills KiB w, w + 4, ... of the tile
-        for (int kb = wv; kb < cnt * (MX_BLOCK_BYTES / 1024); kb += MX_WAVES)
-            __builtin_amdgcn_global_load_lds((pg_gptr_t)(xp + (int64_t)t0 * MX_BLOCK_BYTES + kb * 1024 + lane * 16),
-                                             (pg_lptr_t)(tile + buf * (MX_TILE_BLOCKS * MX_BLOCK_BYTES) + kb * 1024), 16, 0, 0);
+        if (RAW) {
+            // 16 B per lane: chunk c = 64 wv + lane is half (c & 1) of descriptor t0 * 16 + (c >> 1); descriptors past nb are
+            // not read (their columns are masked by the update, their LDS bytes are whatever was there)
+            for (int c0 = 64 * wv; c0 < RAW_BYTES / 16; c0 += 64 * WAVES) {
+                const int c = c0 + lane, d = t0 * 16 + (c >> 1);
+                if (d < nb)
+                    __builtin_amdgcn_global_load_lds((pg_gptr_t)(xp + (int64_t)d * 32 + (c & 1) * 16),
+                                                     (pg_lptr_t)(rawBase + buf * RAW_BYTES + c0 * 16), 16, 0, 0);
+            }
+        } else {
+            const int cnt = min(MX_TILE_BLOCKS, nblocks - t0);
+            // 16 B per lane, wave w fills KiB w, w + WAVES, ... of the tile
+            for (int kb = wv; kb < cnt * (MX_BLOCK_BYTES / 1024); kb += WAVES)
+                __builtin_amdgcn_global_load_lds((pg_gptr_t)(xp + (int64_t)t0 * MX_BLOCK_BYTES + kb * 1024 + lane * 16),
+                                                 (pg_lptr_t)(tile + buf * TILE_BYTES + kb * 1024), 16, 0, 0);
+        }
     };
-    if (nblocks > 0) stage(0, 0);
-    int buf = 0;
-    for (int t0 = 0; t0 < nblocks; t0 += MX_TILE_BLOCKS, buf ^= 1) {
-        const int cnt = min(MX_TILE_BLOCKS, nblocks - t0);
-        __builtin_amdgcn_s_waitcnt(0);                           // this wave's share of tile t0 has landed
-        __syncthreads();                                         // ... everybody's; and buffer buf^1 has been consumed
-        if (t0 + MX_TILE_BLOCKS < nblocks) stage(t0 + MX_TILE_BLOCKS, buf ^ 1);
-        if (!active) continue;
-        const uint8_t* bl = tile + buf * (MX_TILE_BLOCKS * MX_BLOCK_BYTES) + lane * 16;
+    // one staged tile (blocks t0 .. t0 + cnt - 1, operands at `bl` for this lane) against this wave's 64 queries
+    auto compute_tile = [&](const uint8_t* bl, int t0, int cnt) {
         float kc = (float)((256 << (MX_IDX_BITS - 1)) + MX_IDX_MASK - (t0 * 16 + (lane & 15)));
         // blocks that lie entirely below nb take the unmasked update; at most one block per
         // pair is partial (kept out of the hot loop: a select inside it costs 32 register copies)
@@ -254,6 +268,28 @@ __global__ __launch_bounds__(64 * MX_WAVES) void k_match_mfma(const uint8_t* __r
             mx_block(B0, A, pg_v4f{kc, kc, kc, kc}, acc);
             mx_update<true>(acc, (t0 + blk) * 16 + (lane & 15) < nb, k1, k2);
         }
+    };
+    if (nblocks > 0) stage(0, 0);
+    int buf = 0;
+    for (int t0 = 0; t0 < nblocks; t0 += MX_TILE_BLOCKS, buf ^= 1) {
+        const int cnt = min(MX_TILE_BLOCKS, nblocks - t0);
+        __builtin_amdgcn_s_waitcnt(0);                           // this wave's share of tile t0 has landed
+        __syncthreads();                                         // ... everybody's; and buffer buf^1 (RAW: the expanded tile) has been consumed
+        if (!RAW && t0 + MX_TILE_BLOCKS < nblocks) stage(t0 + MX_TILE_BLOCKS, buf ^ 1);
+        if (RAW) {
+            // entry e = (block e >> 7, k-step (e >> 6) & 1, lane e & 63): bits 128 s + 32 (l >> 4) .. of descriptor l & 15
+            const uint32_t* raw32 = reinterpret_cast<const uint32_t*>(rawBase + buf * RAW_BYTES);
+            for (int e = threadIdx.x; e < TILE_BYTES / 16; e += 64 * WAVES) {
+                const int l = e & 63, s = (e >> 6) & 1, blk = e >> 7;
+                *reinterpret_cast<pg_v4i*>(tile + e * 16) = pg_fp4x32(raw32[(blk * 16 + (l & 15)) * 8 + 4 * s + (l >> 4)]);
+            }
+            __syncthreads();                                     // the expanded tile is complete
+            // (the next raw tile is requested only now: with an LDS-DMA outstanding the compiler holds every ds_write behind
+            //  vmcnt(0) -- it cannot tell the two LDS targets apart -- and the expansion would wait for the load it should hide)
+            if (t0 + MX_TILE_BLOCKS < nblocks) stage(t0 + MX_TILE_BLOCKS, buf ^ 1);
+        }
+        if (!active) continue;
+        compute_tile(tile + (RAW ? 0 : buf * TILE_BYTES) + lane * 16, t0, cnt);
     }
     if (!active) return;
     // merge the 16 column classes of a row (lanes with equal lane >> 4)
@@ -383,10 +419,20 @@ static bool mx_use_popcount()
     static const bool v = getenv("PGORB_MATCH_POPCOUNT") != nullptr;
     return g_mx_force_popcount >= 0 ? g_mx_force_popcount != 0 : v;
 }
+// how the train descriptors reach the matrix cores: 2 (default) = taken as they are and expanded in LDS by workgroups of 16 waves
+// (1 024 queries share one expansion of a tile: 0.084 ms per 127 pairs of 2 000, no expanded copy in HBM); 1 = the same with 4-wave
+// workgroups (0.099: the expansion is repeated per 256 queries); 0 = expanded once per pair into a scratch slab by k_expand_trains
+// (0.098, 120 MB of traffic per step for 18.5 MB of descriptors).  PGORB_MATCH_MODE: measurement switch.
+static int mx_mode()
+{
+    static const int v = getenv("PGORB_MATCH_MODE") ? atoi(getenv("PGORB_MATCH_MODE")) : 2;
+    return v;
+}
 bool pg_match_uses_popcount(int cap_per_frame) { return cap_per_frame >= MX_MAX_TRAIN || mx_use_popcount(); }
 
 size_t pg_match_scratch_bytes(int nb_max, int npairs)
 {
+    if (mx_mode() != 0) return 0;                            // (only the slab form needs scratch)
     return (size_t)npairs * (size_t)((nb_max + 15) / 16) * MX_BLOCK_BYTES;
 }
 
@@ -401,10 +447,19 @@ void pg_launch_best2(const uint8_t* d_a, int na, const uint8_t* d_b, int nb, uin
         return;
     }
     const int bpp = (nb + 15) / 16;
-    if (bpp > 0)
-        hipLaunchKernelGGL(k_expand_trains, dim3(bpp, 1), dim3(128), 0, s, d_b, nullptr, nb, nullptr, nb, bpp, d_scratch);
-    hipLaunchKernelGGL(k_match_mfma, dim3(1, (na + 64 * MX_WAVES - 1) / (64 * MX_WAVES)), dim3(64 * MX_WAVES), 0, s,
-                       d_a, d_scratch, nullptr, na, nullptr, nullptr, na, nb, bpp, 1, d_best_idx, d_best, d_second);
+    const int mode = mx_mode();
+    if (mode == 0) {
+        if (bpp > 0)
+            hipLaunchKernelGGL(k_expand_trains, dim3(bpp, 1), dim3(128), 0, s, d_b, nullptr, nb, nullptr, nb, bpp, d_scratch);
+        hipLaunchKernelGGL((k_match_mfma<4, false>), dim3(1, (na + 255) / 256), dim3(256), 0, s,
+                           d_a, d_scratch, nullptr, na, nullptr, nullptr, na, nb, bpp, 1, d_best_idx, d_best, d_second);
+    } else if (mode == 1) {
+        hipLaunchKernelGGL((k_match_mfma<4, true>), dim3(1, (na + 255) / 256), dim3(256), 0, s,
+                           d_a, d_b, nullptr, nb, nullptr, nullptr, na, nb, bpp, 1, d_best_idx, d_best, d_second);
+    } else {
+        hipLaunchKernelGGL((k_match_mfma<16, true>), dim3(1, (na + 1023) / 1024), dim3(1024), 0, s,
+                           d_a, d_b, nullptr, nb, nullptr, nullptr, na, nb, bpp, 1, d_best_idx, d_best, d_second);
+    }
 }
 
 void pg_launch_match_batch(const uint8_t* d_desc, const int32_t* d_n, int cap_per_frame,
@@ -418,7 +473,17 @@ void pg_launch_match_batch(const uint8_t* d_desc, const int32_t* d_n, int cap_pe
         return;
     }
     const int bpp = (cap_per_frame + 15) / 16;
-    hipLaunchKernelGGL(k_expand_trains, dim3(bpp, npairs), dim3(128), 0, s, d_desc, d_n, cap_per_frame, d_pt, 0, bpp, d_scratch);
-    hipLaunchKernelGGL(k_match_mfma, dim3((npairs + 7) & ~7, (cap_per_frame + 64 * MX_WAVES - 1) / (64 * MX_WAVES)), dim3(64 * MX_WAVES), 0, s,
-                       d_desc, d_scratch, d_n, cap_per_frame, d_pq, d_pt, 0, 0, bpp, npairs, d_best_idx, d_best, d_second);
+    const int mode = mx_mode();
+    const dim3 grid4((npairs + 7) & ~7, (cap_per_frame + 255) / 256), grid16((npairs + 7) & ~7, (cap_per_frame + 1023) / 1024);
+    if (mode == 0) {
+        hipLaunchKernelGGL(k_expand_trains, dim3(bpp, npairs), dim3(128), 0, s, d_desc, d_n, cap_per_frame, d_pt, 0, bpp, d_scratch);
+        hipLaunchKernelGGL((k_match_mfma<4, false>), grid4, dim3(256), 0, s,
+                           d_desc, d_scratch, d_n, cap_per_frame, d_pq, d_pt, 0, 0, bpp, npairs, d_best_idx, d_best, d_second);
+    } else if (mode == 1) {
+        hipLaunchKernelGGL((k_match_mfma<4, true>), grid4, dim3(256), 0, s,
+                           d_desc, d_desc, d_n, cap_per_frame, d_pq, d_pt, 0, 0, bpp, npairs, d_best_idx, d_best, d_second);
+    } else {
+        hipLaunchKernelGGL((k_match_mfma<16, true>), grid16, dim3(1024), 0, s,
+                           d_desc, d_desc, d_n, cap_per_frame, d_pq, d_pt, 0, 0, bpp, npairs, d_best_idx, d_best, d_second);
+    }
 }

@@ -123,7 +123,8 @@ def test_hamming_matrix_and_best2(oracle):
     assert np.all(bi == -1) and np.all(b1 == 65535)
 
 
-@pytest.mark.parametrize("na,nb", [(300, 8191), (130, 8192), (70, 9000), (1, 17), (257, 16), (64, 15)])
+@pytest.mark.parametrize("na,nb", [(300, 8191), (130, 8192), (70, 9000), (1, 17), (257, 16), (64, 15),
+                                   (1024, 128), (1025, 129), (2100, 2005), (3000, 127), (960, 1)])   # 16-wave workgroups: 1 024 queries share a staged tile of 128
 def test_best2_index_field_limits(oracle, na, nb):
     """The MFMA matcher packs the train index into 13 key bits (nb < 8192); larger train sets take
     the popcount kernel.  Both sides of the switch, block-size multiples and tiny sets, with near
