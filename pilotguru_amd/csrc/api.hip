@@ -351,6 +351,8 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
     if ((rc = ensure(c, c->sel, selFrame * 32 * B))) return rc;           // one 32-byte selection record per keypoint (quadtree.hip, PgSelRec)
     if ((rc = ensure(c, c->nodes, nodeFrame * 4 * B + 64))) return rc;
     if ((rc = ensure(c, c->counters, (size_t)B * PG_MAXL * 4 * 2 + 64))) return rc;
+    // per-level counts: K3 writes the entries of the plan's levels in every batch, the others stay zero from here on (K4-6 sums all 16)
+    PG_HIP(c, hipMemset(c->counters.p, 0, (size_t)B * PG_MAXL * 4 * 2 + 64));
     for (int l = 0; l < L; l++) {
         PgLevel& V = P.lvl[l];
         V.img = (uint8_t*)c->pyr.p + pyrOff[l] * B;        // level-major: frames of a level adjacent
@@ -508,7 +510,10 @@ int run_batch(pgorb_ctx* c, const uint8_t* d_gray, bool resident_in_level0, int 
             pg_launch_copy_level0(P, d_gray, stride, frame_stride, nframes, s);
         }
     }
-    PG_HIP(c, hipMemsetAsync(P.candCount, 0, (size_t)c->planBatch * PG_MAXL * 4 * 2 + 4, s));
+    // the device status word is per batch: cleared by the first pyramid launch (pyramid.hip) where the order of the kernels allows it,
+    // by a memset otherwise
+    const bool foldClear = !c->pipePyr && P.nlevels > 1;
+    if (!foldClear) PG_HIP(c, hipMemsetAsync(P.status, 0, 16, s));
     hipEvent_t* ev = (c->profExtract < c->profMax) ? &c->evExtract[5 * (size_t)c->profExtract] : nullptr;
     if (ev) PG_HIP(c, hipEventRecord(ev[0], s));
     if (c->pipePyr && P.nlevels > 1 && pg_fast_is_cell_form(P)) {
@@ -556,7 +561,8 @@ int run_batch(pgorb_ctx* c, const uint8_t* d_gray, bool resident_in_level0, int 
                 PG_HIP(c, hipEventCreateWithFlags(&c->evGrpQt[l], hipEventDisableTiming));
             }
         }
-        for (int l = 1; l < P.nlevels; l++) pg_launch_pyramid_level(P, l, nframes, s);
+        for (int l = 1; l < P.nlevels; l++)
+            if (!pg_launch_pyramid_level(P, l, nframes, s, l == 1 ? P.status : nullptr) && l == 1) PG_HIP(c, hipMemsetAsync(P.status, 0, 16, s));
         if (ev) PG_HIP(c, hipEventRecord(ev[1], s));
         for (int beg = 0; beg < P.nlevels;) {
             int end = beg + 1;
@@ -578,7 +584,8 @@ int run_batch(pgorb_ctx* c, const uint8_t* d_gray, bool resident_in_level0, int 
         c->lastFrames = nframes;
         return 0;
     } else {
-        for (int l = 1; l < P.nlevels; l++) pg_launch_pyramid_level(P, l, nframes, s);
+        for (int l = 1; l < P.nlevels; l++)
+            if (!pg_launch_pyramid_level(P, l, nframes, s, l == 1 ? P.status : nullptr) && l == 1) PG_HIP(c, hipMemsetAsync(P.status, 0, 16, s));
         if (ev) PG_HIP(c, hipEventRecord(ev[1], s));
         pg_launch_fast(P, nframes, s);
         if (ev) PG_HIP(c, hipEventRecord(ev[2], s));

@@ -404,11 +404,14 @@ __global__ __launch_bounds__(256) void k_pyr_resize_rows4_lds(
     const uint8_t* __restrict__ src, int spitch, int64_t sfstride, int sh,
     uint8_t* __restrict__ dst, int dpitch, int64_t dfstride, int dw, int dh,
     const PgQuadTab2* __restrict__ qtab, const PgRowGrp* __restrict__ rowgrp, int nx, uint32_t nxMagic,
-    const int32_t* __restrict__ tilex, int cpr, int cprInv, int rowsTile)
+    const int32_t* __restrict__ tilex, int cpr, int cprInv, int rowsTile, int32_t* __restrict__ clearWord)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t pyr_lds[];      // [rowsTile][cpr * 16]
     asm volatile("" :: "s"(src), "s"(spitch), "s"(sfstride), "s"(sh), "s"(dst), "s"(dpitch), "s"(dfstride),
-                 "s"(dw), "s"(dh), "s"(qtab), "s"(rowgrp), "s"(nx), "s"(nxMagic), "s"(tilex), "s"(cpr), "s"(cprInv), "s"(rowsTile));
+                 "s"(dw), "s"(dh), "s"(qtab), "s"(rowgrp), "s"(nx), "s"(nxMagic), "s"(tilex), "s"(cpr), "s"(cprInv), "s"(rowsTile), "s"(clearWord));
+    // the first launch of a batch also clears the context's device status word (K2 / K3 report through it and come later in the
+    // stream): a memset of its own was a 4-us launch in front of every step
+    if (clearWord && blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0 && threadIdx.y == 0) *clearWord = 0;
     const int t = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const int ty = (nx == 1) ? t : (int)__umulhi((uint32_t)t, nxMagic), tx = t - ty * nx;
     const int lane = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
@@ -480,7 +483,8 @@ __global__ __launch_bounds__(256) void k_pyr_resize_rows4_lds(
     }
 }
 
-void pg_launch_pyramid_level(const PgPlan& P, int level, int nframes, hipStream_t s)
+// clearWord: a device word this launch sets to zero (or null).  Returns false when the kernel variant taken cannot do that.
+bool pg_launch_pyramid_level(const PgPlan& P, int level, int nframes, hipStream_t s, int32_t* clearWord)
 {
     const PgLevel& S = P.lvl[level - 1];
     const PgLevel& D = P.lvl[level];
@@ -494,10 +498,10 @@ void pg_launch_pyramid_level(const PgPlan& P, int level, int nframes, hipStream_
         const size_t lds = (size_t)D.pyrRows * D.pyrCpr * 16;
         dim3 block(64, 4), grid(tiles, 1, nframes);
 #define PG_PYR_LDS(G) hipLaunchKernelGGL(k_pyr_resize_rows4_lds<G>, grid, block, lds, s, S.img, S.pitch, S.fstride, S.h, D.img, D.pitch, D.fstride, \
-                                         D.w, D.h, D.qtab2, D.rowgrp, nx, nxMagic, D.tilex, D.pyrCpr, cprInv, D.pyrRows)
+                                         D.w, D.h, D.qtab2, D.rowgrp, nx, nxMagic, D.tilex, D.pyrCpr, cprInv, D.pyrRows, clearWord)
         if (D.pyrGpw == 1) PG_PYR_LDS(1); else if (D.pyrGpw == 4) PG_PYR_LDS(4); else PG_PYR_LDS(2);
 #undef PG_PYR_LDS
-        return;
+        return true;
     }
     if (D.qtab2 && D.yrel) {
         const int nx = (D.w + 255) / 256, ny = (D.h + 31) / 32;
@@ -506,16 +510,17 @@ void pg_launch_pyramid_level(const PgPlan& P, int level, int nframes, hipStream_
         dim3 block(64, 4), grid(tiles, 1, nframes);
         hipLaunchKernelGGL(k_pyr_resize_rows4, grid, block, 0, s, S.img, S.pitch, S.fstride, S.h,
                            D.img, D.pitch, D.fstride, D.w, D.h, D.qtab2, D.rowgrp, nx, nxMagic);
-        return;
+        return false;
     }
     if (D.qtab) {
         dim3 block(64, 4), grid((D.w + 255) / 256, (D.h + 4 * PYR_ROWS - 1) / (4 * PYR_ROWS), nframes);
         hipLaunchKernelGGL(k_pyr_resize_quads, grid, block, 0, s, S.img, S.pitch, S.fstride, S.w,
                            D.img, D.pitch, D.fstride, D.w, D.h, D.qtab, D.yofs, D.ybeta);
-        return;
+        return false;
     }
     dim3 block(64, 4), grid((D.w + 255) / 256, (D.h + 3) / 4, nframes);
     hipLaunchKernelGGL(k_pyr_resize_bilinear_u8, grid, block, 0, s, S.img, S.pitch, S.fstride,
                        D.img, D.pitch, D.fstride, D.w, D.h, D.xofs, D.xofs1, D.xalpha, D.yofs,
                        D.ybeta);
+    return false;
 }
