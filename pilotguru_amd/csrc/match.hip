@@ -195,18 +195,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_match_mfma(const uint8_t* __rest
     const uint8_t* qd = qdesc + (int64_t)fq * cap * 32;
     const int64_t o = (int64_t)p * cap;
 
-    // queries of this wave as MFMA A operands: A[a][s] = rows 16a .. 16a+15, k-step s
+    // queries of this wave as MFMA A operands: A[a][s] = rows 16a .. 16a+15, k-step s (filled below, behind the first tile's request)
     pg_v4i A[4][2];
-#pragma unroll
-    for (int a = 0; a < 4; a++) {
-        const int q = qbase + 16 * a + (lane & 15);
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(qd + (int64_t)q * 32) + (lane >> 4);
-#pragma unroll
-        for (int s = 0; s < 2; s++) {
-            A[a][s] = pg_v4i{0, 0, 0, 0};
-            if (q < na) A[a][s] = pg_fp4x32(src[4 * s]);
-        }
-    }
     float k1[4][4], k2[4][4];
 #pragma unroll
     for (int a = 0; a < 4; a++)
@@ -270,6 +260,17 @@ __global__ __launch_bounds__(64 * WAVES) void k_match_mfma(const uint8_t* __rest
         }
     };
     if (nblocks > 0) stage(0, 0);
+    // (the query loads and their expansion run while the first train tile is on its way)
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        const int q = qbase + 16 * a + (lane & 15);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(qd + (int64_t)q * 32) + (lane >> 4);
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            A[a][s] = pg_v4i{0, 0, 0, 0};
+            if (q < na) A[a][s] = pg_fp4x32(src[4 * s]);
+        }
+    }
     int buf = 0;
     for (int t0 = 0; t0 < nblocks; t0 += MX_TILE_BLOCKS, buf ^= 1) {
         const int cnt = min(MX_TILE_BLOCKS, nblocks - t0);
