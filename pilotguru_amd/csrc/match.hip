@@ -165,6 +165,20 @@ __device__ __forceinline__ void mx_update(const pg_v4f (&acc)[4], bool valid, fl
         }
 }
 
+// the keys of TWO blocks at once: with x, y the new keys of a (row, column class), the largest of {k1, k2, x, y} is max3(k1, x, y) and
+// the second largest max(med3(k1, x, y), k2) (k2 <= k1) -- three instructions for two distances instead of four
+__device__ __forceinline__ void mx_update2(const pg_v4f (&accA)[4], const pg_v4f (&accB)[4], float (&k1)[4][4], float (&k2)[4][4])
+{
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float x = accA[a][r], y = accB[a][r];
+            k2[a][r] = __builtin_fmaxf(pg_med3(k1[a][r], x, y), k2[a][r]);
+            k1[a][r] = __builtin_fmaxf(__builtin_fmaxf(k1[a][r], x), y);
+        }
+}
+
 // grid (pairs padded to a multiple of 8, ceil(cap / 256)): the PAIR is the fast grid index, so the workgroup's
 // linear id mod 8 -- the XCD it is dispatched to -- is pair mod 8 and all query blocks of one pair share one XCD's
 // L2: the pair's expanded trains (128 B per descriptor) come from HBM once instead of once per query block
@@ -240,10 +254,17 @@ __global__ __launch_bounds__(64 * WAVES) void k_match_mfma(const uint8_t* __rest
         for (; blk + 2 <= cntFull; blk += 2, kc -= 32.f) {
             mx_load(bl + (blk + 1) * MX_BLOCK_BYTES, B1);
             mx_block(B0, A, pg_v4f{kc, kc, kc, kc}, acc);
+#ifdef PGORB_MX_SINGLE
             mx_update<false>(acc, true, k1, k2);
             mx_load(bl + (blk + 2) * MX_BLOCK_BYTES, B0);
             mx_block(B1, A, pg_v4f{kc - 16.f, kc - 16.f, kc - 16.f, kc - 16.f}, acc);
             mx_update<false>(acc, true, k1, k2);
+#else
+            pg_v4f accB[4];
+            mx_block(B1, A, pg_v4f{kc - 16.f, kc - 16.f, kc - 16.f, kc - 16.f}, accB);
+            mx_load(bl + (blk + 2) * MX_BLOCK_BYTES, B0);
+            mx_update2(acc, accB, k1, k2);
+#endif
         }
         if (blk < cntFull) {                                     // odd count: one more full block, in B0
             mx_load(bl + (blk + 1) * MX_BLOCK_BYTES, B1);
