@@ -83,6 +83,9 @@ typedef __attribute__((address_space(3))) void* pg_lptr_t;
 
 #define MX_BLOCK_BYTES 2048
 #define MX_TILE_BLOCKS 8          // train blocks staged per LDS tile (128 descriptors, 16 KiB)
+#ifndef MX_TILE_BLOCKS_WIDE
+#define MX_TILE_BLOCKS_WIDE 16    // ... per tile of the 16-wave form (256 descriptors: 0.0787 -> 0.0772 ms against 8; 24: 0.0770)
+#endif
 #define MX_WAVES 4                // 64 queries per wave, 256 per workgroup
 #define MX_IDX_BITS 13
 #define MX_IDX_MASK ((1 << MX_IDX_BITS) - 1)
@@ -194,7 +197,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_match_mfma(const uint8_t* __rest
                                                            int na_single, int nb_single, int blocksPerPair, int npairs,
                                                            int32_t* best_idx, uint16_t* best, uint16_t* second)
 {
-    constexpr int TILE_BYTES = MX_TILE_BLOCKS * MX_BLOCK_BYTES, RAW_BYTES = MX_TILE_BLOCKS * 16 * 32;
+    // blocks per staged tile: 8 (128 descriptors); the 16-wave raw form has the LDS for more and fewer, longer tiles mean fewer barriers
+    constexpr int TB = (RAW && WAVES == 16) ? MX_TILE_BLOCKS_WIDE : MX_TILE_BLOCKS;
+    constexpr int TILE_BYTES = TB * MX_BLOCK_BYTES, RAW_BYTES = TB * 16 * 32;
     // !RAW: two expanded tiles + read-ahead slack.  RAW: one expanded tile + slack, then two raw tiles
     constexpr int EXP_BYTES = (RAW ? 1 : 2) * TILE_BYTES + MX_BLOCK_BYTES;
     __shared__ __attribute__((aligned(16))) uint8_t tile[EXP_BYTES + (RAW ? 2 * RAW_BYTES : 0)];
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_match_mfma(const uint8_t* __rest
                                                      (pg_lptr_t)(rawBase + buf * RAW_BYTES + c0 * 16), 16, 0, 0);
             }
         } else {
-            const int cnt = min(MX_TILE_BLOCKS, nblocks - t0);
+            const int cnt = min(TB, nblocks - t0);
             // 16 B per lane, wave w fills KiB w, w + WAVES, ... of the tile
             for (int kb = wv; kb < cnt * (MX_BLOCK_BYTES / 1024); kb += WAVES)
                 __builtin_amdgcn_global_load_lds((pg_gptr_t)(xp + (int64_t)t0 * MX_BLOCK_BYTES + kb * 1024 + lane * 16),
@@ -293,11 +298,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_match_mfma(const uint8_t* __rest
         }
     }
     int buf = 0;
-    for (int t0 = 0; t0 < nblocks; t0 += MX_TILE_BLOCKS, buf ^= 1) {
-        const int cnt = min(MX_TILE_BLOCKS, nblocks - t0);
+    for (int t0 = 0; t0 < nblocks; t0 += TB, buf ^= 1) {
+        const int cnt = min(TB, nblocks - t0);
         __builtin_amdgcn_s_waitcnt(0);                           // this wave's share of tile t0 has landed
         __syncthreads();                                         // ... everybody's; and buffer buf^1 (RAW: the expanded tile) has been consumed
-        if (!RAW && t0 + MX_TILE_BLOCKS < nblocks) stage(t0 + MX_TILE_BLOCKS, buf ^ 1);
+        if (!RAW && t0 + TB < nblocks) stage(t0 + TB, buf ^ 1);
         if (RAW) {
             // entry e = (block e >> 7, k-step (e >> 6) & 1, lane e & 63): bits 128 s + 32 (l >> 4) .. of descriptor l & 15
             const uint32_t* raw32 = reinterpret_cast<const uint32_t*>(rawBase + buf * RAW_BYTES);
@@ -308,7 +313,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_match_mfma(const uint8_t* __rest
             __syncthreads();                                     // the expanded tile is complete
             // (the next raw tile is requested only now: with an LDS-DMA outstanding the compiler holds every ds_write behind
             //  vmcnt(0) -- it cannot tell the two LDS targets apart -- and the expansion would wait for the load it should hide)
-            if (t0 + MX_TILE_BLOCKS < nblocks) stage(t0 + MX_TILE_BLOCKS, buf ^ 1);
+            if (t0 + TB < nblocks) stage(t0 + TB, buf ^ 1);
         }
         if (!active) continue;
         compute_tile(tile + (RAW ? 0 : buf * TILE_BYTES) + lane * 16, t0, cnt);
