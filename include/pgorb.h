@@ -480,6 +480,8 @@ int      pgorb_stream_frontend_results(pgorb_stream* s, int slot, const int32_t*
  * runs under each).  key "matcher": 0 = the default (fp4 block-scaled MFMA for < 8192 descriptors per
  * frame; the PGORB_MATCH_POPCOUNT environment switch applies again), 1 = the ballot / popcount kernels BASELINE.json's north star describes, for every size.
  * Process-wide.  Returns PGORB_E_ARG for an unknown key.
+ * key "match_mode" (process-wide): how the MFMA matcher gets its train descriptors -- -1 = chosen by the size of the launch (default), 2 = expanded
+ * in LDS by 16-wave workgroups, 1 = by 4-wave workgroups, 0 = expanded into a scratch slab by a kernel of its own (rounds 1-2).
  * key "fast_kernel": 0 = K2 as one wave per 30-px cell (default), 1 (developer builds with -DPGORB_FAST_BLOCKS only; the
  * product library answers PGORB_E_ARG) = K2 as one workgroup per block of
  * "fast_block_cx" x "fast_block_cy" cells (1..4 each, default 4 x 2; changing them rebuilds the plan) -- the tile

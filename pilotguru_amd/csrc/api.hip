@@ -993,6 +993,7 @@ int pgorb_set_option(pgorb_ctx* c, const char* key, int value)
 {
     if (!key) return PGORB_E_ARG;
     if (!strcmp(key, "matcher")) { pg_match_set_popcount(value); return 0; }
+    if (!strcmp(key, "match_mode")) return pg_match_set_mode(value) ? (c ? fail(c, PGORB_E_ARG, "match_mode must be -1, 0, 1 or 2") : PGORB_E_ARG) : 0;
     if (!strcmp(key, "fast_kernel")) {
         if (pg_fast_set_kernel(value)) return c ? fail(c, PGORB_E_ARG, "fast_kernel %d: the block form is a developer build (make EXTRA=-DPGORB_FAST_BLOCKS)", value) : PGORB_E_ARG;
         return 0;

@@ -153,6 +153,7 @@ void pg_launch_best2(const uint8_t* d_a, int na, const uint8_t* d_b, int nb, uin
                      int32_t* d_best_idx, uint16_t* d_best, uint16_t* d_second, hipStream_t s);
 
 void pg_match_set_popcount(int on);
+int  pg_match_set_mode(int m);           // -1 = by grid size (default), 0 | 1 | 2: match.hip; -1 on a bad value
 int  pg_fast_set_kernel(int k);          // 0, or -1 when the requested form is not in this build
 int  pg_fast_get_kernel();
 bool pg_match_uses_popcount(int cap_per_frame);

@@ -125,7 +125,8 @@ def test_hamming_matrix_and_best2(oracle):
 
 @pytest.mark.parametrize("na,nb", [(300, 8191), (130, 8192), (70, 9000), (1, 17), (257, 16), (64, 15),
                                    (1024, 128), (1025, 129), (2100, 2005), (3000, 127), (960, 1)])   # 16-wave workgroups: 1 024 queries share a staged tile of 128
-def test_best2_index_field_limits(oracle, na, nb):
+@pytest.mark.parametrize("mode", [-1, 0, 1, 2])
+def test_best2_index_field_limits(oracle, na, nb, mode):
     """The MFMA matcher packs the train index into 13 key bits (nb < 8192); larger train sets take
     the popcount kernel.  Both sides of the switch, block-size multiples and tiny sets, with near
     duplicates so that ties and the second best are exercised (ORBmatcher.cc:438-459 semantics)."""
@@ -141,7 +142,11 @@ def test_best2_index_field_limits(oracle, na, nb):
             b[k, i % 32] ^= 1 << (i % 8)
     b[nb - 1] = a[0]
     ext = _make(100, 320, 240)
-    bi, b1, b2 = ext.hamming_best2(a, b)
+    ext.set_option("match_mode", mode)       # every way the train descriptors reach the matrix cores (match.hip); -1 = by launch size
+    try:
+        bi, b1, b2 = ext.hamming_best2(a, b)
+    finally:
+        ext.set_option("match_mode", -1)
     obi, ob1, ob2 = oracle.hamming_best2(a, b)
     assert np.array_equal(bi, obi) and np.array_equal(b1, ob1) and np.array_equal(b2, ob2)
 
@@ -402,14 +407,20 @@ def test_match_batch_ragged_frame_sizes(oracle):
     n = torch.tensor(counts, dtype=torch.int32, device="cuda")
     pq = torch.tensor([p[0] for p in pairs], dtype=torch.int32, device="cuda")
     pt = torch.tensor([p[1] for p in pairs], dtype=torch.int32, device="cuda")
-    bi, b1, b2 = ext.match_batch_device(d, n, pq, pt)
-    torch.cuda.synchronize()
-    for k, (q, t) in enumerate(pairs):
-        m = counts[q]
-        obi, ob1, ob2 = oracle.hamming_best2(desc[q, :m], desc[t, :counts[t]])
-        assert np.array_equal(bi[k, :m].cpu().numpy(), obi), (q, t)
-        assert np.array_equal(b1[k, :m].cpu().numpy().view(np.uint16), ob1), (q, t)
-        assert np.array_equal(b2[k, :m].cpu().numpy().view(np.uint16), ob2), (q, t)
+    want = [oracle.hamming_best2(desc[q, :counts[q]], desc[t, :counts[t]]) for q, t in pairs]
+    for mode in (-1, 0, 1, 2):                            # every staging form of the MFMA matcher (match.hip)
+        ext.set_option("match_mode", mode)
+        try:
+            bi, b1, b2 = ext.match_batch_device(d, n, pq, pt)
+            torch.cuda.synchronize()
+        finally:
+            ext.set_option("match_mode", -1)
+        for k, (q, t) in enumerate(pairs):
+            m = counts[q]
+            obi, ob1, ob2 = want[k]
+            assert np.array_equal(bi[k, :m].cpu().numpy(), obi), (mode, q, t)
+            assert np.array_equal(b1[k, :m].cpu().numpy().view(np.uint16), ob1), (mode, q, t)
+            assert np.array_equal(b2[k, :m].cpu().numpy().view(np.uint16), ob2), (mode, q, t)
 
 
 def test_device_entry_points_are_graph_capture_safe(oracle):

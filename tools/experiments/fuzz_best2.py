@@ -23,6 +23,7 @@ for it in range(N):
             if k != j:
                 b[k] = a[i]
                 if rng.randint(0, 2): b[k, rng.randint(0, 32)] ^= 1 << rng.randint(0, 8)
+    ext.set_option("match_mode", int(rng.randint(-1, 3)))
     bi, b1, b2 = ext.hamming_best2(a, b)
     obi, ob1, ob2 = oracle.hamming_best2(a, b)
     nd += na * nb
