@@ -61,8 +61,8 @@ __global__ __launch_bounds__(MT_T) void k_hamming_matrix(const uint8_t* __restri
 // by 4096 and the first MFMA of a tile takes its C operand from a per-lane constant, so the f32
 // accumulator leaves the matrix pipe as the finished sort key
 //     key = (256 - distance) * 8192 + (8191 - train index)            (train index < 8192)
-// -- an integer below 2^22, exact in f32 -- and what stays on the VALU is two v_med3_f32 per
-// distance, which keep the two LARGEST keys (k1 >= k2) of every (row, column class): larger key =
+// -- an integer below 2^22, exact in f32 -- and what stays on the VALU is a median / maximum pair per
+// distance (three instructions per two distances, mx_update2), which keep the two LARGEST keys (k1 >= k2) of every (row, column class): larger key =
 // smaller distance, then smaller index -- the reference's strict-'<' scan with bestDist /
 // bestDist2 (ORBmatcher.cc:438-459), "first minimum wins".  (dot + 256 is even, which is where
 // the 13th index bit comes from.)  tools/ubench/mfma_fp4_dot.hip checks the instruction's
