@@ -652,26 +652,22 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P, int level0
     int* wKey = cntB;                                       // [NC] tile << 16 | arrival index inside the tile
     for (int i = tid; i <= tileCap; i += QT_T) hist[i] = 0;
     __syncthreads();
-    for (int b0 = 0; b0 < ncand; b0 += 4 * QT_T) {
-        uint2 kk[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { const int i = b0 + tid + u * QT_T; kk[u] = (i < ncand) ? keys[i] : make_uint2(0u, 0u); }
-        QT_SETTLE4(kk[0].x, kk[1].x, kk[2].x, kk[3].x); QT_SETTLE4(kk[0].y, kk[1].y, kk[2].y, kk[3].y);
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (b0 + tid + u * QT_T >= ncand) break;
-            const uint2 k = kk[u];
-            const uint32_t x = (k.x & 0xFFF) - 3, y = ((k.x >> 12) & 0xFFF) - 3;
-            const uint32_t cj = (x * mW) >> 20, ci = (y * mH) >> 20;
-            const uint32_t rank = ((ci * nCols + cj) * hCell + (y - ci * hCell)) * wCell + (x - cj * wCell);
-            const unsigned long long key = ((unsigned long long)(k.x >> 24) << 32) | (0xFFFFFFFFu - rank);
-            const int pos = pyrMode ? leafPos[k.y] : (int)(k.y & QT_POS_MASK);
-            if (pos < nsel && best[pos] == key) {
-                const int t = (int)(((k.x >> 12) & 0xFFF) >> tsh) * tilesX + (int)((k.x & 0xFFF) >> tsh);
-                wRec[pos] = (int)k.x;
-                wKey[pos] = (t << 16) | atomicAdd(&hist[t], 1);
-            }
+    // The winner of a node is named by best[p] itself: the key holds the response and the candidate-order rank, and the rank is
+    // (cell, row in the cell, column in the cell) -- so x, y come back out of it and no third pass over the ~2e4 key records is
+    // needed to find the winners (that pass was 18 of the level-0 workgroup's 123 us).
+    for (int p = tid; p < nsel; p += QT_T) {
+        const unsigned long long b = best[p];
+        uint32_t cv = 0u;
+        if (b) {                                            // (every node of the final list holds a key)
+            const uint32_t rank = 0xFFFFFFFFu - (uint32_t)b;
+            const uint32_t t1 = rank / (uint32_t)wCell, xr = rank - t1 * (uint32_t)wCell;
+            const uint32_t cidx = t1 / (uint32_t)hCell, yr = t1 - cidx * (uint32_t)hCell;
+            const uint32_t ci = cidx / (uint32_t)nCols, cj = cidx - ci * (uint32_t)nCols;
+            cv = (cj * wCell + xr + 3u) | ((ci * hCell + yr + 3u) << 12) | ((uint32_t)(b >> 32) << 24);
         }
+        const int t = (int)(((cv >> 12) & 0xFFF) >> tsh) * tilesX + (int)((cv & 0xFFF) >> tsh);
+        wRec[p] = (int)cv;
+        wKey[p] = (t << 16) | atomicAdd(&hist[t], 1);
     }
     __syncthreads();
     qt_scan_excl(hist, tileCap + 1, sh);
