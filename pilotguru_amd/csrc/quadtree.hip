@@ -352,6 +352,16 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P, int level0
     // Generation g splits depth g-1 nodes.  While g <= D the child counts come from the pyramid
     // and no pass over the keys is needed ("pyramid mode"); deeper trees continue with one key
     // pass per generation (keys carry node position | quadrant << 28).
+    // candidate order = (cell row, cell col, y, x); x / wCell by an exact reciprocal (x < 4096, wCell < 256)
+    const int wCell = L.wCell, hCell = L.hCell, nCols = L.nCols;
+    const uint32_t mW = ((1u << 20) + wCell - 1) / wCell, mH = ((1u << 20) + hCell - 1) / hCell;
+    // the 64-bit key a candidate bids for its node with: (response, first in candidate order wins)
+    auto bid = [&](uint32_t cv) {
+        const uint32_t x = (cv & 0xFFF) - 3, y = ((cv >> 12) & 0xFFF) - 3;
+        const uint32_t cj = (x * mW) >> 20, ci = (y * mH) >> 20;
+        const uint32_t rank = ((ci * nCols + cj) * hCell + (y - ci * hCell)) * wCell + (x - cj * wCell);
+        return ((unsigned long long)(cv >> 24) << 32) | (0xFFFFFFFFu - rank);
+    };
     int sorted_mode = 0, gen = 1;
     bool last = false, pyrMode = true;
     while (!last) {
@@ -581,7 +591,11 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P, int level0
                             tgt[u] = np * 4 + q2;
                             rec |= (uint32_t)q2 << 28;
                         }
-                        keys[i].y = rec;
+                        // the last generation's pass is the last time the keys are looked at: each key bids for its final node
+                        // here (the quadrant counters of a generation that will not come are free: 2 ints per node, zeroed above)
+                        // instead of being filed for one more pass over all of them
+                        if (last) atomicMax(&reinterpret_cast<unsigned long long*>(cnt4n)[np], bid(k.x));
+                        else keys[i].y = rec;
                     }
                 }
 #pragma unroll
@@ -596,10 +610,12 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P, int level0
     }
 
     // ---- best response per node, first in candidate order wins (:741-760) ---------------
-    // (best aliases newpos4: the generation loop ended with a barrier)
-    for (int p = tid; p < size; p += QT_T) best[p] = 0ull;
-    int* leafPos = pyr + qt_pyr_off(nIni, D);             // depth-D descendant -> list position
+    // A tree that ended below the count pyramid has its bids already (the last generation's key pass; after the swap above they
+    // sit in cnt4).  A tree that ended inside the pyramid never looked at its keys again: one pass now, every key to the list
+    // position of its depth-D descendant.  (best aliases newpos4 there: the generation loop ended with a barrier)
     if (pyrMode) {
+        for (int p = tid; p < size; p += QT_T) best[p] = 0ull;
+        int* leafPos = pyr + qt_pyr_off(nIni, D);             // depth-D descendant -> list position
         for (int i = tid; i < pyrTotal; i += QT_T) pyr[i] = -1;
         __syncthreads();
         for (int p = tid; p < size; p += QT_T) {
@@ -608,28 +624,23 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P, int level0
         }
         __syncthreads();
         for (int j = tid; j < (nIni << (2 * D)); j += QT_T) leafPos[j] = qt_walk(pyr, j, nIni, D);
-    }
-    __syncthreads();
-    QT_TS(3);
-    // candidate order = (cell row, cell col, y, x); x / wCell by an exact reciprocal (x < 4096, wCell < 256)
-    const int wCell = L.wCell, hCell = L.hCell, nCols = L.nCols;
-    const uint32_t mW = ((1u << 20) + wCell - 1) / wCell, mH = ((1u << 20) + hCell - 1) / hCell;
-    for (int b0 = 0; b0 < ncand; b0 += 4 * QT_T) {
-        uint2 kk[4];
+        __syncthreads();
+        QT_TS(3);
+        for (int b0 = 0; b0 < ncand; b0 += 4 * QT_T) {
+            uint2 kk[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const int i = b0 + tid + u * QT_T; kk[u] = (i < ncand) ? keys[i] : make_uint2(0u, 0u); }
-        QT_SETTLE4(kk[0].x, kk[1].x, kk[2].x, kk[3].x); QT_SETTLE4(kk[0].y, kk[1].y, kk[2].y, kk[3].y);
+            for (int u = 0; u < 4; u++) { const int i = b0 + tid + u * QT_T; kk[u] = (i < ncand) ? keys[i] : make_uint2(0u, 0u); }
+            QT_SETTLE4(kk[0].x, kk[1].x, kk[2].x, kk[3].x); QT_SETTLE4(kk[0].y, kk[1].y, kk[2].y, kk[3].y);
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int i = b0 + tid + u * QT_T;
-            if (i >= ncand) break;
-            const uint2 k = kk[u];
-            const int pos = pyrMode ? leafPos[k.y] : (int)(k.y & QT_POS_MASK);
-            const uint32_t x = (k.x & 0xFFF) - 3, y = ((k.x >> 12) & 0xFFF) - 3;
-            const uint32_t cj = (x * mW) >> 20, ci = (y * mH) >> 20;
-            const uint32_t rank = ((ci * nCols + cj) * hCell + (y - ci * hCell)) * wCell + (x - cj * wCell);
-            atomicMax(&best[pos], ((unsigned long long)(k.x >> 24) << 32) | (0xFFFFFFFFu - rank));
+            for (int u = 0; u < 4; u++) {
+                const int i = b0 + tid + u * QT_T;
+                if (i >= ncand) break;
+                atomicMax(&best[leafPos[kk[u].y]], bid(kk[u].x));
+            }
         }
+    } else {
+        best = reinterpret_cast<unsigned long long*>(cnt4);
+        QT_TS(3);
     }
     __syncthreads();
     QT_TS(6);
@@ -647,7 +658,7 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P, int level0
     int tsh = 6;
     while ((((L.w - 2 * PG_EDGE) >> tsh) + 1) * (((L.h - 2 * PG_EDGE) >> tsh) + 1) > tileCap) tsh++;
     const int tilesX = ((L.w - 2 * PG_EDGE) >> tsh) + 1;
-    int* hist = cnt4;                                       // generation state is dead in the epilogue
+    int* hist = pyrMode ? cnt4 : cnt4n;                     // generation state is dead in the epilogue (cnt4 may hold the bids)
     int* wRec = cntA;                                       // [NC] winner record of list position p
     int* wKey = cntB;                                       // [NC] tile << 16 | arrival index inside the tile
     for (int i = tid; i <= tileCap; i += QT_T) hist[i] = 0;
