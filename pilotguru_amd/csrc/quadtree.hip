@@ -145,8 +145,11 @@ __device__ __forceinline__ int qt_quadrant(const int4 b, uint32_t cv)
 // developer build only (make EXTRA=-DPGORB_QT_TIMING): per-phase time of workgroup (0,0) in
 // 10 ns ticks, read back by tools/experiments/qt_timing.py
 __device__ unsigned long long pg_qt_t[16];
-#define QT_TS(k) do { if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) { const unsigned long long t1_ = wall_clock64(); pg_qt_t[k] += t1_ - qt_t0; qt_t0 = t1_; } } while (0)
-#define QT_CNT(k, v) do { if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) pg_qt_t[k] += (v); } while (0)
+#ifndef QT_TIMING_LEVEL
+#define QT_TIMING_LEVEL 0
+#endif
+#define QT_TS(k) do { if (tid == 0 && blockIdx.x == 0 && blockIdx.y == QT_TIMING_LEVEL) { const unsigned long long t1_ = wall_clock64(); pg_qt_t[k] += t1_ - qt_t0; qt_t0 = t1_; } } while (0)
+#define QT_CNT(k, v) do { if (tid == 0 && blockIdx.x == 0 && blockIdx.y == QT_TIMING_LEVEL) pg_qt_t[k] += (v); } while (0)
 extern "C" int pgorb_debug_qt_times(unsigned long long* out16, int reset)
 {
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(pg_qt_t), sizeof(pg_qt_t)) != hipSuccess) return -1;
