@@ -477,19 +477,24 @@ int      pgorb_stream_frontend_results(pgorb_stream* s, int slot, const int32_t*
                                        const uint32_t** word, const double** weight, const uint32_t** node);
 
 /* Measurement switches (no counterpart in the reference; results never depend on them -- the parity suite
- * runs under each).  key "matcher": 0 = the default (fp4 block-scaled MFMA for < 8192 descriptors per
- * frame; the PGORB_MATCH_POPCOUNT environment switch applies again), 1 = the ballot / popcount kernels BASELINE.json's north star describes, for every size.
- * Process-wide.  Returns PGORB_E_ARG for an unknown key.
- * key "match_mode" (process-wide): how the MFMA matcher gets its train descriptors -- -1 = chosen by the size of the launch (default), 2 = expanded
- * in LDS by 16-wave workgroups, 1 = by 4-wave workgroups, 0 = expanded into a scratch slab by a kernel of its own (rounds 1-2).
- * key "fast_kernel": 0 = K2 as one wave per 30-px cell (default), 1 (developer builds with -DPGORB_FAST_BLOCKS only; the
- * product library answers PGORB_E_ARG) = K2 as one workgroup per block of
- * "fast_block_cx" x "fast_block_cy" cells (1..4 each, default 4 x 2; changing them rebuilds the plan) -- the tile
- * shapes of BASELINE.json configs[2]'s sweep.
+ * runs under each).  Every option belongs to the CONTEXT it is set on (round 4: "matcher" / "match_mode" were process-wide
+ * statics); the environment (PGORB_MATCH_POPCOUNT, PGORB_MATCH_MODE) only seeds pgorb_create.  ctx == NULL or an unknown
+ * key -> PGORB_E_ARG.
+ * key "matcher": 0 = the default (fp4 block-scaled MFMA for < 8192 descriptors per frame, unless PGORB_MATCH_POPCOUNT is
+ * set), 1 = the ballot / popcount kernels BASELINE.json's north star describes, for every size.
+ * key "match_mode": how the MFMA matcher gets its train descriptors -- -1 = chosen by the size of the launch (default), 2 = expanded
+ * in LDS by 16-wave workgroups, 1 = by 4-wave workgroups, 0 = expanded into a scratch slab by a kernel of its own (rounds 1-2;
+ * the slab is sized at every launch, also for streams created before the switch).
+ * key "fast_tile_pitch": K2's LDS window pitch in bytes, the tile-size sweep of BASELINE.json configs[2] -- 0 = automatic
+ * (48 with compile-time offsets for cells up to 36 px: the shipped shape), 48 | 64 | ... | 128 = that pitch through the
+ * run-time-pitch instantiation (values below what the plan's cells need are ignored).
+ * key "fast_waves_per_block": 1 (default) | 4 independent cells (waves) per K2 workgroup.
  * key "pipeline_pyramid": 1 = the resize chain on a side stream beside K2, level by level (slower).
  * key "pipeline_levels": bit l set = a group of levels starts at level l; K3 / K4-6 of one group run on side streams beside K2
  * of the next (slower for every grouping measured).  0 = one launch per kernel (default).
- * key "pipeline_levels_priority": 1 = the K3 side stream is created with the highest priority (read when it is first used). */
+ * key "pipeline_levels_priority": 1 = the K3 side stream is created with the highest priority (read when it is first used).
+ * pgorb_get_option returns the value, or PGORB_OPTION_UNKNOWN for a null context / unknown key (-1 is a legal "match_mode"). */
+#define PGORB_OPTION_UNKNOWN (-2147483647 - 1)
 int  pgorb_set_option(pgorb_ctx* ctx, const char* key, int value);
 int  pgorb_get_option(const pgorb_ctx* ctx, const char* key);
 /* 1 when a match of `cap_per_frame` descriptors per frame takes the popcount kernels, else 0 */

@@ -268,6 +268,110 @@ int orc_search_by_projection_frame(const orc_keypoint* kps, const uint8_t* desc,
     return nmatches;
 }
 
+/* MapPoint::PredictScale's logarithm (src/MapPoint.cc:524: `log(ratio)` on a float with TemplatedVocabulary.h:36's
+ * `using namespace std` in effect = std::log(float) = the platform's logf; likewise Frame.cc:188 for mfLogScaleFactor).
+ * PARITY CONTRACT (like orc_sincos_f): a fixed double-precision sequence, rounded once to float --
+ *   x = m * 2^e, m in [sqrt(1/2), sqrt(2));  s = (m - 1) / (m + 1);  log x = e ln2 + 2 s (1 + s^2/3 + s^4/5 + ... + s^20/21)
+ * (truncation < 2^-56 relative, no FMA) -- within 1 ulp of any libm's logf; tests/test_oracle.py measures the difference from
+ * this box's glibc.  x <= 0 -> -inf (the reference would take the log of maxDistance / dist3D > 0), inf -> inf, NaN -> NaN. */
+float orc_log_f(float xf)
+{
+    if (xf != xf) return xf;
+    if (!(xf > 0.0f)) return -INFINITY;
+    if (xf == INFINITY) return INFINITY;
+    union { double d; uint64_t u; } v;
+    v.d = (double)xf;                                             /* every positive float is a normal double */
+    int e = (int)((v.u >> 52) & 0x7FF) - 1023;
+    v.u = (v.u & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;   /* m in [1, 2) */
+    double m = v.d;
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }           /* m in (sqrt(1/2), sqrt(2)] */
+    const double s = (m - 1.0) / (m + 1.0), z = s * s;
+    double p = 1.0 / 21.0;
+    p = p * z + 1.0 / 19.0; p = p * z + 1.0 / 17.0; p = p * z + 1.0 / 15.0; p = p * z + 1.0 / 13.0; p = p * z + 1.0 / 11.0;
+    p = p * z + 1.0 / 9.0;  p = p * z + 1.0 / 7.0;  p = p * z + 1.0 / 5.0;  p = p * z + 1.0 / 3.0;  p = p * z + 1.0;
+    const double r = (double)e * 0.6931471805599453 + (2.0 * s) * p;
+    return (float)r;
+}
+
+/* MapPoint::PredictScale(currentDist, Frame*), src/MapPoint.cc:516-531.  `(int)ceil(...)` of a NaN or of a value outside
+ * int's range is what x86-64's cvttss2si returns: INT_MIN, i.e. level 0 after the clamp. */
+int orc_predict_scale(float max_distance, float current_dist, float log_scale_factor, int nlevels)
+{
+    const float ratio = max_distance / current_dist;
+    const float q = ceilf(orc_log_f(ratio) / log_scale_factor);
+    int nScale = (q != q || q >= 2147483648.0f || q < -2147483648.0f) ? INT_MIN : (int)q;
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= nlevels) nScale = nlevels - 1;
+    return nScale;
+}
+
+/* The matching loop of ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*>
+ * &sAlreadyFound, float th, int ORBdist), src/ORBmatcher.cc:1476-1603 (Tracking::Relocalization, Tracking.cc:1434,1448:
+ * th 10 / ORBdist 100, then th 3 / ORBdist 64), given per key-frame map point i what the caller's pose arithmetic
+ * (:1497-1517, cv::Mat) produced: valid = pMP && !pMP->isBad(); found = sAlreadyFound.count(pMP); (u, v) the projection;
+ * dist3d = |x3Dw - Ow|; min / max_distance = GetMin/MaxDistanceInvariance(); kf_angle = pKF->mvKeysUn[i].angle.
+ * kp_has_point[i2]: CurrentFrame.mvpMapPoints[i2] != NULL before the call (ANY point blocks, :1542-1543 -- no
+ * Observations() test here).  assigned[i2] = i, or -1.  Returns nmatches. */
+int orc_search_by_projection_keyframe(const orc_keypoint* kps, const uint8_t* desc, int n,
+                                      const int32_t* grid_start, const int32_t* grid_idx,
+                                      float minX, float maxX, float minY, float maxY,
+                                      const float* scale_factors, int nlevels, float log_scale_factor, const uint8_t* kp_has_point,
+                                      int npoints, const uint8_t* valid, const uint8_t* found, const float* u, const float* v,
+                                      const float* dist3d, const float* min_distance, const float* max_distance,
+                                      const float* kf_angle, const uint8_t* pdesc, float th, int ORBdist, int checkOrientation,
+                                      int32_t* assigned)
+{
+    int nmatches = 0;
+    uint8_t* taken = (uint8_t*)malloc(n + 1);
+    for (int i = 0; i < n; i++) { taken[i] = kp_has_point ? (kp_has_point[i] != 0) : 0; assigned[i] = -1; }
+    int32_t* vIndices2 = (int32_t*)malloc(sizeof(int32_t) * (n + 1));
+    int* histBin = (int*)malloc(sizeof(int) * (npoints + 1));
+    int* histIdx = (int*)malloc(sizeof(int) * (npoints + 1));
+    int npush = 0;
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int i = 0; i < npoints; i++) {
+        if (!valid[i] || found[i]) continue;                                          /* :1497-1499 */
+        if (u[i] < minX || u[i] > maxX) continue;                                     /* :1512-1515 */
+        if (v[i] < minY || v[i] > maxY) continue;
+        if (dist3d[i] < min_distance[i] || dist3d[i] > max_distance[i]) continue;     /* :1525-1526 */
+        const int nPredictedLevel = orc_predict_scale(max_distance[i], dist3d[i], log_scale_factor, nlevels);   /* :1528 */
+        const float radius = th * scale_factors[nPredictedLevel];                     /* :1531 */
+        const int nind = orc_features_in_area(kps, grid_start, grid_idx, minX, maxX, minY, maxY, u[i], v[i], radius,
+                                              nPredictedLevel - 1, nPredictedLevel + 1, vIndices2);
+        if (nind == 0) continue;
+        const uint8_t* dMP = pdesc + 32 * (size_t)i;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int k = 0; k < nind; k++) {
+            const int i2 = vIndices2[k];
+            if (taken[i2]) continue;                                                  /* :1542-1543 */
+            const int dist = orc_descriptor_distance(dMP, desc + 32 * (size_t)i2);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= ORBdist && bestIdx2 >= 0) {      /* (ORBdist >= 256 with no candidate left would index -1 in the reference) */
+            assigned[bestIdx2] = i;
+            taken[bestIdx2] = 1;
+            nmatches++;
+            if (checkOrientation) {
+                float rot = kf_angle[i] - kps[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                histBin[npush] = bin; histIdx[npush] = bestIdx2; npush++;
+            }
+        }
+    }
+    if (checkOrientation) {
+        int histo[HISTO_LENGTH] = {0};
+        for (int k = 0; k < npush; k++) histo[histBin[k]]++;
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(histo, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int k = 0; k < npush; k++)
+            if (histBin[k] != ind1 && histBin[k] != ind2 && histBin[k] != ind3) { assigned[histIdx[k]] = -1; nmatches--; }
+    }
+    free(taken); free(vIndices2); free(histBin); free(histIdx);
+    return nmatches;
+}
+
 /* ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches),
  * src/ORBmatcher.cc:161-290.  FeatureVectors as CSR (ascending nodes).  matches[j] = key-frame
  * keypoint whose map point went to vpMapPointMatches[j], or -1.  Returns nmatches. */

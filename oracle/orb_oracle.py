@@ -99,6 +99,13 @@ def lib():
         L.orc_search_by_projection_frame.restype = C.c_int
         L.orc_search_by_projection_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p] + [C.c_float] * 4 + \
             [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_float, C.c_int, C.c_void_p]
+        L.orc_search_by_projection_keyframe.restype = C.c_int
+        L.orc_search_by_projection_keyframe.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p] + [C.c_float] * 4 + \
+            [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int] + [C.c_void_p] * 9 + [C.c_float, C.c_int, C.c_int, C.c_void_p]
+        L.orc_log_f.restype = C.c_float
+        L.orc_log_f.argtypes = [C.c_float]
+        L.orc_predict_scale.restype = C.c_int
+        L.orc_predict_scale.argtypes = [C.c_float, C.c_float, C.c_float, C.c_int]
         L.orc_search_by_bow.restype = C.c_int
         L.orc_search_by_bow.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 2 + [C.c_int] + \
             [C.c_void_p] * 3 + [C.c_int, C.c_float, C.c_int, C.c_void_p]
@@ -467,6 +474,32 @@ def search_by_projection_frame(kps, desc, bounds, scale_factors, kp_has_point, v
     out = np.full(max(len(kps), 1), -1, np.int32)
     nm = lib().orc_search_by_projection_frame(_p(kps), _p(desc), len(kps), _p(gs), _p(gi), *bounds, _p(sf), _p(has), len(a[0]),
                                               *[_p(x) for x in a], th, int(check_orientation), _p(out))
+    return nm, out[:len(kps)].copy()
+
+
+def log_f(x):
+    """PredictScale's logf under the parity contract (match_oracle.c: orc_log_f)."""
+    return float(lib().orc_log_f(float(x)))
+
+
+def predict_scale(max_distance, current_dist, log_scale_factor, nlevels):
+    """MapPoint::PredictScale (src/MapPoint.cc:516-531)."""
+    return int(lib().orc_predict_scale(float(max_distance), float(current_dist), float(log_scale_factor), int(nlevels)))
+
+
+def search_by_projection_keyframe(kps, desc, bounds, scale_factors, kp_has_point, valid, found, u, v, dist3d, min_distance,
+                                  max_distance, log_scale_factor, kf_angle, pdesc, th, orb_dist, check_orientation=True):
+    """ORBmatcher::SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) (src/ORBmatcher.cc:1476-1603), the
+    relocalisation search; scale_factors has nlevels + 1 entries like the extractor's table."""
+    kps, desc, gs, gi, has = _prep(kps, desc, bounds, kp_has_point)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    a = [np.ascontiguousarray(valid, np.uint8), np.ascontiguousarray(found, np.uint8), np.ascontiguousarray(u, np.float32),
+         np.ascontiguousarray(v, np.float32), np.ascontiguousarray(dist3d, np.float32), np.ascontiguousarray(min_distance, np.float32),
+         np.ascontiguousarray(max_distance, np.float32), np.ascontiguousarray(kf_angle, np.float32), np.ascontiguousarray(pdesc, np.uint8)]
+    out = np.full(max(len(kps), 1), -1, np.int32)
+    nm = lib().orc_search_by_projection_keyframe(_p(kps), _p(desc), len(kps), _p(gs), _p(gi), *bounds, _p(sf), len(sf) - 1,
+                                                 float(log_scale_factor), _p(has), len(a[0]), *[_p(x) for x in a],
+                                                 float(th), int(orb_dist), int(check_orientation), _p(out))
     return nm, out[:len(kps)].copy()
 
 

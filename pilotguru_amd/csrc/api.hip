@@ -40,8 +40,8 @@ struct pgorb_ctx {
     int planW = 0, planH = 0, planBatch = 0;
     bool planValid = false;
     // device memory
-    Arena pyr, cand, sel, nodes, counters, tables, cellCand, cellCount, cellTab, cellTabBal, blockTab;
-    int fastBlockCX = 4, fastBlockCY = 2;     // K2 block shape in cells (pgorb_set_option "fast_block_cx" / "_cy")
+    Arena pyr, cand, sel, nodes, counters, tables, cellCand, cellCount, cellTab, cellTabBal;
+    int fastTilePitch = 0, fastWpb = 1;       // K2 tile-shape sweep (pgorb_set_option "fast_tile_pitch" / "fast_waves_per_block")
     // K1 beside K2 (pgorb_set_option "pipeline_pyramid"): the pyramid chain on a high-priority side stream, K2 level by
     // level on a second one as the levels appear
     int pipePyr = 0;
@@ -53,7 +53,8 @@ struct pgorb_ctx {
     hipStream_t sQt = nullptr, sDesc = nullptr;
     hipEvent_t evGrpFast[PG_MAXL] = {}, evGrpQt[PG_MAXL] = {}, evDescDone = nullptr;
     Arena stageKps, stageDesc, stageN, stageA, stageB, stageOut, stageSfi, vocab;
-    Arena xdesc;                              // matcher scratch: train descriptors as +-1 bytes (match.hip)
+    Arena xdesc;                              // matcher scratch: train descriptors as +-1 bytes (match.hip, match_mode 0 only)
+    PgMatchOpts mx;                           // this context's matcher settings (pgorb_set_option "matcher" / "match_mode")
     void* pinned = nullptr;                   // page-locked bounce buffer for bulk result download
     size_t pinnedBytes = 0;
     int vocabK = 0, vocabL = 0, vocabNodes = 0;
@@ -64,6 +65,8 @@ struct pgorb_ctx {
     std::vector<hipEvent_t> evMatch;          // 2 per armed match call
     int profMax = 0, profExtract = 0, profMatch = 0;
     std::vector<pgorb_stream*> streams;       // live pgorb_stream_* objects of this context (pgorb_destroy takes them along)
+    // the matchers' shared scratch arena (stageSfi) may be used from different caller streams: the last use is an event
+    hipEvent_t evSfi = nullptr; hipStream_t sfiStream = nullptr; bool sfiUsed = false;
 };
 
 namespace {
@@ -439,51 +442,7 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
         P.cellTabBal = (const uint32_t*)c->cellTabBal.p;
         P.cellsPerXcdBal = (int)per;
     }
-    P.blockTab = nullptr; P.totalBlocks = 0;
-#ifdef PGORB_FAST_BLOCKS
-    {
-        // K2 block records (fast.hip, k_fast_blocks; developer build only): blocks of blkCX x blkCY cells, row-major per level.
-        // A block's interior must fit 128 x 128 px (32 quads per tile row, 16 steps of 8 rows).
-        std::vector<uint32_t> bt;
-        bool ok = true;
-        for (int l = 0; l < L && ok; l++) {
-            PgLevel& V = P.lvl[l];
-            V.blkCX = std::max(1, std::min(std::min(c->fastBlockCX, 4), 128 / V.wCell));
-            V.blkCY = std::max(1, std::min(std::min(c->fastBlockCY, 4), 128 / V.hCell));
-            if (V.wCell > 128 || V.hCell > 128 || V.nCols > 65535 || V.cellCap > 65535) { ok = false; break; }
-            const int maxBorderX = V.w - PG_EDGE, maxBorderY = V.h - PG_EDGE;
-            for (int bi = 0; bi < V.nRows; bi += V.blkCY)
-                for (int bj = 0; bj < V.nCols; bj += V.blkCX) {
-                    const int ncx = std::min(V.blkCX, V.nCols - bj), ncy = std::min(V.blkCY, V.nRows - bi);
-                    const int iniY = PG_EDGE + bi * V.hCell, iniX = PG_EDGE + bj * V.wCell;
-                    // interior = [iniX + 3, min(iniX + ncx * wCell + 6, maxBorderX) - 3): the cells tile it
-                    const int BW = std::max(0, std::min(iniX + ncx * V.wCell + 6, maxBorderX) - 6 - iniX);
-                    const int BH = std::max(0, std::min(iniY + ncy * V.hCell + 6, maxBorderY) - 6 - iniY);
-                    const uint64_t off = (uint64_t)(pyrOff[l] * B) + (uint64_t)iniY * V.pitch + (uint64_t)(iniX - 1);
-                    const int cidx = bi * V.nCols + bj;
-                    uint32_t r[16] = {0};
-                    r[0] = (uint32_t)l | ((uint32_t)ncx << 4) | ((uint32_t)ncy << 8);
-                    r[1] = (uint32_t)iniX | ((uint32_t)iniY << 16);
-                    r[2] = (uint32_t)BW | ((uint32_t)BH << 8) | ((uint32_t)V.wCell << 16) | ((uint32_t)V.hCell << 24);
-                    r[3] = (uint32_t)V.pitch;
-                    r[4] = (uint32_t)off; r[5] = (uint32_t)(off >> 32);
-                    r[6] = (uint32_t)V.fstride;
-                    r[7] = (uint32_t)(V.cellCandOff + (int64_t)cidx * V.cellCap);
-                    r[8] = (uint32_t)V.nCols | ((uint32_t)V.cellCap << 16);
-                    r[9] = (uint32_t)(V.cellBase + cidx);
-                    r[10] = (uint32_t)(65535 / V.wCell + 1) | ((uint32_t)(65535 / V.hCell + 1) << 16);
-                    bt.insert(bt.end(), r, r + 16);
-                }
-        }
-        P.blockTab = nullptr; P.totalBlocks = 0;
-        if (ok && (uint64_t)pyrFrame * B < ((uint64_t)1 << 40)) {
-            if ((rc = ensure(c, c->blockTab, bt.size() * 4 + 8 * 64))) return rc;      // + 8 records of slack
-            PG_HIP(c, hipMemcpy(c->blockTab.p, bt.data(), bt.size() * 4, hipMemcpyHostToDevice));
-            P.blockTab = (const uint32_t*)c->blockTab.p;
-            P.totalBlocks = (int)(bt.size() / 16);
-        }
-    }
-#endif
+    P.fastTilePitch = c->fastTilePitch; P.fastWpb = c->fastWpb;
     P.cand = (uint32_t*)c->cand.p; P.sel = (uint32_t*)c->sel.p;
     P.nodeScratch = (int32_t*)c->nodes.p;
     P.candCount = (int32_t*)c->counters.p;
@@ -516,7 +475,7 @@ int run_batch(pgorb_ctx* c, const uint8_t* d_gray, bool resident_in_level0, int 
     if (!foldClear) PG_HIP(c, hipMemsetAsync(P.status, 0, 16, s));
     hipEvent_t* ev = (c->profExtract < c->profMax) ? &c->evExtract[5 * (size_t)c->profExtract] : nullptr;
     if (ev) PG_HIP(c, hipEventRecord(ev[0], s));
-    if (c->pipePyr && P.nlevels > 1 && pg_fast_is_cell_form(P)) {
+    if (c->pipePyr && P.nlevels > 1) {
         // K1 is HBM-bound and K2 VALU-issue-bound, and K2 of level l only needs level l: the resize chain runs on a
         // high-priority side stream, K2 level by level on another, each level's K2 behind the launch that wrote it.
         // (Stage events: "pyramid" = start .. end of the chain, "fast" = end of the chain .. end of K2: they overlap.)
@@ -546,7 +505,7 @@ int run_batch(pgorb_ctx* c, const uint8_t* d_gray, bool resident_in_level0, int 
         if (ev) PG_HIP(c, hipEventRecord(ev[1], s));
         PG_HIP(c, hipStreamWaitEvent(s, c->evFastDone, 0));
         if (ev) PG_HIP(c, hipEventRecord(ev[2], s));
-    } else if (c->pipeLev && P.nlevels > 1 && pg_fast_is_cell_form(P)) {
+    } else if (c->pipeLev && P.nlevels > 1) {
         // K2 group by group on the caller's stream; K3 of a group on a second stream as soon as its K2 is done, K4-6 of a
         // group on a third as soon as its K3 is done: the latency-bound quadtree of one group runs under the issue-bound
         // kernels of the others.  (Stage events: "fast" = K2 of all groups, "quadtree" = the wait for the side streams.)
@@ -613,6 +572,24 @@ int pg_ctx_stage(pgorb_ctx* c, int which, size_t bytes, void** p)
     *p = a->p;
     return 0;
 }
+// The matchers' scratch arena (lists, bins) for work queued on stream `s`: SearchForInitialization, the projection searches and
+// SearchByBoW share ONE arena per context, and a caller may queue them on different streams -- the new user waits for the
+// previous user's event (round-3 advisory: BoW's memset of the bins could overtake a projection call still reading its lists).
+// pg_ctx_scratch_done records the event after the last launch that touches the arena.
+int pg_ctx_scratch(pgorb_ctx* c, size_t bytes, hipStream_t s, void** p)
+{
+    int rc = pg_ctx_stage(c, 3, bytes, p);
+    if (rc) return rc;
+    if (c->sfiUsed && c->sfiStream != s) PG_HIP(c, hipStreamWaitEvent(s, c->evSfi, 0));
+    return 0;
+}
+int pg_ctx_scratch_done(pgorb_ctx* c, hipStream_t s)
+{
+    if (!c->evSfi) PG_HIP(c, hipEventCreateWithFlags(&c->evSfi, hipEventDisableTiming));
+    PG_HIP(c, hipEventRecord(c->evSfi, s));
+    c->sfiStream = s; c->sfiUsed = true;
+    return 0;
+}
 int pg_ctx_vocab_store(pgorb_ctx* c, const void* src, size_t nbytes, bool src_on_device, hipStream_t s)
 {
     PG_HIP(c, hipSetDevice(c->prm.device));
@@ -677,6 +654,7 @@ int pgorb_create(const pgorb_params* p, pgorb_ctx** out)
 
     pgorb_ctx* c = new pgorb_ctx();
     c->prm = *p;
+    c->mx = pg_match_default_opts();
     // ORBextractor.cc:415-446
     const int L = p->nlevels;
     c->scaleFactor = p->scale_factor;
@@ -707,7 +685,7 @@ void pgorb_destroy(pgorb_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->prm.device);
     while (!c->streams.empty()) pgorb_stream_destroy(c->streams.back());      // a stream holds a pointer to its context
-    Arena* all[] = {&c->blockTab, &c->cellTab, &c->cellTabBal, &c->cellCand, &c->cellCount, &c->pyr, &c->cand, &c->sel, &c->nodes, &c->counters, &c->tables,
+    Arena* all[] = {&c->cellTab, &c->cellTabBal, &c->cellCand, &c->cellCount, &c->pyr, &c->cand, &c->sel, &c->nodes, &c->counters, &c->tables,
                     &c->stageKps, &c->stageDesc, &c->stageN, &c->stageA, &c->stageB, &c->stageOut, &c->stageSfi, &c->vocab, &c->xdesc};
     for (Arena* a : all) if (a->p) (void)hipFree(a->p);
     if (c->sPyr) {
@@ -723,6 +701,7 @@ void pgorb_destroy(pgorb_ctx* c)
         for (int l = 0; l < PG_MAXL; l++) { (void)hipEventDestroy(c->evGrpFast[l]); (void)hipEventDestroy(c->evGrpQt[l]); }
     }
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->evSfi) (void)hipEventDestroy(c->evSfi);
     for (hipEvent_t e : c->evExtract) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->evMatch) (void)hipEventDestroy(e);
     delete c;
@@ -946,8 +925,8 @@ int pgorb_hamming_best2(pgorb_ctx* c, const uint8_t* a, int na, const uint8_t* b
     int32_t* d_idx = (int32_t*)c->stageOut.p;
     uint16_t* d_b1 = (uint16_t*)(d_idx + na);
     uint16_t* d_b2 = d_b1 + na;
-    if ((rc = ensure(c, c->xdesc, pg_match_scratch_bytes(nb, 1) + 16))) return rc;
-    pg_launch_best2((uint8_t*)c->stageA.p, na, (uint8_t*)c->stageB.p, nb, (uint8_t*)c->xdesc.p, d_idx, d_b1, d_b2, 0);
+    if ((rc = ensure(c, c->xdesc, pg_match_scratch_bytes(c->mx, nb, 1) + 16))) return rc;
+    pg_launch_best2(c->mx, (uint8_t*)c->stageA.p, na, (uint8_t*)c->stageB.p, nb, (uint8_t*)c->xdesc.p, d_idx, d_b1, d_b2, 0);
     PG_HIP(c, hipGetLastError());
     PG_HIP(c, hipMemcpy(best_idx, d_idx, (size_t)na * 4, hipMemcpyDeviceToHost));
     PG_HIP(c, hipMemcpy(best, d_b1, (size_t)na * 2, hipMemcpyDeviceToHost));
@@ -965,10 +944,10 @@ int pgorb_match_batch_device(pgorb_ctx* c, const uint8_t* d_desc, const int32_t*
     PG_HIP(c, hipSetDevice(c->prm.device));
     if (cap >= (1 << 20)) return fail(c, PGORB_E_LIMIT, "more than 2^20 descriptors per frame");
     int rc;
-    if ((rc = ensure(c, c->xdesc, pg_match_scratch_bytes(cap, npairs) + 16))) return rc;
+    if ((rc = ensure(c, c->xdesc, pg_match_scratch_bytes(c->mx, cap, npairs) + 16))) return rc;
     hipEvent_t* ev = (c->profMatch < c->profMax) ? &c->evMatch[2 * (size_t)c->profMatch] : nullptr;
     if (ev) PG_HIP(c, hipEventRecord(ev[0], (hipStream_t)stream));
-    pg_launch_match_batch(d_desc, d_n, cap, d_pq, d_pt, npairs, (uint8_t*)c->xdesc.p, d_best_idx, d_best, d_second,
+    pg_launch_match_batch(c->mx, d_desc, d_n, cap, d_pq, d_pt, npairs, (uint8_t*)c->xdesc.p, d_best_idx, d_best, d_second,
                           (hipStream_t)stream);
     if (ev) { PG_HIP(c, hipEventRecord(ev[1], (hipStream_t)stream)); c->profMatch++; }
     PG_HIP(c, hipGetLastError());
@@ -992,36 +971,43 @@ int pgorb_profile_begin(pgorb_ctx* c, int max_calls)
 int pgorb_set_option(pgorb_ctx* c, const char* key, int value)
 {
     if (!key) return PGORB_E_ARG;
-    if (!strcmp(key, "matcher")) { pg_match_set_popcount(value); return 0; }
-    if (!strcmp(key, "match_mode")) return pg_match_set_mode(value) ? (c ? fail(c, PGORB_E_ARG, "match_mode must be -1, 0, 1 or 2") : PGORB_E_ARG) : 0;
-    if (!strcmp(key, "fast_kernel")) {
-        if (pg_fast_set_kernel(value)) return c ? fail(c, PGORB_E_ARG, "fast_kernel %d: the block form is a developer build (make EXTRA=-DPGORB_FAST_BLOCKS)", value) : PGORB_E_ARG;
+    if (!c) return PGORB_E_ARG;                               // every option belongs to a context (round 4: no process-wide state)
+    if (!strcmp(key, "matcher")) { c->mx.popcount = value ? 1 : pg_match_default_opts().popcount; return 0; }     // 0 = what the environment says
+    if (!strcmp(key, "match_mode")) {
+        if (value < -1 || value > 2) return fail(c, PGORB_E_ARG, "match_mode must be -1, 0, 1 or 2");
+        c->mx.mode = value;
         return 0;
     }
-    if (c && !strcmp(key, "pipeline_pyramid")) { c->pipePyr = value ? 1 : 0; return 0; }
-    if (c && !strcmp(key, "pipeline_levels")) { c->pipeLev = value & ((1 << PG_MAXL) - 2); return 0; }
-    if (c && !strcmp(key, "pipeline_levels_priority")) { c->pipeLevPrio = value ? 1 : 0; return 0; }
-    if (c && (!strcmp(key, "fast_block_cx") || !strcmp(key, "fast_block_cy"))) {
-        if (value < 1 || value > 4) return fail(c, PGORB_E_ARG, "%s must be 1..4", key);
-        (key[12] == 'x' ? c->fastBlockCX : c->fastBlockCY) = value;
-        c->planValid = false;                              // the block table is part of the plan
+    if (!strcmp(key, "fast_tile_pitch")) {
+        if (value != 0 && (value < 48 || value > 128 || value % 16)) return fail(c, PGORB_E_ARG, "fast_tile_pitch must be 0 (automatic) or 48, 64, ... 128");
+        c->fastTilePitch = value; c->plan.fastTilePitch = value;
         return 0;
     }
-    return c ? fail(c, PGORB_E_ARG, "unknown option '%s'", key) : PGORB_E_ARG;
+    if (!strcmp(key, "fast_waves_per_block")) {
+        if (value != 1 && value != 4) return fail(c, PGORB_E_ARG, "fast_waves_per_block must be 1 or 4");
+        c->fastWpb = value; c->plan.fastWpb = value;
+        return 0;
+    }
+    if (!strcmp(key, "pipeline_pyramid")) { c->pipePyr = value ? 1 : 0; return 0; }
+    if (!strcmp(key, "pipeline_levels")) { c->pipeLev = value & ((1 << PG_MAXL) - 2); return 0; }
+    if (!strcmp(key, "pipeline_levels_priority")) { c->pipeLevPrio = value ? 1 : 0; return 0; }
+    return fail(c, PGORB_E_ARG, "unknown option '%s'", key);
 }
 
 int pgorb_get_option(const pgorb_ctx* c, const char* key)
 {
-    if (!key) return PGORB_E_ARG;
-    if (!strcmp(key, "fast_kernel")) return pg_fast_get_kernel();
-    if (c && !strcmp(key, "pipeline_pyramid")) return c->pipePyr;
-    if (c && !strcmp(key, "pipeline_levels")) return c->pipeLev;
-    if (c && !strcmp(key, "fast_block_cx")) return c->fastBlockCX;
-    if (c && !strcmp(key, "fast_block_cy")) return c->fastBlockCY;
-    return PGORB_E_ARG;
+    if (!key || !c) return PGORB_OPTION_UNKNOWN;
+    if (!strcmp(key, "fast_tile_pitch")) return c->fastTilePitch;
+    if (!strcmp(key, "fast_waves_per_block")) return c->fastWpb;
+    if (!strcmp(key, "matcher")) return c->mx.popcount;
+    if (!strcmp(key, "match_mode")) return c->mx.mode;
+    if (!strcmp(key, "pipeline_pyramid")) return c->pipePyr;
+    if (!strcmp(key, "pipeline_levels")) return c->pipeLev;
+    if (!strcmp(key, "pipeline_levels_priority")) return c->pipeLevPrio;
+    return PGORB_OPTION_UNKNOWN;
 }
 
-int pgorb_matcher_is_popcount(const pgorb_ctx*, int cap_per_frame) { return pg_match_uses_popcount(cap_per_frame) ? 1 : 0; }
+int pgorb_matcher_is_popcount(const pgorb_ctx* c, int cap_per_frame) { return pg_match_uses_popcount(c ? c->mx : pg_match_default_opts(), cap_per_frame) ? 1 : 0; }
 
 int pgorb_profile_read(pgorb_ctx* c, double* ms)
 {
@@ -1208,7 +1194,7 @@ int pgorb_stream_create_ingest(pgorb_ctx* c, int src_w, int src_h, int channels,
     ok = ok && hipMalloc((void**)&s->dPrevKps, cap * sizeof(pgorb_keypoint)) == hipSuccess;
     ok = ok && hipMemcpy(s->dPq, pq.data(), B * 4, hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemcpy(s->dPt, pt.data(), B * 4, hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && ensure(c, c->xdesc, pg_match_scratch_bytes(s->cap, batch) + 16) == 0;
+    ok = ok && ensure(c, c->xdesc, pg_match_scratch_bytes(c->mx, s->cap, batch) + 16) == 0;
     if (!ok) { pgorb_stream_destroy(s); return fail(c, PGORB_E_HIP, "pgorb_stream_create: allocation failed"); }
     c->streams.push_back(s);
     *out = s;
@@ -1323,7 +1309,10 @@ static int stream_submit_queue(pgorb_stream* s, pgorb_stream::Slot& sl, int nfra
         rc = run_batch(c, sl.dIn, false, nframes, s->w, s->h, s->w, (int64_t)fbytes, dK + cap, dD + cap * 32, s->cap, dN + 1, s->sRun);
     }
     if (rc) return rc;
-    pg_launch_match_batch(dD, dN, s->cap, s->dPq, s->dPt, nframes, (uint8_t*)c->xdesc.p, (int32_t*)(sl.dOut + s->offI),
+    // the slab form (match_mode 0) may have been selected after the stream was created: size its arena for THIS launch
+    // (ensure() only ever grows; hipFree of the old arena waits for the work that still uses it)
+    if ((rc = ensure(c, c->xdesc, pg_match_scratch_bytes(c->mx, s->cap, nframes) + 16))) return rc;
+    pg_launch_match_batch(c->mx, dD, dN, s->cap, s->dPq, s->dPt, nframes, (uint8_t*)c->xdesc.p, (int32_t*)(sl.dOut + s->offI),
                           (uint16_t*)(sl.dOut + s->offB1), (uint16_t*)(sl.dOut + s->offB2), s->sRun);
     if (s->fe) {
         // what the tracking thread does with a fresh Frame, for the whole batch: the 64x48 grid of every frame

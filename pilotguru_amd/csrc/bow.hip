@@ -75,6 +75,10 @@ bool view_blob(const uint8_t* b, size_t nbytes, BlobView& v)
     }
     for (size_t i = 0; i + 1 < n; i++)
         if (v.children[i] < 1 || (size_t)v.children[i] >= n) return false;
+    // child lists agree with the parent array: no cycle on any path from the root (see k_vocab_validate)
+    for (size_t i = 0; i < n; i++)
+        for (int64_t j = 0; j < v.nchild[i]; j++)
+            if ((size_t)v.parent[v.children[v.child0[i] + j]] != i) return false;
     return true;
 }
 
@@ -116,7 +120,11 @@ int pg_ctx_stage(pgorb_ctx* c, int which, size_t bytes, void** p);
 int pg_ctx_device(pgorb_ctx* c);
 
 // structural checks of a blob that is already on the device (the host path runs view_blob): child ranges inside
-// children[], child ids and parents inside [0, n); *bad != 0 when any node violates them
+// children[], child ids and parents inside [0, n), and every child list agrees with the parent array
+// (parent[children[c0 + j]] == i).  With child ids >= 1 that rules out cycles on any path from the root: a node is
+// only ever entered from its one parent, and the root is never entered -- so k_bow_transform's descent terminates
+// on every blob that passes (round-3 advisory: in-range but cyclic links used to pass and hang the kernel).
+// *bad != 0 when any node violates them
 __global__ __launch_bounds__(256) void k_vocab_validate(const uint8_t* __restrict__ blob, int n, int* __restrict__ bad)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -134,6 +142,11 @@ __global__ __launch_bounds__(256) void k_vocab_validate(const uint8_t* __restric
     if (i && (parent[i] < 0 || parent[i] >= n)) ok = false;
     if (i == 0 && nc < 1) ok = false;
     if (i + 1 < n && (children[i] < 1 || children[i] >= n)) ok = false;
+    if (ok)
+        for (long long j = 0; j < nc; j++) {
+            const int ch = children[c0 + j];
+            if (ch < 1 || ch >= n || parent[ch] != i) { ok = false; break; }
+        }
     if (!ok) atomicExch(bad, 1);
 }
 
@@ -175,7 +188,7 @@ __global__ __launch_bounds__(64) void k_bow_transform(const uint8_t* __restrict_
         }
         cur = best;
         if (level == nid_level) nid = (uint32_t)cur;
-    } while (nchild[cur] > 0);                              // isLeaf() == children.empty() (:328)
+    } while (nchild[cur] > 0 && level < nnodes);            // isLeaf() == children.empty() (:328); (the bound: belt and braces, the validators rule cycles out)
     word[i] = (uint32_t)vword[cur];
     weight[i] = vweight[cur];
     node[i] = nid;

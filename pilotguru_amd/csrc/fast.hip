@@ -704,438 +704,17 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgPlan P, int 
     FT_TS(3);
 }
 
-#ifdef PGORB_FAST_BLOCKS   // developer build (make EXTRA=-DPGORB_FAST_BLOCKS): the tile-shape sweep of BASELINE.json configs[2]; it lost on every shape and is not part of the product library
-// ================================================================================================
-// K2, block form: one workgroup of 256 threads (4 waves) per BLOCK of CX x CY cells (4 x 2 for the
-// common 30..32-px cells), all blocks of all levels of all frames in one grid.
-//
-// Why: in the one-wave-per-cell form every cell paid its own exact-score round, NMS round and wave
-// prologue with ~20 of 64 lanes busy (1.6 % of the pixels pass the necessary test) -- 350 of the 682
-// VALU instructions per cell (profiles/r01_i_pmc.txt).  The FAST score of a pixel does not depend on
-// the cell it lies in; only the NMS rim ("outside the cell interior counts as 0") and the iniThFAST ->
-// minThFAST fallback are per cell (ORBextractor.cc:789-829).  So the block stages ONE tile (less halo
-// than eight private ones: 2.6 KB of LDS per cell instead of 4.9), runs the necessary test over the whole
-// block interior with all 256 lanes, pools the survivors of all its cells in one list, scores them in
-// full rounds, and only then sorts things out per cell:
-//   * the score map gives every cell a private one-pixel zero gutter (map x = ix + cx + 1,
-//     map y = iy + cy + 1), so "neighbour outside the cell = 0" needs no masks;
-//   * survivors are emitted into their cell's own slot range through a per-cell LDS counter;
-//   * cells that came back empty at iniThFAST are retried at minThFAST together: the second necessary
-//     test (four ring pairs) is masked to the pixels of those cells.  Scores written in the first
-//     pass stay valid (a FAST score does not depend on the threshold).
-// Lane -> pixel map of the necessary test: thread = (quad q = tid & 31, row r = tid >> 5); a wave's
-// ds_read_b32 covers two tile rows x 32 consecutive dwords: the 32 lanes of a bank group read 32
-// consecutive banks (the 48-byte pitch of the cell form put rows r and r + 5 on the same banks).
-// Tile pitch 144 B (<= 4 * 32 + 6 + 1 pad, 16-byte chunks for LDS-DMA), map pitch 136.
-#define FB_TP 144
-#define FB_MP 136
-#define FB_LCAP 1024               // pooled candidate list (u16 each)
-#define FB_T 256
-
-// block record, 16 dwords (PgPlan::blockTab, built in api.hip):
-//   w0 level | ncx << 4 | ncy << 8        (cells of the level grid this block covers)
-//   w1 iniX | iniY << 16                  (first cell's window origin)
-//   w2 BW | BH << 8 | wCell << 16 | hCell << 24     (BW x BH = interior pixels of the block, may be 0)
-//   w3 level pitch      w4,w5 byte offset of (iniY, iniX - 1) in frame 0, relative to pyrBase
-//   w6 level frame stride               w7 slot offset of the first cell in the frame's slab
-//   w8 nCols | cellCap << 16            w9 index of the first cell in the frame's cellCount array
-//   w10 invW = ceil(65536 / wCell) | invH << 16
-
-// The necessary test over a rectangle of the block interior: columns [x0, x1), rows [y0, y1).  `nthr` threads
-// (thread index ti; 256 for the whole block, 64 when one wave takes one cell) are laid out as nq quads per row x
-// rps rows per step; quads are the tile's aligned dwords, so a rectangle that starts off a dword boundary takes
-// one quad more and masks the columns outside [x0, x1).  STRONG (wave-uniform, run time: one instance of the code
-// serves both passes) adds the diagonal pairs -- the minThFAST pass.  Survivors are appended to the block's pooled
-// list: per-lane counts -> wave prefix sum (DPP) -> ONE LDS atomic per wave reserves the wave's range (list order
-// is irrelevant: NMS works on the score map).
-__device__ __forceinline__ void fb_quick(const bool STRONG, const uint8_t* tile, int x0, int x1, int y0, int y1, int t,
-                                         uint16_t* list, int* listCount, int ti, int lane, int nq, int invNq, int rps)
-{
-    const int lr = (ti * invNq) >> 16, lq = ti - lr * nq;          // ti / nq, ti % nq
-    const int q0 = x0 >> 2;
-    const int px0 = 4 * (q0 + lq);                                  // first pixel (block interior x) of this thread's quad
-    const uint32_t K15 = 0x80008000u;
-    const uint32_t Kd = (uint32_t)(0x8000 - t - 1) * 0x00010001u;
-    uint32_t colMask = 0;
-    if (lr < rps) {
-        if (px0 + 0 >= x0 && px0 + 0 < x1) colMask |= 1u << 14;
-        if (px0 + 1 >= x0 && px0 + 1 < x1) colMask |= 1u << 15;
-        if (px0 + 2 >= x0 && px0 + 2 < x1) colMask |= 1u << 30;
-        if (px0 + 3 >= x0 && px0 + 3 < x1) colMask |= 1u << 31;
-    }
-    uint32_t acc[2] = {0u, 0u};
-    const uint8_t* base = tile + 4 + px0;                           // interior column px0 of tile row 0
-#pragma unroll
-    for (int wsel = 0; wsel < 2; wsel++) {
-        uint32_t a = 0;
-        for (int step = 0; step < 8; step++) {
-            const int iy = y0 + (wsel * 8 + step) * rps + lr;
-            if (y0 + (wsel * 8 + step) * rps >= y1) break;          // wave-uniform
-            uint32_t m = 0;
-            if (iy < y1 && colMask) {
-                const uint32_t* rc = reinterpret_cast<const uint32_t*>(base + (iy + 3) * FB_TP);
-                const uint32_t* ru = reinterpret_cast<const uint32_t*>(base + iy * FB_TP);
-                const uint32_t* rd = reinterpret_cast<const uint32_t*>(base + (iy + 6) * FB_TP);
-                const uint32_t C = rc[0], Lw = rc[-1], Rw = rc[1], U = ru[0], D = rd[0];
-                const uint32_t OD = 0x0c030c01u;
-                const uint32_t X20 = 0x0c040c02u, X31 = 0x0c050c03u;
-                const uint32_t M02 = 0x00FF00FFu;                   // even bytes -> 16-bit fields with a fast-class v_and_b32
-                const uint32_t Ce = C & M02, Co = __builtin_amdgcn_perm(C, C, OD);
-                const uint32_t Ue = U & M02, Uo = __builtin_amdgcn_perm(U, U, OD);
-                const uint32_t De = D & M02, Do = __builtin_amdgcn_perm(D, D, OD);
-                const uint32_t W12e = __builtin_amdgcn_perm(Lw, Lw, OD);
-                const uint32_t W4o = Rw & M02;
-                const uint32_t W12o = __builtin_amdgcn_perm(C, Lw, X20);
-                const uint32_t W4e = __builtin_amdgcn_perm(Rw, C, X31);
-                uint32_t dkE = pg_pkmax(pg_pkmin(De, Ue), pg_pkmin(W4e, W12e)), brE = pg_pkmin(pg_pkmax(De, Ue), pg_pkmax(W4e, W12e));
-                uint32_t dkO = pg_pkmax(pg_pkmin(Do, Uo), pg_pkmin(W4o, W12o)), brO = pg_pkmin(pg_pkmax(Do, Uo), pg_pkmax(W4o, W12o));
-                if (STRONG) {
-                    const uint32_t* rp = reinterpret_cast<const uint32_t*>(base + (iy + 5) * FB_TP);
-                    const uint32_t* rm = reinterpret_cast<const uint32_t*>(base + (iy + 1) * FB_TP);
-                    const uint32_t Pc = rp[0], Pl = rp[-1], Pr = rp[1], Mc = rm[0], Ml = rm[-1], Mr = rm[1];
-                    const uint32_t r2e = __builtin_amdgcn_perm(Pr, Pc, X20), r14e = __builtin_amdgcn_perm(Pc, Pl, X20);
-                    const uint32_t r6e = __builtin_amdgcn_perm(Mr, Mc, X20), r10e = __builtin_amdgcn_perm(Mc, Ml, X20);
-                    const uint32_t r2o = __builtin_amdgcn_perm(Pr, Pc, X31), r14o = __builtin_amdgcn_perm(Pc, Pl, X31);
-                    const uint32_t r6o = __builtin_amdgcn_perm(Mr, Mc, X31), r10o = __builtin_amdgcn_perm(Mc, Ml, X31);
-                    dkE = pg_pkmax(dkE, pg_pkmax(pg_pkmin(r2e, r10e), pg_pkmin(r6e, r14e)));
-                    brE = pg_pkmin(brE, pg_pkmin(pg_pkmax(r2e, r10e), pg_pkmax(r6e, r14e)));
-                    dkO = pg_pkmax(dkO, pg_pkmax(pg_pkmin(r2o, r10o), pg_pkmin(r6o, r14o)));
-                    brO = pg_pkmin(brO, pg_pkmin(pg_pkmax(r2o, r10o), pg_pkmax(r6o, r14o)));
-                }
-                const uint32_t darkE = (Ce + Kd) - dkE, brightE = brE + (Kd - Ce);
-                const uint32_t darkO = (Co + Kd) - dkO, brightO = brO + (Kd - Co);
-                m = ((((darkE | brightE) & K15) >> 1) | ((darkO | brightO) & K15)) & colMask;
-            }
-            a |= m >> (2 * step);
-        }
-        acc[wsel] = a;
-    }
-    const int cnt = __popc(acc[0]) + __popc(acc[1]);
-    const int incl = wave_incl_scan(cnt);
-    const int wtot = __builtin_amdgcn_readlane(incl, 63);
-    int base_off = 0;
-    if (wtot) {
-        if (lane == 0) base_off = atomicAdd(listCount, wtot);
-        base_off = __builtin_amdgcn_readfirstlane(base_off);
-    }
-    int off = base_off + incl - cnt;
-#pragma unroll
-    for (int wsel = 0; wsel < 2; wsel++) {
-        uint32_t bits = acc[wsel];
-        while (bits) {
-            const int bpos = __ffs((int)bits) - 1;
-            bits &= bits - 1;
-            const int st = wsel * 8 + 7 - ((bpos & 15) >> 1);
-            const int iy = y0 + st * rps + lr;
-            if (off < FB_LCAP) list[off] = (uint16_t)((iy << 8) | (px0 + ((bpos >> 4) << 1) + (bpos & 1)));
-            off++;
-        }
-    }
-}
-
-// exact scores of the pooled list -> score map (per-cell gutters)
-__device__ __forceinline__ void fb_score(const uint8_t* tile, uint8_t* smap, const uint16_t* list, int nlist,
-                                         int t, int tid, int invW, int invH)
-{
-    for (int i = tid; i < nlist; i += FB_T) {
-        const int p = list[i];
-        const int iy = p >> 8, ix = p & 0xFF;
-        const uint8_t* cp = tile + (iy + 3) * FB_TP + 4 + ix;
-        int d[16];
-        ring_load(cp, FB_TP, cp[0], d);
-        const int sc = fast_score16(d);
-        if (sc >= t) {
-            const int cx = (ix * invW) >> 16, cy = (iy * invH) >> 16;
-            smap[(iy + cy + 1) * FB_MP + ix + cx + 1] = (uint8_t)sc;
-        }
-    }
-}
-
-// 3x3 strict NMS on the score map.  Two-level short circuit: most list entries are not corners (s == 0, one
-// byte read); corners read their eight neighbours at once.
-__device__ __forceinline__ int fb_nms(const uint8_t* smap, int my, int mx)
-{
-    const uint8_t* m = smap + my * FB_MP + mx;
-    const int s = m[0];
-    if (!s) return 0;
-    const int a = imax3(m[-FB_MP - 1], m[-FB_MP], m[-FB_MP + 1]);
-    const int b = imax3(m[FB_MP - 1], m[FB_MP], m[FB_MP + 1]);
-    const int c = imax3(m[-1], m[1], max(a, b));
-    return s > c ? s : 0;
-}
-
-#ifdef PGORB_FB_TIMING
-// developer build only (make EXTRA=-DPGORB_FB_TIMING): 10 ns ticks of wall_clock64 per phase of a block, written by
-// thread 0 of every block of frame 0; read back by tools/experiments/fb_timing.py
-#define FBT_MAXB 4096
-__device__ unsigned int pg_fbt_log[FBT_MAXB * 16];
-#define FBT(k) do { const unsigned long long t1_ = wall_clock64(); if (tid == 0 && frame == 0 && blk < FBT_MAXB) pg_fbt_log[blk * 16 + (k)] = (unsigned)(t1_ - fbt_t0); } while (0)
-extern "C" int pgorb_debug_fb_times(unsigned int* out, int nblocks)
-{
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pg_fbt_log), sizeof(unsigned) * 16 * (size_t)nblocks) == hipSuccess ? 0 : -1;
-}
-#else
-#define FBT(k) do {} while (0)
-#endif
-
-// developer statistics (PGORB_FAST_DBGSKIP=9): [0] blocks, [1] pooled candidates pass 0, [2] overflowing blocks,
-// [3] blocks with a minThFAST pass, [4] pooled candidates pass 1, [5] survivors
-__device__ unsigned long long pg_fb_stats[8];
-extern "C" int pgorb_debug_fast_stats(unsigned long long* out, int reset)
-{
-    if (reset) { unsigned long long z[8] = {0}; return hipMemcpyToSymbol(HIP_SYMBOL(pg_fb_stats), z, sizeof(z)) == hipSuccess ? 0 : -1; }
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pg_fb_stats), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : -1;
-}
-
-// slow path (strips): NMS over every interior pixel of the cells in `cellMask`
-__device__ __noinline__ void fb_dense_nms(const uint8_t* smap, int BW, int BH, int invW, int invH, uint32_t cellMask,
-                                          int* lcnt, uint32_t* out, int nCols, int cellCap, int xoff, int yoff,
-                                          int32_t* status, int tid)
-{
-    for (int iy = tid >> 7; iy < BH; iy += 2) {
-        const int ix = tid & 127;
-        if (ix < BW) {
-            const int cx = (ix * invW) >> 16, cy = (iy * invH) >> 16;
-            const int sc = ((cellMask >> (4 * cy + cx)) & 1u) ? fb_nms(smap, iy + cy + 1, ix + cx + 1) : 0;
-            if (sc) {
-                const int pos = atomicAdd(&lcnt[4 * cy + cx], 1);
-                if (pos < cellCap)
-                    out[(cy * nCols + cx) * cellCap + pos] = (uint32_t)(ix + xoff) | ((uint32_t)(iy + yoff) << 12) | ((uint32_t)sc << 24);
-                else
-                    atomicExch(status, PGORB_E_OVERFLOW);
-            }
-        }
-    }
-}
-
-__global__ __launch_bounds__(FB_T, 7) void k_fast_blocks(const PgPlan P, int tileRows, int mapRows, int blocksPerXcd, int dbgSkip)
-{
-    const int tid = threadIdx.x;
-    const int frame = blockIdx.y;
-    const int blk = (blockIdx.x & 7) * blocksPerXcd + (blockIdx.x >> 3);      // XCD-contiguous
-#ifdef PGORB_FB_TIMING
-    const unsigned long long fbt_t0 = wall_clock64();
-#endif
-    const uint8_t* l0img = P.lvl[0].img;
-    const int l0pitch = P.lvl[0].pitch;
-    const int64_t l0fstride = P.lvl[0].fstride;
-    const uint8_t* pyrBase = P.pyrBase;
-    const uint32_t* recp = P.blockTab + 16 * (int64_t)blk;         // (the table has 8 records of slack)
-    const int totalBlocks = P.totalBlocks;
-    asm volatile("" :: "s"(l0img), "s"(l0pitch), "s"(l0fstride), "s"(pyrBase), "s"(totalBlocks));
-    typedef uint32_t pg_u32x16 __attribute__((ext_vector_type(16)));
-    pg_u32x16 rec;
-    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rec) : "s"(recp) : "memory");
-    if (blk >= totalBlocks) return;
-    const int ncx = (rec[0] >> 4) & 15, ncy = (rec[0] >> 8) & 15;
-    const int iniX = rec[1] & 0xFFFF, iniY = rec[1] >> 16;
-    const int BW = rec[2] & 0xFF, BH = (rec[2] >> 8) & 0xFF, wCell = (rec[2] >> 16) & 0xFF, hCell = rec[2] >> 24;
-    const int nCols = rec[8] & 0xFFFF, cellCap = rec[8] >> 16;
-    const int invW = rec[10] & 0xFFFF, invH = rec[10] >> 16;
-    int32_t* cellCnt = P.cellCount + (int64_t)frame * P.totalCells + rec[9];
-
-    uint8_t* tile = pg_fast_smem;                                   // [tileRows][FB_TP]
-    uint8_t* smap = tile + tileRows * FB_TP;                        // [mapRows][FB_MP]
-    uint16_t* list = reinterpret_cast<uint16_t*>(smap + mapRows * FB_MP);     // [FB_LCAP]
-    int* lcnt = reinterpret_cast<int*>(list + FB_LCAP);             // [16] per-cell survivor counters
-    int* listCount = lcnt + 16;                                     // [2] one per pass
-
-    if (BW <= 0 || BH <= 0) {                                       // every cell of the block is skipped (:794, :803)
-        if (tid < ncx * ncy) cellCnt[(tid / ncx) * nCols + (tid % ncx)] = 0;
-        return;
-    }
-    const bool l0 = (rec[0] & 15u) == 0;
-    const int pitch = l0 ? l0pitch : (int)rec[3];
-    const uint8_t* win = l0 ? l0img + (int64_t)frame * l0fstride + (int64_t)iniY * l0pitch + (iniX - 1)
-                            : pyrBase + (((uint64_t)rec[5] << 32) | rec[4]) + (uint64_t)frame * rec[6];
-    // (1) stage the block's window: BH + 6 rows of 9 sixteen-byte chunks, LDS-DMA, byte-unaligned source;
-    // thread g of a pass writes LDS bytes [16 g, 16 g + 16) = (row g / 9, chunk g % 9)
-    {
-        const int H = BH + 6, total = H * 9;
-        const int wbase = tid & ~63;
-        for (int g0 = 0; g0 < total; g0 += FB_T) {
-            const int g = g0 + tid;
-            const int r = (g * 7282) >> 16, ch = g - 9 * r;          // g / 9, g % 9 (g < 2048)
-            if (g0 + wbase < total) {                                // wave-uniform: the DMA's LDS base is per wave
-                const uint8_t* src = win + (int64_t)r * pitch + ch * 16;
-                if (g < total)
-                    __builtin_amdgcn_global_load_lds((pg_gptr_t)src, (pg_lptr_t)(tile + (g0 + wbase) * 16), 16, 0, 0);
-            }
-        }
-        for (int i = tid; i < (mapRows * FB_MP + 15) >> 4; i += FB_T)
-            reinterpret_cast<uint4*>(smap)[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (tid < 18) lcnt[tid] = 0;                                // per-cell counters + the two list counters
-        __builtin_amdgcn_s_waitcnt(0);
-    }
-    __syncthreads();
-
-    FBT(0);
-    if (dbgSkip == 1) return;                                       // timing experiments (PGORB_FAST_DBGSKIP): staging only
-    const int xoff = 3 + iniX - PG_EDGE, yoff = 3 + iniY - PG_EDGE;
-    uint32_t* out = P.cellCand + (int64_t)frame * P.cellCandFrame + rec[7];
-    // cells with a non-empty interior: bit 4 * cy + cx
-    uint32_t liveMask = 0;
-    for (int cy = 0; cy < ncy; cy++)
-        for (int cx = 0; cx < ncx; cx++)
-            if (cx * wCell < BW && cy * hCell < BH) liveMask |= 1u << (4 * cy + cx);
-    uint32_t emptyMask = liveMask;
-    const int lane = tid & 63, wave = tid >> 6;
-
-    for (int pass = 0; pass < 2; pass++) {
-        const int t = pass == 0 ? P.iniTh : P.minTh;
-        // Normal case: one necessary-test sweep fills the pooled list.  Only when the list would overflow (a very
-        // noisy block) the pass is redone in strips whose worst case fits the list; NMS then runs over every
-        // interior pixel of the cells of this pass instead of over the list.
-        bool strips = false;
-        for (;;) {
-            bool overflow = false;
-            if (pass == 0) {
-                // the whole block interior: 32 quads x 8 rows per step, all four waves
-                const int rstep = strips ? 8 : BH;
-                for (int r0 = 0; r0 < BH; r0 += rstep) {
-                    if (strips) {
-                        __syncthreads();
-                        if (tid == 0) listCount[0] = 0;
-                        __syncthreads();
-                    }
-                    fb_quick(false, tile, 0, BW, r0, min(r0 + rstep, BH), t, list, listCount, tid, lane, 32, 2048, 8);
-                    __syncthreads();
-                    FBT(1);
-                    if (dbgSkip == 2) return;                       // ... + the first necessary test and compaction
-                    const int nl = listCount[0];
-                    if (dbgSkip == 9 && tid == 0) {
-                        if (!strips) atomicAdd(&pg_fb_stats[0], 1ull);
-                        atomicAdd(&pg_fb_stats[1], (unsigned long long)nl);
-                        if (nl > FB_LCAP) atomicAdd(&pg_fb_stats[2], 1ull);
-                    }
-                    if (nl > FB_LCAP) { overflow = true; break; }   // (only without strips)
-                    fb_score(tile, smap, list, nl, t, tid, invW, invH);
-                }
-            } else if (!strips) {
-                // minThFAST retry: every cell that came back empty is taken by ONE wave (its 64 lanes laid out
-                // over the cell's own quads and rows, so no lane idles on settled cells), cells dealt round-robin
-                int idx = 0;
-                for (uint32_t mm = emptyMask; mm; mm &= mm - 1, idx++) {
-                    if ((idx & 3) != wave) continue;
-                    const int c = __ffs((int)mm) - 1, cx = c & 3, cy = c >> 2;
-                    const int x0 = cx * wCell, x1 = min(x0 + wCell, BW), y0 = cy * hCell, y1 = min(y0 + hCell, BH);
-                    const int nq = ((x1 + 3) >> 2) - (x0 >> 2);
-                    fb_quick(true, tile, x0, x1, y0, y1, t, list, listCount + 1, lane, lane, nq, 65535 / nq + 1, 64 / nq);
-                }
-                __syncthreads();
-                FBT(5);
-                const int nl = listCount[1];
-                if (dbgSkip == 9 && tid == 0) {
-                    atomicAdd(&pg_fb_stats[3], 1ull);
-                    atomicAdd(&pg_fb_stats[4], (unsigned long long)nl);
-                    if (nl > FB_LCAP) atomicAdd(&pg_fb_stats[2], 1ull);
-                }
-                if (nl > FB_LCAP) overflow = true;
-                else fb_score(tile, smap, list, nl, t, tid, invW, invH);
-            } else {
-                // overflow at minThFAST: cell by cell with all four waves, one step (<= 1024 pixels) per strip
-                for (uint32_t mm = emptyMask; mm; mm &= mm - 1) {
-                    const int c = __ffs((int)mm) - 1, cx = c & 3, cy = c >> 2;
-                    const int x0 = cx * wCell, x1 = min(x0 + wCell, BW), y0 = cy * hCell, y1 = min(y0 + hCell, BH);
-                    const int nq = ((x1 + 3) >> 2) - (x0 >> 2), rps = FB_T / nq;
-                    for (int r0 = y0; r0 < y1; r0 += rps) {
-                        __syncthreads();
-                        if (tid == 0) listCount[1] = 0;
-                        __syncthreads();
-                        fb_quick(true, tile, x0, x1, r0, min(r0 + rps, y1), t, list, listCount + 1, tid, lane, nq, 65535 / nq + 1, rps);
-                        __syncthreads();
-                        fb_score(tile, smap, list, min(listCount[1], FB_LCAP), t, tid, invW, invH);
-                    }
-                }
-            }
-            if (!overflow) break;
-            strips = true;
-        }
-        __syncthreads();
-        FBT(2 + 4 * pass);
-        if (dbgSkip == 4) return;
-        if (!strips) {
-            // NMS + emission into the cell's own slots
-            const int nlist = listCount[pass];
-            for (int i = tid; i < nlist; i += FB_T) {
-                const int p = list[i];
-                const int iy = p >> 8, ix = p & 0xFF;
-                const int cx = (ix * invW) >> 16, cy = (iy * invH) >> 16;
-                const int sc = fb_nms(smap, iy + cy + 1, ix + cx + 1);
-                if (sc) {
-                    const int pos = atomicAdd(&lcnt[4 * cy + cx], 1);
-                    if (pos < cellCap)
-                        out[(cy * nCols + cx) * cellCap + pos] = (uint32_t)(ix + xoff) | ((uint32_t)(iy + yoff) << 12) | ((uint32_t)sc << 24);
-                    else
-                        atomicExch(P.status, PGORB_E_OVERFLOW);          // cannot happen (survivors are never 8-adjacent)
-                }
-            }
-        } else {
-            fb_dense_nms(smap, BW, BH, invW, invH, emptyMask, lcnt, out, nCols, cellCap, xoff, yoff, P.status, tid);
-        }
-        __syncthreads();
-        FBT(3 + 4 * pass);
-        // per-cell outcome: settled cells publish their count; cells still empty go to the minThFAST pass
-        uint32_t still = 0;
-        {
-            const int c = tid & 15, cx = c & 3, cy = c >> 2;
-            const int cnt = lcnt[c];
-            const bool inGrid = cx < ncx && cy < ncy;
-            const bool wasEmpty = (emptyMask >> c) & 1u;            // (pass 0: every live cell)
-            const bool live = (liveMask >> c) & 1u;
-            if (tid < 16 && inGrid && (pass == 1 ? wasEmpty : (cnt > 0 || !live))) cellCnt[cy * nCols + cx] = cnt;
-            const unsigned long long b = __ballot(inGrid && live && wasEmpty && cnt == 0);
-            still = (uint32_t)b & 0xFFFFu;                          // lanes 0..15 of every wave hold the 16 cells
-        }
-        FBT(4 + 4 * pass);
-        if (pass == 1 || still == 0 || dbgSkip == 3) return;         // 3: no minThFAST pass
-        emptyMask = still;
-    }
-}
-
 void pg_launch_fast_cells(const PgPlan& P, int nframes, hipStream_t s, int levelBeg, int levelEnd);
 
-#endif  // PGORB_FAST_BLOCKS
+// K2 for all levels of all frames (the block form of rounds 1-3 -- one workgroup per block of cells, 1.4 x slower on every
+// shape, DESIGN.md section 6 -- left the tree in round 4)
+void pg_launch_fast(const PgPlan& P, int nframes, hipStream_t s) { pg_launch_fast_cells(P, nframes, s, 0, P.nlevels); }
 
-// 0 = one wave per cell (default: 0.915 ms per 128-frame step at 1080p), 1 = block form (1.29 ms: fewer VALU
-// instructions per pixel once the minThFAST pass runs per cell, but four barrier-separated phases per block at 7
-// workgroups per CU leave the SIMDs idle a third of the time -- DESIGN.md section 6); pgorb_set_option "fast_kernel"
-static int g_fast_kernel = 0;
-void pg_launch_fast_cells(const PgPlan& P, int nframes, hipStream_t s, int levelBeg, int levelEnd);
-#ifdef PGORB_FAST_BLOCKS
-int pg_fast_set_kernel(int k) { g_fast_kernel = k; return 0; }
-#else
-int pg_fast_set_kernel(int k) { return k == 0 ? 0 : -1; }      // the block form is not in this build
-#endif
-int pg_fast_get_kernel() { return g_fast_kernel; }
-
-void pg_launch_fast(const PgPlan& P, int nframes, hipStream_t s)
-{
-#ifdef PGORB_FAST_BLOCKS
-    if (g_fast_kernel == 1 && P.blockTab) {
-        int tileRows = 0;
-        for (int l = 0; l < P.nlevels; l++) tileRows = max(tileRows, P.lvl[l].blkCY * P.lvl[l].hCell + 6);
-        const int mapRows = tileRows - 6 + 4 + 1;                  // BH + one gutter row per cell row (<= 4) + rim
-        size_t smem = (size_t)tileRows * FB_TP + (size_t)mapRows * FB_MP + FB_LCAP * 2 + 18 * 4 + 64;
-        if (const char* e = getenv("PGORB_FAST_EXTRA_LDS")) smem += (size_t)atoi(e);
-        (void)hipFuncSetAttribute((const void*)k_fast_blocks, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   // per device, cheap
-        const int blocksPerXcd = (P.totalBlocks + 7) / 8;
-        dim3 grid(blocksPerXcd * 8, nframes), block(FB_T);
-        int dbgSkip = 0;
-        if (const char* e = getenv("PGORB_FAST_DBGSKIP")) dbgSkip = atoi(e);
-        hipLaunchKernelGGL(k_fast_blocks, grid, block, smem, s, P, tileRows, mapRows, blocksPerXcd, dbgSkip);
-        return;
-    }
-#endif
-    pg_launch_fast_cells(P, nframes, s, 0, P.nlevels);
-}
-
-// K2 (cell form) for the levels [levelBeg, levelEnd) only
+// K2 for the levels [levelBeg, levelEnd) only
 void pg_launch_fast_levels(const PgPlan& P, int nframes, int levelBeg, int levelEnd, hipStream_t s)
 {
     pg_launch_fast_cells(P, nframes, s, levelBeg, levelEnd);
 }
-bool pg_fast_is_cell_form(const PgPlan& P) { return g_fast_kernel != 1 || !P.blockTab; }
 
 void pg_launch_fast_cells(const PgPlan& P, int nframes, hipStream_t s, int levelBeg, int levelEnd)
 {
@@ -1147,7 +726,11 @@ void pg_launch_fast_cells(const PgPlan& P, int nframes, hipStream_t s, int level
     int TP = (maxW + 6 + 15) & ~15;                        // byte 0 pad + window + quick-test over-read, 16-B chunks
     const int tileRows = maxH;
     int mapPitch = ((maxW - 6 + 2) + 3) & ~3;
-    const bool common = TP <= 48 && mapPitch <= 40 && maxH <= 126;        // the instantiation with immediate offsets (six window loads of 21 rows)
+    // tile-shape sweep (BASELINE.json configs[2]; pgorb_set_option "fast_tile_pitch"): a forced window pitch takes the
+    // run-time-pitch instantiation -- 48 there measures what the immediate offsets are worth, 64 / 80 / ... what a wider LDS row costs
+    const bool forced = P.fastTilePitch >= TP;
+    if (forced) TP = P.fastTilePitch;
+    const bool common = !forced && TP <= 48 && mapPitch <= 40 && maxH <= 126;        // the instantiation with immediate offsets (six window loads of 21 rows)
     if (common) { TP = 48; mapPitch = 40; }
     const int chunkInv = 65536 / (TP >> 4) + 1;            // lane / (TP/16) == (lane * chunkInv) >> 16 for lane < 64
     const int mapRows = maxH - 6 + 2;
@@ -1160,8 +743,7 @@ void pg_launch_fast_cells(const PgPlan& P, int nframes, hipStream_t s, int level
     const int cellEnd = all ? 8 * P.cellsPerXcdBal : (levelEnd < P.nlevels) ? P.lvl[levelEnd].cellBase : P.totalCells;
     const int cellsPerXcd = all ? P.cellsPerXcdBal : (cellEnd - cell0 + 7) / 8;
     const bool narrow = maxW - 6 <= 32 && maxH - 6 <= 40;      // 8 quads per row, at most 5 steps of 8 rows (quick_pass_b)
-    static const int wpbEnv = getenv("PGORB_FAST_WPB") ? atoi(getenv("PGORB_FAST_WPB")) : 1;     // 4 independent waves per workgroup measured 13 % slower
-    const int wpb = (wpbEnv == 4) ? 4 : 1;
+    const int wpb = (P.fastWpb == 4) ? 4 : 1;                  // 4 independent waves per workgroup measured 13 % slower
     const int waveLds = (int)((smem + 15) & ~(size_t)15);
     dim3 grid(((cellsPerXcd + wpb - 1) / wpb) * 8, nframes), block(64 * wpb);
 #define PG_LAUNCH_CELLS(TPC, MPC, NAR, W) hipLaunchKernelGGL((k_fast_cells<TPC, MPC, NAR, W>), grid, block, (size_t)waveLds * W, s, P, TP, \

@@ -38,6 +38,8 @@
 int pg_ctx_fail(pgorb_ctx* c, int code, const char* msg);
 int pg_ctx_stage(pgorb_ctx* c, int which, size_t bytes, void** p);
 int pg_ctx_device(pgorb_ctx* c);
+int pg_ctx_scratch(pgorb_ctx* c, size_t bytes, hipStream_t s, void** p);      // the matchers' shared arena, ordered across caller streams
+int pg_ctx_scratch_done(pgorb_ctx* c, hipStream_t s);
 
 __device__ __forceinline__ int grid_cell_of(const pgorb_keypoint& kp, float minX, float minY, float invW, float invH)
 {
@@ -1093,7 +1095,7 @@ int pgorb_search_by_bow_batch_device(pgorb_ctx* c, const pgorb_keypoint* d_kps, 
     if (hipSetDevice(pg_ctx_device(c)) != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "hipSetDevice failed");
     // scratch: the rotation bin of every matched frame feature [npairs][cap] i8
     void* scratch;
-    int rcs = pg_ctx_stage(c, 3, (size_t)npairs * cap + 256, &scratch);
+    int rcs = pg_ctx_scratch(c, (size_t)npairs * cap + 256, (hipStream_t)stream, &scratch);
     if (rcs) return rcs;
     int8_t* bins = (int8_t*)scratch;
     if (hipMemsetAsync(d_matches, 0xFF, (size_t)npairs * cap * 4, (hipStream_t)stream) != hipSuccess ||
@@ -1102,7 +1104,7 @@ int pgorb_search_by_bow_batch_device(pgorb_ctx* c, const pgorb_keypoint* d_kps, 
     hipLaunchKernelGGL(k_search_by_bow, dim3(BOW_WAVES, npairs), dim3(64), 0, (hipStream_t)stream, B, nnratio, check_orientation, d_matches, bins);
     hipLaunchKernelGGL(k_bow_finish, dim3(npairs), dim3(64), 0, (hipStream_t)stream, B, check_orientation, d_matches, bins, d_nmatches);
     if (hipGetLastError() != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "k_search_by_bow launch failed");
-    return 0;
+    return pg_ctx_scratch_done(c, (hipStream_t)stream);
 }
 
 // single pair through host buffers: the pair becomes a two-frame batch (key frame = frame 0, frame = frame 1)
@@ -1189,7 +1191,7 @@ int pgorb_search_for_initialization_batch_device(pgorb_ctx* c, const pgorb_keypo
     // scratch of the two passes: lists[npairs][cap][SFI_K] u32 | count[npairs][cap] u8
     const size_t szL = (size_t)npairs * cap * SFI_K * 4;
     void* scratch;
-    int rc = pg_ctx_stage(c, 3, szL + (size_t)npairs * cap + 256, &scratch);
+    int rc = pg_ctx_scratch(c, szL + (size_t)npairs * cap + 256, (hipStream_t)stream, &scratch);
     if (rc) return rc;
     uint32_t* lists = (uint32_t*)scratch;
     uint8_t* listCnt = (uint8_t*)scratch + szL;
@@ -1211,7 +1213,7 @@ int pgorb_search_for_initialization_batch_device(pgorb_ctx* c, const pgorb_keypo
                        d_n, cap, d_grid_start, d_grid_idx, d_pair_f1, d_pair_f2, min_x, min_y, invW, invH,
                        d_prev_matched, d_matches12, d_nmatches, window_size, nnratio, check_orientation, lists, listCnt);
     if (hipGetLastError() != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "k_search_for_initialization launch failed");
-    return 0;
+    return pg_ctx_scratch_done(c, (hipStream_t)stream);
 }
 
 static int pg_search_by_projection_batch(pgorb_ctx* c, int mode, const pgorb_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, int cap,
@@ -1237,7 +1239,7 @@ static int pg_search_by_projection_batch(pgorb_ctx* c, int mode, const pgorb_key
     // scratch of the two passes: lists[npairs][qcap][PROJ_K] u32 | count[npairs][qcap] u8
     const size_t szL = (size_t)npairs * qcap * PROJ_K * 4;
     void* scratch;
-    int rcs = pg_ctx_stage(c, 3, szL + (size_t)npairs * qcap + 256, &scratch);
+    int rcs = pg_ctx_scratch(c, szL + (size_t)npairs * qcap + 256, stream, &scratch);
     if (rcs) return rcs;
     uint32_t* lists = (uint32_t*)scratch;
     uint8_t* listCnt = (uint8_t*)scratch + szL;
@@ -1249,7 +1251,7 @@ static int pg_search_by_projection_batch(pgorb_ctx* c, int mode, const pgorb_key
     hipLaunchKernelGGL(k_search_by_projection, dim3(npairs), dim3(64), lds, stream, B, min_x, min_y, invW, invH, mode, nnratio,
                        check_orientation, lists, listCnt, d_assigned, d_nmatches);
     if (hipGetLastError() != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "k_search_by_projection launch failed");
-    return 0;
+    return pg_ctx_scratch_done(c, stream);
 }
 
 int pgorb_search_by_projection_points_batch_device(pgorb_ctx* c, const pgorb_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n,

@@ -437,54 +437,49 @@ void pg_launch_hamming_matrix(const uint8_t* d_a, int na, const uint8_t* d_b, in
     hipLaunchKernelGGL(k_hamming_matrix, grid, block, 0, s, d_a, na, d_b, nb, d_out);
 }
 
-// PGORB_MATCH_POPCOUNT=1 forces the v_bcnt kernels for every size (the variant BASELINE.json's north star
-// describes), so both matchers can be timed on the same frames; results are identical.
-static int g_mx_force_popcount = -1;                     // -1: environment decides; pgorb_set_option("matcher", ...)
-void pg_match_set_popcount(int on) { g_mx_force_popcount = on ? 1 : -1; }      // 0 = back to the default (the environment decides)
-static bool mx_use_popcount()
-{
-    static const bool v = getenv("PGORB_MATCH_POPCOUNT") != nullptr;
-    return g_mx_force_popcount >= 0 ? g_mx_force_popcount != 0 : v;
-}
+// PGORB_MATCH_POPCOUNT=1 (or pgorb_set_option "matcher" 1) forces the v_bcnt kernels for every size (the variant
+// BASELINE.json's north star describes), so both matchers can be timed on the same frames; results are identical.
 // how the train descriptors reach the matrix cores: 2 = taken as they are and expanded in LDS by workgroups of 16 waves (1 024 queries
 // share one expansion of a tile: 0.077 ms per 127 pairs of 2 000, no expanded copy in HBM); 1 = the same with 4-wave workgroups
 // (0.099: the expansion is repeated per 256 queries); 0 = expanded once per pair into a scratch slab by k_expand_trains (0.098,
 // 120 MB of traffic per step for 18.5 MB of descriptors).  Default: 2 when that makes at least 192 workgroups (a 16-wave workgroup
 // takes a whole CU's matrix time: 31 pairs of 4 006 are 124 of them and ran 0.128 ms against 0.10), else 1.
 // PGORB_MATCH_MODE = 0 | 1 | 2, or pgorb_set_option("match_mode", ...) (-1 = by grid size again), forces one (measurement switch).
-static int g_mx_mode = -2;                                   // -2: not read yet; -1: by grid size; 0 | 1 | 2 forced
-static int mx_mode_env()
+// Both settings belong to a CONTEXT (PgMatchOpts, round 4; they were file-scope statics): the environment only seeds pgorb_create.
+PgMatchOpts pg_match_default_opts()
 {
-    if (g_mx_mode == -2) g_mx_mode = getenv("PGORB_MATCH_MODE") ? atoi(getenv("PGORB_MATCH_MODE")) : -1;
-    return g_mx_mode;
+    PgMatchOpts o;
+    o.popcount = getenv("PGORB_MATCH_POPCOUNT") != nullptr ? 1 : 0;
+    const char* e = getenv("PGORB_MATCH_MODE");
+    const int m = e ? atoi(e) : -1;
+    o.mode = (m >= 0 && m <= 2) ? m : -1;
+    return o;
 }
-int pg_match_set_mode(int m) { if (m < -1 || m > 2) return -1; g_mx_mode = m; return 0; }      // pgorb_set_option("match_mode", ...)
-static int mx_mode(int npairs, int nq)
+static int mx_mode(const PgMatchOpts& o, int npairs, int nq)
 {
-    const int e = mx_mode_env();
-    if (e >= 0) return e;
+    if (o.mode >= 0) return o.mode;
     return (long long)npairs * ((nq + 1023) / 1024) >= 192 ? 2 : 1;
 }
-bool pg_match_uses_popcount(int cap_per_frame) { return cap_per_frame >= MX_MAX_TRAIN || mx_use_popcount(); }
+bool pg_match_uses_popcount(const PgMatchOpts& o, int cap_per_frame) { return cap_per_frame >= MX_MAX_TRAIN || o.popcount; }
 
-size_t pg_match_scratch_bytes(int nb_max, int npairs)
+size_t pg_match_scratch_bytes(const PgMatchOpts& o, int nb_max, int npairs)
 {
-    if (mx_mode_env() != 0) return 0;                        // (only the slab form needs scratch)
+    if (o.mode != 0 || pg_match_uses_popcount(o, nb_max)) return 0;      // (only the slab form needs scratch)
     return (size_t)npairs * (size_t)((nb_max + 15) / 16) * MX_BLOCK_BYTES;
 }
 
 // single pair: a (na descriptors) against b (nb descriptors); scratch >= pg_match_scratch_bytes(nb, 1)
-void pg_launch_best2(const uint8_t* d_a, int na, const uint8_t* d_b, int nb, uint8_t* d_scratch,
+void pg_launch_best2(const PgMatchOpts& o, const uint8_t* d_a, int na, const uint8_t* d_b, int nb, uint8_t* d_scratch,
                      int32_t* d_best_idx, uint16_t* d_best, uint16_t* d_second, hipStream_t s)
 {
     if (na <= 0) return;
-    if (nb >= MX_MAX_TRAIN || mx_use_popcount()) {
+    if (pg_match_uses_popcount(o, nb)) {
         hipLaunchKernelGGL(k_hamming_best2, dim3((na + MT_T - 1) / MT_T), dim3(MT_T * MT_WAVES), 0, s, d_a, na, d_b, nb,
                            d_best_idx, d_best, d_second);
         return;
     }
     const int bpp = (nb + 15) / 16;
-    const int mode = mx_mode(1, na);
+    const int mode = mx_mode(o, 1, na);
     if (mode == 0) {
         if (bpp > 0)
             hipLaunchKernelGGL(k_expand_trains, dim3(bpp, 1), dim3(128), 0, s, d_b, nullptr, nb, nullptr, nb, bpp, d_scratch);
@@ -499,18 +494,18 @@ void pg_launch_best2(const uint8_t* d_a, int na, const uint8_t* d_b, int nb, uin
     }
 }
 
-void pg_launch_match_batch(const uint8_t* d_desc, const int32_t* d_n, int cap_per_frame,
+void pg_launch_match_batch(const PgMatchOpts& o, const uint8_t* d_desc, const int32_t* d_n, int cap_per_frame,
                            const int32_t* d_pq, const int32_t* d_pt, int npairs, uint8_t* d_scratch,
                            int32_t* d_best_idx, uint16_t* d_best, uint16_t* d_second, hipStream_t s)
 {
     if (npairs <= 0) return;
-    if (cap_per_frame >= MX_MAX_TRAIN || mx_use_popcount()) {
+    if (pg_match_uses_popcount(o, cap_per_frame)) {
         hipLaunchKernelGGL(k_match_batch, dim3((cap_per_frame + MT_T - 1) / MT_T, npairs), dim3(MT_T * MT_WAVES), 0, s,
                            d_desc, d_n, cap_per_frame, d_pq, d_pt, d_best_idx, d_best, d_second);
         return;
     }
     const int bpp = (cap_per_frame + 15) / 16;
-    const int mode = mx_mode(npairs, cap_per_frame);
+    const int mode = mx_mode(o, npairs, cap_per_frame);
     const dim3 grid4((npairs + 7) & ~7, (cap_per_frame + 255) / 256), grid16((npairs + 7) & ~7, (cap_per_frame + 1023) / 1024);
     if (mode == 0) {
         hipLaunchKernelGGL(k_expand_trains, dim3(bpp, npairs), dim3(128), 0, s, d_desc, d_n, cap_per_frame, d_pt, 0, bpp, d_scratch);

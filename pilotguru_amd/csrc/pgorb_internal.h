@@ -60,7 +60,6 @@ struct PgLevel {
                               // PGORB_PYR_TILE_ROWS = 16 | 32 | 64 at plan time, for the tile-size sweep in DESIGN.md)
     // cell grid (ORBextractor.cc:781-787)
     int32_t  nCols, nRows, wCell, hCell, cellBase;
-    int32_t  blkCX, blkCY;    // cells per K2 block in x / y (fast.hip, block form)
     // quadtree (ORBextractor.cc:539-563)
     int32_t  quota, nIni, selCap;
     float    hX;
@@ -113,9 +112,8 @@ struct PgPlan {
     // level's cells; unused tail positions hold a padding record (cell index 0x0FFFFFFF): the wave returns at once
     const uint32_t* cellTabBal;
     int32_t  cellsPerXcdBal;
-    // [totalBlocks] 64-byte record per K2 block of blkCX x blkCY cells (fast.hip: k_fast_blocks), or null
-    const uint32_t* blockTab;
-    int32_t  totalBlocks;
+    int32_t  fastTilePitch;   // K2 tile-shape sweep: 0 = automatic, else the LDS window pitch in bytes (run-time-pitch instantiation)
+    int32_t  fastWpb;         // K2 waves (= independent cells) per workgroup: 1 (default) or 4
     const uint8_t*  pyrBase;  // pyramid arena
     uint32_t* cand;           // K3: dense uint2 key records (2 u32 per key)
     uint32_t* sel;
@@ -134,8 +132,7 @@ void pg_launch_color_to_gray(const PgPlan& P, const uint8_t* src, int stride, in
                              int rgb_order, int nframes, hipStream_t s);
 bool pg_launch_pyramid_level(const PgPlan& P, int level, int nframes, hipStream_t s, int32_t* clearWord = nullptr);
 void pg_launch_fast(const PgPlan& P, int nframes, hipStream_t s);
-void pg_launch_fast_levels(const PgPlan& P, int nframes, int levelBeg, int levelEnd, hipStream_t s);   // cell form only
-bool pg_fast_is_cell_form(const PgPlan& P);
+void pg_launch_fast_levels(const PgPlan& P, int nframes, int levelBeg, int levelEnd, hipStream_t s);
 void pg_launch_quadtree(const PgPlan& P, int nframes, hipStream_t s);
 void pg_launch_quadtree_levels(const PgPlan& P, int nframes, int levelBeg, int levelEnd, hipStream_t s);
 void pg_launch_describe(const PgPlan& P, int nframes, pgorb_keypoint* d_kps, uint8_t* d_desc,
@@ -145,17 +142,18 @@ void pg_launch_describe_levels(const PgPlan& P, int nframes, pgorb_keypoint* d_k
 void pg_launch_hamming_matrix(const uint8_t* d_a, int na, const uint8_t* d_b, int nb,
                               uint16_t* d_out, hipStream_t s);
 void pg_launch_prev_matched_init(const pgorb_keypoint* d_kps, int64_t rows, float* d_out, hipStream_t s);   // frame.hip
-size_t pg_match_scratch_bytes(int nb_max, int npairs);
-void pg_launch_match_batch(const uint8_t* d_desc, const int32_t* d_n, int cap_per_frame,
+// matcher settings of ONE context (pgorb_set_option "matcher" / "match_mode"; defaults from the environment at pgorb_create)
+struct PgMatchOpts {
+    int popcount = 0;         // 1: the v_bcnt kernels for every size (PGORB_MATCH_POPCOUNT)
+    int mode = -1;            // -1 = by grid size, 0 | 1 | 2 forced (PGORB_MATCH_MODE; match.hip)
+};
+PgMatchOpts pg_match_default_opts();      // what the environment says
+size_t pg_match_scratch_bytes(const PgMatchOpts& o, int nb_max, int npairs);
+void pg_launch_match_batch(const PgMatchOpts& o, const uint8_t* d_desc, const int32_t* d_n, int cap_per_frame,
                            const int32_t* d_pq, const int32_t* d_pt, int npairs, uint8_t* d_scratch,
                            int32_t* d_best_idx, uint16_t* d_best, uint16_t* d_second, hipStream_t s);
-void pg_launch_best2(const uint8_t* d_a, int na, const uint8_t* d_b, int nb, uint8_t* d_scratch,
+void pg_launch_best2(const PgMatchOpts& o, const uint8_t* d_a, int na, const uint8_t* d_b, int nb, uint8_t* d_scratch,
                      int32_t* d_best_idx, uint16_t* d_best, uint16_t* d_second, hipStream_t s);
-
-void pg_match_set_popcount(int on);
-int  pg_match_set_mode(int m);           // -1 = by grid size (default), 0 | 1 | 2: match.hip; -1 on a bad value
-int  pg_fast_set_kernel(int k);          // 0, or -1 when the requested form is not in this build
-int  pg_fast_get_kernel();
-bool pg_match_uses_popcount(int cap_per_frame);
+bool pg_match_uses_popcount(const PgMatchOpts& o, int cap_per_frame);
 
 static_assert(sizeof(PgPlan) <= 4000, "PgPlan is passed by value as a kernel argument (4 KiB limit)");

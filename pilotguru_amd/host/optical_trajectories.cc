@@ -379,8 +379,9 @@ int main(int argc, char** argv)
         ext = new pgorb::ORBextractor(nFeatures, scaleFactor, nLevels, iniTh, minTh, upW, upH, B, F.device);
         if (pgorb_vocab_upload(ext->context(), voc) != PGORB_OK) check_failed("vocabulary upload");
         if (pgorb_max_keypoints(ext->context(), upW, upH) < 0) check_failed("frame size usable for the ORB cell grid");
-        // frames as read; rotation, flips and the grey conversion on the device (Camera_RGB: 1 = RGB, 0 = BGR; Tracking.cc:247-260)
-        if (pgorb_stream_create_ingest(ext->context(), src.w, src.h, src.channels, (int)get("Camera_RGB", 1) != 0, F.rotation,
+        // frames as read; rotation, flips and the grey conversion on the device (Camera_RGB: 1 = RGB, 0 = BGR; Tracking.cc:247-260).
+        // A settings file without the key means BGR: `int nRGB = fSettings["Camera_RGB"]` reads 0 from an empty cv::FileNode (Tracking.cc:102)
+        if (pgorb_stream_create_ingest(ext->context(), src.w, src.h, src.channels, (int)get("Camera_RGB", 0) != 0, F.rotation,
                                        F.vertical_flip, F.horizontal_flip, B, DEPTH, &st) != PGORB_OK) check_failed(pgorb_last_error(ext->context()));
         // Frame::ComputeImageBounds without distortion: [0, cols] x [0, rows] (Frame.cc:462-466); ORBmatcher(0.9, true)
         // .SearchForInitialization(mInitialFrame, mCurrentFrame, mvbPrevMatched, mvIniMatches, 100) (Tracking.cc:596-597);

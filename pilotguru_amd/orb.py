@@ -7,6 +7,7 @@ so the parity tests read like tests of the reference classes.  All compute happe
 libpgorb.so (HIP, gfx950); numpy / torch only carry buffers.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -40,9 +41,12 @@ class ORBextractor:
         if rc != 0:
             raise _lib.PgorbError(rc, self._L.pgorb_last_error(None).decode())
         self._h = h
+        self._streams = weakref.WeakSet()             # FrameStreams of this context: pgorb_destroy takes them along
 
     def close(self):
         if getattr(self, "_h", None):
+            for st in list(self._streams):            # the C context destroys its live streams: their handles die with it
+                st._s = None
             self._L.pgorb_destroy(self._h)
             self._h = None
 
@@ -206,9 +210,15 @@ class ORBextractor:
     def matcher_name(self, cap_per_frame):
         return "popcount" if self._L.pgorb_matcher_is_popcount(self._h, int(cap_per_frame)) else "mfma_fp4"
 
+    def get_option(self, key):
+        v = self._L.pgorb_get_option(self._h, key.encode())
+        if v == -2147483648:                                     # PGORB_OPTION_UNKNOWN
+            raise KeyError(key)
+        return v
+
     def fast_kernel_name(self):
-        """Name of the K2 kernel the common cell geometry takes (for bench.py's roofline object)."""
-        return "k_fast_blocks" if self._L.pgorb_get_option(self._h, b"fast_kernel") == 1 else "k_fast_cells"
+        """Name of the K2 kernel (for bench.py's roofline object)."""
+        return "k_fast_cells"
 
     STAGES = ("pyramid", "fast", "quadtree", "describe", "match")
 
@@ -412,6 +422,7 @@ class FrameStream:
                                                             int(rotate_degrees), int(bool(vertical_flip)), int(bool(horizontal_flip)),
                                                             self.batch, self.depth, C.byref(hs)))
         self._s = hs
+        extractor._streams.add(self)
 
     def close(self):
         """Frees the page-locked slots: every array input() / wait() / frontend_results() returned is invalid afterwards."""

@@ -616,68 +616,96 @@ def test_levels_with_one_tall_cell_row(oracle, w, h, scale, nlev, nf):
     assert len(kp) == len(okp) > 0 and kp.tobytes() == okp.tobytes() and np.array_equal(desc, odesc)
 
 
-def _block_form_available():
-    import pilotguru_amd as pg
-    ext = pg.ORBextractor(100, 1.2, 2, 20, 7, max_width=320, max_height=240)
-    try:
-        ext.set_option("fast_kernel", 1)
-    except Exception:
-        return False
-    ext.set_option("fast_kernel", 0)
-    return True
-
-
-@pytest.mark.parametrize("cx,cy", [(4, 2), (2, 2), (1, 1), (4, 4), (3, 1), (1, 3)])
-def test_fast_block_form_every_tile_shape_bit_exact(oracle, cx, cy):
-    """K2's block form (pgorb_set_option "fast_kernel" = 1; a developer build since round 3: make EXTRA=-DPGORB_FAST_BLOCKS)
-    for the tile shapes of BASELINE.json configs[2]'s sweep: textured, driving-like (minThFAST retry per cell), pure noise
-    (candidate list overflow -> row-chunked passes) and panoramic frames (cells up to 59 px, partial blocks), candidate
-    sets and final output against the oracle.  With the product library the same hard cases run once through the
-    shipped cell form."""
+@pytest.mark.parametrize("pitch,wpb", [(0, 1), (48, 1), (64, 1), (80, 1), (96, 1), (128, 1), (0, 4), (64, 4)])
+def test_fast_every_tile_shape_bit_exact(oracle, pitch, wpb):
+    """BASELINE.json configs[2]: "LDS tile-size sweep ... bit-exact at every tile size".  K2's LDS window pitch
+    (pgorb_set_option "fast_tile_pitch": 0 = the shipped 48-byte pitch with immediate offsets, 48 ... 128 = the same window in
+    an LDS row of that many bytes, run-time pitch) x waves per workgroup (1 | 4), on the hard scenes: textured, driving-like
+    (minThFAST retry per cell), pure noise (candidate list overflow -> row-chunked passes) and panoramic frames (cells up to
+    59 px).  Candidate sets and the final output against the oracle.  (Rounds 1-3 swept a block form -- one workgroup
+    per block of cells -- that lost on every shape and left the tree in round 4; profiles/r04_k2_tile_sweep_2160p.txt times these.)"""
     import pilotguru_amd as pg
     from pilotguru_amd.synth import synth_scene_road
-    block_form = _block_form_available()
-    if not block_form and (cx, cy) != (4, 2):
-        pytest.skip("block form not in this build (make EXTRA=-DPGORB_FAST_BLOCKS)")
     rng = np.random.RandomState(1)
     cases = [(synth_scene(7, 641, 479), 1000, 8), (synth_scene_road(2, 640, 480), 1000, 8),
              ((128 + rng.randint(-9, 10, (300, 400))).astype(np.uint8), 500, 8),
              (synth_scene(43, 700, 100), 300, 3), (synth_scene(42, 100, 150), 120, 2)]
-    try:
-        for img, nf, nlevels in cases:
-            h, w = img.shape
-            ora = oracle.OrbOracle(nf, 1.2, nlevels, 20, 7)
-            okp, odesc = ora.extract(img)
-            ext = pg.ORBextractor(nf, 1.2, nlevels, 20, 7, max_width=w, max_height=h)
-            if block_form:
-                ext.set_option("fast_kernel", 1)
-                ext.set_option("fast_block_cx", cx)
-                ext.set_option("fast_block_cy", cy)
-                assert ext.fast_kernel_name() == "k_fast_blocks"
-            kp, desc = ext(img)
-            for l in range(nlevels):
-                x, y, r = ext.debug_level_candidates(0, l)
-                oc = ora.level_candidates(l)
-                assert sorted(zip(y.tolist(), x.tolist(), r.tolist())) == \
-                    sorted(zip(oc["y"].tolist(), oc["x"].tolist(), oc["response"].tolist())), "level %d" % l
-            assert len(kp) == len(okp) > 0 and kp.tobytes() == okp.tobytes() and np.array_equal(desc, odesc)
-    finally:
-        pg.ORBextractor(100, 1.2, 2, 20, 7, max_width=320, max_height=240).set_option("fast_kernel", 0)
-
-
-def test_fast_block_form_at_bench_shape(oracle):
-    import pilotguru_amd as pg
-    if not _block_form_available():
-        pytest.skip("block form not in this build (make EXTRA=-DPGORB_FAST_BLOCKS)")
-    img = synth_scene(2, 1920, 1080)
-    okp, odesc = oracle.OrbOracle(2000, 1.2, 8, 20, 7).extract(img)
-    ext = _make(2000, 1920, 1080)
-    try:
-        ext.set_option("fast_kernel", 1)
+    for img, nf, nlevels in cases:
+        h, w = img.shape
+        ora = oracle.OrbOracle(nf, 1.2, nlevels, 20, 7)
+        okp, odesc = ora.extract(img)
+        ext = pg.ORBextractor(nf, 1.2, nlevels, 20, 7, max_width=w, max_height=h)
+        ext.set_option("fast_tile_pitch", pitch)
+        ext.set_option("fast_waves_per_block", wpb)
+        assert ext.get_option("fast_tile_pitch") == pitch and ext.get_option("fast_waves_per_block") == wpb
         kp, desc = ext(img)
-    finally:
-        ext.set_option("fast_kernel", 0)
+        for l in range(nlevels):
+            x, y, r = ext.debug_level_candidates(0, l)
+            oc = ora.level_candidates(l)
+            assert sorted(zip(y.tolist(), x.tolist(), r.tolist())) == \
+                sorted(zip(oc["y"].tolist(), oc["x"].tolist(), oc["response"].tolist())), "level %d" % l
+        assert len(kp) == len(okp) > 0 and kp.tobytes() == okp.tobytes() and np.array_equal(desc, odesc)
+
+
+@pytest.mark.parametrize("pitch", [64, 96])
+def test_fast_tile_shapes_at_2160p(oracle, pitch):
+    """configs[2]'s frame shape (3840 x 2160 / 4000) through two of the swept tile shapes."""
+    img = synth_scene(2, 3840, 2160)
+    okp, odesc = oracle.OrbOracle(4000, 1.2, 8, 20, 7).extract(img)
+    ext = _make(4000, 3840, 2160)
+    ext.set_option("fast_tile_pitch", pitch)
+    kp, desc = ext(img)
     assert kp.tobytes() == okp.tobytes() and np.array_equal(desc, odesc)
+
+
+def test_options_belong_to_a_context(oracle):
+    """pgorb_set_option writes the CONTEXT (round 4; "matcher" / "match_mode" were process-wide statics): two contexts with
+    different settings in one process keep them, and both produce the oracle's matches.  Also the round-3 advisory: the
+    slab form (match_mode 0) selected AFTER a stream exists must size its arena at submit time."""
+    import pilotguru_amd as pg
+    from pilotguru_amd._lib import PgorbError
+    w, h, nf = 640, 480, 1000
+    a, b = _make(nf, w, h, batch=4), _make(nf, w, h, batch=4)
+    a.set_option("matcher", 1); a.set_option("fast_tile_pitch", 64)
+    b.set_option("match_mode", 0)
+    assert a.get_option("matcher") == 1 and b.get_option("matcher") == 0
+    assert a.get_option("match_mode") == -1 and b.get_option("match_mode") == 0
+    assert a.get_option("fast_tile_pitch") == 64 and b.get_option("fast_tile_pitch") == 0
+    assert a.matcher_name(2000) == "popcount" and b.matcher_name(2000) == "mfma_fp4"
+    with pytest.raises(PgorbError):
+        a.set_option("match_mode", 3)
+    with pytest.raises(PgorbError):
+        a.set_option("fast_tile_pitch", 50)
+    rng = np.random.RandomState(3)
+    qa = rng.randint(0, 256, (700, 32)).astype(np.uint8)
+    tb = rng.randint(0, 256, (900, 32)).astype(np.uint8)
+    tb[17] = qa[5]
+    exp = oracle.hamming_best2(qa, tb)
+    for ext in (a, b):
+        got = ext.hamming_best2(qa, tb)
+        assert all(np.array_equal(g, e) for g, e in zip(got, exp))
+    # a stream created under the default mode, then the slab form switched on: 4 frames x 1000 descriptors need 0.5 MB of slab
+    ride = synth_ride(9, w, h, 8)
+    c = _make(nf, w, h, batch=4)
+    st = pg.FrameStream(c, w, h, 4, 2)
+    c.set_option("match_mode", 0)
+    ora = oracle.OrbOracle(nf, 1.2, 8, 20, 7)
+    prev = None
+    for blk in range(2):
+        st.input(blk)[:4] = ride[4 * blk:4 * blk + 4]
+        st.submit(blk, 4)
+        rn, rk, rd, rbi, rb1, rb2 = st.wait(blk)
+        for f in range(4):
+            okp, odesc = ora.extract(ride[4 * blk + f])
+            n = int(rn[f])
+            assert n == len(okp) and np.array_equal(rd[f, :n], odesc)
+            if prev is not None:
+                obi, ob1, ob2 = oracle.hamming_best2(odesc, prev)
+                assert np.array_equal(rbi[f, :n], obi) and np.array_equal(rb1[f, :n], ob1) and np.array_equal(rb2[f, :n], ob2)
+            prev = odesc
+        del rn, rk, rd, rbi, rb1, rb2
+    st.close(); c.close()
+    st.close()                                          # closing a stream after its extractor: a no-op (round-3 advisory)
 
 
 def test_device_sincos_equals_the_oracle_for_every_input():
