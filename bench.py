@@ -375,6 +375,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-upload-leg", action="store_true")
+    ap.add_argument("--no-single-frame-leg", action="store_true",
+                    help="skip the one-frame-per-synchronous-call leg (the reference's call shape, tools/single_frame_bench.py)")
     ap.add_argument("--n1-fps", type=float, default=None,
                     help="the N = 1 frames/s of the same configuration; adds scaling_efficiency to the line")
     args = ap.parse_args()
@@ -628,6 +630,15 @@ def main():
             out["two_batches_in_flight"] = inflight2
         if uploaded is not None:
             out["frames_uploaded"] = uploaded
+        if not args.no_single_frame_leg and world == 1:
+            # the reference's call shape (Frame.cc:251-257): ONE frame per synchronous call from pageable host memory; outside
+            # the timed region like frames_uploaded, never `value`
+            try:
+                sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+                import single_frame_bench
+                out["single_frame"] = single_frame_bench.run(W, H, NF, calls=2000)
+            except Exception as e:                             # (a leg, not the measurement: report and go on)
+                out["single_frame"] = {"error": str(e)[:200]}
         if not args.no_cpu_baseline and world == 1:            # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(W, H, NF, args.scene)
             out["speedup_vs_cpu_all_cores"] = fps / out["cpu_baseline"]["value"]

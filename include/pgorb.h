@@ -251,6 +251,31 @@ int  pgorb_search_by_projection_frame(pgorb_ctx* ctx,
         const uint8_t* point_has_obs, float th, int check_orientation,
         int32_t* assigned /*[n]*/);                                       /* returns nmatches        */
 
+/*   pgorb_search_by_projection_keyframe   the matching loop of ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF,
+ *       const set<MapPoint*> &sAlreadyFound, float th, int ORBdist)  src/ORBmatcher.cc:1476-1603 -- the projection search of
+ *       Tracking::Relocalization (src/Tracking.cc:1434: th 10, ORBdist 100; :1448: th 3, ORBdist 64).  Per map point i of the
+ *       key frame the caller passes what its pose arithmetic (:1497-1517, cv::Mat) produced: valid = pMP && !pMP->isBad();
+ *       already_found = sAlreadyFound.count(pMP); (u, v) the projection into the current frame; dist3d = |x3Dw - Ow|;
+ *       min / max_distance = pMP->GetMin/MaxDistanceInvariance(); kf_angle = pKF->mvKeysUn[i].angle; GetDescriptor().
+ *       The device does the rest: the image-bounds and depth-range tests (:1512-1526), MapPoint::PredictScale
+ *       (src/MapPoint.cc:516-531) with log_scale_factor = CurrentFrame.mfLogScaleFactor, radius th * mvScaleFactors[level],
+ *       levels level - 1 .. level + 1, best match only with ORBdist, rotation histogram.  Here ANY point in
+ *       CurrentFrame.mvpMapPoints[i2] blocks a keypoint (:1542-1543: no Observations() test): kp_has_point[i2] != 0.
+ *       PredictScale's `log` is the platform's logf in the reference; here a fixed double-precision sequence rounded once
+ *       (pgorb_log_f; DESIGN.md section 5, parity contract 5), and pgorb_log_scale_factor is mfLogScaleFactor under it. */
+int  pgorb_search_by_projection_keyframe(pgorb_ctx* ctx,
+        const pgorb_keypoint* kps, const uint8_t* desc, int n,            /* CurrentFrame            */
+        float min_x, float max_x, float min_y, float max_y,
+        const uint8_t* kp_has_point,
+        int npoints, const uint8_t* valid, const uint8_t* already_found, const float* u, const float* v,
+        const float* dist3d, const float* min_distance, const float* max_distance,
+        const float* kf_angle, const uint8_t* point_desc,
+        float log_scale_factor, float th, int orb_dist, int check_orientation,
+        int32_t* assigned /*[n]*/);                                       /* returns nmatches        */
+float pgorb_log_f(float x);
+float pgorb_log_scale_factor(const pgorb_ctx* ctx);                      /* Frame::mfLogScaleFactor (Frame.cc:188)     */
+int   pgorb_predict_scale(const pgorb_ctx* ctx, float max_distance, float current_dist);   /* MapPoint::PredictScale */
+
 /*   pgorb_search_by_bow   ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame &F, vector<MapPoint*>
  *       &vpMapPointMatches)  src/ORBmatcher.cc:161-290 (Tracking::TrackReferenceKeyFrame,
  *       src/Tracking.cc:758; relocalisation :1359).  Both FeatureVectors come as the CSR arrays
@@ -287,6 +312,14 @@ int  pgorb_search_by_projection_frame_batch_device(pgorb_ctx* ctx,
         int qcap, const int32_t* d_nq, const uint8_t* d_valid, const float* d_u, const float* d_v,
         const int32_t* d_last_octave, const float* d_last_angle, const uint8_t* d_point_desc, const uint8_t* d_point_has_obs,
         float th, int check_orientation, int32_t* d_assigned, int32_t* d_nmatches, void* hip_stream);
+int  pgorb_search_by_projection_keyframe_batch_device(pgorb_ctx* ctx,
+        const pgorb_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, int cap_per_frame,
+        const int32_t* d_grid_start, const int32_t* d_grid_idx, const int32_t* d_pair_frame, int npairs,
+        float min_x, float max_x, float min_y, float max_y, const uint8_t* d_kp_has_point,
+        int qcap, const int32_t* d_nq, const uint8_t* d_valid, const uint8_t* d_already_found, const float* d_u, const float* d_v,
+        const float* d_dist3d, const float* d_min_distance, const float* d_max_distance, const float* d_kf_angle,
+        const uint8_t* d_point_desc, float log_scale_factor, float th, int orb_dist, int check_orientation,
+        int32_t* d_assigned, int32_t* d_nmatches, void* hip_stream);
 /* FeatureVector of every frame on the device: from the per-feature node ids pgorb_bow_transform_device wrote
  * (d_node [nframes][cap]) the CSR arrays of DBoW2's FeatureVector (FeatureVector.cpp:31-45: node ids ascending,
  * feature indices of a node in feature order): d_fv_node / d_fv_feat [nframes][cap], d_fv_start [nframes][cap + 1],
@@ -499,6 +532,12 @@ int  pgorb_set_option(pgorb_ctx* ctx, const char* key, int value);
 int  pgorb_get_option(const pgorb_ctx* ctx, const char* key);
 /* 1 when a match of `cap_per_frame` descriptors per frame takes the popcount kernels, else 0 */
 int  pgorb_matcher_is_popcount(const pgorb_ctx* ctx, int cap_per_frame);
+
+/* Host-side phases of the pgorb_extract / pgorb_extract_batch calls since the last reset, summed, in microseconds:
+ * us[0] input staging + upload issue, us[1] kernel launches + download issue, us[2] wait for the GPU, us[3] results into the
+ * caller's buffers.  Returns the number of calls covered; reset != 0 clears the sums (us may be NULL).  The one-frame-per-call
+ * shape of the reference (Frame.cc:251-257) is measured with it: bench.py "single_frame", tools/single_frame_bench.py. */
+int  pgorb_profile_host(pgorb_ctx* ctx, double* us /*[4]*/, int reset);
 
 /* Stage taps for parity tests (host buffers, synchronous; operate on the LAST batch). */
 int  pgorb_debug_level_size(const pgorb_ctx* ctx, int level, int* w, int* h);

@@ -20,7 +20,7 @@ SYMBOLS = (
     "pgorb_extract_batch_device", "pgorb_check_async", "pgorb_descriptor_distance",
     "pgorb_hamming_matrix", "pgorb_hamming_best2", "pgorb_match_batch_device",
     "pgorb_debug_level_size", "pgorb_debug_level_image", "pgorb_debug_level_candidates",
-    "pgorb_debug_level_keypoints", "pgorb_profile_begin", "pgorb_profile_read",
+    "pgorb_debug_level_keypoints", "pgorb_profile_begin", "pgorb_profile_read", "pgorb_profile_host",
     "pgorb_vocab_load_text", "pgorb_vocab_from_blob", "pgorb_vocab_blob", "pgorb_vocab_info",
     "pgorb_vocab_free", "pgorb_vocab_upload", "pgorb_vocab_upload_device", "pgorb_bow_transform",
     "pgorb_bow_transform_device", "pgorb_bow_vectors", "pgorb_bow_score_l1",
@@ -30,6 +30,8 @@ SYMBOLS = (
     "pgorb_search_by_projection_points", "pgorb_search_by_projection_frame", "pgorb_search_by_bow",
     "pgorb_search_by_projection_points_batch_device", "pgorb_search_by_projection_frame_batch_device",
     "pgorb_feature_vectors_batch_device", "pgorb_search_by_bow_batch_device",
+    "pgorb_search_by_projection_keyframe", "pgorb_search_by_projection_keyframe_batch_device",
+    "pgorb_log_f", "pgorb_log_scale_factor", "pgorb_predict_scale",
     "pgorb_undistort_keypoints", "pgorb_undistort_keypoints_batch_device", "pgorb_image_bounds",
     "pgorb_host_alloc", "pgorb_host_free", "pgorb_stream_create", "pgorb_stream_create_ingest", "pgorb_stream_destroy", "pgorb_stream_input", "pgorb_stream_reset", "pgorb_stream_submit",
     "pgorb_stream_wait", "pgorb_stream_frontend", "pgorb_stream_frontend_results", "pgorb_set_option", "pgorb_get_option", "pgorb_matcher_is_popcount",
@@ -117,6 +119,7 @@ def lib():
     L.pgorb_matcher_is_popcount.argtypes = [vp, C.c_int]
     L.pgorb_profile_begin.argtypes = [vp, C.c_int]
     L.pgorb_profile_read.argtypes = [vp, C.POINTER(C.c_double)]
+    L.pgorb_profile_host.argtypes = [vp, C.POINTER(C.c_double), C.c_int]
     f4 = [C.c_float] * 4
     L.pgorb_frame_grid.argtypes = [vp, vp, C.c_int] + f4 + [vp, vp]
     L.pgorb_frame_grid_batch_device.argtypes = [vp, vp, vp, C.c_int, C.c_int] + f4 + [vp, vp, vp]
@@ -132,6 +135,12 @@ def lib():
         [C.c_float, C.c_float, vp, vp, vp]
     L.pgorb_search_by_projection_frame_batch_device.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int] + f4 + [vp, C.c_int, vp] + [vp] * 7 + \
         [C.c_float, C.c_int, vp, vp, vp]
+    L.pgorb_search_by_projection_keyframe.argtypes = [vp, vp, vp, C.c_int] + f4 + [vp, C.c_int] + [vp] * 9 + [C.c_float, C.c_float, C.c_int, C.c_int, vp]
+    L.pgorb_search_by_projection_keyframe_batch_device.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int] + f4 + [vp, C.c_int, vp] + [vp] * 9 + \
+        [C.c_float, C.c_float, C.c_int, C.c_int, vp, vp, vp]
+    L.pgorb_log_f.argtypes = [C.c_float]
+    L.pgorb_log_scale_factor.argtypes = [vp]
+    L.pgorb_predict_scale.argtypes = [vp, C.c_float, C.c_float]
     L.pgorb_feature_vectors_batch_device.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
     L.pgorb_search_by_bow_batch_device.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_float, C.c_int, vp, vp, vp]
     L.pgorb_undistort_keypoints.argtypes = [vp, vp, C.c_int, vp, vp, vp]
@@ -171,7 +180,9 @@ def lib():
     L.pgorb_bow_score_l1.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int]
     for name in SYMBOLS:
         if name not in ("pgorb_destroy", "pgorb_last_error", "pgorb_vocab_free", "pgorb_bow_score_l1",
-                        "pgorb_host_alloc", "pgorb_host_free", "pgorb_stream_destroy", "pgorb_stream_input"):
+                        "pgorb_host_alloc", "pgorb_host_free", "pgorb_stream_destroy", "pgorb_stream_input", "pgorb_log_f", "pgorb_log_scale_factor"):
             getattr(L, name).restype = C.c_int
+    L.pgorb_log_f.restype = C.c_float
+    L.pgorb_log_scale_factor.restype = C.c_float
     _lib = L
     return L

@@ -9,9 +9,11 @@
 // Everything per-pixel / per-keypoint runs in the HIP kernels; there is no CPU fallback.
 #include "pgorb_internal.h"
 
+#include <chrono>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -52,11 +54,22 @@ struct pgorb_ctx {
     int pipeLev = 0, pipeLevPrio = 0;
     hipStream_t sQt = nullptr, sDesc = nullptr;
     hipEvent_t evGrpFast[PG_MAXL] = {}, evGrpQt[PG_MAXL] = {}, evDescDone = nullptr;
-    Arena stageKps, stageDesc, stageN, stageA, stageB, stageOut, stageSfi, vocab;
+    Arena stageA, stageB, stageOut, stageSfi, vocab;
     Arena xdesc;                              // matcher scratch: train descriptors as +-1 bytes (match.hip, match_mode 0 only)
     PgMatchOpts mx;                           // this context's matcher settings (pgorb_set_option "matcher" / "match_mode")
     void* pinned = nullptr;                   // page-locked bounce buffer for bulk result download
     size_t pinnedBytes = 0;
+    uint8_t* pinIn = nullptr;                 // page-locked input staging of the host-frame calls (pgorb_extract*)
+    size_t pinInBytes = 0;
+    int chunkBytes = 512 << 10, noStage = 1;  // PGORB_EXTRACT_STAGE=1: frames through the context's page-locked staging buffer in chunks of this size (measured SLOWER
+                                              // than the runtime's own pageable-copy path, DESIGN.md section 6 round 4: kept as the A/B switch)
+    Arena outBlk;                             // status word | counts | keypoints | descriptors of a host-frame call: one download
+    double hostUs[4] = {0, 0, 0, 0}; int hostCalls = 0;
+    // the host-frame calls run on a stream of the context's own, and replay their kernel chain (K1..K6 + the result download)
+    // as a HIP graph from the second call with the same plan / batch size on (PGORB_EXTRACT_NO_GRAPH=1: direct launches)
+    hipStream_t sHost = nullptr;
+    int useGraph = 1, planEpoch = 0;
+    struct HostGraph { hipGraph_t g = nullptr; hipGraphExec_t exec = nullptr; int nframes = 0, epoch = -1, seenFrames = 0, seenEpoch = -1; void* pinned = nullptr; size_t outBytes = 0; } hg;
     int vocabK = 0, vocabL = 0, vocabNodes = 0;
     int lastFrames = 0;
     bool lastAliased = false;
@@ -328,7 +341,11 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
         // node arrays of the quadtree: LDS when 30 ints per node fit its 140 KB, else a global slab
         // (quotas above ~1180 keypoints on one level: slower, but no configuration is refused)
         V.nodeOff = -1;
-        if ((size_t)V.nodeCap * 30 * sizeof(int) > 140 * 1024) {
+        // K3 keeps a level's node arrays (28 ints per node) in LDS beside its count pyramid (17 KB static) and its aux area
+        // (max(pyramid leaves <= 3072, cells of the largest level + 1) ints); what does not fit 160 KB goes to a global slab
+        const size_t qtAux = std::max((size_t)3072, (size_t)g[0].nCols * g[0].nRows + 1);
+        const size_t qtTab = (size_t)2 * ((g[0].w - 2 * PG_EDGE) + (g[0].h - 2 * PG_EDGE));      // the prologue's coordinate tables share the node area
+        if (std::max((size_t)V.nodeCap * 28, qtTab) * sizeof(int) + qtAux * sizeof(int) + 17 * 1024 > 160 * 1024) {
             V.nodeOff = (int64_t)nodeFrame;
             nodeFrame += align_up((size_t)V.nodeCap * 30, 64);
         }
@@ -447,8 +464,16 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
     P.nodeScratch = (int32_t*)c->nodes.p;
     P.candCount = (int32_t*)c->counters.p;
     P.kpCount = P.candCount + (size_t)B * PG_MAXL;
-    P.status = P.kpCount + (size_t)B * PG_MAXL;
+    // the status word heads the result block of the host-frame calls (pgorb_extract*: one download brings status, counts,
+    // keypoints and descriptors); K1's first launch of a batch clears it
+    {
+        const size_t ob = 64 + (((size_t)B * 4 + 63) & ~(size_t)63) + (((size_t)B * selTotal * sizeof(pgorb_keypoint) + 63) & ~(size_t)63) + (size_t)B * selTotal * 32 + 64;
+        if ((rc = ensure(c, c->outBlk, ob))) return rc;
+        PG_HIP(c, hipMemset(c->outBlk.p, 0, 64));
+    }
+    P.status = (int32_t*)c->outBlk.p;
     c->planW = w; c->planH = h; c->planBatch = B; c->planValid = true;
+    c->planEpoch++;                                            // (captured graphs hold the old plan by value)
     return 0;
 }
 
@@ -590,6 +615,19 @@ int pg_ctx_scratch_done(pgorb_ctx* c, hipStream_t s)
     c->sfiStream = s; c->sfiUsed = true;
     return 0;
 }
+int pg_ctx_pinned(pgorb_ctx* c, size_t bytes, void** p)
+{
+    if (c->pinnedBytes < bytes) {
+        PG_HIP(c, hipSetDevice(c->prm.device));
+        if (c->pinned) (void)hipHostFree(c->pinned);
+        c->pinned = nullptr; c->pinnedBytes = 0;
+        const size_t want = (bytes + (bytes >> 2) + 4095) & ~(size_t)4095;
+        PG_HIP(c, hipHostMalloc(&c->pinned, want, hipHostMallocDefault));
+        c->pinnedBytes = want;
+    }
+    *p = c->pinned;
+    return 0;
+}
 int pg_ctx_vocab_store(pgorb_ctx* c, const void* src, size_t nbytes, bool src_on_device, hipStream_t s)
 {
     PG_HIP(c, hipSetDevice(c->prm.device));
@@ -655,6 +693,9 @@ int pgorb_create(const pgorb_params* p, pgorb_ctx** out)
     pgorb_ctx* c = new pgorb_ctx();
     c->prm = *p;
     c->mx = pg_match_default_opts();
+    if (const char* e = getenv("PGORB_EXTRACT_CHUNK_KB")) { const int kb = atoi(e); if (kb >= 16) c->chunkBytes = kb << 10; }
+    c->noStage = getenv("PGORB_EXTRACT_STAGE") == nullptr;
+    c->useGraph = getenv("PGORB_EXTRACT_NO_GRAPH") == nullptr;
     // ORBextractor.cc:415-446
     const int L = p->nlevels;
     c->scaleFactor = p->scale_factor;
@@ -686,7 +727,7 @@ void pgorb_destroy(pgorb_ctx* c)
     (void)hipSetDevice(c->prm.device);
     while (!c->streams.empty()) pgorb_stream_destroy(c->streams.back());      // a stream holds a pointer to its context
     Arena* all[] = {&c->cellTab, &c->cellTabBal, &c->cellCand, &c->cellCount, &c->pyr, &c->cand, &c->sel, &c->nodes, &c->counters, &c->tables,
-                    &c->stageKps, &c->stageDesc, &c->stageN, &c->stageA, &c->stageB, &c->stageOut, &c->stageSfi, &c->vocab, &c->xdesc};
+                    &c->outBlk, &c->stageA, &c->stageB, &c->stageOut, &c->stageSfi, &c->vocab, &c->xdesc};
     for (Arena* a : all) if (a->p) (void)hipFree(a->p);
     if (c->sPyr) {
         (void)hipStreamSynchronize(c->sPyr); (void)hipStreamSynchronize(c->sFast);
@@ -701,6 +742,10 @@ void pgorb_destroy(pgorb_ctx* c)
         for (int l = 0; l < PG_MAXL; l++) { (void)hipEventDestroy(c->evGrpFast[l]); (void)hipEventDestroy(c->evGrpQt[l]); }
     }
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->pinIn) (void)hipHostFree(c->pinIn);
+    if (c->hg.exec) (void)hipGraphExecDestroy(c->hg.exec);
+    if (c->hg.g) (void)hipGraphDestroy(c->hg.g);
+    if (c->sHost) { (void)hipStreamSynchronize(c->sHost); (void)hipStreamDestroy(c->sHost); }
     if (c->evSfi) (void)hipEventDestroy(c->evSfi);
     for (hipEvent_t e : c->evExtract) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->evMatch) (void)hipEventDestroy(e);
@@ -805,6 +850,14 @@ int pgorb_check_async(pgorb_ctx* c, void* stream)
     return 0;
 }
 
+// Frames in host memory, results to host memory: the reference's call shape (ORBextractor::operator() on a pageable cv::Mat,
+// one frame per synchronous call: Frame.cc:251-257, Tracking.cc:262-266).  Round 4 cut the call's fixed costs:
+//   * input: hipMemcpy2DAsync straight from the caller's (pageable) memory.  A page-locked staging buffer of the context's own,
+//     filled in row chunks while the DMA engine moves the previous chunk, measured 24 us SLOWER per 1080p frame than the
+//     runtime's pageable path (each extra copy command costs more than the overlap saves; PGORB_EXTRACT_STAGE=1 keeps the form);
+//   * output: status word, counts, keypoints and descriptors live in ONE device block (PgPlan::status points into it) and come
+//     back with one download and one synchronisation (there were two synchronous 4-byte copies in front of it).
+// Host phases of the last calls: pgorb_profile_host.
 int pgorb_extract_batch(pgorb_ctx* c, const uint8_t* const* gray, int nframes, int w, int h,
                         int stride, pgorb_keypoint* kps, uint8_t* desc, int cap, int* n)
 {
@@ -814,49 +867,140 @@ int pgorb_extract_batch(pgorb_ctx* c, const uint8_t* const* gray, int nframes, i
     if (nframes < 1 || !gray) return fail(c, PGORB_E_ARG, "bad argument to pgorb_extract_batch");
     if (w <= 0 || h <= 0) return 0;          // empty image: the reference returns silently (:1045)
     if (!kps || !desc || cap < 1 || stride < w) return fail(c, PGORB_E_ARG, "bad argument to pgorb_extract_batch");
+    const auto t0 = std::chrono::steady_clock::now();
     PG_HIP(c, hipSetDevice(c->prm.device));
     int rc = make_plan(c, w, h, nframes);
     if (rc) return rc;
+    for (int f = 0; f < nframes; f++) if (!gray[f]) return fail(c, PGORB_E_ARG, "null frame %d", f);
     const PgLevel& L0 = c->plan.lvl[0];
-    for (int f = 0; f < nframes; f++) {
-        if (!gray[f]) return fail(c, PGORB_E_ARG, "null frame %d", f);
-        PG_HIP(c, hipMemcpy2DAsync(L0.img + (int64_t)f * L0.fstride, L0.pitch, gray[f], stride, w, h,
-                                   hipMemcpyHostToDevice, 0));
+    const int need = c->plan.selTotal;       // the device block always holds the full bound
+    // device result block of this call: status (64 B) | n[nframes] | kps[nframes][need] | desc[nframes][need][32]
+    auto al64 = [](size_t v) { return (v + 63) & ~(size_t)63; };
+    const size_t oN = 64, oK = oN + al64((size_t)nframes * 4), oD = oK + al64((size_t)nframes * need * sizeof(pgorb_keypoint)),
+                 outBytes = oD + (size_t)nframes * need * 32;
+    uint8_t* blk = (uint8_t*)c->outBlk.p;    // (make_plan sized it for max_batch frames)
+    void* hv;
+    if ((rc = pg_ctx_pinned(c, outBytes, &hv))) return rc;
+    if (!c->sHost) PG_HIP(c, hipStreamCreateWithFlags(&c->sHost, hipStreamNonBlocking));
+    hipStream_t hs = c->sHost;
+    // ---- upload ----
+    const size_t frameBytes = (size_t)w * h;
+    const bool stage = frameBytes * nframes <= ((size_t)64 << 20) && !c->noStage;
+    if (stage) {
+        if (c->pinInBytes < frameBytes * nframes) {
+            if (c->pinIn) (void)hipHostFree(c->pinIn);
+    if (c->hg.exec) (void)hipGraphExecDestroy(c->hg.exec);
+    if (c->hg.g) (void)hipGraphDestroy(c->hg.g);
+    if (c->sHost) { (void)hipStreamSynchronize(c->sHost); (void)hipStreamDestroy(c->sHost); }
+            c->pinIn = nullptr; c->pinInBytes = 0;
+            const size_t want = (frameBytes * std::min(nframes > 1 ? c->prm.max_batch : 1, (int)(((size_t)64 << 20) / frameBytes + 1)) + 4095) & ~(size_t)4095;
+            PG_HIP(c, hipHostMalloc((void**)&c->pinIn, std::max(want, frameBytes * nframes), hipHostMallocDefault));
+            c->pinInBytes = std::max(want, frameBytes * nframes);
+        }
     }
-    const int need = c->plan.selTotal;       // device staging always holds the full bound
-    if ((rc = ensure(c, c->stageKps, (size_t)c->prm.max_batch * need * sizeof(pgorb_keypoint)))) return rc;
-    if ((rc = ensure(c, c->stageDesc, (size_t)c->prm.max_batch * need * 32))) return rc;
-    if ((rc = ensure(c, c->stageN, (size_t)c->prm.max_batch * 4))) return rc;
-    rc = run_batch(c, nullptr, true, nframes, w, h, stride, 0, (pgorb_keypoint*)c->stageKps.p,
-                   (uint8_t*)c->stageDesc.p, need, (int32_t*)c->stageN.p, 0);
-    if (rc) return rc;
-    if ((rc = pgorb_check_async(c, 0))) return rc;
-    std::vector<int32_t> cnt(nframes);
-    PG_HIP(c, hipMemcpy(cnt.data(), c->stageN.p, (size_t)nframes * 4, hipMemcpyDeviceToHost));
+    const int rowsPer = std::max(1, (int)(((size_t)c->chunkBytes + w - 1) / w));
+    for (int f = 0; f < nframes; f++) {
+        bool direct = !stage;
+        if (stage) {
+            hipPointerAttribute_t at;
+            if (hipPointerGetAttributes(&at, gray[f]) == hipSuccess && at.type == hipMemoryTypeHost) direct = true;   // already page-locked
+            else (void)hipGetLastError();
+        }
+        uint8_t* dst = L0.img + (int64_t)f * L0.fstride;
+        if (direct) {
+            PG_HIP(c, hipMemcpy2DAsync(dst, L0.pitch, gray[f], stride, w, h, hipMemcpyHostToDevice, hs));
+            continue;
+        }
+        uint8_t* pin = c->pinIn + (size_t)f * frameBytes;
+        for (int r0 = 0; r0 < h; r0 += rowsPer) {
+            const int rows = std::min(rowsPer, h - r0);
+            if (stride == w) memcpy(pin + (size_t)r0 * w, gray[f] + (size_t)r0 * stride, (size_t)rows * w);
+            else for (int r = 0; r < rows; r++) memcpy(pin + (size_t)(r0 + r) * w, gray[f] + (size_t)(r0 + r) * stride, w);
+            if (L0.pitch == w) PG_HIP(c, hipMemcpyAsync(dst + (size_t)r0 * w, pin + (size_t)r0 * w, (size_t)rows * w, hipMemcpyHostToDevice, hs));
+            else PG_HIP(c, hipMemcpy2DAsync(dst + (size_t)r0 * L0.pitch, L0.pitch, pin + (size_t)r0 * w, w, w, rows, hipMemcpyHostToDevice, hs));
+        }
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    // ---- kernels ----
+    // Direct launches the first time a (plan, batch size) is seen -- the launchers may still allocate or configure --, captured
+    // into a graph the second time, replayed from then on: the 10 launches + the download become one submission (the 7 resize
+    // launches of a single frame are launch-bound: ~5 us apiece for ~2 us of work).  Not while a profile is armed (its events
+    // would be captured) or a multi-stream pipeline option is on.
+    pgorb_ctx::HostGraph& G = c->hg;
+    const bool graphable = c->useGraph && c->profExtract >= c->profMax && !c->pipePyr && !c->pipeLev;
+    const bool replay = graphable && G.exec && G.nframes == nframes && G.epoch == c->planEpoch && G.pinned == hv && G.outBytes == outBytes;
+    if (replay) {
+        PG_HIP(c, hipGraphLaunch(G.exec, hs));
+        c->lastFrames = nframes; c->lastAliased = false;
+    } else {
+        const bool capture = graphable && G.seenFrames == nframes && G.seenEpoch == c->planEpoch;
+        G.seenFrames = nframes; G.seenEpoch = c->planEpoch;
+        if (capture) PG_HIP(c, hipStreamBeginCapture(hs, hipStreamCaptureModeRelaxed));
+        rc = run_batch(c, nullptr, true, nframes, w, h, stride, 0, (pgorb_keypoint*)(blk + oK), blk + oD, need, (int32_t*)(blk + oN), hs);
+        hipError_t e1 = rc ? hipSuccess : hipMemcpyAsync(hv, blk, outBytes, hipMemcpyDeviceToHost, hs);
+        if (capture) {
+            hipGraph_t g = nullptr;
+            const hipError_t e2 = hipStreamEndCapture(hs, &g);
+            if (rc || e1 != hipSuccess || e2 != hipSuccess || !g) {
+                if (g) (void)hipGraphDestroy(g);
+                (void)hipGetLastError();
+                c->useGraph = 0;                               // capture failed: direct launches, now and from here on
+                if (rc) return rc;
+                if ((rc = run_batch(c, nullptr, true, nframes, w, h, stride, 0, (pgorb_keypoint*)(blk + oK), blk + oD, need, (int32_t*)(blk + oN), hs))) return rc;
+                PG_HIP(c, hipMemcpyAsync(hv, blk, outBytes, hipMemcpyDeviceToHost, hs));
+                goto launched;
+            }
+            if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; }
+            if (G.g) { (void)hipGraphDestroy(G.g); G.g = nullptr; }
+            hipGraphExec_t ex = nullptr;
+            if (hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) {
+                (void)hipGraphDestroy(g); (void)hipGetLastError(); c->useGraph = 0;
+                if ((rc = run_batch(c, nullptr, true, nframes, w, h, stride, 0, (pgorb_keypoint*)(blk + oK), blk + oD, need, (int32_t*)(blk + oN), hs))) return rc;
+                PG_HIP(c, hipMemcpyAsync(hv, blk, outBytes, hipMemcpyDeviceToHost, hs));
+                goto launched;
+            }
+            G.g = g; G.exec = ex; G.nframes = nframes; G.epoch = c->planEpoch; G.pinned = hv; G.outBytes = outBytes;
+            PG_HIP(c, hipGraphLaunch(G.exec, hs));
+        } else {
+            if (rc) return rc;
+            if (e1 != hipSuccess) return fail(c, PGORB_E_HIP, "hipMemcpyAsync D2H failed: %s", hipGetErrorString(e1));
+        }
+    }
+launched:
+    const auto t2 = std::chrono::steady_clock::now();
+    PG_HIP(c, hipStreamSynchronize(hs));
+    const auto t3 = std::chrono::steady_clock::now();
+    // ---- results ----
+    const uint8_t* hb = (const uint8_t*)hv;
+    const int32_t st = *(const int32_t*)hb;
+    if (st) return fail(c, st, st == PGORB_E_TOOSMALL ? "device status %d (a pyramid level more than twice as tall as wide has candidates: the reference divides by zero there)"
+                                                     : "device status %d (internal candidate capacity exceeded)", st);
+    const int32_t* cnt = (const int32_t*)(hb + oN);
     for (int f = 0; f < nframes; f++)
         if (cnt[f] > cap)
             return fail(c, PGORB_E_CAP, "frame %d has %d keypoints, capacity %d", f, cnt[f], cap);
-    // one bulk download of the used part of the staging slabs into page-locked memory, then scatter
-    const size_t kBytes = (size_t)nframes * need * sizeof(pgorb_keypoint), dBytes = (size_t)nframes * need * 32;
-    if (c->pinnedBytes < kBytes + dBytes) {
-        if (c->pinned) (void)hipHostFree(c->pinned);
-        c->pinned = nullptr; c->pinnedBytes = 0;
-        const size_t want = ((size_t)c->prm.max_batch * need * (sizeof(pgorb_keypoint) + 32) + 4095) & ~(size_t)4095;
-        PG_HIP(c, hipHostMalloc(&c->pinned, want, hipHostMallocDefault));
-        c->pinnedBytes = want;
-    }
-    uint8_t* hk = (uint8_t*)c->pinned;
-    uint8_t* hd = hk + kBytes;
-    PG_HIP(c, hipMemcpyAsync(hk, c->stageKps.p, kBytes, hipMemcpyDeviceToHost, 0));
-    PG_HIP(c, hipMemcpyAsync(hd, c->stageDesc.p, dBytes, hipMemcpyDeviceToHost, 0));
-    PG_HIP(c, hipStreamSynchronize(0));
     for (int f = 0; f < nframes; f++) {
         n[f] = cnt[f];
         if (!cnt[f]) continue;
-        memcpy(kps + (size_t)f * cap, hk + (size_t)f * need * sizeof(pgorb_keypoint), (size_t)cnt[f] * sizeof(pgorb_keypoint));
-        memcpy(desc + (size_t)f * cap * 32, hd + (size_t)f * need * 32, (size_t)cnt[f] * 32);
+        memcpy(kps + (size_t)f * cap, hb + oK + (size_t)f * need * sizeof(pgorb_keypoint), (size_t)cnt[f] * sizeof(pgorb_keypoint));
+        memcpy(desc + (size_t)f * cap * 32, hb + oD + (size_t)f * need * 32, (size_t)cnt[f] * 32);
     }
+    const auto t4 = std::chrono::steady_clock::now();
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    c->hostUs[0] += us(t0, t1); c->hostUs[1] += us(t1, t2); c->hostUs[2] += us(t2, t3); c->hostUs[3] += us(t3, t4); c->hostCalls++;
     return 0;
+}
+
+// mean host-side phase times (microseconds) of the pgorb_extract / pgorb_extract_batch calls since the last reset:
+// us[0] input staging + upload issue, us[1] kernel launches + download issue, us[2] wait for the GPU, us[3] results to the caller's buffers.
+// Returns the number of calls the sums cover; reset != 0 clears them (us may be NULL then).
+int pgorb_profile_host(pgorb_ctx* c, double* us, int reset)
+{
+    if (!c) return PGORB_E_ARG;
+    const int k = c->hostCalls;
+    if (us) for (int i = 0; i < 4; i++) us[i] = c->hostUs[i];
+    if (reset) { for (double& v : c->hostUs) v = 0; c->hostCalls = 0; }
+    return k;
 }
 
 void* pgorb_host_alloc(int64_t bytes)
@@ -972,6 +1116,7 @@ int pgorb_set_option(pgorb_ctx* c, const char* key, int value)
 {
     if (!key) return PGORB_E_ARG;
     if (!c) return PGORB_E_ARG;                               // every option belongs to a context (round 4: no process-wide state)
+    c->planEpoch++;                                            // (a captured graph of the host-frame path holds the old settings)
     if (!strcmp(key, "matcher")) { c->mx.popcount = value ? 1 : pg_match_default_opts().popcount; return 0; }     // 0 = what the environment says
     if (!strcmp(key, "match_mode")) {
         if (value < -1 || value > 2) return fail(c, PGORB_E_ARG, "match_mode must be -1, 0, 1 or 2");
@@ -1061,17 +1206,23 @@ int pgorb_debug_level_candidates(pgorb_ctx* c, int frame, int level, int32_t* x,
     const PgPlan& P = c->plan;
     PG_HIP(c, hipSetDevice(c->prm.device));
     PG_HIP(c, hipDeviceSynchronize());
-    int32_t cnt = 0;
-    PG_HIP(c, hipMemcpy(&cnt, P.candCount + frame * PG_MAXL + level, 4, hipMemcpyDeviceToHost));
-    if (cnt > P.lvl[level].candCap) cnt = P.lvl[level].candCap;
-    std::vector<uint32_t> buf(cnt > 0 ? 2 * (size_t)cnt : 2);
-    if (cnt > 0)
-        PG_HIP(c, hipMemcpy(buf.data(), P.cand + ((int64_t)frame * P.candFrame + P.lvl[level].candOff) * 2,
-                            (size_t)cnt * 8, hipMemcpyDeviceToHost));
-    for (int i = 0; i < cnt && i < cap; i++) {
-        const uint32_t v = buf[2 * (size_t)i];
-        x[i] = v & 0xFFF; y[i] = (v >> 12) & 0xFFF; response[i] = v >> 24;
-    }
+    // K2's per-cell slots of the level (K3 reads them in place since round 4: no dense candidate records exist any more)
+    const PgLevel& V = P.lvl[level];
+    const int ncells = V.nCols * V.nRows;
+    std::vector<int32_t> cc(ncells);
+    std::vector<uint32_t> slots((size_t)ncells * V.cellCap);
+    PG_HIP(c, hipMemcpy(cc.data(), P.cellCount + (int64_t)frame * P.totalCells + V.cellBase, (size_t)ncells * 4, hipMemcpyDeviceToHost));
+    PG_HIP(c, hipMemcpy(slots.data(), P.cellCand + (int64_t)frame * P.cellCandFrame + V.cellCandOff, slots.size() * 4, hipMemcpyDeviceToHost));
+    int cnt = 0;
+    for (int ci = 0; ci < ncells; ci++)
+        for (int j = 0; j < std::min(cc[ci], V.cellCap); j++, cnt++) {
+            if (cnt >= cap) continue;
+            const uint32_t v = slots[(size_t)ci * V.cellCap + j];
+            x[cnt] = v & 0xFFF; y[cnt] = (v >> 12) & 0xFFF; response[cnt] = v >> 24;
+        }
+    int32_t k3 = 0;                                            // K3's own count of the same slots must agree
+    PG_HIP(c, hipMemcpy(&k3, P.candCount + frame * PG_MAXL + level, 4, hipMemcpyDeviceToHost));
+    if (k3 != cnt) return fail(c, PGORB_E_OVERFLOW, "level %d: K3 counted %d candidates, the cell slots hold %d", level, k3, cnt);
     return cnt;
 }
 

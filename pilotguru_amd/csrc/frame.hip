@@ -27,6 +27,7 @@
 // All per-pair state (vMatchedDistance, vnMatches21, vnMatches12) lives in LDS.
 #include "pgorb_internal.h"
 #include <algorithm>
+#include <string.h>
 #include <vector>
 
 #define GRID_COLS PGORB_GRID_COLS
@@ -40,6 +41,7 @@ int pg_ctx_stage(pgorb_ctx* c, int which, size_t bytes, void** p);
 int pg_ctx_device(pgorb_ctx* c);
 int pg_ctx_scratch(pgorb_ctx* c, size_t bytes, hipStream_t s, void** p);      // the matchers' shared arena, ordered across caller streams
 int pg_ctx_scratch_done(pgorb_ctx* c, hipStream_t s);
+int pg_ctx_pinned(pgorb_ctx* c, size_t bytes, void** p);                       // the context's page-locked bounce buffer (synchronous host calls only)
 
 __device__ __forceinline__ int grid_cell_of(const pgorb_keypoint& kp, float minX, float minY, float invW, float invH)
 {
@@ -477,6 +479,9 @@ struct PgProjBatch {
     const uint8_t* valid; const float* x; const float* y; const int32_t* level; const float* aux;   // aux: view cos (mode 0) / angle (mode 1)
     const uint8_t* desc; const uint8_t* hasObs;
     float sf[PG_MAXL + 1]; int nlevels; float th;
+    // mode 2 (key frame, relocalisation): level = PredictScale(dist3d), aux = the key frame keypoint's angle
+    const uint8_t* found; const float* dist3d; const float* minDist; const float* maxDist; float logSf; int orbDist;
+    float maxX, maxY;                      // mnMaxX / mnMaxY (the kernels derive everything else from minX / minY and the inverse cell sizes)
 };
 
 #define TH_HIGH 100
@@ -491,10 +496,25 @@ struct PgProjBatch {
 __device__ __forceinline__ bool proj_query(const PgProjBatch& B, int64_t qi, int mode, float minX, float minY, float invW, float invH,
                                            float& x, float& y, float& r, int& minLevel, int& maxLevel, int& cx0, int& cx1, int& cy0, int& cy1)
 {
-    const int lvl = B.level[qi];
-    if (!B.valid[qi] || lvl < 0 || lvl >= B.nlevels) return false;
+    if (!B.valid[qi]) return false;
     x = B.x[qi]; y = B.y[qi];
-    if (mode == 0) {
+    int lvl;
+    if (mode == 2) {
+        // ORBmatcher.cc:1497-1531: not already found, projection inside the image bounds, depth inside the point's scale
+        // invariance range, level from MapPoint::PredictScale
+        if (B.found[qi]) return false;
+        if (x < minX || x > B.maxX || y < minY || y > B.maxY) return false;          // :1512-1515
+        const float d3 = B.dist3d[qi], dmin = B.minDist[qi], dmax = B.maxDist[qi];
+        if (d3 < dmin || d3 > dmax) return false;
+        lvl = pg_predict_scale(dmax, d3, B.logSf, B.nlevels);
+    } else {
+        lvl = B.level[qi];
+        if (lvl < 0 || lvl >= B.nlevels) return false;
+    }
+    if (mode == 2) {
+        r = __fmul_rn(B.th, B.sf[lvl]);                               // th * CurrentFrame.mvScaleFactors[nPredictedLevel] (:1531)
+        minLevel = lvl - 1; maxLevel = lvl + 1;                       // :1533
+    } else if (mode == 0) {
         r = ((double)B.aux[qi] > 0.998) ? 2.5f : 4.0f;                // RadiusByViewingCos (:133-139)
         if (B.th != 1.0f) r = __fmul_rn(r, B.th);                     // bFactor (:50, :65-66)
         r = __fmul_rn(r, B.sf[lvl]);                                  // r * F.mvScaleFactors[nPredictedLevel] (:69)
@@ -559,7 +579,7 @@ __global__ __launch_bounds__(256) void k_proj_candidates(PgProjBatch B, float mi
     const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
     const uint4 q0 = reinterpret_cast<const uint4*>(B.desc + qi * 32)[0];
     const uint4 q1 = reinterpret_cast<const uint4*>(B.desc + qi * 32)[1];
-    const float qangle = mode == 1 ? B.aux[qi] : 0.f;
+    const float qangle = mode != 0 ? B.aux[qi] : 0.f;
     uint32_t* out = lists + qi * PROJ_K;
     int total = 0;
     for (int base = 0; base < M; base += 64) {
@@ -571,7 +591,7 @@ __global__ __launch_bounds__(256) void k_proj_candidates(PgProjBatch B, float mi
             ok = true;
             if (bCheckLevels && (kp2.octave < minLevel || (maxLevel >= 0 && kp2.octave > maxLevel))) ok = false;
             if (!(fabsf(__fsub_rn(kp2.x, x)) < r && fabsf(__fsub_rn(kp2.y, y)) < r)) ok = false;
-            if (ok) e = proj_entry(sfi_distance(q0, q1, D + (int64_t)i2 * 32), mode == 1 ? proj_bin(qangle, kp2.angle) : 0, kp2.octave, i2);
+            if (ok) e = proj_entry(sfi_distance(q0, q1, D + (int64_t)i2 * 32), mode != 0 ? proj_bin(qangle, kp2.angle) : 0, kp2.octave, i2);
         }
         const unsigned long long m = __ballot(ok);
         const int pos = total + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
@@ -596,7 +616,7 @@ __device__ __noinline__ uint2 proj_eval_in_place(const PgProjBatch B, int64_t qi
     const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
     const uint4 q0 = reinterpret_cast<const uint4*>(B.desc + qi * 32)[0];
     const uint4 q1 = reinterpret_cast<const uint4*>(B.desc + qi * 32)[1];
-    const float qangle = mode == 1 ? B.aux[qi] : 0.f;
+    const float qangle = mode != 0 ? B.aux[qi] : 0.f;
     unsigned long long b1 = ~0ull, b2 = ~0ull;              // (distance << 48 | scan position << 32 | entry): the lane's two smallest
     int posBase = 0;
     for (int ix = cx0; ix <= cx1; ix++)
@@ -610,7 +630,7 @@ __device__ __noinline__ uint2 proj_eval_in_place(const PgProjBatch B, int64_t qi
                 if (taken[i2]) continue;
                 const int dist = sfi_distance(q0, q1, D + (int64_t)i2 * 32);
                 const unsigned long long key = ((unsigned long long)dist << 48) | ((unsigned long long)(posBase + k) << 32) |
-                                               proj_entry(dist, mode == 1 ? proj_bin(qangle, kp2.angle) : 0, kp2.octave, i2);
+                                               proj_entry(dist, mode != 0 ? proj_bin(qangle, kp2.angle) : 0, kp2.octave, i2);
                 if (key < b1) { b2 = b1; b1 = key; } else if (key < b2) b2 = key;
             }
             posBase += cnt;
@@ -650,7 +670,7 @@ __global__ __launch_bounds__(64) void k_search_by_projection(
     uint16_t* qBest = active + B.qcap;                                    // [qcap]
     int8_t* rotBin = reinterpret_cast<int8_t*>(qBest + B.qcap);           // [qcap]
     for (int i = lane; i < n; i += 64) { taken[i] = kpHasPoint ? (kpHasPoint[i] != 0) : 0; asg[i] = -1; }
-    if (mode == 1) for (int i = lane; i < nq; i += 64) rotBin[i] = -1;
+    if (mode != 0) for (int i = lane; i < nq; i += 64) rotBin[i] = -1;
     int nact = 0;
     for (int base = 0; base < nq; base += 512) {
         uint8_t cv[8];
@@ -674,7 +694,7 @@ __global__ __launch_bounds__(64) void k_search_by_projection(
             Q[j] = -1; Cn[j] = 0; E[j] = 0; O[j] = 0;
             if (a < nact) {
                 const int q = active[a];
-                Q[j] = q; Cn[j] = LC[q]; O[j] = B.hasObs[qo + q];
+                Q[j] = q; Cn[j] = LC[q]; O[j] = mode == 2 ? 1 : (int)B.hasObs[qo + q];      // (key-frame form: any point blocks, :1542-1543)
                 E[j] = L[(int64_t)q * PROJ_K + lane];                        // (all 64 slots; slots past the count are masked below)
             }
         }
@@ -713,15 +733,15 @@ __global__ __launch_bounds__(64) void k_search_by_projection(
                 if (bestDist <= TH_HIGH)                                    // :113-123
                     accept = !(bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(nnratio, (float)bestDist2));
             } else {
-                accept = bestDist <= TH_HIGH;                               // :1421
-                if (accept && checkOrientation) bin = (int)((e1 >> 18) & 31u);     // :1426-1436 (computed in pass A)
+                accept = bestDist <= (mode == 2 ? B.orbDist : TH_HIGH);     // :1421 / :1554
+                if (accept && checkOrientation) bin = (int)((e1 >> 18) & 31u);     // :1426-1436 / :1559-1569 (computed in pass A)
             }
             if (accept) {
                 nmatches++;
                 if (lane == 0) {
                     asg[bestIdx] = q;                                       // F.mvpMapPoints[bestIdx] = pMP
                     taken[bestIdx] = curO[j] != 0;
-                    if (mode == 1) { rotBin[q] = (int8_t)bin; qBest[q] = (uint16_t)bestIdx; }
+                    if (mode != 0) { rotBin[q] = (int8_t)bin; qBest[q] = (uint16_t)bestIdx; }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
@@ -730,7 +750,7 @@ __global__ __launch_bounds__(64) void k_search_by_projection(
         for (int j = 0; j < PROJ_G; j++) { curE[j] = nxtE[j]; curC[j] = nxtC[j]; curQ[j] = nxtQ[j]; curO[j] = nxtO[j]; }
     }
     __syncthreads();
-    if (mode == 1 && checkOrientation) {                       // :1443-1469
+    if (mode != 0 && checkOrientation) {                       // :1443-1469 / :1575-1600
         int h = 0;
         for (int i = 0; i < nq; i++) h += (rotBin[i] == lane);
         int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
@@ -1216,15 +1236,22 @@ int pgorb_search_for_initialization_batch_device(pgorb_ctx* c, const pgorb_keypo
     return pg_ctx_scratch_done(c, (hipStream_t)stream);
 }
 
+// what the key-frame form (mode 2) takes beyond the common query arrays
+struct PgProjKeyFrame { const uint8_t* found; const float* dist3d; const float* minDist; const float* maxDist; float logSf; int orbDist; };
+
 static int pg_search_by_projection_batch(pgorb_ctx* c, int mode, const pgorb_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, int cap,
                                          const int32_t* d_grid_start, const int32_t* d_grid_idx, const int32_t* d_pair_frame, int npairs,
                                          float min_x, float max_x, float min_y, float max_y, const uint8_t* d_kp_has_point, int qcap,
                                          const int32_t* d_nq, const uint8_t* d_valid, const float* d_x, const float* d_y, const int32_t* d_level,
                                          const float* d_aux, const uint8_t* d_qdesc, const uint8_t* d_qobs, float th, float nnratio,
-                                         int check_orientation, int32_t* d_assigned, int32_t* d_nmatches, hipStream_t stream)
+                                         int check_orientation, int32_t* d_assigned, int32_t* d_nmatches, hipStream_t stream,
+                                         const PgProjKeyFrame* kf = nullptr)
 {
+    const bool m2 = mode == 2;
     if (!d_kps || !d_desc || !d_n || cap < 1 || !d_grid_start || !d_grid_idx || npairs < 0 || qcap < 0 ||
-        (npairs && (!d_nq || !d_assigned || !d_nmatches)) || (npairs && qcap && (!d_valid || !d_x || !d_y || !d_level || !d_aux || !d_qdesc || !d_qobs)) ||
+        (npairs && (!d_nq || !d_assigned || !d_nmatches)) ||
+        (npairs && qcap && (!d_valid || !d_x || !d_y || !d_aux || !d_qdesc || (!m2 && (!d_level || !d_qobs)))) ||
+        (m2 && (!kf || (npairs && qcap && (!kf->found || !kf->dist3d || !kf->minDist || !kf->maxDist)) || !(kf->logSf > 0.0f))) ||
         !(max_x > min_x) || !(max_y > min_y))
         return pg_ctx_fail(c, PGORB_E_ARG, "bad argument to pgorb_search_by_projection_*");
     if (cap > 16000 || qcap > 16000) return pg_ctx_fail(c, PGORB_E_LIMIT, "more than 16000 keypoints / queries");
@@ -1234,6 +1261,8 @@ static int pg_search_by_projection_batch(pgorb_ctx* c, int mode, const pgorb_key
     B.K = d_kps; B.D = d_desc; B.n = d_n; B.cap = cap; B.gstart = d_grid_start; B.gidx = d_grid_idx; B.pairFrame = d_pair_frame;
     B.kpHasPoint = d_kp_has_point; B.qcap = qcap; B.nq = d_nq; B.valid = d_valid; B.x = d_x; B.y = d_y; B.level = d_level; B.aux = d_aux;
     B.desc = d_qdesc; B.hasObs = d_qobs; B.nlevels = pgorb_levels(c); B.th = th;
+    B.found = nullptr; B.dist3d = B.minDist = B.maxDist = nullptr; B.logSf = 1.0f; B.orbDist = TH_HIGH; B.maxX = max_x; B.maxY = max_y;
+    if (m2) { B.found = kf->found; B.dist3d = kf->dist3d; B.minDist = kf->minDist; B.maxDist = kf->maxDist; B.logSf = kf->logSf; B.orbDist = kf->orbDist; }
     pgorb_scale_tables(c, B.sf, nullptr, nullptr, nullptr);
     const float invW = (float)GRID_COLS / (max_x - min_x), invH = (float)GRID_ROWS / (max_y - min_y);
     // scratch of the two passes: lists[npairs][qcap][PROJ_K] u32 | count[npairs][qcap] u8
@@ -1280,54 +1309,109 @@ int pgorb_search_by_projection_frame_batch_device(pgorb_ctx* c, const pgorb_keyp
                                          d_point_has_obs, th, 0.f, check_orientation, d_assigned, d_nmatches, (hipStream_t)stream);
 }
 
-// single frame through host buffers: a one-pair batch
+int pgorb_search_by_projection_keyframe_batch_device(pgorb_ctx* c, const pgorb_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n,
+        int cap_per_frame, const int32_t* d_grid_start, const int32_t* d_grid_idx, const int32_t* d_pair_frame, int npairs,
+        float min_x, float max_x, float min_y, float max_y, const uint8_t* d_kp_has_point, int qcap, const int32_t* d_nq,
+        const uint8_t* d_valid, const uint8_t* d_already_found, const float* d_u, const float* d_v, const float* d_dist3d,
+        const float* d_min_distance, const float* d_max_distance, const float* d_kf_angle, const uint8_t* d_point_desc,
+        float log_scale_factor, float th, int orb_dist, int check_orientation, int32_t* d_assigned, int32_t* d_nmatches, void* stream)
+{
+    if (!c) return PGORB_E_ARG;
+    const PgProjKeyFrame kf = {d_already_found, d_dist3d, d_min_distance, d_max_distance, log_scale_factor, orb_dist};
+    return pg_search_by_projection_batch(c, 2, d_kps, d_desc, d_n, cap_per_frame, d_grid_start, d_grid_idx, d_pair_frame, npairs, min_x, max_x,
+                                         min_y, max_y, d_kp_has_point, qcap, d_nq, d_valid, d_u, d_v, nullptr, d_kf_angle, d_point_desc,
+                                         nullptr, th, 0.f, check_orientation, d_assigned, d_nmatches, (hipStream_t)stream, &kf);
+}
+
+// the contract's logarithm and the Frame's mfLogScaleFactor under it (Frame.cc:188), MapPoint::PredictScale (MapPoint.cc:516-531)
+float pgorb_log_f(float x) { return pg_log_f(x); }
+float pgorb_log_scale_factor(const pgorb_ctx* c)
+{
+    if (!c) return 0.0f;
+    float sf[PG_MAXL + 1];
+    pgorb_scale_tables(c, sf, nullptr, nullptr, nullptr);
+    return pg_log_f(sf[1]);                              // mvScaleFactor[1] = (float)(1.0f * (double)scaleFactor) = mfScaleFactor
+}
+int pgorb_predict_scale(const pgorb_ctx* c, float max_distance, float current_dist)
+{
+    if (!c) return PGORB_E_ARG;
+    return pg_predict_scale(max_distance, current_dist, pgorb_log_scale_factor(c), pgorb_levels(c));
+}
+
+// single frame through host buffers: a one-pair batch.  Round 4: the eleven input arrays are packed into the context's
+// page-locked bounce buffer and travel as ONE asynchronous upload, the results (assignment array + count) as one
+// download -- eleven synchronous pageable hipMemcpy calls were 0.3 ms of a 1.6-ms call.
+struct PgProjHostKF { const uint8_t* found; const float* dist3d; const float* minDist; const float* maxDist; float logSf; int orbDist; };
 static int pg_search_by_projection_host(pgorb_ctx* c, int mode, const pgorb_keypoint* kps, const uint8_t* desc, int n,
                                         float min_x, float max_x, float min_y, float max_y, const uint8_t* kp_has_point,
                                         int nq, const uint8_t* valid, const float* qx, const float* qy, const int32_t* level,
                                         const float* aux, const uint8_t* qdesc, const uint8_t* qobs, float th, float nnratio,
-                                        int check_orientation, int32_t* assigned)
+                                        int check_orientation, int32_t* assigned, const PgProjHostKF* kf = nullptr)
 {
-    if (n < 0 || nq < 0 || (n && (!kps || !desc || !assigned)) || (nq && (!valid || !qx || !qy || !level || !aux || !qdesc || !qobs)) ||
+    const bool m2 = mode == 2;
+    if (n < 0 || nq < 0 || (n && (!kps || !desc || !assigned)) ||
+        (nq && (!valid || !qx || !qy || !aux || !qdesc || (!m2 && (!level || !qobs)))) ||
+        (m2 && (!kf || (nq && (!kf->found || !kf->dist3d || !kf->minDist || !kf->maxDist)))) ||
         !(max_x > min_x) || !(max_y > min_y))
         return pg_ctx_fail(c, PGORB_E_ARG, "bad argument to pgorb_search_by_projection_*");
     for (int i = 0; i < n; i++) assigned[i] = -1;
     if (!n || !nq) return 0;
     if (n > 16000 || nq > 16000) return pg_ctx_fail(c, PGORB_E_LIMIT, "more than 16000 keypoints / queries");
     auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
-    const size_t oK = 0, oD = oK + al((size_t)n * sizeof(pgorb_keypoint)), oGS = oD + al((size_t)n * 32),
-                 oGI = oGS + al((size_t)(GRID_CELLS + 1) * 4), oH = oGI + al((size_t)n * 4), oV = oH + al(n),
-                 oX = oV + al(nq), oY = oX + al((size_t)nq * 4), oL = oY + al((size_t)nq * 4), oA = oL + al((size_t)nq * 4),
-                 oQD = oA + al((size_t)nq * 4), oO = oQD + al((size_t)nq * 32), oAs = oO + al(nq), oN = oAs + al((size_t)n * 4),
-                 total = oN + 64;
-    void* dv;
+    // uploaded part first (one copy), device-only scratch and the results behind it
+    size_t off = 0;
+    auto place = [&](size_t bytes) { const size_t o = off; off += al(bytes); return o; };
+    const size_t oN = place(64), oK = place((size_t)n * sizeof(pgorb_keypoint)), oD = place((size_t)n * 32), oH = place(n), oV = place(nq),
+                 oX = place((size_t)nq * 4), oY = place((size_t)nq * 4), oL = place((size_t)nq * 4), oA = place((size_t)nq * 4),
+                 oQD = place((size_t)nq * 32), oO = place(nq), oF = place(m2 ? nq : 0), oD3 = place(m2 ? (size_t)nq * 4 : 0),
+                 oDmin = place(m2 ? (size_t)nq * 4 : 0), oDmax = place(m2 ? (size_t)nq * 4 : 0);
+    const size_t upBytes = off;
+    const size_t oGS = place((size_t)(GRID_CELLS + 1) * 4), oGI = place((size_t)n * 4);
+    const size_t oAs = place((size_t)n * 4), oR = place(64);
+    const size_t total = off, downBytes = total - oAs;
+    void *dv, *hv;
     int rc = pg_ctx_stage(c, 0, total, &dv);
     if (rc) return rc;
-    uint8_t* d = (uint8_t*)dv;
+    if ((rc = pg_ctx_pinned(c, std::max(upBytes, downBytes), &hv))) return rc;
+    uint8_t* d = (uint8_t*)dv; uint8_t* h = (uint8_t*)hv;
     const int32_t cnt[2] = {n, nq};
-    bool ok = hipMemcpy(d + oK, kps, (size_t)n * sizeof(pgorb_keypoint), hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(d + oD, desc, (size_t)n * 32, hipMemcpyHostToDevice) == hipSuccess &&
-              (!kp_has_point || hipMemcpy(d + oH, kp_has_point, n, hipMemcpyHostToDevice) == hipSuccess) &&
-              hipMemcpy(d + oV, valid, nq, hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(d + oX, qx, (size_t)nq * 4, hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(d + oY, qy, (size_t)nq * 4, hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(d + oL, level, (size_t)nq * 4, hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(d + oA, aux, (size_t)nq * 4, hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(d + oQD, qdesc, (size_t)nq * 32, hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(d + oO, qobs, nq, hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(d + oN, cnt, 8, hipMemcpyHostToDevice) == hipSuccess;
-    if (!ok) return pg_ctx_fail(c, PGORB_E_HIP, "hipMemcpy H2D failed");
+    memcpy(h + oN, cnt, 8);
+    memcpy(h + oK, kps, (size_t)n * sizeof(pgorb_keypoint)); memcpy(h + oD, desc, (size_t)n * 32);
+    if (kp_has_point) memcpy(h + oH, kp_has_point, n);
+    memcpy(h + oV, valid, nq); memcpy(h + oX, qx, (size_t)nq * 4); memcpy(h + oY, qy, (size_t)nq * 4);
+    if (level) memcpy(h + oL, level, (size_t)nq * 4);
+    memcpy(h + oA, aux, (size_t)nq * 4); memcpy(h + oQD, qdesc, (size_t)nq * 32);
+    if (qobs) memcpy(h + oO, qobs, nq);
+    if (m2) { memcpy(h + oF, kf->found, nq); memcpy(h + oD3, kf->dist3d, (size_t)nq * 4); memcpy(h + oDmin, kf->minDist, (size_t)nq * 4); memcpy(h + oDmax, kf->maxDist, (size_t)nq * 4); }
+    if (hipMemcpyAsync(d, h, upBytes, hipMemcpyHostToDevice, 0) != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "hipMemcpy H2D failed");
     if ((rc = pgorb_frame_grid_batch_device(c, (pgorb_keypoint*)(d + oK), (int32_t*)(d + oN), 1, n, min_x, max_x, min_y,
                                             max_y, (int32_t*)(d + oGS), (int32_t*)(d + oGI), 0))) return rc;
+    const PgProjKeyFrame dkf = {d + oF, (float*)(d + oD3), (float*)(d + oDmin), (float*)(d + oDmax), m2 ? kf->logSf : 1.0f, m2 ? kf->orbDist : 0};
     rc = pg_search_by_projection_batch(c, mode, (pgorb_keypoint*)(d + oK), d + oD, (int32_t*)(d + oN), n, (int32_t*)(d + oGS), (int32_t*)(d + oGI),
                                        nullptr, 1, min_x, max_x, min_y, max_y, kp_has_point ? d + oH : nullptr, nq, (int32_t*)(d + oN) + 1, d + oV,
                                        (float*)(d + oX), (float*)(d + oY), (int32_t*)(d + oL), (float*)(d + oA), d + oQD, d + oO, th, nnratio,
-                                       check_orientation, (int32_t*)(d + oAs), (int32_t*)(d + oN) + 2, 0);
+                                       check_orientation, (int32_t*)(d + oAs), (int32_t*)(d + oR), 0, m2 ? &dkf : nullptr);
     if (rc) return rc;
-    int32_t nm = 0;
-    ok = hipMemcpy(assigned, d + oAs, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess &&
-         hipMemcpy(&nm, d + oN + 8, 4, hipMemcpyDeviceToHost) == hipSuccess;
-    if (!ok) return pg_ctx_fail(c, PGORB_E_HIP, "hipMemcpy D2H failed");
+    if (hipMemcpyAsync(h, d + oAs, downBytes, hipMemcpyDeviceToHost, 0) != hipSuccess || hipStreamSynchronize(0) != hipSuccess)
+        return pg_ctx_fail(c, PGORB_E_HIP, "hipMemcpy D2H failed");
+    memcpy(assigned, h, (size_t)n * 4);
+    int32_t nm;
+    memcpy(&nm, h + (oR - oAs), 4);
     return nm;
+}
+
+int pgorb_search_by_projection_keyframe(pgorb_ctx* c, const pgorb_keypoint* kps, const uint8_t* desc, int n, float min_x,
+                                        float max_x, float min_y, float max_y, const uint8_t* kp_has_point, int npoints,
+                                        const uint8_t* valid, const uint8_t* already_found, const float* u, const float* v,
+                                        const float* dist3d, const float* min_distance, const float* max_distance,
+                                        const float* kf_angle, const uint8_t* point_desc, float log_scale_factor, float th,
+                                        int orb_dist, int check_orientation, int32_t* assigned)
+{
+    if (!c) return PGORB_E_ARG;
+    if (!(log_scale_factor > 0.0f)) return pg_ctx_fail(c, PGORB_E_ARG, "pgorb_search_by_projection_keyframe: log_scale_factor must be positive");
+    const PgProjHostKF kf = {already_found, dist3d, min_distance, max_distance, log_scale_factor, orb_dist};
+    return pg_search_by_projection_host(c, 2, kps, desc, n, min_x, max_x, min_y, max_y, kp_has_point, npoints, valid, u, v, nullptr,
+                                        kf_angle, point_desc, nullptr, th, 0.f, check_orientation, assigned, &kf);
 }
 
 int pgorb_search_by_projection_points(pgorb_ctx* c, const pgorb_keypoint* kps, const uint8_t* desc, int n, float min_x,

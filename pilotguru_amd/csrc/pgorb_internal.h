@@ -123,6 +123,57 @@ struct PgPlan {
     int32_t*  status;         // device status word
 };
 
+// MapPoint::PredictScale's logarithm (thirdparty/orb-slam2/src/MapPoint.cc:524 and Frame.cc:188: std::log(float), the platform's
+// logf) under the parity contract shared with oracle/match_oracle.c (orc_log_f): a fixed double-precision sequence, rounded
+// once to float -- x = m 2^e, m in (sqrt(1/2), sqrt(2)], s = (m - 1) / (m + 1), log x = e ln2 + 2 s (1 + s^2/3 + ... + s^20/21), no FMA.
+__host__ __device__ inline float pg_log_f(float xf)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+#define PGL_M(a, b) __dmul_rn((a), (b))
+#define PGL_A(a, b) __dadd_rn((a), (b))
+#define PGL_D(a, b) __ddiv_rn((a), (b))
+#else
+#define PGL_M(a, b) ((a) * (b))
+#define PGL_A(a, b) ((a) + (b))
+#define PGL_D(a, b) ((a) / (b))
+#endif
+    if (xf != xf) return xf;
+    if (!(xf > 0.0f)) return -__builtin_huge_valf();
+    if (xf == __builtin_huge_valf()) return xf;
+    double d = (double)xf;                                          // every positive float is a normal double
+    uint64_t u = __builtin_bit_cast(uint64_t, d);
+    int e = (int)((u >> 52) & 0x7FF) - 1023;
+    u = (u & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+    double m = __builtin_bit_cast(double, u);                        // [1, 2)
+    if (m > 1.4142135623730951) { m = PGL_M(m, 0.5); e += 1; }
+    const double s = PGL_D(PGL_A(m, -1.0), PGL_A(m, 1.0)), z = PGL_M(s, s);
+    double p = 1.0 / 21.0;
+    p = PGL_A(PGL_M(p, z), 1.0 / 19.0); p = PGL_A(PGL_M(p, z), 1.0 / 17.0); p = PGL_A(PGL_M(p, z), 1.0 / 15.0);
+    p = PGL_A(PGL_M(p, z), 1.0 / 13.0); p = PGL_A(PGL_M(p, z), 1.0 / 11.0); p = PGL_A(PGL_M(p, z), 1.0 / 9.0);
+    p = PGL_A(PGL_M(p, z), 1.0 / 7.0);  p = PGL_A(PGL_M(p, z), 1.0 / 5.0);  p = PGL_A(PGL_M(p, z), 1.0 / 3.0);
+    p = PGL_A(PGL_M(p, z), 1.0);
+    return (float)PGL_A(PGL_M((double)e, 0.6931471805599453), PGL_M(PGL_M(2.0, s), p));
+#undef PGL_M
+#undef PGL_A
+#undef PGL_D
+}
+// MapPoint::PredictScale(currentDist, Frame*) (MapPoint.cc:516-531); (int)ceil(...) of a NaN / out-of-range value is what
+// x86-64's cvttss2si returns, INT_MIN, i.e. level 0 after the clamp
+__host__ __device__ inline int pg_predict_scale(float maxDistance, float currentDist, float logScaleFactor, int nlevels)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+    const float ratio = __fdiv_rn(maxDistance, currentDist);
+    const float q = ceilf(__fdiv_rn(pg_log_f(ratio), logScaleFactor));
+#else
+    const float ratio = maxDistance / currentDist;
+    const float q = ceilf(pg_log_f(ratio) / logScaleFactor);
+#endif
+    int nScale = (q != q || q >= 2147483648.0f || q < -2147483648.0f) ? (-2147483647 - 1) : (int)q;
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= nlevels) nScale = nlevels - 1;
+    return nScale;
+}
+
 // kernel launchers (each in its own .hip file)
 void pg_launch_copy_level0(const PgPlan& P, const uint8_t* src, int stride, int64_t fstride,
                            int nframes, hipStream_t s);

@@ -34,9 +34,10 @@
 //   * at the end a (descendant -> list position) table gives every key its node with one LDS
 //     read; best response per node by 64-bit LDS atomicMax on (response, ~candidate order).
 //
-// The prologue compacts K2's per-cell candidate slots into dense 8-byte key records, one
-// thread per RECORD (cells hold 0..100+ records; any per-cell mapping leaves one wave with the
-// long cells): the record's cell is found by binary search over the cell offsets in LDS.
+// The prologue (round 4) is the ONLY pass over the ~2e4 candidates of a tree that ends inside the count pyramid: it reads K2's
+// per-cell slots in place (16 lanes per cell: no compaction, no search), histograms every candidate's depth-D descendant and keeps
+// the best candidate per descendant; the winner of a final node is then the best of its descendants' winners.  Dense 8-byte key
+// records are only built (qt_build_keys: scan over the cells + one binary search per record) when a tree leaves the pyramid.
 //
 // Integer/compare work on ~2e4 keys; latency-bound (the level-0 workgroup's critical path is
 // the kernel), not bandwidth-bound.  tools/experiments/qt_timing.py prints its phases.
@@ -164,8 +165,8 @@ extern "C" int pgorb_debug_qt_times(unsigned long long* out16, int reset)
 // Depth of the count pyramid for a level with nIni roots: the largest D <= 5 whose pyramid
 // (nIni * (4^(D+1)-1)/3 counters) fits QT_PYR_CAP ints of LDS.
 #define QT_PYR_CAP 4096
-__device__ __forceinline__ int qt_pyr_off(int nIni, int d) { return nIni * (((1 << (2 * d)) - 1) / 3); }
-__device__ __forceinline__ int qt_pyr_depth(int nIni)
+__host__ __device__ __forceinline__ int qt_pyr_off(int nIni, int d) { return nIni * (((1 << (2 * d)) - 1) / 3); }
+__host__ __device__ __forceinline__ int qt_pyr_depth(int nIni)
 {
     int D = 5;
     while (D > 0 && qt_pyr_off(nIni, D + 1) > QT_PYR_CAP) D--;
@@ -203,10 +204,58 @@ __device__ __forceinline__ int qt_walk(const int* map, int leaf, int nIni, int D
     return 0;                                            // unreachable: list nodes partition the keys
 }
 
+// Dense 8-byte key records {candidate, depth-D descendant} of a (frame, level) from K2's per-cell slots -- what the key
+// passes of a tree that grows below the count pyramid work on (rounds 1-3 built them for every problem, in the prologue).
+// One thread per OUTPUT record: record i belongs to the last cell whose offset is <= i, a binary search over the scanned
+// cell counts in LDS whose first steps are wave-uniform; QT_HU searches per thread run interleaved.  cellOff: cells + 1 ints.
+// All threads must call; returns the record count.
+// (plain values only: a reference to the kernel's PgPlan argument would put the whole 4-KB struct into scratch memory)
+__device__ __forceinline__ int qt_build_keys(const int32_t* __restrict__ cc, const uint32_t* __restrict__ slots, int ncells, int cellCap,
+                                             int* cellOff, int* sh, uint2* keys, float hX, int nIni, int regionH, int D)
+{
+    const int tid = threadIdx.x;
+    for (int i = tid; i < ncells; i += QT_T) cellOff[i] = min(cc[i], cellCap);
+    __syncthreads();
+    const int ncand = qt_scan_excl(cellOff, ncells, sh);
+    if (tid == 0) cellOff[ncells] = ncand;
+    __syncthreads();
+    int steps = 0;
+    while ((1 << steps) < ncells) steps++;
+    for (int b0 = 0; b0 < ncand; b0 += QT_HU * QT_T) {
+        int lo[QT_HU], hi[QT_HU];
+#pragma unroll
+        for (int u = 0; u < QT_HU; u++) { lo[u] = 0; hi[u] = ncells - 1; }
+        for (int st = 0; st < steps; st++) {
+#pragma unroll
+            for (int u = 0; u < QT_HU; u++) {
+                const int mid = (lo[u] + hi[u] + 1) >> 1;
+                const bool le = cellOff[mid] <= b0 + u * QT_T + tid;
+                lo[u] = le ? mid : lo[u];
+                hi[u] = le ? hi[u] : mid - 1;
+            }
+        }
+        uint32_t v[QT_HU];
+#pragma unroll
+        for (int u = 0; u < QT_HU; u++) {
+            const int i = b0 + u * QT_T + tid;
+            v[u] = (i < ncand) ? slots[(int64_t)lo[u] * cellCap + (i - cellOff[lo[u]])] : 0u;
+        }
+        QT_SETTLE4(v[0], v[1], v[2], v[3]);
+        if (QT_HU == 8) QT_SETTLE4(v[4 % QT_HU], v[5 % QT_HU], v[6 % QT_HU], v[7 % QT_HU]);
+#pragma unroll
+        for (int u = 0; u < QT_HU; u++) {
+            const int i = b0 + u * QT_T + tid;
+            if (i < ncand) keys[i] = make_uint2(v[u], (uint32_t)qt_leaf(v[u], hX, nIni, regionH, D));
+        }
+    }
+    __syncthreads();
+    return ncand;
+}
+
 // BIG: the level's node arrays do not fit LDS (quota above ~1180) and live in a global slab;
 // the same code, just slower.  Each instantiation skips the levels of the other kind.
 template <bool BIG>
-__global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P, int level0)
+__global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P, int level0, int leafOffInts)
 {
     __shared__ int sh[3 * QT_W + 8];
     __shared__ int pyr[QT_PYR_CAP];                       // count pyramid, later the node map
@@ -238,10 +287,15 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P, int level0
     int* rnk = tailpos + NC;                            // [NC]  processing rank or -1
     int* ord = rnk + NC;                                // [NC]  node at processing rank r
     int* cinc = ord + NC;                               // [NC]  inclusive sum of child counts
-    int* tmp = cinc + NC;                               // [NC]
-    int* ecnt = tmp + NC;                               // [NC]  sizes of expandable nodes
+    // (28 ints per node.)  The two scratch arrays of a "largest first" generation's ranking share newpos4: that is written
+    // by the generation's list-writing phase, behind the ranking and a barrier, and read by the key pass that ends the generation
+    int* tmp = newpos4;                                 // [NC]
+    int* ecnt = newpos4 + NC;                           // [NC]  sizes of expandable nodes
     unsigned long long* best = reinterpret_cast<unsigned long long*>(newpos4);    // [NC] (epilogue)
-    int* cellOff = qt_lds;                              // [cells + 1] (prologue only)
+    // aux area behind the node arrays (max(leaves, cells + 1) ints): the best candidate of every depth-D descendant,
+    // (response << 24 | ~order rank), while the tree is inside the count pyramid; the scanned cell counts while key records are built
+    uint32_t* leafBest = reinterpret_cast<uint32_t*>(qt_lds + leafOffInts);
+    int* cellOff = qt_lds + leafOffInts;
 
     const int N = L.quota;
     const int regionH = L.h - 2 * PG_EDGE;              // maxY - minY
@@ -250,18 +304,118 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P, int level0
     const int D = qt_pyr_depth(nIni);
     const int pyrTotal = qt_pyr_off(nIni, D + 1);
 
-    // ---- prologue: K2's per-cell slots -> dense key records + leaf histogram ------------------
+    // candidate order = (cell row, cell col, y, x); x / wCell by an exact reciprocal (x < 4096, wCell < 256)
+    const int wCell = L.wCell, hCell = L.hCell, nCols = L.nCols;
+    const uint32_t mW = ((1u << 20) + wCell - 1) / wCell, mH = ((1u << 20) + hCell - 1) / hCell;
+    auto order_rank = [&](uint32_t cv) {
+        const uint32_t x = (cv & 0xFFF) - 3, y = ((cv >> 12) & 0xFFF) - 3;
+        const uint32_t cj = (x * mW) >> 20, ci = (y * mH) >> 20;
+        return ((ci * nCols + cj) * hCell + (y - ci * hCell)) * wCell + (x - cj * wCell);
+    };
+    // the 64-bit key a candidate bids for its node with: (response, first in candidate order wins)
+    auto bid = [&](uint32_t cv) { return ((unsigned long long)(cv >> 24) << 32) | (0xFFFFFFFFu - order_rank(cv)); };
+    // ... and its 32-bit form, when every order rank of the level fits 24 bits (levels up to ~16 Mpx: all the reference runs)
+    const bool rank24 = (long long)L.nCols * L.nRows * hCell * wCell <= (1 << 24);
+
+    // ---- prologue (round 4): K2's per-cell slots -> leaf histogram + best candidate per leaf, NO key records ------------
+    // A candidate's path through the first D generations is pure geometry, the generations need only counts, and the winner of
+    // a final node is the best of the winners of its depth-D descendants -- so a tree that ends inside the count pyramid (the
+    // common case) never needs its ~2e4 candidates again: this pass is the only one over them.  (Rounds 1-3 compacted the slots
+    // into dense 8-byte key records first -- a scan over the cells, one binary search per record, 31 MB written and read twice
+    // per step -- and ran a second pass over all records for the winners: 71 of the level-0 workgroup's 107 us.)  Trees that
+    // grow deeper build the key records when they leave the pyramid (qt_build_keys).
+    // Mapping: 16 lanes per cell, 4 cells per wave and round -- one 64-byte sector of a cell's slots per 16 lanes, no search, no
+    // scan; cells with more than 16 records take more rounds.  Two groups of cells are in flight per wave.
     int ncand;
+    bool keysBuilt = false;
     {
         const int ncells = L.nCols * L.nRows;
         const int32_t* cc = P.cellCount + (int64_t)frame * P.totalCells + L.cellBase;
         const uint32_t* slots = P.cellCand + (int64_t)frame * P.cellCandFrame + L.cellCandOff;
-        for (int i = tid; i < ncells; i += QT_T) cellOff[i] = min(cc[i], L.cellCap);
+        const int nleaf = nIni << (2 * D);
         for (int i = tid; i < pyrTotal; i += QT_T) pyr[i] = 0;
+        for (int i = tid; i < nleaf; i += QT_T) leafBest[i] = 0u;
+        if (tid == 0) sh[QT_W + 2] = 0;
+        // Both things the pass needs of a candidate are SEPARABLE in x and y: DivideNode splits a node at the middle of its x range
+        // and of its y range independently (:483-485), so the depth-D descendant index is (root and x-path bits) | (y-path bits);
+        // and the candidate-order rank ((cell row * nCols + cell col) * hCell + row in cell) * wCell + col in cell is a y term
+        // plus an x term.  Two tables of (descendant part, rank part) per region column / row, built here by the workgroup
+        // (3 entries per thread at 1080p) in the LDS the node arrays will take later, turn ~65 instructions per candidate
+        // (five split steps, two reciprocal divisions) into two 8-byte LDS reads, an OR and an add.
+        const int regionW = L.w - 2 * PG_EDGE;
+        uint2* xTab = reinterpret_cast<uint2*>(qt_lds);           // [regionW]
+        uint2* yTab = xTab + regionW;                             // [regionH]
+        for (int i = tid; i < regionW + regionH; i += QT_T) {
+            const bool isY = i >= regionW;
+            const int c = isY ? i - regionW : i;                  // the coordinate as K2 stores it (region-relative)
+            int part, a0, a1;
+            if (isY) { part = 0; a0 = 0; a1 = regionH; }
+            else {
+                int r = (int)__fdiv_rn((float)c, hX);             // vpIniNodes[kp.pt.x/hX]  (:569)
+                r = min(max(r, 0), max(nIni, 1) - 1);
+                part = r; a0 = (int)__fmul_rn(hX, (float)r); a1 = (int)__fmul_rn(hX, (float)(r + 1));
+            }
+            for (int d = 0; d < D; d++) {
+                const int mid = a0 + ((a1 - a0 + 1) >> 1);
+                const bool q = c >= mid;
+                part = part * 4 + (q ? 1 : 0);
+                a0 = q ? mid : a0; a1 = q ? a1 : mid;
+            }
+            const uint32_t cm = (uint32_t)max(c - 3, 0);          // (order_rank's x - 3 / y - 3; K2's coordinates start at 3)
+            uint2 e;
+            if (isY) { const uint32_t ci = (cm * mH) >> 20; e = make_uint2((uint32_t)part << 1, (ci * nCols * hCell + (cm - ci * hCell)) * wCell); }
+            else { const uint32_t cj = (cm * mW) >> 20; e = make_uint2((uint32_t)part, cj * hCell * wCell + (cm - cj * wCell)); }
+            (isY ? yTab : xTab)[c] = e;
+        }
         __syncthreads();
-        ncand = qt_scan_excl(cellOff, ncells, sh);
-        if (tid == 0) { cellOff[ncells] = ncand; P.candCount[frame * PG_MAXL + l] = ncand; }
+        QT_TS(8);
+        int* hD = pyr + qt_pyr_off(nIni, D);
+        const int lane = tid & 63, sub = lane >> 4, sl = lane & 15;
+        // (the wave index as a scalar: with cb / cEnd in VGPRs the compiler made the cell loop a per-lane loop around the cross-lane
+        //  shuffles below, and that build hung the kernel -- found by a timed-out run, round 4)
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int cellCap = L.cellCap;
+        // a wave takes a contiguous range of cells, 32 cells (8 groups of 4) per step: their counts in one coalesced load (the
+        // next step's counts are in flight meanwhile), then one round of 16 slots per cell -- eight independent loads per lane
+        // in flight -- per 16 records of the fullest cell
+        const int cpw = (((ncells + QT_W - 1) / QT_W) + 31) & ~31;
+        const int cBeg = wv * cpw, cEnd = min(ncells, cBeg + cpw);
+        int mine = 0;                                       // records counted by this lane
+        int cntNext = (lane < 32 && cBeg + lane < cEnd) ? cc[cBeg + lane] : 0;
+        for (int cb = cBeg; cb < cEnd; cb += 32) {
+            const int myc = min(cntNext, cellCap);
+            cntNext = (lane < 32 && cb + 32 + lane < cEnd) ? cc[cb + 32 + lane] : 0;
+            mine += myc;
+            int n[8];
+            int maxn = myc;
+#pragma unroll
+            for (int g = 0; g < 8; g++) n[g] = __shfl(myc, 4 * g + sub);
+#pragma unroll
+            for (int d = 1; d < 32; d <<= 1) maxn = max(maxn, __shfl_xor(maxn, d));
+            maxn = __builtin_amdgcn_readfirstlane(maxn);
+            const uint32_t* sp = slots + (int64_t)(cb + sub) * cellCap + sl;
+            for (int base = 0; base < maxn; base += 16) {       // (wave-uniform trip count)
+                uint32_t v[8];
+#pragma unroll
+                for (int g = 0; g < 8; g++) v[g] = (base + sl < n[g]) ? sp[(int64_t)(4 * g) * cellCap + base] : 0u;
+                QT_SETTLE4(v[0], v[1], v[2], v[3]); QT_SETTLE4(v[4], v[5], v[6], v[7]);
+#pragma unroll
+                for (int g = 0; g < 8; g++) {
+                    if (base + sl < n[g]) {
+                        const uint2 tx = xTab[v[g] & 0xFFF], ty = yTab[(v[g] >> 12) & 0xFFF];
+                        const int lf = (int)(tx.x | ty.x);
+                        atomicAdd(&hD[lf], 1);
+                        if (rank24) atomicMax(&leafBest[lf], (v[g] & 0xFF000000u) | (0xFFFFFFu - (tx.y + ty.y)));
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+        if (lane == 0 && mine) atomicAdd(&sh[QT_W + 2], mine);
         __syncthreads();
+        ncand = sh[QT_W + 2];
+        if (tid == 0) P.candCount[frame * PG_MAXL + l] = ncand;
         if (ncand <= 0 || nIni < 1) {
             // no keypoint on this level: every slot of its selection slab is marked unused for K4-6
             PgSelRec* selE = reinterpret_cast<PgSelRec*>(P.sel) + ((int64_t)frame * P.selFrame + L.selOff);
@@ -270,52 +424,11 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P, int level0
             if (ncand > 0 && tid == 0) atomicExch(P.status, PGORB_E_TOOSMALL);      // see api.hip level_geometry: reference UB, reported
             return;
         }
-        QT_TS(8);
-        // One thread per OUTPUT record (cells hold 0..cellCap records, ~10 on average but 100+ in
-        // dense texture: any per-cell mapping leaves one wave with the long cells).  Record i
-        // belongs to the last cell whose offset is <= i: a binary search in LDS whose first steps
-        // are wave-uniform (broadcast reads); four searches per thread run interleaved.
-        int* hD = pyr + qt_pyr_off(nIni, D);
-        int steps = 0;
-        while ((1 << steps) < ncells) steps++;
-        for (int b0 = 0; b0 < ncand; b0 += QT_HU * QT_T) {
-            int lo[QT_HU], hi[QT_HU];
-#pragma unroll
-            for (int u = 0; u < QT_HU; u++) { lo[u] = 0; hi[u] = ncells - 1; }
-            for (int st = 0; st < steps; st++) {
-#pragma unroll
-                for (int u = 0; u < QT_HU; u++) {
-                    const int mid = (lo[u] + hi[u] + 1) >> 1;
-                    const bool le = cellOff[mid] <= b0 + u * QT_T + tid;
-                    lo[u] = le ? mid : lo[u];
-                    hi[u] = le ? hi[u] : mid - 1;
-                }
-            }
-            uint32_t v[QT_HU];
-#pragma unroll
-            for (int u = 0; u < QT_HU; u++) {
-                const int i = b0 + u * QT_T + tid;
-                v[u] = (i < ncand) ? slots[(int64_t)lo[u] * L.cellCap + (i - cellOff[lo[u]])] : 0u;
-            }
-            QT_SETTLE4(v[0], v[1], v[2], v[3]);
-            if (QT_HU == 8) QT_SETTLE4(v[4 % QT_HU], v[5 % QT_HU], v[6 % QT_HU], v[7 % QT_HU]);
-            // (all records are finished and stored before the first counting call: control flow
-            //  between a store and the next use of a loaded value costs a full s_waitcnt vmcnt(0))
-            int leaf[QT_HU];
-#pragma unroll
-            for (int u = 0; u < QT_HU; u++) {
-                const int i = b0 + u * QT_T + tid;
-                leaf[u] = 0;
-                if (i < ncand) {
-                    leaf[u] = qt_leaf(v[u], hX, nIni, regionH, D);
-                    keys[i] = make_uint2(v[u], (uint32_t)leaf[u]);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < QT_HU; u++) qt_wave_count(hD, leaf[u], b0 + u * QT_T + tid < ncand);
-        }
-        __syncthreads();
         QT_TS(9);
+        if (!rank24) {                                      // order ranks beyond 24 bits: the winners come from a key pass (64-bit bids)
+            qt_build_keys(cc, slots, ncells, cellCap, cellOff, sh, keys, hX, nIni, regionH, D);
+            keysBuilt = true;
+        }
         // counts of the shallower descendants
         for (int d = D - 1; d >= 0; d--) {
             const int* src = pyr + qt_pyr_off(nIni, d + 1);
@@ -355,21 +468,17 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P, int level0
     // Generation g splits depth g-1 nodes.  While g <= D the child counts come from the pyramid
     // and no pass over the keys is needed ("pyramid mode"); deeper trees continue with one key
     // pass per generation (keys carry node position | quadrant << 28).
-    // candidate order = (cell row, cell col, y, x); x / wCell by an exact reciprocal (x < 4096, wCell < 256)
-    const int wCell = L.wCell, hCell = L.hCell, nCols = L.nCols;
-    const uint32_t mW = ((1u << 20) + wCell - 1) / wCell, mH = ((1u << 20) + hCell - 1) / hCell;
-    // the 64-bit key a candidate bids for its node with: (response, first in candidate order wins)
-    auto bid = [&](uint32_t cv) {
-        const uint32_t x = (cv & 0xFFF) - 3, y = ((cv >> 12) & 0xFFF) - 3;
-        const uint32_t cj = (x * mW) >> 20, ci = (y * mH) >> 20;
-        const uint32_t rank = ((ci * nCols + cj) * hCell + (y - ci * hCell)) * wCell + (x - cj * wCell);
-        return ((unsigned long long)(cv >> 24) << 32) | (0xFFFFFFFFu - rank);
-    };
     int sorted_mode = 0, gen = 1;
     bool last = false, pyrMode = true;
     while (!last) {
         if (pyrMode && gen > D) {
-            // leave pyramid mode: node map, then every key finds its node and is counted into its quadrant
+            // leave pyramid mode: the dense key records (only now: the pyramid generations did not need them), the node map,
+            // then every key finds its node and is counted into its quadrant
+            if (!keysBuilt) {
+                qt_build_keys(P.cellCount + (int64_t)frame * P.totalCells + L.cellBase, P.cellCand + (int64_t)frame * P.cellCandFrame + L.cellCandOff,
+                              L.nCols * L.nRows, L.cellCap, cellOff, sh, keys, hX, nIni, regionH, D);       // (cellOff shares the aux area with leafBest, which is dead from here on)
+                keysBuilt = true;
+            }
             for (int i = tid; i < pyrTotal; i += QT_T) pyr[i] = -1;
             for (int i = tid; i < 4 * size; i += QT_T) cnt4[i] = 0;
             __syncthreads();
@@ -626,19 +735,29 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P, int level0
             pyr[qt_pyr_off(nIni, pid >> 28) + (pid & QT_POS_MASK)] = p;
         }
         __syncthreads();
-        for (int j = tid; j < (nIni << (2 * D)); j += QT_T) leafPos[j] = qt_walk(pyr, j, nIni, D);
-        __syncthreads();
-        QT_TS(3);
-        for (int b0 = 0; b0 < ncand; b0 += 4 * QT_T) {
-            uint2 kk[4];
+        const int nleaf = nIni << (2 * D);
+        if (!keysBuilt) {
+            // the winner of a node = the best of its leaves' winners (prologue): one step per LEAF (<= 3072), not per candidate
+            for (int j = tid; j < nleaf; j += QT_T) {
+                const uint32_t k = leafBest[j];
+                if (k) atomicMax(&best[qt_walk(pyr, j, nIni, D)], ((unsigned long long)(k >> 24) << 32) | (0xFF000000u | (k & 0xFFFFFFu)));   // the 64-bit bid
+            }
+            QT_TS(3);
+        } else {
+            for (int j = tid; j < nleaf; j += QT_T) leafPos[j] = qt_walk(pyr, j, nIni, D);
+            __syncthreads();
+            QT_TS(3);
+            for (int b0 = 0; b0 < ncand; b0 += 4 * QT_T) {
+                uint2 kk[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const int i = b0 + tid + u * QT_T; kk[u] = (i < ncand) ? keys[i] : make_uint2(0u, 0u); }
-            QT_SETTLE4(kk[0].x, kk[1].x, kk[2].x, kk[3].x); QT_SETTLE4(kk[0].y, kk[1].y, kk[2].y, kk[3].y);
+                for (int u = 0; u < 4; u++) { const int i = b0 + tid + u * QT_T; kk[u] = (i < ncand) ? keys[i] : make_uint2(0u, 0u); }
+                QT_SETTLE4(kk[0].x, kk[1].x, kk[2].x, kk[3].x); QT_SETTLE4(kk[0].y, kk[1].y, kk[2].y, kk[3].y);
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int i = b0 + tid + u * QT_T;
-                if (i >= ncand) break;
-                atomicMax(&best[leafPos[kk[u].y]], bid(kk[u].x));
+                for (int u = 0; u < 4; u++) {
+                    const int i = b0 + tid + u * QT_T;
+                    if (i >= ncand) break;
+                    atomicMax(&best[leafPos[kk[u].y]], bid(kk[u].x));
+                }
             }
         }
     } else {
@@ -701,11 +820,19 @@ void pg_launch_quadtree(const PgPlan& P, int nframes, hipStream_t s) { pg_launch
 // K3 for the levels [levelBeg, levelEnd) only: a (frame, level) problem depends on nothing but K2's slots of that level
 void pg_launch_quadtree_levels(const PgPlan& P, int nframes, int levelBeg, int levelEnd, hipStream_t s)
 {
-    int need[2] = {0, 0};                                 // dynamic LDS ints: [LDS-node levels], [global-node levels]
+    // dynamic LDS: [node arrays, 28 ints per node (LDS-node levels only) / the prologue's coordinate tables] [aux: max(leaves of the count pyramid, cells + 1) ints]
+    int nodes[2] = {0, 0}, aux[2] = {0, 0};
+    bool any[2] = {false, false};
     for (int l = levelBeg; l < levelEnd; l++) {
+        const int big = P.lvl[l].nodeOff >= 0 ? 1 : 0;
         const int cells = P.lvl[l].nCols * P.lvl[l].nRows + 1;
-        if (P.lvl[l].nodeOff >= 0) need[1] = max(need[1], cells);
-        else need[0] = max(need[0], max(P.lvl[l].nodeCap * 30, cells));
+        const int nIni = max(P.lvl[l].nIni, 1);
+        const int leaves = nIni << (2 * qt_pyr_depth(nIni));
+        any[big] = true;
+        aux[big] = max(aux[big], max(cells, leaves));
+        // (the prologue's coordinate tables, 2 ints per region column and row, use the node area before the nodes do)
+        nodes[big] = max(nodes[big], 2 * ((P.lvl[l].w - 2 * PG_EDGE) + (P.lvl[l].h - 2 * PG_EDGE)));
+        if (!big) nodes[0] = max(nodes[0], P.lvl[l].nodeCap * 28);
     }
     static size_t configuredDev[64][2] = {{0, 0}};            // (the attribute is per device)
     int dev = 0;
@@ -713,14 +840,14 @@ void pg_launch_quadtree_levels(const PgPlan& P, int nframes, int levelBeg, int l
     size_t* configured = configuredDev[dev & 63];
     dim3 grid(nframes, levelEnd - levelBeg), block(QT_T);
     for (int big = 0; big < 2; big++) {
-        if (!need[big]) continue;
-        const size_t lds = (size_t)need[big] * sizeof(int);
+        if (!any[big]) continue;
+        const size_t lds = (size_t)(nodes[big] + aux[big]) * sizeof(int);
         const void* fn = big ? reinterpret_cast<const void*>(k_quadtree<true>) : reinterpret_cast<const void*>(k_quadtree<false>);
         if (lds > configured[big]) {
             (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             configured[big] = lds;
         }
-        if (big) hipLaunchKernelGGL(k_quadtree<true>, grid, block, lds, s, P, levelBeg);
-        else hipLaunchKernelGGL(k_quadtree<false>, grid, block, lds, s, P, levelBeg);
+        if (big) hipLaunchKernelGGL(k_quadtree<true>, grid, block, lds, s, P, levelBeg, nodes[big]);
+        else hipLaunchKernelGGL(k_quadtree<false>, grid, block, lds, s, P, levelBeg, nodes[big]);
     }
 }

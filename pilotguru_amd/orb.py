@@ -203,6 +203,14 @@ class ORBextractor:
             C.c_void_p(out[2].data_ptr()), C.c_void_p(s)))
         return out
 
+    def log_scale_factor(self):
+        """Frame::mfLogScaleFactor = log(mfScaleFactor) (Frame.cc:188) under the library's log contract."""
+        return float(self._L.pgorb_log_scale_factor(self._h))
+
+    def predict_scale(self, max_distance, current_dist):
+        """MapPoint::PredictScale(currentDist, pF) (src/MapPoint.cc:516-531)."""
+        return self._check(self._L.pgorb_predict_scale(self._h, float(max_distance), float(current_dist)))
+
     def set_option(self, key, value):
         """Measurement switches of the library (include/pgorb.h: pgorb_set_option)."""
         self._check(self._L.pgorb_set_option(self._h, key.encode(), int(value)))
@@ -360,6 +368,23 @@ class ORBmatcher:
         nm = ext._check(ext._L.pgorb_search_by_projection_frame(
             ext._h, _p(F.mvKeysUndistorted), _p(F.mDescriptors), F.N, *F.bounds, _p(has), len(a[0]),
             *[_p(x) for x in a], float(th), int(self.mbCheckOrientation), _p(out)))
+        return nm, out[:F.N].copy()
+
+    def SearchByProjectionKeyFrame(self, CurrentFrame, valid, already_found, u, v, dist3d, min_distance, max_distance, kf_angle,
+                                   point_desc, th, ORBdist, kp_has_point=None):
+        """The matching loop of SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, sAlreadyFound, th, ORBdist)
+        (src/ORBmatcher.cc:1476-1603; Tracking::Relocalization) for given projections (u, v) and depths: the bounds / depth
+        tests, MapPoint::PredictScale, the window search and the rotation histogram run on the device."""
+        ext = CurrentFrame.ext
+        F = CurrentFrame
+        has = np.ascontiguousarray(kp_has_point if kp_has_point is not None else np.zeros(max(F.N, 1), np.uint8), np.uint8)
+        a = [np.ascontiguousarray(valid, np.uint8), np.ascontiguousarray(already_found, np.uint8), np.ascontiguousarray(u, np.float32),
+             np.ascontiguousarray(v, np.float32), np.ascontiguousarray(dist3d, np.float32), np.ascontiguousarray(min_distance, np.float32),
+             np.ascontiguousarray(max_distance, np.float32), np.ascontiguousarray(kf_angle, np.float32), np.ascontiguousarray(point_desc, np.uint8)]
+        out = np.full(max(F.N, 1), -1, np.int32)
+        nm = ext._check(ext._L.pgorb_search_by_projection_keyframe(
+            ext._h, _p(F.mvKeysUndistorted), _p(F.mDescriptors), F.N, *F.bounds, _p(has), len(a[0]), *[_p(x) for x in a],
+            ext.log_scale_factor(), float(th), int(ORBdist), int(self.mbCheckOrientation), _p(out)))
         return nm, out[:F.N].copy()
 
     def SearchByBoW(self, ext, kf_desc, kf_angle, kf_point_valid, kf_featvec, F, f_featvec):

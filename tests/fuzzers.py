@@ -336,7 +336,8 @@ def fuzz_matchers(cases=100, seed=1, log=True, nf_range=(150, 3000), size_range=
             nq = len(sel)
             dist3d = (rng.uniform(0.5, 30.0, nq)).astype(np.float32)
             # max distance such that the predicted level is near the keypoint's own level (sometimes far off / out of range)
-            lf = float(np.log(np.float32(scale)))
+            lf = oracle.log_f(sf[1])
+            if np.float32(lf).view(np.uint32) != np.float32(ext.log_scale_factor()).view(np.uint32): report("log_scale_factor", it, cfg)
             maxd = (dist3d * np.power(np.float32(scale), lvl.astype(np.float32) + rng.uniform(-1.5, 1.5, nq).astype(np.float32))).astype(np.float32)
             mind = (maxd / np.float32(scale) ** np.float32(nlev - 1) * rng.choice([1.0, 1.0, 1.3], nq)).astype(np.float32)
             found = (rng.uniform(size=nq) > 0.85).astype(np.uint8)

@@ -201,6 +201,103 @@ def test_gpu_search_by_projection_last_frame(oracle, th, ori):
     assert nm == onm and np.array_equal(asg, oasg) and nm > 100
 
 
+def _keyframe_queries(F1keys, F1desc, shift, rng, sf, nlevels, w, h):
+    """Key-frame map points for the relocalisation search: projections near frame 2's keypoints (some outside the image
+    bounds), depths whose predicted level is the keypoint's own level +- 1 (some outside the point's scale-invariance range),
+    a few points already found."""
+    sel, valid, px, py, lvl, _, pd, _ = _synthetic_map_points(F1keys, F1desc, shift, rng)
+    nq = len(sel)
+    px[::31] = -5.0; py[5::37] = np.float32(h + 3)                          # outside mnMinX / mnMaxY (:1512-1515)
+    dist3d = rng.uniform(0.5, 30.0, nq).astype(np.float32)
+    scale = np.float32(sf[1])
+    # PredictScale = ceil(log(max / dist) / log(scale)): max = dist * scale^(level + d), d in (-1.5, 0.5) -> level - 1 .. level + 1
+    maxd = (dist3d * scale ** (lvl.astype(np.float32) + rng.uniform(-1.5, 0.5, nq).astype(np.float32))).astype(np.float32)
+    mind = (maxd / scale ** np.float32(nlevels - 1)).astype(np.float32)
+    mind[3::41] = dist3d[3::41] * np.float32(1.5)                           # dist3D < minDistance (:1525)
+    maxd[7::43] = dist3d[7::43] * np.float32(0.5)                           # dist3D > maxDistance
+    found = (rng.uniform(size=nq) > 0.9).astype(np.uint8)
+    ang = F1keys["angle"][sel].copy()
+    ang[::7] = (ang[::7] + 100.0) % 360.0                                   # some rotation-inconsistent matches
+    return sel, valid, found, px, py, dist3d, mind, maxd, ang, pd
+
+
+def test_log_contract_and_predict_scale(oracle):
+    """MapPoint::PredictScale (src/MapPoint.cc:516-531): `log` there is the platform's logf.  The contract (orc_log_f ==
+    pgorb_log_f, a fixed double sequence rounded once) equals the correctly rounded logarithm on these samples, lies within
+    1 ulp of this box's glibc logf, and the product's host code is the same function bit for bit."""
+    import ctypes as C
+    from pilotguru_amd import _lib
+    L = _lib.lib()
+    rng = np.random.RandomState(2)
+    xs = np.concatenate([np.exp(rng.uniform(-30, 30, 20000)), rng.uniform(0.5, 2.0, 20000), np.float32(1.2) ** np.arange(-12, 13),
+                         [1.0, 1e-45, 3.4e38, 2.0, 0.5, 1.4142135, 1.4142137]]).astype(np.float32)
+    got = np.array([oracle.log_f(x) for x in xs], np.float32)
+    exact = np.log(xs.astype(np.float64)).astype(np.float32)
+    assert np.array_equal(got.view(np.uint32), exact.view(np.uint32))
+    prod = np.array([L.pgorb_log_f(C.c_float(float(x))) for x in xs], np.float32)
+    assert np.array_equal(prod.view(np.uint32), got.view(np.uint32))
+    libm = C.CDLL("libm.so.6"); libm.logf.restype = C.c_float; libm.logf.argtypes = [C.c_float]
+    glibc = np.array([libm.logf(float(x)) for x in xs], np.float32)
+    ulp = np.abs(got.view(np.int32).astype(np.int64) - glibc.view(np.int32).astype(np.int64))
+    assert ulp.max() <= 1 and (ulp > 0).mean() < 0.02
+    assert oracle.log_f(0.0) == -np.inf and oracle.log_f(np.inf) == np.inf and np.isnan(oracle.log_f(np.nan))
+    lf = oracle.log_f(np.float32(1.2))
+    assert oracle.predict_scale(10.0, 10.0, lf, 8) == 0 and oracle.predict_scale(10.0, 20.0, lf, 8) == 0      # ratio <= 1 -> level 0
+    assert oracle.predict_scale(12.5, 10.0, lf, 8) == 2                                                       # 1.25 > 1.2 -> ceil(1.22)
+    assert oracle.predict_scale(1000.0, 1.0, lf, 8) == 7 and oracle.predict_scale(0.0, 1.0, lf, 8) == 0         # clamped; log(0) = -inf
+    assert oracle.predict_scale(1.0, 0.0, lf, 8) == 0                     # ratio = inf: (int)ceil(inf) is INT_MIN on x86-64 -> 0
+
+
+def test_oracle_search_by_projection_keyframe_consistency(oracle):
+    ride, fr = _frames(oracle, nf=1200)
+    (k1, d1), (k2, d2) = fr
+    rng = np.random.RandomState(8)
+    ora = oracle.OrbOracle(1200)
+    sf = ora.scale_factors
+    sel, valid, found, px, py, dist3d, mind, maxd, ang, pd = _keyframe_queries(k1, d1, (7, 3), rng, sf, 8, 640, 480)
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    lf = oracle.log_f(sf[1])
+    nm, asg = oracle.search_by_projection_keyframe(k2, d2, bounds, sf, None, valid, found, px, py, dist3d, mind, maxd, lf, ang, pd, 10.0, 100, True)
+    assert nm == int((asg >= 0).sum()) > 200                    # every assignment blocks its keypoint: one point per keypoint
+    good = asg >= 0
+    q = asg[good]
+    assert np.all(valid[q] == 1) and np.all(found[q] == 0) and len(set(q.tolist())) == nm
+    assert np.all((px[q] >= 0) & (px[q] <= 640) & (py[q] >= 0) & (py[q] <= 480) & (dist3d[q] >= mind[q]) & (dist3d[q] <= maxd[q]))
+    lv = np.array([oracle.predict_scale(maxd[i], dist3d[i], lf, 8) for i in q])
+    assert np.all(np.abs(k2["octave"][good] - lv) <= 1)
+    assert np.all(np.abs(k2["x"][good] - px[q]) < 10.0 * sf[lv]) and np.all(np.abs(k2["y"][good] - py[q]) < 10.0 * sf[lv])
+    nm2, _ = oracle.search_by_projection_keyframe(k2, d2, bounds, sf, None, valid, found, px, py, dist3d, mind, maxd, lf, ang, pd, 3.0, 64, True)
+    assert 0 < nm2 <= nm
+    # kp_has_point blocks: with every keypoint taken nothing is assigned
+    nm3, asg3 = oracle.search_by_projection_keyframe(k2, d2, bounds, sf, np.ones(len(k2), np.uint8), valid, found, px, py, dist3d, mind, maxd, lf, ang, pd, 10.0, 100, True)
+    assert nm3 == 0 and np.all(asg3 == -1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("th,orbdist,ori", [(10.0, 100, True), (3.0, 64, True), (10.0, 100, False), (6.0, 256, True)])
+def test_gpu_search_by_projection_keyframe(oracle, th, orbdist, ori):
+    """ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1476-1603) at the two
+    call sites of Tracking::Relocalization (Tracking.cc:1434: 10 / 100; :1448: 3 / 64), without the orientation check, and
+    with an ORBdist that accepts everything."""
+    import pilotguru_amd as pg
+    w, h, nf = 640, 480, 1200
+    ride = synth_ride(4, w, h, 2, dx=7, dy=3)
+    ext = pg.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    F1, F2 = pg.Frame(ext, ride[0]), pg.Frame(ext, ride[1])
+    rng = np.random.RandomState(9)
+    sf = ext.GetScaleFactors()
+    sel, valid, found, px, py, dist3d, mind, maxd, ang, pd = _keyframe_queries(F1.mvKeys, F1.mDescriptors, (7, 3), rng, sf, 8, w, h)
+    lf = ext.log_scale_factor()
+    assert np.float32(lf).view(np.uint32) == np.float32(oracle.log_f(sf[1])).view(np.uint32)
+    for i in range(0, len(sel), 97):
+        assert ext.predict_scale(maxd[i], dist3d[i]) == oracle.predict_scale(maxd[i], dist3d[i], lf, 8)
+    has = (rng.uniform(size=F2.N) > 0.9).astype(np.uint8)
+    onm, oasg = oracle.search_by_projection_keyframe(F2.mvKeys, F2.mDescriptors, F2.bounds, sf, has, valid, found, px, py, dist3d, mind, maxd,
+                                                     lf, ang, pd, th, orbdist, ori)
+    nm, asg = pg.ORBmatcher(0.9, ori).SearchByProjectionKeyFrame(F2, valid, found, px, py, dist3d, mind, maxd, ang, pd, th, orbdist, has)
+    assert nm == onm and np.array_equal(asg, oasg) and nm > 50
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("ratio,ori", [(0.7, True), (0.9, False)])
 def test_gpu_search_by_bow(tmp_path, oracle, ratio, ori):
@@ -343,6 +440,26 @@ def test_gpu_batched_resident_forms_of_the_slam_state_matchers(tmp_path, oracle)
         for j, q in enumerate(Q):
             onm, oasg = oracle.search_by_projection_frame(K[j + 1], D[j + 1], bounds, sf, None, q[1], q[2], q[3], q[4], ang_np[j, :len(q[0])], q[6], q[7], th, ori)
             assert int(nm[j]) == onm > 100 and np.array_equal(asg[j, :nh[j + 1]].cpu().numpy(), oasg), "frame pair %d" % j
+    # the relocalisation search (key-frame form), all pairs in one launch
+    KQ = [_keyframe_queries(K[j], D[j], shift, rng, sf, 8, w, h) for j in range(npairs)]
+    qcap2 = max(len(q[0]) for q in KQ) + 5
+    def pack2(idx, dtype, width=None):
+        a = np.zeros((npairs, qcap2) + ((width,) if width else ()), dtype)
+        for j, q in enumerate(KQ):
+            a[j, :len(q[idx])] = q[idx]
+        return torch.from_numpy(a).cuda()
+    kv, kfnd, ku, kvv, kd3, kmin, kmax, kang, kpd = (pack2(1, np.uint8), pack2(2, np.uint8), pack2(3, np.float32), pack2(4, np.float32), pack2(5, np.float32),
+                                                    pack2(6, np.float32), pack2(7, np.float32), pack2(8, np.float32), pack2(9, np.uint8, 32))
+    nq2 = torch.tensor([len(q[0]) for q in KQ], dtype=torch.int32, device="cuda")
+    lf = ext.log_scale_factor()
+    for th, orbdist, ori in ((10.0, 100, True), (3.0, 64, True)):
+        ext._check(L.pgorb_search_by_projection_keyframe_batch_device(hdl, p(kps), p(desc), p(n), cap, p(gs), p(gi), p(pair_frame), npairs, *bounds,
+                   p(has), qcap2, p(nq2), p(kv), p(kfnd), p(ku), p(kvv), p(kd3), p(kmin), p(kmax), p(kang), p(kpd), lf, th, orbdist, int(ori), p(asg), p(nm), s))
+        torch.cuda.synchronize()
+        for j, q in enumerate(KQ):
+            onm, oasg = oracle.search_by_projection_keyframe(K[j + 1], D[j + 1], bounds, sf, has_np[j, :nh[j + 1]], q[1], q[2], q[3], q[4], q[5], q[6], q[7],
+                                                             lf, q[8], q[9], th, orbdist, ori)
+            assert int(nm[j]) == onm > 30 and np.array_equal(asg[j, :nh[j + 1]].cpu().numpy(), oasg), "key-frame pair %d" % j
     # BoW: transform on the device, FeatureVectors on the device, key frame j vs frame j + 1
     vdesc, weight, parent = V.synth_vocabulary(6, 4, seed=4)
     path = os.path.join(str(tmp_path), "voc.txt")

@@ -708,6 +708,45 @@ def test_options_belong_to_a_context(oracle):
     st.close()                                          # closing a stream after its extractor: a no-op (round-3 advisory)
 
 
+def test_host_frame_calls_replay_a_graph(oracle):
+    """pgorb_extract (the reference's call shape: one frame per synchronous call, Frame.cc:251-257) launches its kernels directly
+    the first time it sees a frame size, captures them into a HIP graph the second time and replays the graph from then on:
+    every call against the oracle -- across different frames of one size, a size change and back, a batch-size change, an option
+    change (the captured plan is stale) and a call with a stage profile armed (direct launches again)."""
+    import pilotguru_amd as pg
+    nf = 600
+    ext = pg.ORBextractor(nf, 1.2, 8, 20, 7, max_width=640, max_height=480, max_batch=3)
+    ora = oracle.OrbOracle(nf, 1.2, 8, 20, 7)
+
+    def check(img):
+        kp, desc = ext(img)
+        okp, odesc = ora.extract(img)
+        assert len(kp) == len(okp) > 0 and kp.tobytes() == okp.tobytes() and np.array_equal(desc, odesc)
+    for seed in range(5):
+        check(synth_scene(50 + seed, 640, 480))                  # direct, capture, replay x 3
+    for seed in range(3):
+        check(synth_scene(60 + seed, 500, 380))                  # a new plan: direct, capture, replay
+    check(synth_scene(70, 640, 480))                             # back (a third plan epoch)
+    check(synth_scene(71, 640, 480))
+    frames = [synth_scene(80 + k, 640, 480) for k in range(3)]
+    for rep in range(3):                                         # batch of 3 through the same path
+        out = ext.extract_batch(frames)
+        for k in range(3):
+            okp, odesc = ora.extract(frames[k])
+            assert out[k][0].tobytes() == okp.tobytes() and np.array_equal(out[k][1], odesc)
+    check(synth_scene(72, 640, 480)); check(synth_scene(73, 640, 480)); check(synth_scene(74, 640, 480))
+    ext.set_option("fast_tile_pitch", 64)                        # the captured graph holds the old plan by value
+    check(synth_scene(75, 640, 480)); check(synth_scene(76, 640, 480)); check(synth_scene(77, 640, 480))
+    ext.profile_begin(2)
+    check(synth_scene(78, 640, 480)); check(synth_scene(79, 640, 480))
+    ncalls, ms = ext.profile_read()
+    assert ncalls == 2 and ms["fast"] > 0
+    check(synth_scene(90, 640, 480))
+    k, d = ext(np.full((480, 640), 128, np.uint8))               # a flat frame through the replayed graph: no keypoints
+    assert len(k) == 0
+    ext.close()
+
+
 def test_device_sincos_equals_the_oracle_for_every_input():
     """SURVEY.md hard part 4: the argument of computeOrbDescriptor's cos / sin (ORBextractor.cc:112-113) is a
     float in [0, 2 pi] -- 1.09e9 bit patterns.  EVERY one of them through the device's pg_sincos_f and the

@@ -19,6 +19,6 @@ for B in (1, 128):
         torch.cuda.synchronize()
         fn(out, 1)
     t = [out[i] * 0.01 for i in range(10)]
-    names = ["prologue+hist", "roots", "generations", "node map", "-", "-", "best", "select", "cell scan", "hist pass"]
+    names = ["pyramid sums", "roots", "generations", "node map + best", "-", "-", "(barrier)", "select", "zeroing", "candidate pass"]
     print("batch", B, "ncand", out[10], "bfs gens", out[11], "sorted gens", out[12], "total us", round(sum(t), 1))
     for nm, v in zip(names, t): print("   %-16s %7.1f us" % (nm, v))

@@ -1,0 +1,105 @@
+"""The reference's call shape, measured: ORBextractor::operator() is called synchronously, one frame per call, from a
+pageable cv::Mat (thirdparty/orb-slam2/src/Frame.cc:251-257, Tracking.cc:262-266) -- INTEGRATION.md section 1's adaptor does
+exactly that with pgorb_extract.  Wall clock per call (p50 / p99 / mean over `calls` calls after a warm-up), the kernel stage
+times of the same calls (HIP events) and the host phases the library reports; then the calls Tracking makes per frame
+around it: + Frame grid + SearchForInitialization (before initialisation), + the BoW transform (after).
+usage: python tools/single_frame_bench.py [--calls 2000] [--width 1920 --height 1080 --features 2000] [--out file]
+bench.py's `single_frame` leg imports run()."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def _pct(ts):
+    a = np.sort(np.asarray(ts, np.float64)) / 1e3
+    return {"p50_us": round(float(a[len(a) // 2]), 1), "p99_us": round(float(a[int(len(a) * 0.99)]), 1), "mean_us": round(float(a.mean()), 1),
+            "min_us": round(float(a[0]), 1)}
+
+
+def run(width=1920, height=1080, features=2000, calls=2000, warmup=100, with_frontend=True):
+    import pilotguru_amd as pg
+    from pilotguru_amd.synth import synth_ride
+    from pilotguru_amd import vocab as V
+    ride = synth_ride(0, width, height, 2)                       # two frames of a ride: consecutive frames match
+    ext = pg.ORBextractor(features, 1.2, 8, 20, 7, max_width=width, max_height=height, max_batch=1)
+    L, h = ext._L, ext._h
+    cap = ext.max_keypoints(width, height)
+    kps = np.zeros(cap, pg.orb.KEYPOINT_DTYPE); desc = np.zeros((cap, 32), np.uint8); n = C.c_int(0)
+    frames = [np.ascontiguousarray(ride[0]), np.ascontiguousarray(ride[1])]          # pageable host memory, like a cv::Mat
+    pk, pd = C.c_void_p(kps.ctypes.data), C.c_void_p(desc.ctypes.data)
+    pf = [C.c_void_p(f.ctypes.data) for f in frames]
+
+    def call(i):
+        rc = L.pgorb_extract(h, pf[i & 1], width, height, width, pk, pd, cap, C.byref(n))
+        if rc: ext._check(rc)
+    for i in range(warmup): call(i)
+    out = {"workload": "%dx%d grayscale, %d features, ONE frame per synchronous call from pageable host memory (pgorb_extract)" % (width, height, features),
+           "calls": calls, "keypoints": int(n.value)}
+    has_host = hasattr(L, "pgorb_profile_host")
+    if has_host:
+        L.pgorb_profile_host(h, None, 1)
+    ts = []
+    for i in range(calls):                                       # the timed loop: nothing armed, the library replays its graph
+        t0 = time.perf_counter_ns(); call(i); ts.append(time.perf_counter_ns() - t0)
+    out["extract"] = _pct(ts)
+    if has_host:
+        us = (C.c_double * 8)()
+        k = L.pgorb_profile_host(h, us, 1)
+        names = ["upload_issue", "kernel_launch_issue", "wait_for_gpu", "copy_out"]
+        out["extract"]["host_phase_us"] = {nm: round(us[i] / max(k, 1), 1) for i, nm in enumerate(names)}
+    # kernel stage times from a second, shorter loop with the stage profile armed (HIP events between the kernels: the library
+    # launches directly then, so the wall clock of THESE calls is not the number above)
+    pc = min(calls, 300)
+    ext.profile_begin(pc)
+    ts = []
+    for i in range(pc):
+        t0 = time.perf_counter_ns(); call(i); ts.append(time.perf_counter_ns() - t0)
+    ncalls, ms = ext.profile_read()
+    out["extract"]["kernel_stage_us"] = {k: round(v * 1e3, 1) for k, v in ms.items() if k != "match"}
+    out["extract"]["kernel_sum_us"] = round(sum(v for k, v in ms.items() if k != "match") * 1e3, 1)
+    out["extract"]["p50_us_direct_launches_profiled"] = _pct(ts)["p50_us"]
+    if with_frontend:
+        # what Tracking does with the frame before the map is initialised: Frame::Frame = extract + undistort (identity here) + grid
+        # (Frame.cc:178-232), then ORBmatcher(0.9, true).SearchForInitialization(mInitialFrame, mCurrentFrame, ..., 100) (Tracking.cc:596-597)
+        F1 = pg.Frame(ext, frames[0])
+        prev0 = np.stack([F1.mvKeys["x"], F1.mvKeys["y"]], 1).astype(np.float32)
+        m = pg.ORBmatcher(0.9, True)
+        ts = []
+        for i in range(max(calls // 4, 50) + 20):
+            t0 = time.perf_counter_ns()
+            F2 = pg.Frame(ext, frames[1])
+            nm, m12 = m.SearchForInitialization(F1, F2, prev0.copy(), 100)
+            if i >= 20: ts.append(time.perf_counter_ns() - t0)
+        out["extract_grid_search_for_initialization"] = dict(_pct(ts), matches=int(nm), note="python wrappers included (pg.Frame + ORBmatcher)")
+        # after initialisation every frame gets its BoW vectors (Frame::ComputeBoW, Frame.cc:399-406) on a k = 10, L = 6 tree
+        dsc, wgt, par = V.synth_vocabulary_fast(10, 6, seed=7)
+        voc = V.ORBVocabulary(blob=V.pack_vocabulary(10, 6, dsc, wgt, par))
+        voc.upload(ext)
+        ts = []
+        for i in range(max(calls // 4, 50) + 20):
+            t0 = time.perf_counter_ns()
+            F2 = pg.Frame(ext, frames[i & 1])
+            bv, fv = voc.transform(F2.mDescriptors, 4)
+            if i >= 20: ts.append(time.perf_counter_ns() - t0)
+        out["extract_grid_bow_transform"] = dict(_pct(ts), words=int(len(bv[0])), note="python wrappers included; BowVector / FeatureVector maps built on the host")
+    ext.close()
+    return out
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--width", type=int, default=1920); ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--features", type=int, default=2000); ap.add_argument("--calls", type=int, default=2000)
+    ap.add_argument("--no-frontend", action="store_true"); ap.add_argument("--out")
+    a = ap.parse_args()
+    r = run(a.width, a.height, a.features, a.calls, with_frontend=not a.no_frontend)
+    txt = json.dumps(r, indent=1)
+    print(txt)
+    if a.out: open(a.out, "w").write(txt + "\n")
