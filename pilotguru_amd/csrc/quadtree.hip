@@ -55,6 +55,20 @@
 #endif
 #define QT_SETTLE4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
 
+// inclusive prefix sum over the 64 lanes with DPP row shifts / broadcasts (six VALU moves; the __shfl_up form goes through the
+// LDS crossbar six times, and the generations pay every one of those in full: they are barrier-to-barrier latency)
+__device__ __forceinline__ int qt_wave_incl_scan(int x)
+{
+    int v = x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);      // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);      // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);      // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);      // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);     // row_bcast:15
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);     // row_bcast:31
+    return v;
+}
+
 // Exclusive prefix sum of a[0..n) in place (a in LDS or global); returns the total.
 // All threads must call.  sh: >= QT_W + 1 ints of LDS.
 __device__ int qt_scan_excl(int* a, int n, int* sh)
@@ -64,21 +78,12 @@ __device__ int qt_scan_excl(int* a, int n, int* sh)
     const int b = tid * per, e = min(b + per, n);
     int sum = 0;
     for (int i = b; i < e; i++) sum += a[i];
-    int incl = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(incl, d);
-        if (lane >= d) incl += o;
-    }
+    const int incl = qt_wave_incl_scan(sum);
     if (lane == 63) sh[wv] = incl;
     __syncthreads();
     if (wv == 0) {
-        int v = (lane < QT_W) ? sh[lane] : 0, w = v;
-#pragma unroll
-        for (int d = 1; d < QT_W; d <<= 1) {
-            const int o = __shfl_up(w, d);
-            if (lane >= d) w += o;
-        }
+        const int v = (lane < QT_W) ? sh[lane] : 0;
+        const int w = qt_wave_incl_scan(v);
         if (lane < QT_W) sh[lane] = w - v;
         if (lane == QT_W - 1) sh[QT_W] = w;
     }
@@ -96,12 +101,7 @@ __device__ int qt_scan_excl(int* a, int n, int* sh)
 __device__ __forceinline__ void qt_scan3_threads(int& a, int& b, int& c, int* tot, int* sh)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int ia = a, ib = b, ic = c;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int oa = __shfl_up(ia, d), ob = __shfl_up(ib, d), oc = __shfl_up(ic, d);
-        if (lane >= d) { ia += oa; ib += ob; ic += oc; }
-    }
+    const int ia = qt_wave_incl_scan(a), ib = qt_wave_incl_scan(b), ic = qt_wave_incl_scan(c);
     if (lane == 63) { sh[wv] = ia; sh[QT_W + wv] = ib; sh[2 * QT_W + wv] = ic; }
     __syncthreads();
     int pa = 0, pb = 0, pc = 0, ta = 0, tb = 0, tc = 0;
