@@ -350,6 +350,10 @@ int  pgorb_search_by_bow_batch_device(pgorb_ctx* ctx,
  * root child with an uninitialised descriptor for a trailing newline). */
 typedef struct pgorb_vocab pgorb_vocab;
 int  pgorb_vocab_load_text(const char* path, pgorb_vocab** out);
+/* As pgorb_vocab_load_text, through a binary cache `<path>.pgvoc` beside the text file (header: the text file's size and
+ * modification time; then the blob): a matching cache is loaded instead of parsing the text, anything else parses and rewrites
+ * the cache (failures to write are ignored).  *from_cache (may be NULL): 1 when the cache was used. */
+int  pgorb_vocab_load_cached(const char* path, pgorb_vocab** out, int* from_cache);
 int  pgorb_vocab_from_blob(const void* blob, int64_t nbytes, pgorb_vocab** out);   /* copies */
 int  pgorb_vocab_blob(const pgorb_vocab* v, const void** blob, int64_t* nbytes);
 int  pgorb_vocab_info(const pgorb_vocab* v, int* k, int* L, int* nnodes, int* nwords,

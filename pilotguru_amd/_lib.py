@@ -21,7 +21,7 @@ SYMBOLS = (
     "pgorb_hamming_matrix", "pgorb_hamming_best2", "pgorb_match_batch_device",
     "pgorb_debug_level_size", "pgorb_debug_level_image", "pgorb_debug_level_candidates",
     "pgorb_debug_level_keypoints", "pgorb_profile_begin", "pgorb_profile_read", "pgorb_profile_host",
-    "pgorb_vocab_load_text", "pgorb_vocab_from_blob", "pgorb_vocab_blob", "pgorb_vocab_info",
+    "pgorb_vocab_load_text", "pgorb_vocab_load_cached", "pgorb_vocab_from_blob", "pgorb_vocab_blob", "pgorb_vocab_info",
     "pgorb_vocab_free", "pgorb_vocab_upload", "pgorb_vocab_upload_device", "pgorb_bow_transform",
     "pgorb_bow_transform_device", "pgorb_bow_vectors", "pgorb_bow_score_l1",
     "pgorb_frame_grid", "pgorb_frame_grid_batch_device", "pgorb_search_for_initialization",
@@ -166,6 +166,7 @@ def lib():
     L.pgorb_host_free.restype = None
     L.pgorb_host_free.argtypes = [vp]
     L.pgorb_vocab_load_text.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.pgorb_vocab_load_cached.argtypes = [C.c_char_p, C.POINTER(vp), i32p]
     L.pgorb_vocab_from_blob.argtypes = [vp, C.c_int64, C.POINTER(vp)]
     L.pgorb_vocab_blob.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64)]
     L.pgorb_vocab_info.argtypes = [vp] + [i32p] * 6

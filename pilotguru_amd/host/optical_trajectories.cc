@@ -51,6 +51,7 @@ struct Flags {
     std::string vocabulary_file, camera_settings, out_dir, in_video, trajectory_in, poses_in, dump_features;
     bool visualize = true, vertical_flip = false, horizontal_flip = false, output_per_segment_videos = false;
     bool init_extractor = false;       // front-end mode has no map: --init_extractor treats the ride as "not initialised yet"
+    bool vocabulary_cache = true;      // <vocabulary_file>.pgvoc beside the text file (--novocabulary_cache: always parse the text)
     long long rotation_smooth_sigma = -1;
     int device = 0, batch = 64, max_frames = -1, segment_id = 0, rotation = 0;
     int copy_threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));     // slot filling and the per-frame BoW maps
@@ -69,7 +70,7 @@ bool parse_flags(int argc, char** argv, Flags& F)
         {"out_dir", &F.out_dir}, {"in_video", &F.in_video}, {"trajectory_in", &F.trajectory_in}, {"poses_in", &F.poses_in}, {"dump_features", &F.dump_features}};
     std::map<std::string, bool*> bl = {{"visualize", &F.visualize}, {"vertical_flip", &F.vertical_flip},
         {"horizontal_flip", &F.horizontal_flip}, {"output_per_segment_videos", &F.output_per_segment_videos},
-        {"init_extractor", &F.init_extractor}};
+        {"init_extractor", &F.init_extractor}, {"vocabulary_cache", &F.vocabulary_cache}};
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         if (a.rfind("--", 0) == 0) a = a.substr(2); else if (a.rfind("-", 0) == 0) a = a.substr(1); else return false;
@@ -342,10 +343,41 @@ int main(int argc, char** argv)
     if (!src.open(F.in_video, (int)get("Camera_width", 0), (int)get("Camera_height", 0), get("Camera_fps", 30.0)))
         check_failed("input video opens (y4m, PGM pattern or .gray + Camera_width/Camera_height)");
 
+    // Start-up (round 4): creating the device context -- HIP runtime start, the context's arenas, the stream's page-locked slots --
+    // was 0.45 s of a 0.56-s run on a 2 048-frame clip, one thing after the other.  Now a second thread creates context and stream
+    // while this one loads the vocabulary (from its binary cache beside the text file when there is one) and reads the first frame.
+    const auto tStart = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count(); };
+    const bool timing = getenv("PGORB_CLI_TIMING") != nullptr;
+    const int B = std::max(1, F.batch), DEPTH = 3;
+    // the upright frame the extractor sees (the reader's rotation swaps the sides for 90 / 270)
+    const bool swapSides = F.rotation == 90 || F.rotation == 270;
+    const int upW = swapSides ? src.h : src.w, upH = swapSides ? src.w : src.h;
+    pgorb::ORBextractor* ext = nullptr;
+    pgorb_stream* st = nullptr;
+    std::string devError;
+    double tCtx = 0, tStream = 0;
+    std::thread devThread([&] {
+        try { ext = new pgorb::ORBextractor(nFeatures, scaleFactor, nLevels, iniTh, minTh, upW, upH, B, F.device); }
+        catch (const std::exception& e) { devError = e.what(); return; }
+        tCtx = since();
+        if (pgorb_max_keypoints(ext->context(), upW, upH) < 0) { devError = "frame size usable for the ORB cell grid"; return; }
+        // frames as read; rotation, flips and the grey conversion on the device (Camera_RGB: 1 = RGB, 0 = BGR; Tracking.cc:247-260).
+        // A settings file without the key means BGR: `int nRGB = fSettings["Camera_RGB"]` reads 0 from an empty cv::FileNode (Tracking.cc:102)
+        if (pgorb_stream_create_ingest(ext->context(), src.w, src.h, src.channels, (int)get("Camera_RGB", 0) != 0, F.rotation,
+                                       F.vertical_flip, F.horizontal_flip, B, DEPTH, &st) != PGORB_OK) { devError = pgorb_last_error(ext->context()); return; }
+        tStream = since();
+    });
+
     pgorb_vocab* voc = nullptr;
-    if (pgorb_vocab_load_text(F.vocabulary_file.c_str(), &voc) != PGORB_OK)           // ORBVocabulary.cc:8 CHECK
+    int vocFromCache = 0;
+    if ((F.vocabulary_cache ? pgorb_vocab_load_cached(F.vocabulary_file.c_str(), &voc, &vocFromCache)
+                            : pgorb_vocab_load_text(F.vocabulary_file.c_str(), &voc)) != PGORB_OK) {           // ORBVocabulary.cc:8 CHECK
+        devThread.join();
         check_failed("vocabulary loads (ORB vocabulary text file)");
+    }
     int vk, vL, vn, vw, vs, vwt; pgorb_vocab_info(voc, &vk, &vL, &vn, &vw, &vs, &vwt);
+    const double tVoc = since();
 
     // The frame loop of TrackImageSequence (src/slam/track_image_sequence.cc:43-52) as a stream of batches
     // (include/pgorb.h, pgorb_stream_*): the source writes every frame straight into a page-locked slot; upload,
@@ -353,7 +385,6 @@ int main(int argc, char** argv)
     // Frame::ComputeBoW's transform and MonocularInitialization's SearchForInitialization(previous, current) -- runs on
     // the device for the whole batch as the stream's front-end stage (pgorb_stream_frontend); the host only folds the
     // per-feature words into BowVector / FeatureVector and writes the report.
-    const int B = std::max(1, F.batch), DEPTH = 3;
     // --shard: frames [firstExtracted, stop) are read, frames from firstOwned on are reported (the frame before
     // firstOwned is extracted only as the predecessor of the first owned match)
     long firstOwned = 0;
@@ -364,30 +395,22 @@ int main(int argc, char** argv)
         const long first = F.shard_rank * per + std::min<long>(F.shard_rank, extra), stop = first + per + (F.shard_rank < extra ? 1 : 0);
         const long firstExtracted = stop > first ? std::max<long>(first - 1, 0) : first;
         firstOwned = first;
-        if (!src.skip(firstExtracted)) check_failed("input video holds the frames of this shard");
+        if (!src.skip(firstExtracted)) { devThread.join(); check_failed("input video holds the frames of this shard"); }
         F.max_frames = (int)(stop - firstExtracted);
     }
     std::vector<uint8_t> frame0;                              // the first frame tells the size
     long long t0 = 0, id0 = 0;
     if (!((F.max_frames < 0 || F.max_frames > 0) && src.next(frame0, &t0, &id0))) frame0.clear();
-    pgorb::ORBextractor* ext = nullptr;
-    pgorb_stream* st = nullptr;
-    // the upright frame the extractor sees (the reader's rotation swaps the sides for 90 / 270)
-    const bool swapSides = F.rotation == 90 || F.rotation == 270;
-    const int upW = swapSides ? src.h : src.w, upH = swapSides ? src.w : src.h;
-    if (!frame0.empty()) {
-        ext = new pgorb::ORBextractor(nFeatures, scaleFactor, nLevels, iniTh, minTh, upW, upH, B, F.device);
-        if (pgorb_vocab_upload(ext->context(), voc) != PGORB_OK) check_failed("vocabulary upload");
-        if (pgorb_max_keypoints(ext->context(), upW, upH) < 0) check_failed("frame size usable for the ORB cell grid");
-        // frames as read; rotation, flips and the grey conversion on the device (Camera_RGB: 1 = RGB, 0 = BGR; Tracking.cc:247-260).
-        // A settings file without the key means BGR: `int nRGB = fSettings["Camera_RGB"]` reads 0 from an empty cv::FileNode (Tracking.cc:102)
-        if (pgorb_stream_create_ingest(ext->context(), src.w, src.h, src.channels, (int)get("Camera_RGB", 0) != 0, F.rotation,
-                                       F.vertical_flip, F.horizontal_flip, B, DEPTH, &st) != PGORB_OK) check_failed(pgorb_last_error(ext->context()));
-        // Frame::ComputeImageBounds without distortion: [0, cols] x [0, rows] (Frame.cc:462-466); ORBmatcher(0.9, true)
-        // .SearchForInitialization(mInitialFrame, mCurrentFrame, mvbPrevMatched, mvIniMatches, 100) (Tracking.cc:596-597);
-        // transform(..., 4) (Frame.cc:404)
-        if (pgorb_stream_frontend(st, 0.f, (float)upW, 0.f, (float)upH, 100, 0.9f, 1, 4) != PGORB_OK) check_failed(pgorb_last_error(ext->context()));
-    }
+    devThread.join();
+    if (!devError.empty()) check_failed(devError.c_str());
+    if (pgorb_vocab_upload(ext->context(), voc) != PGORB_OK) check_failed("vocabulary upload");
+    // Frame::ComputeImageBounds without distortion: [0, cols] x [0, rows] (Frame.cc:462-466); ORBmatcher(0.9, true)
+    // .SearchForInitialization(mInitialFrame, mCurrentFrame, mvbPrevMatched, mvIniMatches, 100) (Tracking.cc:596-597);
+    // transform(..., 4) (Frame.cc:404)
+    if (pgorb_stream_frontend(st, 0.f, (float)upW, 0.f, (float)upH, 100, 0.9f, 1, 4) != PGORB_OK) check_failed(pgorb_last_error(ext->context()));
+    if (timing)
+        fprintf(stderr, "start-up: vocabulary %s at %.3f s, context at %.3f s, stream at %.3f s, front-end stage ready at %.3f s\n",
+                vocFromCache ? "(from its cache)" : "(text parsed)", tVoc, tCtx, tStream, since());
     const size_t fbytes = src.frame_bytes();
     std::vector<std::vector<long long>> tusS(DEPTH, std::vector<long long>(B)), idsS(DEPTH, std::vector<long long>(B));
     std::ostringstream js;

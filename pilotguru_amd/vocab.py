@@ -122,12 +122,18 @@ class ORBVocabulary:
     (thirdparty/orb-slam2/include/ORBVocabulary.h:29-34): load from the text format or from a
     packed blob, upload to an extractor context, transform descriptors."""
 
-    def __init__(self, text_file=None, blob=None):
+    def __init__(self, text_file=None, blob=None, cache=False):
+        """cache=True: through the binary cache `<text_file>.pgvoc` (pgorb_vocab_load_cached); self.from_cache tells which way."""
         import ctypes as C
         from . import _lib
         self._L = _lib.lib()
         h = C.c_void_p()
-        if text_file is not None:
+        self.from_cache = False
+        if text_file is not None and cache:
+            fc = C.c_int32(0)
+            rc = self._L.pgorb_vocab_load_cached(str(text_file).encode(), C.byref(h), C.byref(fc))
+            self.from_cache = bool(fc.value)
+        elif text_file is not None:
             rc = self._L.pgorb_vocab_load_text(str(text_file).encode(), C.byref(h))
         else:
             blob = np.ascontiguousarray(blob, np.uint8)

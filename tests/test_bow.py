@@ -33,6 +33,36 @@ def test_text_loader_matches_oracle_and_python_pack(tmp_path, oracle):
         V.ORBVocabulary(blob=np.zeros(128, np.uint8))
 
 
+def test_vocabulary_cache_beside_the_text_file(tmp_path):
+    """pgorb_vocab_load_cached: the first load parses the text and writes `<file>.pgvoc`, the second takes the cache (same blob);
+    a changed text file (size / mtime) or a damaged cache falls back to the text and rewrites the cache."""
+    path = _vocab_file(tmp_path, 5, 3, seed=3)[0]
+    ref = V.ORBVocabulary(text_file=path).blob()
+    a = V.ORBVocabulary(text_file=path, cache=True)
+    assert not a.from_cache and os.path.exists(path + ".pgvoc") and np.array_equal(a.blob(), ref)
+    b = V.ORBVocabulary(text_file=path, cache=True)
+    assert b.from_cache and np.array_equal(b.blob(), ref)
+    # another vocabulary under the same name: the cache is stale
+    path2 = _vocab_file(tmp_path, 4, 3, seed=9)[0]
+    assert path2 == path
+    os.utime(path, ns=(1_700_000_000_000_000_000, 1_700_000_000_123_456_789))
+    ref2 = V.ORBVocabulary(text_file=path).blob()
+    c = V.ORBVocabulary(text_file=path, cache=True)
+    assert not c.from_cache and np.array_equal(c.blob(), ref2) and not np.array_equal(ref2[:64], ref[:64])
+    assert V.ORBVocabulary(text_file=path, cache=True).from_cache
+    # a damaged cache (truncated; flipped structure bytes) is ignored
+    raw = open(path + ".pgvoc", "rb").read()
+    open(path + ".pgvoc", "wb").write(raw[:len(raw) // 2])
+    d = V.ORBVocabulary(text_file=path, cache=True)
+    assert not d.from_cache and np.array_equal(d.blob(), ref2)
+    bad = bytearray(open(path + ".pgvoc", "rb").read()); bad[32 + 16] ^= 0xFF      # the blob header's node count
+    open(path + ".pgvoc", "wb").write(bytes(bad))
+    e = V.ORBVocabulary(text_file=path, cache=True)
+    assert not e.from_cache and np.array_equal(e.blob(), ref2)
+    with pytest.raises(ValueError):
+        V.ORBVocabulary(text_file=os.path.join(str(tmp_path), "missing.txt"), cache=True)
+
+
 def test_bow_vectors_match_real_reference_code(oracle):
     """pgorb_bow_vectors (product, host) == reference BowVector::addWeight/normalize and
     FeatureVector::addFeature, bit for bit (oracle/_ref built from /root/reference)."""

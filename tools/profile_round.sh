@@ -7,7 +7,7 @@ TAG=${1:-r01_x}; shift || true
 OUT=gpurun_out/$TAG
 export TMPDIR=/tmp
 mkdir -p "$OUT"
-ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-overlap-leg $*"
+ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-overlap-leg --no-single-frame-leg --no-upload-leg $*"
 run() { name=$1; shift; rocprofv3 "$@" -d "$OUT/$name" -- python bench.py $ARGS > "$OUT/$name.log" 2>&1 || true; find "$OUT/$name" -name '*.db' | head -1; }
 db=$(run stats --kernel-trace --stats)
 { echo "# rocprofv3 --kernel-trace --stats -- python bench.py $ARGS   (durations in us)"; python tools/rocpd_summary.py stats "$db"; } > "$OUT/${TAG}_kernel_stats.txt"
@@ -60,3 +60,5 @@ res = {"_comment": "HBM traffic per dispatch from the rocprofv3 PMC passes of %s
 json.dump(res, open("%s/%s_traffic.json" % (out, tag), "w"), indent=2)
 PY
 cat "$OUT/${TAG}_kernel_stats.txt"; cat "$OUT/${TAG}_pmc.txt"; cat "$OUT/${TAG}_bench_line.json"
+# the rocprofv3 databases are large (gpurun copies back at most 64 MiB): keep the summaries only
+find "$OUT" -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +
