@@ -158,9 +158,56 @@ void pg_launch_prev_matched_init(const pgorb_keypoint* d_kps, int64_t rows, floa
 
 extern __shared__ __attribute__((aligned(16))) uint8_t pg_sfi_smem[];
 
-#define SFI_K 64                 // stored candidates per F1 keypoint (one per lane of the sequential pass)
-#define SFI_OVER 255             // count value: more than SFI_K survivors, evaluate in place
-#define SFI_G 8                  // keypoints per prefetch group
+// ---- candidate lists of the two-pass matchers (round 4: variable length) -----------------------------------------------
+// Pass A stores EVERY surviving candidate of a query in the reference's scan order: the first LIST_K in the query's fixed slots,
+// the rest in the pair's pool (one atomic per query that needs it).  Rounds 2-3 capped the lists at 64 and re-evaluated denser
+// queries in place inside the sequential pass -- the initialisation workload's cliff.  Only when a pair's pool is full (an
+// average of LIST_K + LIST_POOL candidates per query) is a query still evaluated in place (count LIST_OVER).
+#define LIST_K 64
+#define LIST_POOL 256
+#define LIST_OVER 0xFFFFu
+#define SFI_K LIST_K
+struct PgLists {
+    uint32_t* fixed;             // [rows][LIST_K]
+    uint16_t* cnt;               // [rows]   survivors of the query (LIST_OVER: evaluate in place)
+    uint32_t* ovf;               // [rows]   where the query's entries LIST_K.. start in its pair's pool
+    uint32_t* pool;              // [npairs][poolPerPair]
+    int32_t*  poolTop;           // [npairs] (zeroed before pass A)
+    uint32_t  poolPerPair;
+};
+// scratch layout for npairs x rowsPerPair rows; returns the bytes needed
+static size_t pg_lists_layout(void* scratch, int npairs, int rowsPerPair, PgLists* L)
+{
+    const size_t rows = (size_t)npairs * rowsPerPair;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t off = 0;
+    uint8_t* b = (uint8_t*)scratch;
+    L->poolTop = (int32_t*)(b + off); off += al((size_t)npairs * 4);
+    L->fixed = (uint32_t*)(b + off); off += al(rows * LIST_K * 4);
+    L->cnt = (uint16_t*)(b + off); off += al(rows * 2);
+    L->ovf = (uint32_t*)(b + off); off += al(rows * 4);
+    L->poolPerPair = (uint32_t)((size_t)rowsPerPair * LIST_POOL);
+    L->pool = (uint32_t*)(b + off); off += al((size_t)npairs * L->poolPerPair * 4);
+    return off;
+}
+// entry `pos` (any position) of a query row; chunk = 64 consecutive entries, one per lane
+__device__ __forceinline__ uint32_t pg_list_chunk(const PgLists& L, int64_t row, int p, uint32_t ovf, int ch, int lane)
+{
+    return ch == 0 ? L.fixed[row * LIST_K + lane] : L.pool[(size_t)p * L.poolPerPair + ovf + (uint32_t)(ch - 1) * 64u + (uint32_t)lane];
+}
+// Pass A, the tail of a query's wave: `total` survivors are about to be written.  Reserves pool space when they do not fit the
+// fixed slots; returns the pool offset (wave-uniform) and sets `over` when the pair's pool is full.
+__device__ __forceinline__ uint32_t pg_list_reserve(const PgLists& L, int p, int total, int lane, bool& over)
+{
+    over = false;
+    if (total <= LIST_K) return 0u;
+    const int need = (total - LIST_K + 63) & ~63;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&L.poolTop[p], need);
+    base = __builtin_amdgcn_readfirstlane(base);
+    over = (uint32_t)base + (uint32_t)need > L.poolPerPair;
+    return (uint32_t)base;
+}
 
 // GetFeaturesInArea's cell window (Frame.cc:336-350); false = the reference returns an empty vector
 __device__ __forceinline__ bool sfi_window(float x, float y, float r, float minX, float minY, float invW, float invH,
@@ -189,15 +236,15 @@ __global__ __launch_bounds__(256) void k_sfi_candidates(
     const pgorb_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc, const int32_t* __restrict__ nper,
     int cap, const int32_t* __restrict__ gstart, const int32_t* __restrict__ gidx,
     const int32_t* __restrict__ pairF1, const int32_t* __restrict__ pairF2,
-    float minX, float minY, float invW, float invH, const float* __restrict__ prevMatched, int windowSize,
-    uint32_t* __restrict__ lists, uint8_t* __restrict__ listCnt)
+    float minX, float minY, float invW, float invH, const float* __restrict__ prevMatched, int windowSize, PgLists Ls)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, p = blockIdx.y;
     const int i1 = blockIdx.x * 4 + wv;
     const int f1 = pairF1[p], f2 = pairF2[p];
     const int n1 = min(nper[f1], cap);
     if (i1 >= n1) return;
-    uint8_t* cntOut = listCnt + (int64_t)p * cap + i1;
+    const int64_t row = (int64_t)p * cap + i1;
+    uint16_t* cntOut = Ls.cnt + row;
     const pgorb_keypoint kp1 = kps[(int64_t)f1 * cap + i1];
     int cx0, cx1, cy0, cy1;
     const float x = prevMatched[((int64_t)p * cap + i1) * 2], y = prevMatched[((int64_t)p * cap + i1) * 2 + 1];
@@ -229,27 +276,32 @@ __global__ __launch_bounds__(256) void k_sfi_candidates(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const uint4 q0 = reinterpret_cast<const uint4*>(desc + ((int64_t)f1 * cap + i1) * 32)[0];
     const uint4 q1 = reinterpret_cast<const uint4*>(desc + ((int64_t)f1 * cap + i1) * 32)[1];
-    uint32_t* out = lists + ((int64_t)p * cap + i1) * SFI_K;
+    // bCheckLevels is true for minLevel = maxLevel = 0 (Frame.cc:354): octave must equal level1
+    auto survives = [&](int k, int& i2) {
+        i2 = candList[k];
+        const pgorb_keypoint kp2 = K2[i2];
+        return kp2.octave == level1 && fabsf(__fsub_rn(kp2.x, x)) < r && fabsf(__fsub_rn(kp2.y, y)) < r;
+    };
+    // survivors beyond the fixed slots go to the pair's pool, reserved in one piece the moment the 65th survivor turns up -- for what
+    // is left of the window's M keypoints, an upper bound (counting the survivors first cost a second pass over the keypoints, and
+    // reserving for every query with M > 64 an atomic per query on the pair's counter: + 25 % / + 100 % on the whole matcher)
     int total = 0;
+    bool over = false, reserved = false;
+    uint32_t ovf = 0;
+    uint32_t* out = Ls.fixed + row * LIST_K;
+    uint32_t* outPool = Ls.pool + (size_t)p * Ls.poolPerPair;
     for (int base = 0; base < M; base += 64) {
         const int k = base + lane;
-        bool ok = false; uint32_t e = 0;
-        if (k < M) {
-            const int i2 = candList[k];
-            const pgorb_keypoint kp2 = K2[i2];
-            // bCheckLevels is true for minLevel = maxLevel = 0 (Frame.cc:354): octave must equal level1
-            const float distx = __fsub_rn(kp2.x, x), disty = __fsub_rn(kp2.y, y);
-            if (kp2.octave == level1 && fabsf(distx) < r && fabsf(disty) < r) {
-                ok = true;
-                e = ((uint32_t)sfi_distance(q0, q1, D2 + (int64_t)i2 * 32) << 16) | (uint32_t)i2;
-            }
-        }
+        int i2 = 0;
+        const bool ok = k < M && survives(k, i2);
+        const uint32_t e = ok ? (((uint32_t)sfi_distance(q0, q1, D2 + (int64_t)i2 * 32) << 16) | (uint32_t)i2) : 0u;
         const unsigned long long m = __ballot(ok);
         const int pos = total + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-        if (ok && pos < SFI_K) out[pos] = e;
         total += __popcll(m);
+        if (total > LIST_K && !reserved) { ovf = pg_list_reserve(Ls, p, LIST_K + (M - base), lane, over); reserved = true; }     // (wave-uniform)
+        if (ok) { if (pos < LIST_K) out[pos] = e; else if (!over) outPool[ovf + (uint32_t)(pos - LIST_K)] = e; }
     }
-    if (lane == 0) *cntOut = (uint8_t)(total > SFI_K ? SFI_OVER : total);
+    if (lane == 0) { *cntOut = (uint16_t)(over ? LIST_OVER : total); Ls.ovf[row] = ovf; }
 }
 
 // A keypoint of F1 with more than SFI_K candidates in its window (rare: every keypoint of a dense patch within 100 px):
@@ -288,15 +340,19 @@ __device__ __noinline__ uint3 sfi_eval_in_place(const pgorb_keypoint kp1, float 
     return make_uint3(wkey, wave_min_u32(min(mine, (unsigned)b2)), (unsigned)bestIdx2);
 }
 
-// Phase 2: the sequential pass, one wave per pair.
+#define SFI_G 8                  // keypoints per prefetch group
+// Phase 2: the sequential pass, one wave per pair.  (Round 4 also built this pass as ROUNDS of independent keypoints -- the scheme
+// k_search_by_projection runs below -- and measured it slower here: every listed keypoint of a pair is a level-0 keypoint with a
+// 200-px window, the lists overlap heavily, and the conservative readiness rule left ~10 % of the keypoints per round: 1.33 ms per 127
+// pairs of 4 000 features against 0.68 ms for this walk; profiles/r04_next_tier.txt.  The lists are variable length now: a dense
+// window no longer falls back to the evaluation in place.)
 __global__ __launch_bounds__(64) void k_search_for_initialization(
     const pgorb_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc, const int32_t* __restrict__ nper,
     int cap, const int32_t* __restrict__ gstart, const int32_t* __restrict__ gidx,
     const int32_t* __restrict__ pairF1, const int32_t* __restrict__ pairF2,
     float minX, float minY, float invW, float invH,
     float* __restrict__ prevMatched, int32_t* __restrict__ matches12out, int32_t* __restrict__ nmatchesOut,
-    int windowSize, float nnratio, int checkOrientation,
-    const uint32_t* __restrict__ lists, const uint8_t* __restrict__ listCnt)
+    int windowSize, float nnratio, int checkOrientation, PgLists Ls)
 {
     const int lane = threadIdx.x, p = blockIdx.x;
     const int f1 = pairF1[p], f2 = pairF2[p];
@@ -309,8 +365,9 @@ __global__ __launch_bounds__(64) void k_search_for_initialization(
     const int32_t* idx2 = gidx + (int64_t)f2 * cap;
     float* prev = prevMatched + (int64_t)p * cap * 2;
     int32_t* m12out = matches12out + (int64_t)p * cap;
-    const uint32_t* L = lists + (int64_t)p * cap * SFI_K;
-    const uint8_t* LC = listCnt + (int64_t)p * cap;
+    const int64_t row0 = (int64_t)p * cap;
+    const uint32_t* L = Ls.fixed + row0 * LIST_K;
+    const uint16_t* LC = Ls.cnt + row0;
 
     uint16_t* matchedDist = reinterpret_cast<uint16_t*>(pg_sfi_smem);      // [cap] vMatchedDistance (0xFFFF = INT_MAX)
     int16_t* m21 = reinterpret_cast<int16_t*>(matchedDist + cap);          // [cap] vnMatches21
@@ -320,9 +377,9 @@ __global__ __launch_bounds__(64) void k_search_for_initialization(
     for (int i = lane; i < cap; i += 64) { matchedDist[i] = 0xFFFF; m21[i] = -1; m12[i] = -1; push2[i] = -1; }
     int nact = 0;
     for (int base = 0; base < n1; base += 512) {                             // (8 count loads in flight, not one round trip per 64 keypoints)
-        uint8_t cv[8];
+        uint16_t cv[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const int i = base + 64 * u + lane; cv[u] = i < n1 ? LC[i] : (uint8_t)0; }
+        for (int u = 0; u < 8; u++) { const int i = base + 64 * u + lane; cv[u] = i < n1 ? LC[i] : (uint16_t)0; }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const bool on = cv[u] != 0;
@@ -358,13 +415,30 @@ __global__ __launch_bounds__(64) void k_search_for_initialization(
             const int i1 = curI[j];
             if (i1 < 0) break;                                              // (wave-uniform)
             unsigned wkey; int bestIdx2 = -1; unsigned second;
-            if (curC[j] != SFI_OVER) {
+            if (curC[j] <= LIST_K) {
+                // the common case, straight: the whole list is the prefetched chunk
                 const int i2 = (int)(curE[j] & 0xFFFFu), dist = (int)(curE[j] >> 16);
                 const bool keep = lane < curC[j] && !((int)matchedDist[i2] <= dist);       // :445-446
                 const unsigned key = keep ? (((unsigned)dist << 16) | (unsigned)lane) : 0xFFFFFFFFu;
                 wave_min2_u32(key, wkey, second);                           // smallest key, and the smallest of the others
                 if (wkey == 0xFFFFFFFFu) continue;
                 bestIdx2 = __builtin_amdgcn_readlane(i2, (int)(wkey & 0xFFFFu));
+                second = (second == 0xFFFFFFFFu) ? 0x7fffffffu : (second >> 16);
+            } else if (curC[j] != (int)LIST_OVER) {
+                // a dense window: the list 64 entries at a time, continued in the pair's pool (rounds 2-3 re-evaluated such a keypoint in place)
+                wkey = 0xFFFFFFFFu; second = 0xFFFFFFFFu;
+                const uint32_t ovf = Ls.ovf[row0 + i1];
+                for (int ch = 0; ch * 64 < curC[j]; ch++) {
+                    const uint32_t ee = ch == 0 ? curE[j] : pg_list_chunk(Ls, row0 + i1, p, ovf, ch, lane);
+                    const int i2 = (int)(ee & 0xFFFFu), dist = (int)(ee >> 16);
+                    const bool keep = ch * 64 + lane < curC[j] && !((int)matchedDist[i2] <= dist);       // :445-446
+                    const unsigned key = keep ? (((unsigned)dist << 16) | (unsigned)(ch * 64 + lane)) : 0xFFFFFFFFu;
+                    unsigned k1, k2;
+                    wave_min2_u32(key, k1, k2);
+                    if (k1 < wkey) { second = min(wkey, k2); wkey = k1; bestIdx2 = __builtin_amdgcn_readlane(i2, (int)(k1 & 63u)); }
+                    else second = min(second, k1);
+                }
+                if (wkey == 0xFFFFFFFFu) continue;
                 second = (second == 0xFFFFFFFFu) ? 0x7fffffffu : (second >> 16);
             } else {
                 // more than SFI_K candidates: evaluate in place, cell by cell in the reference's order
@@ -464,6 +538,8 @@ __global__ __launch_bounds__(64) void k_search_for_initialization(
     if (lane == 0) nmatchesOut[p] = nmatches;
 }
 
+#define RR_T 1024
+#define RR_W (RR_T / 64)
 // ---- SearchByProjection (local map points / last frame), src/ORBmatcher.cc:46-131, 1355-1474 ----
 // One wave per frame; queries in order.  mode 0: best + second with the same-level ratio test
 // (:83-125); mode 1: best only + rotation histogram (:1390-1469).
@@ -489,8 +565,7 @@ struct PgProjBatch {
 // Round 3, two passes like SearchForInitialization: the candidates of a query and their distances do not depend on the
 // assignments made so far (only `taken` does), so pass A computes them for every query of every pair in parallel and
 // pass B -- one wave per pair, the reference's order -- only filters the stored candidates by `taken` and picks.
-#define PROJ_K 64                // stored candidates per query (one per lane of pass B)
-#define PROJ_OVER 255            // count value: more than PROJ_K survivors, pass B evaluates the query in place
+#define PROJ_K LIST_K            // candidates in a query's fixed slots; the rest of its list is in the pair's pool (PgLists)
 
 // GetFeaturesInArea's window and the level range of query q; false = the reference skips the query
 __device__ __forceinline__ bool proj_query(const PgProjBatch& B, int64_t qi, int mode, float minX, float minY, float invW, float invH,
@@ -541,8 +616,7 @@ __device__ __forceinline__ int proj_bin(float qangle, float kangle)
 }
 
 // Pass A: workgroup = 4 waves = 4 consecutive queries of pair blockIdx.y
-__global__ __launch_bounds__(256) void k_proj_candidates(PgProjBatch B, float minX, float minY, float invW, float invH, int mode,
-                                                         uint32_t* __restrict__ lists, uint8_t* __restrict__ listCnt)
+__global__ __launch_bounds__(256) void k_proj_candidates(PgProjBatch B, float minX, float minY, float invW, float invH, int mode, PgLists Ls)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, p = blockIdx.y;
     const int q = blockIdx.x * 4 + wv;
@@ -550,7 +624,7 @@ __global__ __launch_bounds__(256) void k_proj_candidates(PgProjBatch B, float mi
     if (q >= nq) return;
     const int frame = B.pairFrame ? B.pairFrame[p] : p, cap = B.cap;
     const int64_t qi = (int64_t)p * B.qcap + q;
-    uint8_t* cntOut = listCnt + qi;
+    uint16_t* cntOut = Ls.cnt + qi;
     float x, y, r; int minLevel, maxLevel, cx0, cx1, cy0, cy1;
     if (!proj_query(B, qi, mode, minX, minY, invW, invH, x, y, r, minLevel, maxLevel, cx0, cx1, cy0, cy1)) {
         if (lane == 0) *cntOut = 0;
@@ -580,25 +654,30 @@ __global__ __launch_bounds__(256) void k_proj_candidates(PgProjBatch B, float mi
     const uint4 q0 = reinterpret_cast<const uint4*>(B.desc + qi * 32)[0];
     const uint4 q1 = reinterpret_cast<const uint4*>(B.desc + qi * 32)[1];
     const float qangle = mode != 0 ? B.aux[qi] : 0.f;
-    uint32_t* out = lists + qi * PROJ_K;
+    auto survives = [&](int k, int& i2, pgorb_keypoint& kp2) {
+        i2 = candList[k];
+        kp2 = K[i2];
+        if (bCheckLevels && (kp2.octave < minLevel || (maxLevel >= 0 && kp2.octave > maxLevel))) return false;
+        return fabsf(__fsub_rn(kp2.x, x)) < r && fabsf(__fsub_rn(kp2.y, y)) < r;
+    };
+    // (survivors beyond the fixed slots: the pair's pool, reserved when the 65th turns up -- see k_sfi_candidates)
     int total = 0;
+    bool over = false, reserved = false;
+    uint32_t ovf = 0;
+    uint32_t* out = Ls.fixed + qi * LIST_K;
+    uint32_t* outPool = Ls.pool + (size_t)p * Ls.poolPerPair;
     for (int base = 0; base < M; base += 64) {
         const int k = base + lane;
-        bool ok = false; uint32_t e = 0;
-        if (k < M) {
-            const int i2 = candList[k];
-            const pgorb_keypoint kp2 = K[i2];
-            ok = true;
-            if (bCheckLevels && (kp2.octave < minLevel || (maxLevel >= 0 && kp2.octave > maxLevel))) ok = false;
-            if (!(fabsf(__fsub_rn(kp2.x, x)) < r && fabsf(__fsub_rn(kp2.y, y)) < r)) ok = false;
-            if (ok) e = proj_entry(sfi_distance(q0, q1, D + (int64_t)i2 * 32), mode != 0 ? proj_bin(qangle, kp2.angle) : 0, kp2.octave, i2);
-        }
+        int i2 = 0; pgorb_keypoint kp2;
+        const bool ok = k < M && survives(k, i2, kp2);
+        const uint32_t e = ok ? proj_entry(sfi_distance(q0, q1, D + (int64_t)i2 * 32), mode != 0 ? proj_bin(qangle, kp2.angle) : 0, kp2.octave, i2) : 0u;
         const unsigned long long m = __ballot(ok);
         const int pos = total + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-        if (ok && pos < PROJ_K) out[pos] = e;
         total += __popcll(m);
+        if (total > LIST_K && !reserved) { ovf = pg_list_reserve(Ls, p, LIST_K + (M - base), lane, over); reserved = true; }     // (wave-uniform)
+        if (ok) { if (pos < LIST_K) out[pos] = e; else if (!over) outPool[ovf + (uint32_t)(pos - LIST_K)] = e; }
     }
-    if (lane == 0) *cntOut = (uint8_t)(total > PROJ_K ? PROJ_OVER : total);
+    if (lane == 0) { *cntOut = (uint16_t)(over ? LIST_OVER : total); Ls.ovf[qi] = ovf; }
 }
 
 // a query with more than PROJ_K candidates: the whole evaluation in place, in the reference's order (the round-2 form of the
@@ -645,137 +724,203 @@ __device__ __noinline__ uint2 proj_eval_in_place(const PgProjBatch B, int64_t qi
     return make_uint2(w1 == ~0ull ? 0xFFFFFFFFu : (uint32_t)w1, w2 == ~0ull ? 0xFFFFFFFFu : (uint32_t)w2);
 }
 
-#define PROJ_G 8                 // queries per prefetch group of pass B
-
-// Pass B: one wave per pair, queries in order
-__global__ __launch_bounds__(64) void k_search_by_projection(
+// Pass B (round 4): the queries of a pair in the reference's ORDER without its sequence.  What query q decides depends on earlier
+// queries only through the "holds a point" state of the keypoints in q's own list (:79-81 / :1397-1399 / :1542-1543), and a query
+// only ever writes that state for the ONE keypoint it takes, a candidate of its list within the acceptance threshold (TH_HIGH, or
+// ORBdist in the key-frame form): its "takeable" candidates.  So q can be decided as soon as no UNDECIDED earlier query has a takeable
+// candidate in q's list -- and (mode 0 only: the second best of its ratio test reads candidates beyond TH_HIGH too; the best-only
+// forms decide the same either way) q must not take a keypoint an undecided earlier query still has to read -- "deterministic reservations":
+//   round:  minq[i]   = the smallest undecided query with keypoint i among its takeable candidates     (LDS atomicMin, all undecided in parallel)
+//           minAny[i] = the smallest undecided query with keypoint i anywhere in its list              (mode 0)
+//           q is ready  <=>  minq[i] >= q for every i in q's list (and minAny[i] >= q for every takeable i of it);
+//           ready queries decide from the state as it is (reads only), then, behind a barrier, apply their decisions
+//           (two ready queries never take the same keypoint: the later one would not be ready).
+// The smallest undecided query is always ready, so the rounds end; map points project to different places, a query conflicts with a
+// handful of neighbours, and about half of the undecided ones fall in every round.  One workgroup of 16 waves per pair, a wave per
+// query and round, four queries' lists in flight per wave.  (Rounds 2-3: one wave walked the ~1 500-3 000 queries of a pair one after
+// the other, ~0.4 us each: 1.64 ms for a single 3 200-point call against 0.58 ms on one CPU core; now 0.49 ms, and 127 pairs in
+// 0.52 ms instead of 1.04.)  A query whose list did not fit the pool (LIST_OVER) waits until it is the smallest undecided one, holds
+// back everything behind it, and is evaluated in place.  The rule against the plain sequence on random lists, without a GPU:
+// tests/test_host_logic.py.  (SearchForInitialization keeps its sequential wave: see there.)
+__global__ __launch_bounds__(RR_T) void k_search_by_projection(
     PgProjBatch B, float minX, float minY, float invW, float invH, int mode, float nnratio, int checkOrientation,
-    const uint32_t* __restrict__ lists, const uint8_t* __restrict__ listCnt,
-    int32_t* __restrict__ assignedOut, int32_t* __restrict__ nmatchesOut)
+    PgLists Ls, int32_t* __restrict__ assignedOut, int32_t* __restrict__ nmatchesOut)
 {
     const int p = blockIdx.x, frame = B.pairFrame ? B.pairFrame[p] : p;
     const int cap = B.cap, n = min(B.n[frame], cap), nq = min(B.nq[p], B.qcap);
     const uint8_t* kpHasPoint = B.kpHasPoint ? B.kpHasPoint + (int64_t)p * cap : nullptr;
     const int64_t qo = (int64_t)p * B.qcap;
-    const uint32_t* L = lists + qo * PROJ_K;
-    const uint8_t* LC = listCnt + qo;
     assignedOut += (int64_t)p * cap; nmatchesOut += p;
-    const int lane = threadIdx.x;
-    // state in LDS: taken[i] = keypoint i holds a point with observations (before or by this call); asg[i] = query assigned
-    // to keypoint i by this call; rotBin[q] / qBest[q] = histogram bin and keypoint of accepted query q (mode 1);
-    // active = the queries that have candidates, in order
-    uint8_t* taken = pg_sfi_smem;                                         // [cap]
-    int32_t* asg = reinterpret_cast<int32_t*>(pg_sfi_smem + ((cap + 15) & ~15));    // [cap]
-    uint16_t* active = reinterpret_cast<uint16_t*>(asg + cap);            // [qcap]
-    uint16_t* qBest = active + B.qcap;                                    // [qcap]
-    int8_t* rotBin = reinterpret_cast<int8_t*>(qBest + B.qcap);           // [qcap]
-    for (int i = lane; i < n; i += 64) { taken[i] = kpHasPoint ? (kpHasPoint[i] != 0) : 0; asg[i] = -1; }
-    if (mode != 0) for (int i = lane; i < nq; i += 64) rotBin[i] = -1;
-    int nact = 0;
-    for (int base = 0; base < nq; base += 512) {
-        uint8_t cv[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) { const int i = base + 64 * u + lane; cv[u] = i < nq ? LC[i] : (uint8_t)0; }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const bool on = cv[u] != 0;
-            const unsigned long long m = __ballot(on);
-            if (on) active[nact + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] = (uint16_t)(base + 64 * u + lane);
-            nact += __popcll(m);
-        }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int thTake = mode == 2 ? B.orbDist : TH_HIGH;
+    // state in LDS: taken[i] = keypoint i holds a point (with observations, modes 0 / 1) before or by this call; asg[i] = query
+    // assigned to keypoint i by this call; per query: list length, decision (keypoint, rotation bin), state
+    uint32_t* minq = reinterpret_cast<uint32_t*>(pg_sfi_smem);            // [cap] smallest undecided query that may TAKE keypoint i
+    uint32_t* minAny = minq + cap;                                        // [cap] smallest undecided query that LISTS keypoint i (mode 0: the second best of the ratio test)
+    int32_t* asg = reinterpret_cast<int32_t*>(minAny + cap);               // [cap]
+    int* ctrl = asg + cap;                                                // [8] counters, [8..40) the rotation histogram
+    uint16_t* listA = reinterpret_cast<uint16_t*>(ctrl + 40);             // [qcap] undecided queries (two buffers)
+    uint16_t* listB = listA + B.qcap;
+    uint16_t* cntL = listB + B.qcap;                                      // [qcap]
+    uint16_t* qBest = cntL + B.qcap;                                      // [qcap] keypoint the query takes
+    int8_t* rotBin = reinterpret_cast<int8_t*>(qBest + B.qcap);           // [qcap] rotation bin of an accepted query (modes 1 / 2), or -1
+    uint8_t* done = reinterpret_cast<uint8_t*>(rotBin + B.qcap);          // [qcap] 0 undecided, 1 decided to take qBest (to be applied), 2 finished
+    uint8_t* taken = done + B.qcap;                                       // [cap]
+    for (int i = tid; i < cap; i += RR_T) { taken[i] = (kpHasPoint && i < n) ? (kpHasPoint[i] != 0) : 0; asg[i] = -1; }
+    if (tid < 40) ctrl[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < nq; i += RR_T) {
+        const uint16_t c = Ls.cnt[qo + i];
+        cntL[i] = c; rotBin[i] = -1; done[i] = 0;
+        if (c) listA[atomicAdd(&ctrl[0], 1)] = (uint16_t)i;
     }
     __syncthreads();
-    int nmatches = 0;
-    uint32_t curE[PROJ_G], nxtE[PROJ_G]; int curC[PROJ_G], nxtC[PROJ_G], curQ[PROJ_G], nxtQ[PROJ_G], curO[PROJ_G], nxtO[PROJ_G];
-    auto load_group = [&](int g, uint32_t (&E)[PROJ_G], int (&Cn)[PROJ_G], int (&Q)[PROJ_G], int (&O)[PROJ_G]) {
+    uint16_t* cur = listA; uint16_t* nxt = listB;
+    int curC = 0;
+    while (true) {
+        const int nun = ctrl[curC];
+        if (nun == 0) break;
+        for (int k = tid; k < cap; k += RR_T) { minq[k] = 0xFFFFFFFFu; minAny[k] = 0xFFFFFFFFu; }
+        if (tid == 0) { ctrl[1 - curC] = 0; ctrl[3] = 0x7fffffff; ctrl[4] = 0x7fffffff; }
+        __syncthreads();
+        // ---- takeable candidates of every undecided query ----
+        for (int u0 = wv * 4; u0 < nun; u0 += RR_W * 4) {
+            int q[4], c[4]; uint32_t e[4];
 #pragma unroll
-        for (int j = 0; j < PROJ_G; j++) {
-            const int a = g * PROJ_G + j;
-            Q[j] = -1; Cn[j] = 0; E[j] = 0; O[j] = 0;
-            if (a < nact) {
-                const int q = active[a];
-                Q[j] = q; Cn[j] = LC[q]; O[j] = mode == 2 ? 1 : (int)B.hasObs[qo + q];      // (key-frame form: any point blocks, :1542-1543)
-                E[j] = L[(int64_t)q * PROJ_K + lane];                        // (all 64 slots; slots past the count are masked below)
+            for (int j = 0; j < 4; j++) {
+                q[j] = u0 + j < nun ? (int)cur[u0 + j] : -1;
+                c[j] = q[j] >= 0 ? (int)cntL[q[j]] : 0;
+                e[j] = (c[j] != (int)LIST_OVER && lane < min(c[j], LIST_K)) ? Ls.fixed[(qo + q[j]) * LIST_K + lane] : 0u;
             }
-        }
-    };
-    const int ngroups = (nact + PROJ_G - 1) / PROJ_G;
-    if (ngroups) load_group(0, curE, curC, curQ, curO);
-    for (int g = 0; g < ngroups; g++) {
-        if (g + 1 < ngroups) load_group(g + 1, nxtE, nxtC, nxtQ, nxtO);
 #pragma unroll
-        for (int j = 0; j < PROJ_G; j++) {
-            const int q = curQ[j];
-            if (q < 0) break;                                               // (wave-uniform)
-            uint32_t e1, e2;                                                // entries of the best and the second candidate
-            if (curC[j] != PROJ_OVER) {
-                const uint32_t e = curE[j];
-                const bool keep = lane < curC[j] && !taken[e & 0x3FFFu];    // mvpMapPoints[idx] with Observations() > 0 (:79-81 / :1397-1399)
-                const unsigned key = keep ? (((e >> 23) << 16) | (unsigned)lane) : 0xFFFFFFFFu;
-                unsigned k1, k2;
-                wave_min2_u32(key, k1, k2);
-                if (k1 == 0xFFFFFFFFu) continue;
-                e1 = (uint32_t)__builtin_amdgcn_readlane((int)e, (int)(k1 & 63u));
-                e2 = (k2 == 0xFFFFFFFFu) ? 0xFFFFFFFFu : (uint32_t)__builtin_amdgcn_readlane((int)e, (int)(k2 & 63u));
-            } else {
-                const uint2 ev = proj_eval_in_place(B, qo + q, frame, mode, minX, minY, invW, invH, taken, lane);
-                e1 = ev.x; e2 = ev.y;
-                if (e1 == 0xFFFFFFFFu) continue;
-            }
-            const int bestDist = (int)(e1 >> 23), bestIdx = (int)(e1 & 0x3FFFu);
-            if (bestDist >= 256) continue;                                  // bestDist starts at 256 (:74 / :1390)
-            bool accept = false;
-            int bin = -1;
-            if (mode == 0) {
-                const bool has2 = e2 != 0xFFFFFFFFu && (int)(e2 >> 23) < 256;
-                const int bestDist2 = has2 ? (int)(e2 >> 23) : 256;
-                const int bestLevel = (int)((e1 >> 14) & 15u), bestLevel2 = has2 ? (int)((e2 >> 14) & 15u) : -1;
-                if (bestDist <= TH_HIGH)                                    // :113-123
-                    accept = !(bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(nnratio, (float)bestDist2));
-            } else {
-                accept = bestDist <= (mode == 2 ? B.orbDist : TH_HIGH);     // :1421 / :1554
-                if (accept && checkOrientation) bin = (int)((e1 >> 18) & 31u);     // :1426-1436 / :1559-1569 (computed in pass A)
-            }
-            if (accept) {
-                nmatches++;
-                if (lane == 0) {
-                    asg[bestIdx] = q;                                       // F.mvpMapPoints[bestIdx] = pMP
-                    taken[bestIdx] = curO[j] != 0;
-                    if (mode != 0) { rotBin[q] = (int8_t)bin; qBest[q] = (uint16_t)bestIdx; }
+            for (int j = 0; j < 4; j++) {
+                if (q[j] < 0) break;
+                if (lane == 0) atomicMin(&ctrl[4], q[j]);
+                if (c[j] == (int)LIST_OVER) { if (lane == 0) atomicMin(&ctrl[3], q[j]); continue; }
+                const uint32_t ovf = c[j] > LIST_K ? Ls.ovf[qo + q[j]] : 0u;
+                for (int ch = 0; ch * 64 < c[j]; ch++) {
+                    const uint32_t ee = ch == 0 ? e[j] : pg_list_chunk(Ls, qo + q[j], p, ovf, ch, lane);
+                    if (ch * 64 + lane < c[j]) {
+                        if (mode == 0) atomicMin(&minAny[ee & 0x3FFFu], (uint32_t)q[j]);
+                        if ((int)(ee >> 23) <= thTake) atomicMin(&minq[ee & 0x3FFFu], (uint32_t)q[j]);
+                    }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
         }
+        __syncthreads();
+        const int minOver = ctrl[3], minAll = ctrl[4];
+        // ---- ready queries decide ----
+        for (int u0 = wv * 4; u0 < nun; u0 += RR_W * 4) {
+            int q[4], c[4]; uint32_t e[4];
 #pragma unroll
-        for (int j = 0; j < PROJ_G; j++) { curE[j] = nxtE[j]; curC[j] = nxtC[j]; curQ[j] = nxtQ[j]; curO[j] = nxtO[j]; }
+            for (int j = 0; j < 4; j++) {
+                q[j] = u0 + j < nun ? (int)cur[u0 + j] : -1;
+                c[j] = q[j] >= 0 ? (int)cntL[q[j]] : 0;
+                e[j] = (c[j] != (int)LIST_OVER && lane < min(c[j], LIST_K)) ? Ls.fixed[(qo + q[j]) * LIST_K + lane] : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int qq = q[j];
+                if (qq < 0) break;
+                const bool isOver = c[j] == (int)LIST_OVER;
+                const uint32_t ovf = (!isOver && c[j] > LIST_K) ? Ls.ovf[qo + qq] : 0u;
+                bool ready = isOver ? (qq == minAll) : (qq < minOver);
+                if (ready && !isOver)
+                    for (int ch = 0; ch * 64 < c[j]; ch++) {
+                        const uint32_t ee = ch == 0 ? e[j] : pg_list_chunk(Ls, qo + qq, p, ovf, ch, lane);
+                        // (mode 0 only: a query must not take a keypoint an undecided EARLIER query still has to read -- the second best of
+                        //  its ratio test looks at candidates beyond TH_HIGH too; the best-only forms decide the same either way)
+                        const bool blocked = minq[ee & 0x3FFFu] < (uint32_t)qq ||
+                                             (mode == 0 && (int)(ee >> 23) <= thTake && minAny[ee & 0x3FFFu] < (uint32_t)qq);
+                        if (__ballot(ch * 64 + lane < c[j] && blocked) != 0ull) { ready = false; break; }
+                    }
+                if (!ready) { if (lane == 0) nxt[atomicAdd(&ctrl[1 - curC], 1)] = (uint16_t)qq; continue; }
+                // best and second best of the candidates that hold no point (:79-81 / :1397-1399 / :1542-1543); first minimum wins:
+                // key = distance << 16 | position in the list
+                uint32_t e1 = 0xFFFFFFFFu, e2 = 0xFFFFFFFFu;
+                if (!isOver) {
+                    unsigned w1 = 0xFFFFFFFFu, w2 = 0xFFFFFFFFu;
+                    for (int ch = 0; ch * 64 < c[j]; ch++) {
+                        const uint32_t ee = ch == 0 ? e[j] : pg_list_chunk(Ls, qo + qq, p, ovf, ch, lane);
+                        const bool keep = ch * 64 + lane < c[j] && !taken[ee & 0x3FFFu];
+                        const unsigned key = keep ? (((ee >> 23) << 16) | (unsigned)(ch * 64 + lane)) : 0xFFFFFFFFu;
+                        unsigned k1, k2;
+                        wave_min2_u32(key, k1, k2);
+                        const uint32_t c1 = k1 == 0xFFFFFFFFu ? 0xFFFFFFFFu : (uint32_t)__builtin_amdgcn_readlane((int)ee, (int)(k1 & 63u));
+                        const uint32_t c2 = k2 == 0xFFFFFFFFu ? 0xFFFFFFFFu : (uint32_t)__builtin_amdgcn_readlane((int)ee, (int)(k2 & 63u));
+                        if (k1 < w1) {
+                            if (w1 < k2) { w2 = w1; e2 = e1; } else { w2 = k2; e2 = c2; }
+                            w1 = k1; e1 = c1;
+                        } else if (k1 < w2) { w2 = k1; e2 = c1; }
+                    }
+                } else {
+                    const uint2 ev = proj_eval_in_place(B, qo + qq, frame, mode, minX, minY, invW, invH, taken, lane);
+                    e1 = ev.x; e2 = ev.y;
+                }
+                bool accept = false;
+                int bin = -1, bestIdx = 0;
+                if (e1 != 0xFFFFFFFFu && (int)(e1 >> 23) < 256) {                   // bestDist starts at 256 (:74 / :1390 / :1536)
+                    const int bestDist = (int)(e1 >> 23);
+                    bestIdx = (int)(e1 & 0x3FFFu);
+                    if (mode == 0) {
+                        const bool has2 = e2 != 0xFFFFFFFFu && (int)(e2 >> 23) < 256;
+                        const int bestDist2 = has2 ? (int)(e2 >> 23) : 256;
+                        const int bestLevel = (int)((e1 >> 14) & 15u), bestLevel2 = has2 ? (int)((e2 >> 14) & 15u) : -1;
+                        if (bestDist <= TH_HIGH)                                    // :113-123
+                            accept = !(bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(nnratio, (float)bestDist2));
+                    } else {
+                        accept = bestDist <= thTake;                                // :1421 / :1554
+                        if (accept && checkOrientation) bin = (int)((e1 >> 18) & 31u);     // :1426-1436 / :1559-1569 (computed in pass A)
+                    }
+                }
+                if (lane == 0) {
+                    if (accept) { qBest[qq] = (uint16_t)bestIdx; rotBin[qq] = (int8_t)bin; done[qq] = 1; }
+                    else done[qq] = 2;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- apply: F.mvpMapPoints[bestIdx] = pMP (two queries of one round never take the same keypoint) ----
+        for (int u = tid; u < nun; u += RR_T) {
+            const int qq = cur[u];
+            if (done[qq] != 1) continue;
+            const int k = qBest[qq];
+            asg[k] = qq;
+            taken[k] = mode == 2 ? 1 : (B.hasObs[qo + qq] != 0);                  // (key-frame form: any point blocks, :1542-1543)
+            atomicAdd(&ctrl[2], 1);
+            done[qq] = 3;                                                           // accepted and applied
+        }
+        __syncthreads();
+        uint16_t* t = cur; cur = nxt; nxt = t;
+        curC = 1 - curC;
     }
     __syncthreads();
     if (mode != 0 && checkOrientation) {                       // :1443-1469 / :1575-1600
-        int h = 0;
-        for (int i = 0; i < nq; i++) h += (rotBin[i] == lane);
+        int* hist = ctrl + 8;
+        for (int i = tid; i < nq; i += RR_T) if (rotBin[i] >= 0) atomicAdd(&hist[rotBin[i]], 1);
+        __syncthreads();
         int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
         for (int i = 0; i < HISTO_LENGTH; i++) {
-            const int s = __shfl(h, i);
-            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
-            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
-            else if (s > max3) { max3 = s; ind3 = i; }
+            const int sz = hist[i];
+            if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+            else if (sz > max3) { max3 = sz; ind3 = i; }
         }
         if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
         else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
         // rotHist[bin] holds bestIdx2 of every accepted query; every entry of a rejected bin resets
         // its keypoint to NULL and is counted out once (:1458-1465)
         int removed = 0;
-        for (int i = lane; i < nq; i += 64) {
-            const int b = rotBin[i];
-            if (b >= 0 && b != ind1 && b != ind2 && b != ind3) { asg[qBest[i]] = -1; removed++; }
+        for (int i = tid; i < nq; i += RR_T) {
+            const int bb = rotBin[i];
+            if (bb >= 0 && bb != ind1 && bb != ind2 && bb != ind3) { asg[qBest[i]] = -1; removed++; }
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) removed += __shfl_xor(removed, d);
-        nmatches -= removed;
+        if (removed) atomicSub(&ctrl[2], removed);
         __syncthreads();
     }
-    for (int i = lane; i < cap; i += 64) assignedOut[i] = i < n ? asg[i] : -1;
-    if (lane == 0) *nmatchesOut = nmatches;
+    for (int i = tid; i < cap; i += RR_T) assignedOut[i] = i < n ? asg[i] : -1;
+    if (tid == 0) *nmatchesOut = ctrl[2];
 }
 
 // ---- SearchByBoW(KeyFrame*, Frame&), src/ORBmatcher.cc:161-290 -----------------------------------
@@ -1076,7 +1221,7 @@ int pgorb_image_bounds(int cols, int rows, const float camera[4], const float di
 // per-device "dynamic LDS limit already raised to" bookkeeping of the three latency kernels below
 static bool pg_raise_lds(pgorb_ctx* c, const void* fn, int which, size_t lds)
 {
-    static size_t configured[4][64] = {{0}};
+    static size_t configured[6][64] = {{0}};
     const int dv = pg_ctx_device(c) & 63;
     if (lds > 160 * 1024) return false;
     if (lds > configured[which][dv]) {
@@ -1208,30 +1353,23 @@ int pgorb_search_for_initialization_batch_device(pgorb_ctx* c, const pgorb_keypo
     if (!npairs) return 0;
     if (hipSetDevice(pg_ctx_device(c)) != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "hipSetDevice failed");
     const float invW = (float)GRID_COLS / (max_x - min_x), invH = (float)GRID_ROWS / (max_y - min_y);
-    // scratch of the two passes: lists[npairs][cap][SFI_K] u32 | count[npairs][cap] u8
-    const size_t szL = (size_t)npairs * cap * SFI_K * 4;
+    // scratch of the two passes: the candidate lists of every F1 keypoint of every pair (PgLists)
+    PgLists Ls;
+    const size_t szL = pg_lists_layout(nullptr, npairs, cap, &Ls);
     void* scratch;
-    int rc = pg_ctx_scratch(c, szL + (size_t)npairs * cap + 256, (hipStream_t)stream, &scratch);
+    int rc = pg_ctx_scratch(c, szL + 256, (hipStream_t)stream, &scratch);
     if (rc) return rc;
-    uint32_t* lists = (uint32_t*)scratch;
-    uint8_t* listCnt = (uint8_t*)scratch + szL;
+    pg_lists_layout(scratch, npairs, cap, &Ls);
     const size_t ldsA = (size_t)4 * cap * 2, ldsB = (size_t)cap * 10 + 192;      // (+ the 32-bin histogram)
-    // (the attribute is per DEVICE: a process-wide "already configured" flag left a second GPU's kernels at the 64 KB default)
-    static size_t configuredA[64] = {0}, configuredB[64] = {0};
-    const int dv = pg_ctx_device(c) & 63;
-    if (ldsA > configuredA[dv]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sfi_candidates), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA);
-        configuredA[dv] = ldsA;
-    }
-    if (ldsB > configuredB[dv]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_for_initialization), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
-        configuredB[dv] = ldsB;
-    }
+    if (!pg_raise_lds(c, reinterpret_cast<const void*>(k_sfi_candidates), 4, ldsA) ||
+        !pg_raise_lds(c, reinterpret_cast<const void*>(k_search_for_initialization), 5, ldsB))
+        return pg_ctx_fail(c, PGORB_E_LIMIT, "SearchForInitialization state exceeds the LDS");
+    if (hipMemsetAsync(Ls.poolTop, 0, (size_t)npairs * 4, (hipStream_t)stream) != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "hipMemsetAsync failed");
     hipLaunchKernelGGL(k_sfi_candidates, dim3((cap + 3) / 4, npairs), dim3(256), ldsA, (hipStream_t)stream, d_kps, d_desc, d_n, cap,
-                       d_grid_start, d_grid_idx, d_pair_f1, d_pair_f2, min_x, min_y, invW, invH, d_prev_matched, window_size, lists, listCnt);
+                       d_grid_start, d_grid_idx, d_pair_f1, d_pair_f2, min_x, min_y, invW, invH, d_prev_matched, window_size, Ls);
     hipLaunchKernelGGL(k_search_for_initialization, dim3(npairs), dim3(64), ldsB, (hipStream_t)stream, d_kps, d_desc,
                        d_n, cap, d_grid_start, d_grid_idx, d_pair_f1, d_pair_f2, min_x, min_y, invW, invH,
-                       d_prev_matched, d_matches12, d_nmatches, window_size, nnratio, check_orientation, lists, listCnt);
+                       d_prev_matched, d_matches12, d_nmatches, window_size, nnratio, check_orientation, Ls);
     if (hipGetLastError() != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "k_search_for_initialization launch failed");
     return pg_ctx_scratch_done(c, (hipStream_t)stream);
 }
@@ -1265,20 +1403,21 @@ static int pg_search_by_projection_batch(pgorb_ctx* c, int mode, const pgorb_key
     if (m2) { B.found = kf->found; B.dist3d = kf->dist3d; B.minDist = kf->minDist; B.maxDist = kf->maxDist; B.logSf = kf->logSf; B.orbDist = kf->orbDist; }
     pgorb_scale_tables(c, B.sf, nullptr, nullptr, nullptr);
     const float invW = (float)GRID_COLS / (max_x - min_x), invH = (float)GRID_ROWS / (max_y - min_y);
-    // scratch of the two passes: lists[npairs][qcap][PROJ_K] u32 | count[npairs][qcap] u8
-    const size_t szL = (size_t)npairs * qcap * PROJ_K * 4;
+    // scratch of the two passes: the candidate lists of every query of every pair (PgLists)
+    PgLists Ls;
+    const size_t szL = pg_lists_layout(nullptr, npairs, std::max(qcap, 1), &Ls);
     void* scratch;
-    int rcs = pg_ctx_scratch(c, szL + (size_t)npairs * qcap + 256, stream, &scratch);
+    int rcs = pg_ctx_scratch(c, szL + 256, stream, &scratch);
     if (rcs) return rcs;
-    uint32_t* lists = (uint32_t*)scratch;
-    uint8_t* listCnt = (uint8_t*)scratch + szL;
+    pg_lists_layout(scratch, npairs, std::max(qcap, 1), &Ls);
     const size_t ldsA = (size_t)4 * cap * 2;
-    const size_t lds = (size_t)((cap + 15) & ~15) + (size_t)cap * 4 + (size_t)qcap * 5 + 64;
+    const size_t lds = (size_t)cap * 13 + (size_t)qcap * 10 + 256;
     if (!pg_raise_lds(c, reinterpret_cast<const void*>(k_search_by_projection), 0, lds) ||
-        !pg_raise_lds(c, reinterpret_cast<const void*>(k_proj_candidates), 3, ldsA)) return pg_ctx_fail(c, PGORB_E_LIMIT, "SearchByProjection state exceeds the LDS");
-    if (qcap) hipLaunchKernelGGL(k_proj_candidates, dim3((qcap + 3) / 4, npairs), dim3(256), ldsA, stream, B, min_x, min_y, invW, invH, mode, lists, listCnt);
-    hipLaunchKernelGGL(k_search_by_projection, dim3(npairs), dim3(64), lds, stream, B, min_x, min_y, invW, invH, mode, nnratio,
-                       check_orientation, lists, listCnt, d_assigned, d_nmatches);
+        !pg_raise_lds(c, reinterpret_cast<const void*>(k_proj_candidates), 3, ldsA)) return pg_ctx_fail(c, PGORB_E_LIMIT, "SearchByProjection state exceeds the LDS (keypoints * 13 + queries * 10 bytes, 160 KB)");
+    if (hipMemsetAsync(Ls.poolTop, 0, (size_t)npairs * 4, stream) != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "hipMemsetAsync failed");
+    if (qcap) hipLaunchKernelGGL(k_proj_candidates, dim3((qcap + 3) / 4, npairs), dim3(256), ldsA, stream, B, min_x, min_y, invW, invH, mode, Ls);
+    hipLaunchKernelGGL(k_search_by_projection, dim3(npairs), dim3(RR_T), lds, stream, B, min_x, min_y, invW, invH, mode, nnratio,
+                       check_orientation, Ls, d_assigned, d_nmatches);
     if (hipGetLastError() != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "k_search_by_projection launch failed");
     return pg_ctx_scratch_done(c, stream);
 }

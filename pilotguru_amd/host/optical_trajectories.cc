@@ -352,16 +352,39 @@ int main(int argc, char** argv)
     const int B = std::max(1, F.batch), DEPTH = 3;
     // the upright frame the extractor sees (the reader's rotation swaps the sides for 90 / 270)
     const bool swapSides = F.rotation == 90 || F.rotation == 270;
-    const int upW = swapSides ? src.h : src.w, upH = swapSides ? src.w : src.h;
     pgorb::ORBextractor* ext = nullptr;
     pgorb_stream* st = nullptr;
     std::string devError;
     double tCtx = 0, tStream = 0;
+    // --shard: frames [firstExtracted, stop) are read, frames from firstOwned on are reported (the frame before
+    // firstOwned is extracted only as the predecessor of the first owned match)
+    long firstOwned = 0;
+    if (F.shard_world > 1) {
+        long nframes = src.count();
+        if (F.max_frames >= 0) nframes = std::min<long>(nframes, F.max_frames);
+        const long per = nframes / F.shard_world, extra = nframes % F.shard_world;
+        const long first = F.shard_rank * per + std::min<long>(F.shard_rank, extra), stop = first + per + (F.shard_rank < extra ? 1 : 0);
+        const long firstExtracted = stop > first ? std::max<long>(first - 1, 0) : first;
+        firstOwned = first;
+        if (!src.skip(firstExtracted)) check_failed("input video holds the frames of this shard");
+        F.max_frames = (int)(stop - firstExtracted);
+    }
+    // (a printf pattern of PGM / PPM files only knows its frame size once the first file is read: read it first then)
+    std::vector<uint8_t> frame0;                              // the first frame tells the size
+    long long t0 = 0, id0 = 0;
+    bool frame0Read = false;
+    if (src.w <= 0 || src.h <= 0) {
+        if (!((F.max_frames < 0 || F.max_frames > 0) && src.next(frame0, &t0, &id0))) frame0.clear();
+        frame0Read = true;
+    }
+    const int upW2 = swapSides ? src.h : src.w, upH2 = swapSides ? src.w : src.h;
+    const bool haveSize = src.w > 0 && src.h > 0;            // (false: an empty pattern source / an empty shard of one -- nothing to extract)
     std::thread devThread([&] {
-        try { ext = new pgorb::ORBextractor(nFeatures, scaleFactor, nLevels, iniTh, minTh, upW, upH, B, F.device); }
+        if (!haveSize) return;
+        try { ext = new pgorb::ORBextractor(nFeatures, scaleFactor, nLevels, iniTh, minTh, upW2, upH2, B, F.device); }
         catch (const std::exception& e) { devError = e.what(); return; }
         tCtx = since();
-        if (pgorb_max_keypoints(ext->context(), upW, upH) < 0) { devError = "frame size usable for the ORB cell grid"; return; }
+        if (pgorb_max_keypoints(ext->context(), upW2, upH2) < 0) { devError = "frame size usable for the ORB cell grid"; return; }
         // frames as read; rotation, flips and the grey conversion on the device (Camera_RGB: 1 = RGB, 0 = BGR; Tracking.cc:247-260).
         // A settings file without the key means BGR: `int nRGB = fSettings["Camera_RGB"]` reads 0 from an empty cv::FileNode (Tracking.cc:102)
         if (pgorb_stream_create_ingest(ext->context(), src.w, src.h, src.channels, (int)get("Camera_RGB", 0) != 0, F.rotation,
@@ -385,29 +408,16 @@ int main(int argc, char** argv)
     // Frame::ComputeBoW's transform and MonocularInitialization's SearchForInitialization(previous, current) -- runs on
     // the device for the whole batch as the stream's front-end stage (pgorb_stream_frontend); the host only folds the
     // per-feature words into BowVector / FeatureVector and writes the report.
-    // --shard: frames [firstExtracted, stop) are read, frames from firstOwned on are reported (the frame before
-    // firstOwned is extracted only as the predecessor of the first owned match)
-    long firstOwned = 0;
-    if (F.shard_world > 1) {
-        long nframes = src.count();
-        if (F.max_frames >= 0) nframes = std::min<long>(nframes, F.max_frames);
-        const long per = nframes / F.shard_world, extra = nframes % F.shard_world;
-        const long first = F.shard_rank * per + std::min<long>(F.shard_rank, extra), stop = first + per + (F.shard_rank < extra ? 1 : 0);
-        const long firstExtracted = stop > first ? std::max<long>(first - 1, 0) : first;
-        firstOwned = first;
-        if (!src.skip(firstExtracted)) { devThread.join(); check_failed("input video holds the frames of this shard"); }
-        F.max_frames = (int)(stop - firstExtracted);
-    }
-    std::vector<uint8_t> frame0;                              // the first frame tells the size
-    long long t0 = 0, id0 = 0;
-    if (!((F.max_frames < 0 || F.max_frames > 0) && src.next(frame0, &t0, &id0))) frame0.clear();
+    if (!frame0Read && !((F.max_frames < 0 || F.max_frames > 0) && src.next(frame0, &t0, &id0))) frame0.clear();
     devThread.join();
     if (!devError.empty()) check_failed(devError.c_str());
+    if (ext) {
     if (pgorb_vocab_upload(ext->context(), voc) != PGORB_OK) check_failed("vocabulary upload");
     // Frame::ComputeImageBounds without distortion: [0, cols] x [0, rows] (Frame.cc:462-466); ORBmatcher(0.9, true)
     // .SearchForInitialization(mInitialFrame, mCurrentFrame, mvbPrevMatched, mvIniMatches, 100) (Tracking.cc:596-597);
     // transform(..., 4) (Frame.cc:404)
-    if (pgorb_stream_frontend(st, 0.f, (float)upW, 0.f, (float)upH, 100, 0.9f, 1, 4) != PGORB_OK) check_failed(pgorb_last_error(ext->context()));
+    if (pgorb_stream_frontend(st, 0.f, (float)upW2, 0.f, (float)upH2, 100, 0.9f, 1, 4) != PGORB_OK) check_failed(pgorb_last_error(ext->context()));
+    }
     if (timing)
         fprintf(stderr, "start-up: vocabulary %s at %.3f s, context at %.3f s, stream at %.3f s, front-end stage ready at %.3f s\n",
                 vocFromCache ? "(from its cache)" : "(text parsed)", tVoc, tCtx, tStream, since());
@@ -507,14 +517,22 @@ int main(int argc, char** argv)
        << "}\n}";
     if (dump) fclose(dump);
     const std::string out = (F.out_dir.empty() ? std::string(".") : F.out_dir) + "/frontend-" + std::to_string(F.shard_world > 1 ? F.shard_rank : 0) + ".json";
-    std::ofstream o(out);
-    if (!o.good()) check_failed("out_dir is writable");
-    o << js.str() << std::endl;
+    {
+        std::ofstream o(out);
+        if (!o.good()) check_failed("out_dir is writable");
+        o << js.str() << std::endl;
+    }
     const double loopSec = std::chrono::duration<double>(std::chrono::steady_clock::now() - loopStart).count();
     fprintf(stderr, "optical_trajectories (front-end mode): %ld frames -> %s (frame loop: %.3f s, %.0f frames/s)\n", total, out.c_str(),
             loopSec, loopSec > 0 ? total / loopSec : 0.0);
-    if (st) pgorb_stream_destroy(st);
-    delete ext;
-    pgorb_vocab_free(voc);
-    return EXIT_SUCCESS;
+    if (timing) fprintf(stderr, "report written at %.3f s\n", since());
+    if (getenv("PGORB_CLI_TEARDOWN")) {                       // orderly teardown (leak checkers): unpinning and freeing the arenas takes ~0.2 s
+        if (st) pgorb_stream_destroy(st);
+        delete ext;
+        pgorb_vocab_free(voc);
+        return EXIT_SUCCESS;
+    }
+    // the report is on disk (closed above): leave without unmapping gigabytes of page-locked and device memory one piece at a time
+    fflush(nullptr);
+    _exit(EXIT_SUCCESS);
 }

@@ -316,13 +316,13 @@ def fuzz_matchers(cases=100, seed=1, log=True, nf_range=(150, 3000), size_range=
         sf = ext.GetScaleFactors()
         drop, dup, jit = float(rng.uniform(0, 0.6)), float(rng.uniform(0, 0.5)), float(rng.choice([0.5, 1.5, 4.0]))
         sel, valid, px, py, lvl, vc, pd, obs = map_points(F1.mvKeys, F1.mDescriptors, (dx, dy), drop, dup, jit)
-        th = float(rng.choice([1.0, 3.0, 5.0, 8.0])); ratio = float(rng.choice([0.8, 0.6, 0.9]))
+        th = float(rng.choice([1.0, 3.0, 5.0, 8.0, 16.0, 45.0])); ratio = float(rng.choice([0.8, 0.6, 0.9]))     # (16 / 45: dense windows, lists beyond 64 candidates)
         has = (rng.uniform(size=F2.N) > rng.choice([0.9, 0.5, 1.1])).astype(np.uint8)
         onm, oasg = oracle.search_by_projection_points(F2.mvKeys, F2.mDescriptors, F2.bounds, sf, has, valid, px, py, lvl, vc, pd, obs, th, ratio)
         nm, asg = pg.ORBmatcher(ratio, True).SearchByProjection(F2, pg.MapPoints(valid, px, py, lvl, vc, pd, obs), th, has)
         checks += 1; stats["proj"] += onm
         if not (nm == onm and np.array_equal(asg, oasg)): report("SearchByProjection(points)", it, dict(cfg, th=th, ratio=ratio, drop=drop, dup=dup, jit=jit))
-        th = float(rng.choice([7.0, 15.0, 30.0, 3.0])); ori = bool(rng.randint(0, 2))
+        th = float(rng.choice([7.0, 15.0, 30.0, 3.0, 100.0])); ori = bool(rng.randint(0, 2))
         ang = F1.mvKeys["angle"][sel].copy()
         ang[::7] = (ang[::7] + 100.0) % 360.0
         onm, oasg = oracle.search_by_projection_frame(F2.mvKeys, F2.mDescriptors, F2.bounds, sf, None, valid, px, py, lvl, ang, pd, obs, th, ori)
@@ -331,7 +331,7 @@ def fuzz_matchers(cases=100, seed=1, log=True, nf_range=(150, 3000), size_range=
         if not (nm == onm and np.array_equal(asg, oasg)): report("SearchByProjection(last frame)", it, dict(cfg, th=th, ori=ori))
         # SearchByProjection (key frame, relocalisation): PredictScale level windows, ORBdist, sAlreadyFound
         if hasattr(oracle, "search_by_projection_keyframe"):
-            th, orbdist = [(10.0, 100), (3.0, 64), (10.0, 256), (5.0, 40)][int(rng.randint(0, 4))]
+            th, orbdist = [(10.0, 100), (3.0, 64), (10.0, 256), (5.0, 40), (80.0, 100)][int(rng.randint(0, 5))]
             ori = bool(rng.randint(0, 2))
             nq = len(sel)
             dist3d = (rng.uniform(0.5, 30.0, nq)).astype(np.float32)

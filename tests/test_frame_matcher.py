@@ -167,7 +167,7 @@ def test_oracle_search_by_projection_consistency(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("th,ratio", [(3.0, 0.8), (1.0, 0.8), (5.0, 0.6)])
+@pytest.mark.parametrize("th,ratio", [(3.0, 0.8), (1.0, 0.8), (5.0, 0.6), (14.0, 0.6), (40.0, 0.9)])
 def test_gpu_search_by_projection_points(oracle, th, ratio):
     import pilotguru_amd as pg
     w, h, nf = 640, 480, 1200
@@ -184,7 +184,7 @@ def test_gpu_search_by_projection_points(oracle, th, ratio):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("th,ori", [(15.0, True), (7.0, False), (30.0, True)])
+@pytest.mark.parametrize("th,ori", [(15.0, True), (7.0, False), (30.0, True), (90.0, True)])
 def test_gpu_search_by_projection_last_frame(oracle, th, ori):
     import pilotguru_amd as pg
     w, h, nf = 640, 480, 1200
@@ -199,6 +199,35 @@ def test_gpu_search_by_projection_last_frame(oracle, th, ori):
                                                   valid, px, py, lvl, ang, pd, obs, th, ori)
     nm, asg = pg.ORBmatcher(0.9, ori).SearchByProjectionLastFrame(F2, valid, px, py, lvl, ang, pd, obs, th)
     assert nm == onm and np.array_equal(asg, oasg) and nm > 100
+
+
+@pytest.mark.gpu
+def test_gpu_search_by_projection_when_the_list_pool_overflows(oracle):
+    """One pyramid level, > 1 200 keypoints on 640 x 480 and search radii of 160 px: a query's window holds a third of the frame's
+    keypoints, the lists of a pair add up to several times the pool (64 fixed + 256 pooled entries per query on average), and the
+    later queries are marked LIST_OVER: they wait until every earlier query is decided and are evaluated in place.  All three forms."""
+    import pilotguru_amd as pg
+    w, h, nf = 640, 480, 4000
+    ride = synth_ride(14, w, h, 2, dx=5, dy=2)
+    ext = pg.ORBextractor(nf, 1.2, 1, 20, 7, max_width=w, max_height=h)
+    F1, F2 = pg.Frame(ext, ride[0]), pg.Frame(ext, ride[1])
+    assert F2.N > 1200                                       # (radius 160 px: a window holds a third of them, > 64 + 256 per query)
+    rng = np.random.RandomState(15)
+    sf = ext.GetScaleFactors()
+    sel, valid, px, py, lvl, vc, pd, obs = _synthetic_map_points(F1.mvKeys, F1.mDescriptors, (5, 2), rng)
+    has = (rng.uniform(size=F2.N) > 0.9).astype(np.uint8)
+    onm, oasg = oracle.search_by_projection_points(F2.mvKeys, F2.mDescriptors, F2.bounds, sf, has, valid, px, py, lvl, vc, pd, obs, 40.0, 0.7)
+    nm, asg = pg.ORBmatcher(0.7, True).SearchByProjection(F2, pg.MapPoints(valid, px, py, lvl, vc, pd, obs), 40.0, has)
+    assert nm == onm and np.array_equal(asg, oasg) and nm > 100
+    ang = F1.mvKeys["angle"][sel].copy(); ang[::7] = (ang[::7] + 100.0) % 360.0
+    onm, oasg = oracle.search_by_projection_frame(F2.mvKeys, F2.mDescriptors, F2.bounds, sf, None, valid, px, py, lvl, ang, pd, obs, 160.0, True)
+    nm, asg = pg.ORBmatcher(0.9, True).SearchByProjectionLastFrame(F2, valid, px, py, lvl, ang, pd, obs, 160.0)
+    assert nm == onm and np.array_equal(asg, oasg) and nm > 100
+    # SearchForInitialization with a 250-px window on the same frames: lists beyond the fixed slots and, late in the pair, beyond the pool
+    prev = np.stack([F1.mvKeys["x"], F1.mvKeys["y"]], 1).astype(np.float32)
+    onm, om12, oprev = oracle.search_for_initialization(F1.mvKeys, F1.mDescriptors, F2.mvKeys, F2.mDescriptors, F2.bounds, prev.copy(), 250, 0.9, True)
+    nm, m12 = pg.ORBmatcher(0.9, True).SearchForInitialization(F1, F2, prev, 250)
+    assert nm == onm and np.array_equal(m12, om12) and prev.tobytes() == oprev.tobytes() and nm > 100
 
 
 def _keyframe_queries(F1keys, F1desc, shift, rng, sf, nlevels, w, h):
@@ -274,7 +303,7 @@ def test_oracle_search_by_projection_keyframe_consistency(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("th,orbdist,ori", [(10.0, 100, True), (3.0, 64, True), (10.0, 100, False), (6.0, 256, True)])
+@pytest.mark.parametrize("th,orbdist,ori", [(10.0, 100, True), (3.0, 64, True), (10.0, 100, False), (6.0, 256, True), (70.0, 100, True)])
 def test_gpu_search_by_projection_keyframe(oracle, th, orbdist, ori):
     """ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1476-1603) at the two
     call sites of Tracking::Relocalization (Tracking.cc:1434: 10 / 100; :1448: 3 / 64), without the orientation check, and
@@ -425,7 +454,9 @@ def test_gpu_batched_resident_forms_of_the_slam_state_matchers(tmp_path, oracle)
     pair_frame = torch.arange(1, B, dtype=torch.int32, device="cuda")
     asg = torch.empty((npairs, cap), dtype=torch.int32, device="cuda"); nm = torch.empty(npairs, dtype=torch.int32, device="cuda")
     sf = ext.GetScaleFactors()
-    for th, ratio in ((3.0, 0.8), (1.0, 0.8)):
+    # (th 12 / 60: DENSE windows, most queries hold more than the 64 candidates of their fixed list slots -- the rest of a list lives
+    #  in the pair's pool; rounds 2-3 re-evaluated such queries in place, the "initialisation workload cliff" of VERDICT r3)
+    for th, ratio in ((3.0, 0.8), (1.0, 0.8), (12.0, 0.7)):
         ext._check(L.pgorb_search_by_projection_points_batch_device(hdl, p(kps), p(desc), p(n), cap, p(gs), p(gi), p(pair_frame), npairs, *bounds,
                    p(has), qcap, p(nq), p(valid), p(px), p(py), p(lvl), p(vc), p(pd), p(obs), th, ratio, p(asg), p(nm), s))
         torch.cuda.synchronize()
@@ -433,7 +464,7 @@ def test_gpu_batched_resident_forms_of_the_slam_state_matchers(tmp_path, oracle)
             onm, oasg = oracle.search_by_projection_points(K[j + 1], D[j + 1], bounds, sf, has_np[j, :nh[j + 1]], q[1], q[2], q[3], q[4], q[5], q[6], q[7], th, ratio)
             assert int(nm[j]) == onm > 100 and np.array_equal(asg[j, :nh[j + 1]].cpu().numpy(), oasg), "points pair %d" % j
             assert bool((asg[j, nh[j + 1]:] == -1).all())
-    for th, ori in ((15.0, True), (7.0, False)):
+    for th, ori in ((15.0, True), (7.0, False), (60.0, True)):
         ext._check(L.pgorb_search_by_projection_frame_batch_device(hdl, p(kps), p(desc), p(n), cap, p(gs), p(gi), p(pair_frame), npairs, *bounds,
                    None, qcap, p(nq), p(valid), p(px), p(py), p(lvl), p(ang), p(pd), p(obs), th, int(ori), p(asg), p(nm), s))
         torch.cuda.synchronize()

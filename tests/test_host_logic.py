@@ -68,3 +68,91 @@ def test_bench_cpu_core_count_respects_the_cgroup_quota(tmp_path, monkeypatch):
     ab = bench.algorithmic_bytes([(1920, 1080), (1600, 900)], 2000.0)
     assert ab["fast"] == 1920 * 1080 + 1600 * 900 and ab["pyramid"] == 1920 * 1080 + 1600 * 900
     assert ab["describe"] == 2000 * (43 * 43 + 60) and ab["match"] == 2 * 2000 * 32 + 2000 * 8
+
+
+def test_round_scheduling_rule_of_the_guided_matchers_equals_the_sequence():
+    """The guided matchers (frame.hip, round 4) decide a pair's queries in ROUNDS instead of one after the other.  The rule --
+    query q is ready when no undecided EARLIER query can take a keypoint of q's list, and no undecided earlier query lists a
+    keypoint q can take -- must reproduce the plain sequence of ORBmatcher.cc:46-131 (taken flags, ratio test with levels) and of
+    :407-522 (vMatchedDistance, matches taken over): checked here on random candidate lists, without the GPU."""
+    rng = np.random.RandomState(0)
+
+    def projection(lists, obs, nk, ratio, has, th, by_rounds):
+        taken = has.copy(); asg = -np.ones(nk, int); nm = 0
+
+        def decide(q):
+            best = (256, -1, -1); second = (256, -1)
+            for (d, k, lv) in lists[q]:
+                if taken[k]: continue
+                if d < best[0]: second = (best[0], best[2]); best = (d, k, lv)
+                elif d < second[0]: second = (d, lv)
+            if best[0] <= th and not (best[2] == second[1] and best[0] > ratio * second[0]): return best[1]
+            return -1
+        if not by_rounds:
+            for q in range(len(lists)):
+                k = decide(q)
+                if k >= 0: asg[k] = q; taken[k] = obs[q]; nm += 1
+            return nm, asg
+        unres = [q for q, L in enumerate(lists) if L]
+        while unres:
+            mtake = np.full(nk, 10 ** 9); many = np.full(nk, 10 ** 9)
+            for q in unres:
+                for (d, k, lv) in lists[q]:
+                    many[k] = min(many[k], q)
+                    if d <= th: mtake[k] = min(mtake[k], q)
+            ready = [q for q in unres if not any(mtake[k] < q or (d <= th and many[k] < q) for (d, k, lv) in lists[q])]
+            assert ready and ready[0] == unres[0]                     # the smallest undecided query is always ready
+            dec = [(q, decide(q)) for q in ready]                     # decisions from the state as it is ...
+            for q, k in dec:                                          # ... applied afterwards
+                if k >= 0: asg[k] = q; taken[k] = obs[q]; nm += 1
+            unres = [q for q in unres if q not in set(ready)]
+        return nm, asg
+
+    def initialisation(lists, n2, ratio, by_rounds):
+        TH_LOW = 50
+        md = np.full(n2, 10 ** 9); m21 = -np.ones(n2, int); m12 = -np.ones(len(lists), int); nm = 0
+
+        def decide(q):
+            best = 10 ** 9; second = 10 ** 9; bi = -1
+            for (d, k) in lists[q]:
+                if md[k] <= d: continue
+                if d < best: second = best; best = d; bi = k
+                elif d < second: second = d
+            return (bi, best) if (best <= TH_LOW and best < second * ratio) else (-1, 0)
+
+        def apply(q, k, d):
+            nonlocal nm
+            if m21[k] >= 0: m12[m21[k]] = -1; nm -= 1
+            m12[q] = k; m21[k] = q; md[k] = d; nm += 1
+        if not by_rounds:
+            for q in range(len(lists)):
+                k, d = decide(q)
+                if k >= 0: apply(q, k, d)
+            return nm, m12
+        unres = [q for q, L in enumerate(lists) if L]
+        while unres:
+            mtake = np.full(n2, 10 ** 9); many = np.full(n2, 10 ** 9)
+            for q in unres:
+                for (d, k) in lists[q]:
+                    many[k] = min(many[k], q)
+                    if d <= TH_LOW: mtake[k] = min(mtake[k], q)
+            ready = [q for q in unres if not any(mtake[k] < q or (d <= TH_LOW and many[k] < q) for (d, k) in lists[q])]
+            dec = [(q,) + decide(q) for q in ready]
+            for q, k, d in dec:
+                if k >= 0: apply(q, k, d)
+            unres = [q for q in unres if q not in set(ready)]
+        return nm, m12
+
+    for it in range(150):
+        nk = int(rng.randint(3, 120)); nq = int(rng.randint(2, 160))
+        lists = []
+        for q in range(nq):
+            ks = rng.choice(nk, size=min(int(rng.randint(0, 9)), nk), replace=False)
+            lists.append([(int(rng.choice([10, 30, 50, 90, 100, 101, 120, 200])), int(k), int(rng.randint(0, 3))) for k in ks])
+        obs = rng.uniform(size=nq) > 0.2; has = rng.uniform(size=nk) > 0.9
+        ratio = float(rng.choice([0.6, 0.8, 0.9])); th = int(rng.choice([100, 64, 256]))
+        a = projection(lists, obs, nk, ratio, has, th, False); b = projection(lists, obs, nk, ratio, has, th, True)
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]), it
+        l2 = [[(int(rng.choice([5, 20, 40, 50, 51, 70])), k) for (_, k, _) in L] for L in lists]
+        a = initialisation(l2, nk, ratio, False); b = initialisation(l2, nk, ratio, True)
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]), it
