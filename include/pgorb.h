@@ -233,7 +233,8 @@ int  pgorb_search_for_initialization_batch_device(pgorb_ctx* ctx, const pgorb_ke
  * Common state: kp_has_point[i] != 0 when the frame's keypoint i already holds a map point with
  * Observations() > 0 before the call (:79-81 / :1397-1399); assigned[i] receives the index of the
  * query (map point) written to F.mvpMapPoints[i] by this call, or -1.  Queries are processed in
- * order (each assignment changes what later queries may take), one 64-lane wave per frame. */
+ * order (each assignment changes what later queries may take): the results equal the reference's
+ * sequence; since round 4 the device decides provably independent queries together. */
 int  pgorb_search_by_projection_points(pgorb_ctx* ctx,
         const pgorb_keypoint* kps, const uint8_t* desc, int n,            /* the frame F             */
         float min_x, float max_x, float min_y, float max_y,
@@ -295,7 +296,8 @@ int  pgorb_search_by_bow(pgorb_ctx* ctx,
  * (NULL: frame p).  Query arrays are [npairs][qcap] with d_nq[p] entries in use; d_kp_has_point (NULL = none) and
  * d_assigned are [npairs][cap_per_frame], d_nmatches [npairs].  The reference's order dependence (an assignment is seen
  * by every later query, ORBmatcher.cc:75-79, :1398-1402, :236-240) stays inside a pair; pairs run concurrently.  SearchByProjection:
- * two passes (candidates and distances of every query in parallel, then one wave per pair in the reference's order);
+ * two passes (candidates and distances of every query in parallel; then one workgroup per pair decides the queries in rounds
+ * of independent ones, every decision equal to the reference's sequence -- round 4);
  * SearchByBoW: one wave per common vocabulary node (a frame feature belongs to one node, so nodes are independent).  Call sites: Tracking::SearchLocalPoints (Tracking.cc:1175), TrackWithMotionModel (:876, :882),
  * TrackReferenceKeyFrame (:758). */
 int  pgorb_search_by_projection_points_batch_device(pgorb_ctx* ctx,
@@ -526,6 +528,9 @@ int      pgorb_stream_frontend_results(pgorb_stream* s, int slot, const int32_t*
  * (48 with compile-time offsets for cells up to 36 px: the shipped shape), 48 | 64 | ... | 128 = that pitch through the
  * run-time-pitch instantiation (values below what the plan's cells need are ignored).
  * key "fast_waves_per_block": 1 (default) | 4 independent cells (waves) per K2 workgroup.
+ * key "quadtree_split": K3's pass over the candidates -- 0 = inside the quadtree kernel (one launch), 1 = as a kernel of its own
+ * (many small workgroups; pays for single frames and large frames), 2 = chosen per launch from the frame size and the number of
+ * frames (default; the measured table is profiles/r04_k3_split_grid.txt).  PGORB_QT_SPLIT seeds it.
  * key "pipeline_pyramid": 1 = the resize chain on a side stream beside K2, level by level (slower).
  * key "pipeline_levels": bit l set = a group of levels starts at level l; K3 / K4-6 of one group run on side streams beside K2
  * of the next (slower for every grouping measured).  0 = one launch per kernel (default).

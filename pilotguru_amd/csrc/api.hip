@@ -43,7 +43,8 @@ struct pgorb_ctx {
     int planW = 0, planH = 0, planBatch = 0;
     bool planValid = false;
     // device memory
-    Arena pyr, cand, sel, nodes, counters, tables, cellCand, cellCount, cellTab, cellTabBal;
+    Arena pyr, cand, sel, nodes, counters, tables, cellCand, cellCount, cellTab, cellTabBal, qtTab, qtLeaf;
+    int qtSplit = 2;                          // K3's candidate pass as its own launch: 0 no, 1 yes, 2 by frame size and batch (pgorb_set_option "quadtree_split")
     int fastTilePitch = 0, fastWpb = 1;       // K2 tile-shape sweep (pgorb_set_option "fast_tile_pitch" / "fast_waves_per_block")
     // K1 beside K2 (pgorb_set_option "pipeline_pyramid"): the pyramid chain on a high-priority side stream, K2 level by
     // level on a second one as the levels appear
@@ -365,7 +366,7 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
     P.candFrame = (int64_t)candFrame; P.selFrame = (int64_t)selFrame; P.nodeFrame = (int64_t)nodeFrame;
     if ((rc = ensure(c, c->pyr, pyrFrame * B))) return rc;
     if ((rc = ensure(c, c->cand, candFrame * 8 * B))) return rc;          // uint2 key records
-    if ((rc = ensure(c, c->cellCand, cellCandFrame * 4 * B))) return rc;
+    if ((rc = ensure(c, c->cellCand, cellCandFrame * 4 * B + 64))) return rc;      // (+64: K3's pass reads a cell's slots 16 bytes at a time)
     if ((rc = ensure(c, c->cellCount, (size_t)cells * 4 * B + 64))) return rc;
     selFrame = align_up(selFrame, 16);
     P.selFrame = (int64_t)selFrame;
@@ -459,6 +460,36 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
         PG_HIP(c, hipMemcpy(c->cellTabBal.p, cb.data(), cb.size() * 4, hipMemcpyHostToDevice));
         P.cellTabBal = (const uint32_t*)c->cellTabBal.p;
         P.cellsPerXcdBal = (int)per;
+    }
+    {
+        // K3's coordinate tables for its pass kernel (quadtree.hip, k_qt_leaves: leaf column / row and candidate-order rank are separable
+        // in x and y), per level: [regionW] x entries, [regionH] y entries, [2^D + 1] first y of every leaf row
+        std::vector<uint2> qt;
+        for (int l = 0; l < L; l++) {
+            PgLevel& V = P.lvl[l];
+            const int regionW = V.w - 2 * PG_EDGE, regionH = V.h - 2 * PG_EDGE, D = qt_pyr_depth(V.nIni);
+            V.qtTabOff = (int32_t)qt.size();
+            for (int x = 0; x < regionW; x++) {
+                const uint2 e = qt_tab_entry(false, x, V.hX, V.nIni, regionH, D, V.wCell, V.hCell, V.nCols);
+                qt.push_back(make_uint2(((e.x >> (2 * D)) << D) | qt_compact_bits(e.x & ((1u << (2 * D)) - 1)), e.y));
+            }
+            std::vector<int> rowY((size_t)(1 << D) + 1, regionH);
+            for (int y = regionH - 1; y >= 0; y--) {
+                const uint2 e = qt_tab_entry(true, y, V.hX, V.nIni, regionH, D, V.wCell, V.hCell, V.nCols);
+                const uint32_t row = qt_compact_bits(e.x >> 1);
+                for (uint32_t r = 0; r <= row; r++) rowY[r] = std::min(rowY[r], y);       // first y whose row is >= r
+            }
+            for (int y = 0; y < regionH; y++) {
+                const uint2 e = qt_tab_entry(true, y, V.hX, V.nIni, regionH, D, V.wCell, V.hCell, V.nCols);
+                qt.push_back(make_uint2(qt_compact_bits(e.x >> 1), e.y));
+            }
+            for (int r = 0; r <= (1 << D); r++) qt.push_back(make_uint2((uint32_t)rowY[r], 0u));
+        }
+        if ((rc = ensure(c, c->qtTab, qt.size() * sizeof(uint2) + 64))) return rc;
+        PG_HIP(c, hipMemcpy(c->qtTab.p, qt.data(), qt.size() * sizeof(uint2), hipMemcpyHostToDevice));
+        const size_t leafBytes = (size_t)B * L * PG_QT_LEAF_CAP * sizeof(uint2);
+        if ((rc = ensure(c, c->qtLeaf, leafBytes))) return rc;
+        P.qtTab = (const uint2*)c->qtTab.p; P.qtLeaf = (uint2*)c->qtLeaf.p; P.qtSplit = c->qtSplit;
     }
     P.fastTilePitch = c->fastTilePitch; P.fastWpb = c->fastWpb;
     P.cand = (uint32_t*)c->cand.p; P.sel = (uint32_t*)c->sel.p;
@@ -697,6 +728,7 @@ int pgorb_create(const pgorb_params* p, pgorb_ctx** out)
     if (const char* e = getenv("PGORB_EXTRACT_CHUNK_KB")) { const int kb = atoi(e); if (kb >= 16) c->chunkBytes = kb << 10; }
     c->noStage = getenv("PGORB_EXTRACT_STAGE") == nullptr;
     c->useGraph = getenv("PGORB_EXTRACT_NO_GRAPH") == nullptr;
+    if (const char* e = getenv("PGORB_QT_SPLIT")) { const int v = atoi(e); if (v >= 0 && v <= 2) c->qtSplit = v; }      // A / B switch of K3's two forms (option "quadtree_split")
     // ORBextractor.cc:415-446
     const int L = p->nlevels;
     c->scaleFactor = p->scale_factor;
@@ -727,7 +759,7 @@ void pgorb_destroy(pgorb_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->prm.device);
     while (!c->streams.empty()) pgorb_stream_destroy(c->streams.back());      // a stream holds a pointer to its context
-    Arena* all[] = {&c->cellTab, &c->cellTabBal, &c->cellCand, &c->cellCount, &c->pyr, &c->cand, &c->sel, &c->nodes, &c->counters, &c->tables,
+    Arena* all[] = {&c->cellTab, &c->cellTabBal, &c->cellCand, &c->cellCount, &c->pyr, &c->cand, &c->sel, &c->nodes, &c->counters, &c->tables, &c->qtTab, &c->qtLeaf,
                     &c->outBlk, &c->stageA, &c->stageB, &c->stageOut, &c->stageSfi, &c->vocab, &c->xdesc};
     for (Arena* a : all) if (a->p) (void)hipFree(a->p);
     if (c->sPyr) {
@@ -1134,6 +1166,11 @@ int pgorb_set_option(pgorb_ctx* c, const char* key, int value)
         c->fastWpb = value; c->plan.fastWpb = value;
         return 0;
     }
+    if (!strcmp(key, "quadtree_split")) {
+        if (value < 0 || value > 2) return fail(c, PGORB_E_ARG, "quadtree_split must be 0 (one launch), 1 (two) or 2 (automatic)");
+        c->qtSplit = value; c->plan.qtSplit = value;
+        return 0;
+    }
     if (!strcmp(key, "pipeline_pyramid")) { c->pipePyr = value ? 1 : 0; return 0; }
     if (!strcmp(key, "pipeline_levels")) { c->pipeLev = value & ((1 << PG_MAXL) - 2); return 0; }
     if (!strcmp(key, "pipeline_levels_priority")) { c->pipeLevPrio = value ? 1 : 0; return 0; }
@@ -1145,6 +1182,7 @@ int pgorb_get_option(const pgorb_ctx* c, const char* key)
     if (!key || !c) return PGORB_OPTION_UNKNOWN;
     if (!strcmp(key, "fast_tile_pitch")) return c->fastTilePitch;
     if (!strcmp(key, "fast_waves_per_block")) return c->fastWpb;
+    if (!strcmp(key, "quadtree_split")) return c->qtSplit;
     if (!strcmp(key, "matcher")) return c->mx.popcount;
     if (!strcmp(key, "match_mode")) return c->mx.mode;
     if (!strcmp(key, "pipeline_pyramid")) return c->pipePyr;

@@ -1296,29 +1296,35 @@ int pgorb_search_by_bow(pgorb_ctx* c, const uint8_t* kf_desc, const float* kf_an
     const size_t oK = place((size_t)2 * cap * sizeof(pgorb_keypoint)), oD = place((size_t)2 * cap * 32), oN = place(8), oV = place(cap),
                  oFN = place((size_t)2 * cap * 4), oFS = place((size_t)2 * (cap + 1) * 4), oFF = place((size_t)2 * cap * 4), oNF = place(8),
                  oP = place(8), oM = place((size_t)cap * 4), oNM = place(64);
-    void* dv;
+    void *dv, *hv;
     int rc = pg_ctx_stage(c, 0, off, &dv);
     if (rc) return rc;
-    uint8_t* d = (uint8_t*)dv;
-    std::vector<pgorb_keypoint> kk((size_t)2 * cap);
+    // everything the host supplies sits before oM: one upload from the page-locked buffer; oM.. is one download
+    const size_t upBytes = oM, downBytes = off - oM;
+    if ((rc = pg_ctx_pinned(c, std::max(upBytes, downBytes), &hv))) return rc;
+    uint8_t* d = (uint8_t*)dv; uint8_t* h = (uint8_t*)hv;
+    pgorb_keypoint* kk = (pgorb_keypoint*)(h + oK);
+    memset(kk, 0, (size_t)2 * cap * sizeof(pgorb_keypoint));
     for (int i = 0; i < nkf; i++) kk[i].angle = kf_angle[i];
     for (int i = 0; i < nf; i++) kk[(size_t)cap + i].angle = f_angle[i];
     const int32_t nn[2] = {nkf, nf}, nfvs[2] = {kf_nfv, f_nfv}, pr[2] = {0, 1};
-    auto up = [&](size_t o, const void* p, size_t n) { return n == 0 || hipMemcpy(d + o, p, n, hipMemcpyHostToDevice) == hipSuccess; };
-    if (!(up(oK, kk.data(), kk.size() * sizeof(pgorb_keypoint)) && up(oD, kf_desc, (size_t)nkf * 32) && up(oD + (size_t)cap * 32, f_desc, (size_t)nf * 32) &&
-          up(oN, nn, 8) && up(oV, kf_point_valid, nkf) && up(oFN, kf_fv_node, (size_t)kf_nfv * 4) && up(oFN + (size_t)cap * 4, f_fv_node, (size_t)f_nfv * 4) &&
-          up(oFS, kf_fv_start, (size_t)(kf_nfv + 1) * 4) && up(oFS + (size_t)(cap + 1) * 4, f_fv_start, (size_t)(f_nfv + 1) * 4) &&
-          up(oFF, kf_fv_feat, (size_t)kf_fv_start[kf_nfv] * 4) && up(oFF + (size_t)cap * 4, f_fv_feat, (size_t)f_fv_start[f_nfv] * 4) &&
-          up(oNF, nfvs, 8) && up(oP, pr, 8)))
-        return pg_ctx_fail(c, PGORB_E_HIP, "hipMemcpy H2D failed");
+    auto up = [&](size_t o, const void* p, size_t n) { if (n) memcpy(h + o, p, n); };
+    up(oD, kf_desc, (size_t)nkf * 32); up(oD + (size_t)cap * 32, f_desc, (size_t)nf * 32);
+    up(oN, nn, 8); up(oV, kf_point_valid, nkf);
+    up(oFN, kf_fv_node, (size_t)kf_nfv * 4); up(oFN + (size_t)cap * 4, f_fv_node, (size_t)f_nfv * 4);
+    up(oFS, kf_fv_start, (size_t)(kf_nfv + 1) * 4); up(oFS + (size_t)(cap + 1) * 4, f_fv_start, (size_t)(f_nfv + 1) * 4);
+    up(oFF, kf_fv_feat, (size_t)kf_fv_start[kf_nfv] * 4); up(oFF + (size_t)cap * 4, f_fv_feat, (size_t)f_fv_start[f_nfv] * 4);
+    up(oNF, nfvs, 8); up(oP, pr, 8);
+    if (hipMemcpyAsync(d, h, upBytes, hipMemcpyHostToDevice, 0) != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "hipMemcpy H2D failed");
     rc = pgorb_search_by_bow_batch_device(c, (const pgorb_keypoint*)(d + oK), d + oD, (const int32_t*)(d + oN), cap, (const uint32_t*)(d + oFN),
                                           (const int32_t*)(d + oFS), (const uint32_t*)(d + oFF), (const int32_t*)(d + oNF), (const int32_t*)(d + oP),
                                           (const int32_t*)(d + oP) + 1, 1, d + oV, nnratio, check_orientation, (int32_t*)(d + oM), (int32_t*)(d + oNM), nullptr);
     if (rc) return rc;
-    int32_t nm = 0;
-    if (hipMemcpy(matches, d + oM, (size_t)nf * 4, hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(&nm, d + oNM, 4, hipMemcpyDeviceToHost) != hipSuccess)
+    if (hipMemcpyAsync(h, d + oM, downBytes, hipMemcpyDeviceToHost, 0) != hipSuccess || hipStreamSynchronize(0) != hipSuccess)
         return pg_ctx_fail(c, PGORB_E_HIP, "hipMemcpy D2H failed");
+    memcpy(matches, h, (size_t)nf * 4);
+    int32_t nm;
+    memcpy(&nm, h + (oNM - oM), 4);
     return nm;
 }
 
@@ -1581,20 +1587,23 @@ int pgorb_frame_grid(pgorb_ctx* c, const pgorb_keypoint* kps, int n, float min_x
     if (!c) return PGORB_E_ARG;
     if (n < 0 || (n && (!kps || !grid_idx)) || !grid_start) return pg_ctx_fail(c, PGORB_E_ARG, "bad argument to pgorb_frame_grid");
     const int cap = n > 0 ? n : 1;
-    void* d;
-    int rc = pg_ctx_stage(c, 0, (size_t)cap * sizeof(pgorb_keypoint) + 64 + (size_t)(GRID_CELLS + 1) * 4 + (size_t)cap * 4, &d);
+    // [n | keypoints] go up in one copy, [grid_start | grid_idx] come back in one
+    const size_t oK = 64, oS = oK + (((size_t)cap * sizeof(pgorb_keypoint) + 63) & ~(size_t)63);
+    const size_t oI = oS + (size_t)(GRID_CELLS + 1) * 4, total = oI + (size_t)cap * 4;
+    void *dv, *hv;
+    int rc = pg_ctx_stage(c, 0, total, &dv);
     if (rc) return rc;
-    pgorb_keypoint* dk = (pgorb_keypoint*)d;
-    int32_t* dn = (int32_t*)((uint8_t*)d + (((size_t)cap * sizeof(pgorb_keypoint) + 15) & ~(size_t)15));
-    int32_t* ds = dn + 4;
-    int32_t* di = ds + GRID_CELLS + 1;
-    if (n && hipMemcpy(dk, kps, (size_t)n * sizeof(pgorb_keypoint), hipMemcpyHostToDevice) != hipSuccess)
+    if ((rc = pg_ctx_pinned(c, std::max(oS, total - oS), &hv))) return rc;
+    uint8_t* d = (uint8_t*)dv; uint8_t* h = (uint8_t*)hv;
+    memcpy(h, &n, 4);
+    if (n) memcpy(h + oK, kps, (size_t)n * sizeof(pgorb_keypoint));
+    if (hipMemcpyAsync(d, h, oS, hipMemcpyHostToDevice, 0) != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "hipMemcpy failed");
+    if ((rc = pgorb_frame_grid_batch_device(c, (pgorb_keypoint*)(d + oK), (int32_t*)d, 1, cap, min_x, max_x, min_y, max_y,
+                                            (int32_t*)(d + oS), (int32_t*)(d + oI), 0))) return rc;
+    if (hipMemcpyAsync(h, d + oS, total - oS, hipMemcpyDeviceToHost, 0) != hipSuccess || hipStreamSynchronize(0) != hipSuccess)
         return pg_ctx_fail(c, PGORB_E_HIP, "hipMemcpy failed");
-    if (hipMemcpy(dn, &n, 4, hipMemcpyHostToDevice) != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "hipMemcpy failed");
-    if ((rc = pgorb_frame_grid_batch_device(c, dk, dn, 1, cap, min_x, max_x, min_y, max_y, ds, di, 0))) return rc;
-    if (hipMemcpy(grid_start, ds, (size_t)(GRID_CELLS + 1) * 4, hipMemcpyDeviceToHost) != hipSuccess ||
-        (n && hipMemcpy(grid_idx, di, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess))
-        return pg_ctx_fail(c, PGORB_E_HIP, "hipMemcpy failed");
+    memcpy(grid_start, h, (size_t)(GRID_CELLS + 1) * 4);
+    if (n) memcpy(grid_idx, h + (oI - oS), (size_t)n * 4);
     return 0;
 }
 
@@ -1608,41 +1617,46 @@ int pgorb_search_for_initialization(pgorb_ctx* c, const pgorb_keypoint* kps1, co
         return pg_ctx_fail(c, PGORB_E_ARG, "bad argument to pgorb_search_for_initialization");
     if (n1 == 0) return 0;
     const int cap = (n1 > n2 ? n1 : n2) > 0 ? (n1 > n2 ? n1 : n2) : 1;
-    // one staging slab: 2 frames of kps + desc, counts, grids, pair ids, prev, matches, nmatches
-    const size_t szK = (((size_t)2 * cap * sizeof(pgorb_keypoint)) + 63) & ~(size_t)63;
-    const size_t szD = (((size_t)2 * cap * 32) + 63) & ~(size_t)63;
-    const size_t szG = (((size_t)2 * (GRID_CELLS + 1) * 4) + 63) & ~(size_t)63;
-    const size_t szI = (((size_t)2 * cap * 4) + 63) & ~(size_t)63;
-    const size_t szP = (((size_t)cap * 8) + 63) & ~(size_t)63;
-    const size_t szM = (((size_t)cap * 4) + 63) & ~(size_t)63;
-    void* d;
-    int rc = pg_ctx_stage(c, 0, szK + szD + szG + szI + szP + szM + 256, &d);
+    // One slab, laid out so that everything the host supplies is one upload and everything it reads back one
+    // download: [misc | kps x2 | desc x2 | prev | matches | nmatches] then the device-only grids.
+    auto up64 = [](size_t v) { return (v + 63) & ~(size_t)63; };
+    const size_t oMisc = 0;
+    const size_t oK = 64;
+    const size_t oD = oK + up64((size_t)2 * cap * sizeof(pgorb_keypoint));
+    const size_t oP = oD + up64((size_t)2 * cap * 32);
+    const size_t oM = oP + up64((size_t)cap * 8);
+    const size_t oNm = oM + up64((size_t)cap * 4);
+    const size_t oGS = oNm + 64;
+    const size_t oGI = oGS + up64((size_t)2 * (GRID_CELLS + 1) * 4);
+    const size_t total = oGI + up64((size_t)2 * cap * 4);
+    const size_t upBytes = oM, downBytes = oGS - oP;
+    void *dv, *hv;
+    int rc = pg_ctx_stage(c, 0, total, &dv);
     if (rc) return rc;
-    uint8_t* b = (uint8_t*)d;
-    pgorb_keypoint* dk = (pgorb_keypoint*)b; b += szK;
-    uint8_t* dd = b; b += szD;
-    int32_t* dgs = (int32_t*)b; b += szG;
-    int32_t* dgi = (int32_t*)b; b += szI;
-    float* dp = (float*)b; b += szP;
-    int32_t* dm = (int32_t*)b; b += szM;
-    int32_t* dmisc = (int32_t*)b;            // n[2], f1, f2, nmatches
-    const int32_t misc[5] = {n1, n2, 0, 1, 0};
-    bool ok = hipMemcpy(dk, kps1, (size_t)n1 * sizeof(pgorb_keypoint), hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(dd, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice) == hipSuccess &&
-              (!n2 || (hipMemcpy(dk + cap, kps2, (size_t)n2 * sizeof(pgorb_keypoint), hipMemcpyHostToDevice) == hipSuccess &&
-                       hipMemcpy(dd + (size_t)cap * 32, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice) == hipSuccess)) &&
-              hipMemcpy(dp, prev_matched, (size_t)n1 * 8, hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(dmisc, misc, sizeof(misc), hipMemcpyHostToDevice) == hipSuccess;
-    if (!ok) return pg_ctx_fail(c, PGORB_E_HIP, "hipMemcpy H2D failed");
-    if ((rc = pgorb_frame_grid_batch_device(c, dk, dmisc, 2, cap, min_x, max_x, min_y, max_y, dgs, dgi, 0))) return rc;
-    if ((rc = pgorb_search_for_initialization_batch_device(c, dk, dd, dmisc, cap, dgs, dgi, dmisc + 2, dmisc + 3, 1,
-                                                           min_x, max_x, min_y, max_y, dp, dm, dmisc + 4, window_size,
-                                                           nnratio, check_orientation, 0))) return rc;
-    int32_t nm = 0;
-    ok = hipMemcpy(prev_matched, dp, (size_t)n1 * 8, hipMemcpyDeviceToHost) == hipSuccess &&
-         hipMemcpy(matches12, dm, (size_t)n1 * 4, hipMemcpyDeviceToHost) == hipSuccess &&
-         hipMemcpy(&nm, dmisc + 4, 4, hipMemcpyDeviceToHost) == hipSuccess;
-    if (!ok) return pg_ctx_fail(c, PGORB_E_HIP, "hipMemcpy D2H failed");
+    if ((rc = pg_ctx_pinned(c, std::max(upBytes, downBytes), &hv))) return rc;
+    uint8_t* d = (uint8_t*)dv; uint8_t* h = (uint8_t*)hv;
+    const int32_t misc[5] = {n1, n2, 0, 1, 0};   // n[2], f1, f2
+    memcpy(h + oMisc, misc, sizeof(misc));
+    memcpy(h + oK, kps1, (size_t)n1 * sizeof(pgorb_keypoint));
+    memcpy(h + oD, desc1, (size_t)n1 * 32);
+    if (n2) {
+        memcpy(h + oK + (size_t)cap * sizeof(pgorb_keypoint), kps2, (size_t)n2 * sizeof(pgorb_keypoint));
+        memcpy(h + oD + (size_t)cap * 32, desc2, (size_t)n2 * 32);
+    }
+    memcpy(h + oP, prev_matched, (size_t)n1 * 8);
+    if (hipMemcpyAsync(d, h, upBytes, hipMemcpyHostToDevice, 0) != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "hipMemcpy H2D failed");
+    pgorb_keypoint* dk = (pgorb_keypoint*)(d + oK);
+    int32_t* dmisc = (int32_t*)(d + oMisc);
+    if ((rc = pgorb_frame_grid_batch_device(c, dk, dmisc, 2, cap, min_x, max_x, min_y, max_y, (int32_t*)(d + oGS), (int32_t*)(d + oGI), 0))) return rc;
+    if ((rc = pgorb_search_for_initialization_batch_device(c, dk, d + oD, dmisc, cap, (int32_t*)(d + oGS), (int32_t*)(d + oGI), dmisc + 2,
+                                                           dmisc + 3, 1, min_x, max_x, min_y, max_y, (float*)(d + oP), (int32_t*)(d + oM),
+                                                           (int32_t*)(d + oNm), window_size, nnratio, check_orientation, 0))) return rc;
+    if (hipMemcpyAsync(h, d + oP, downBytes, hipMemcpyDeviceToHost, 0) != hipSuccess || hipStreamSynchronize(0) != hipSuccess)
+        return pg_ctx_fail(c, PGORB_E_HIP, "hipMemcpy D2H failed");
+    memcpy(prev_matched, h, (size_t)n1 * 8);
+    memcpy(matches12, h + (oM - oP), (size_t)n1 * 4);
+    int32_t nm;
+    memcpy(&nm, h + (oNm - oP), 4);
     return nm;
 }
 

@@ -72,6 +72,7 @@ struct PgLevel {
     int64_t  nodeOff;         // int offset of this level's node arrays inside a frame's node-scratch slab,
                               // or -1 when they fit the quadtree workgroup's LDS (the normal case)
     int32_t  nodeCap;
+    int32_t  qtTabOff;        // K3's coordinate tables of this level inside PgPlan::qtTab
     float    scale;           // mvScaleFactor[level]
     float    patchSize;       // (float)(int)(31*scale)  ORBextractor.cc:836
 };
@@ -88,6 +89,7 @@ struct PgSelRec {
 };
 static_assert(sizeof(PgSelRec) == 32, "one s_load_dwordx8");
 
+#define PG_QT_LEAF_CAP 4096   // >= the leaves of any count pyramid (quadtree.hip, QT_PYR_CAP)
 struct PgPlan {
     PgLevel  lvl[PG_MAXL];
     int32_t  nlevels, totalCells, iniTh, minTh, tieMode;
@@ -120,8 +122,70 @@ struct PgPlan {
     int32_t*  nodeScratch;
     int32_t*  candCount;      // [frame][PG_MAXL]
     int32_t*  kpCount;        // [frame][PG_MAXL]
+    // K3 in two launches (round 4, quadtree.hip): the candidate pass runs on many small workgroups (k_qt_leaves) and leaves, per
+    // (frame, level), the count and the best candidate of every depth-D descendant of the roots here; k_quadtree reads them
+    const uint2* qtTab;       // per level: [regionW] {leaf column, rank part}, [regionH] {leaf row, rank part}, [2^D + 1] {first y of leaf row r, 0} (built with the plan)
+    uint2*    qtLeaf;         // [frame][nlevels][PG_QT_LEAF_CAP] {count, (response << 24) | (0xFFFFFF - rank)}: every leaf written by k_qt_leaves in every batch
+    int32_t   qtSplit;        // option "quadtree_split": 0 = the pass inside k_quadtree, 1 = two launches, 2 = chosen per launch (default; pg_launch_quadtree_levels)
     int32_t*  status;         // device status word
 };
+
+// K3's count pyramid: depth for a level with nIni roots = the largest D <= 5 whose pyramid (nIni * (4^(D+1)-1)/3 counters)
+// fits QT_PYR_CAP ints of LDS
+#define QT_PYR_CAP 4096
+__host__ __device__ __forceinline__ int qt_pyr_off(int nIni, int d) { return nIni * (((1 << (2 * d)) - 1) / 3); }
+__host__ __device__ __forceinline__ int qt_pyr_depth(int nIni)
+{
+    int D = 5;
+    while (D > 0 && qt_pyr_off(nIni, D + 1) > QT_PYR_CAP) D--;
+    return D;
+}
+// One entry of K3's coordinate tables (quadtree.hip, the candidate pass): for region column c (isY = false) or row c (isY = true),
+// as K2 stores coordinates, {its bits of the depth-D descendant index, its part of the candidate-order rank}.  The same text builds
+// the tables with the plan on the host (api.hip) and inside k_quadtree on the device: single IEEE operations, nothing to contract.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PG_FDIV_RN(a, b) __fdiv_rn(a, b)
+#define PG_FMUL_RN(a, b) __fmul_rn(a, b)
+#else
+#define PG_FDIV_RN(a, b) ((a) / (b))          /* host: one IEEE single-precision operation either way */
+#define PG_FMUL_RN(a, b) ((a) * (b))
+#endif
+__host__ __device__ inline uint2 qt_tab_entry(bool isY, int c, float hX, int nIni, int regionH, int D, int wCell, int hCell, int nCols)
+{
+    const uint32_t mW = ((1u << 20) + wCell - 1) / wCell, mH = ((1u << 20) + hCell - 1) / hCell;
+    int part, a0, a1;
+    if (isY) { part = 0; a0 = 0; a1 = regionH; }
+    else {
+        int r = nIni >= 1 ? (int)PG_FDIV_RN((float)c, hX) : 0; // vpIniNodes[kp.pt.x/hX]  (:569)   (no root: the table is never read)
+        const int top = (nIni > 1 ? nIni : 1) - 1;
+        r = r < 0 ? 0 : (r > top ? top : r);
+        part = r; a0 = (int)PG_FMUL_RN(hX, (float)r); a1 = (int)PG_FMUL_RN(hX, (float)(r + 1));
+    }
+    for (int d = 0; d < D; d++) {
+        const int mid = a0 + ((a1 - a0 + 1) >> 1);
+        const bool q = c >= mid;
+        part = part * 4 + (q ? 1 : 0);
+        a0 = q ? mid : a0; a1 = q ? a1 : mid;
+    }
+    const uint32_t cm = (uint32_t)(c - 3 > 0 ? c - 3 : 0);    // (order_rank's x - 3 / y - 3; K2's coordinates start at 3)
+    if (isY) { const uint32_t ci = (cm * mH) >> 20; return make_uint2((uint32_t)part << 1, (ci * nCols * hCell + (cm - ci * hCell)) * wCell); }
+    const uint32_t cj = (cm * mW) >> 20;
+    return make_uint2((uint32_t)part, cj * hCell * wCell + (cm - cj * wCell));
+}
+
+// K3's candidate pass as its own launch (k_qt_leaves): a workgroup OWNS `rowsPer` of the 2^D leaf rows of a (frame, level) problem
+// (a leaf row = the depth-D descendants with the same y path) and walks the cell rows that overlap them -- about QTP_CELLS cells
+#define QTP_CELLS 256
+__host__ __device__ __forceinline__ int qt_pass_rows_per_group(int ncells, int D)
+{
+    const int rows = 1 << D;
+    int per = (rows * QTP_CELLS + (ncells > 1 ? ncells : 1) - 1) / (ncells > 1 ? ncells : 1);
+    per = per < 1 ? 1 : (per > rows ? rows : per);
+    return per;
+}
+__host__ __device__ __forceinline__ int qt_pass_groups(int ncells, int D) { const int per = qt_pass_rows_per_group(ncells, D); return ((1 << D) + per - 1) / per; }
+__host__ __device__ __forceinline__ uint32_t qt_spread_bits(uint32_t v) { uint32_t r = 0; for (int k = 0; k < 6; k++) r |= ((v >> k) & 1u) << (2 * k); return r; }     // Morton: bit k -> bit 2k
+__host__ __device__ __forceinline__ uint32_t qt_compact_bits(uint32_t v) { uint32_t r = 0; for (int k = 0; k < 6; k++) r |= ((v >> (2 * k)) & 1u) << k; return r; }
 
 // MapPoint::PredictScale's logarithm (thirdparty/orb-slam2/src/MapPoint.cc:524 and Frame.cc:188: std::log(float), the platform's
 // logf) under the parity contract shared with oracle/match_oracle.c (orc_log_f): a fixed double-precision sequence, rounded

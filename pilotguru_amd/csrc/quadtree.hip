@@ -145,33 +145,24 @@ __device__ __forceinline__ int qt_quadrant(const int4 b, uint32_t cv)
 #ifdef PGORB_QT_TIMING
 // developer build only (make EXTRA=-DPGORB_QT_TIMING): per-phase time of workgroup (0,0) in
 // 10 ns ticks, read back by tools/experiments/qt_timing.py
-__device__ unsigned long long pg_qt_t[16];
+__device__ unsigned long long pg_qt_t[24];
 #ifndef QT_TIMING_LEVEL
 #define QT_TIMING_LEVEL 0
 #endif
 #define QT_TS(k) do { if (tid == 0 && blockIdx.x == 0 && blockIdx.y == QT_TIMING_LEVEL) { const unsigned long long t1_ = wall_clock64(); pg_qt_t[k] += t1_ - qt_t0; qt_t0 = t1_; } } while (0)
 #define QT_CNT(k, v) do { if (tid == 0 && blockIdx.x == 0 && blockIdx.y == QT_TIMING_LEVEL) pg_qt_t[k] += (v); } while (0)
-extern "C" int pgorb_debug_qt_times(unsigned long long* out16, int reset)
+#define QTP_TS(k) do { if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) { const unsigned long long t1_ = wall_clock64(); pg_qt_t[k] += t1_ - qt_t0; qt_t0 = t1_; } } while (0)
+extern "C" int pgorb_debug_qt_times(unsigned long long* out24, int reset)
 {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(pg_qt_t), sizeof(pg_qt_t)) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(pg_qt_t), z, sizeof(z)) != hipSuccess) return -1; }
+    if (hipMemcpyFromSymbol(out24, HIP_SYMBOL(pg_qt_t), sizeof(pg_qt_t)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[24] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(pg_qt_t), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
 #else
 #define QT_TS(k) do {} while (0)
 #define QT_CNT(k, v) do {} while (0)
+#define QTP_TS(k) do {} while (0)
 #endif
-
-// Depth of the count pyramid for a level with nIni roots: the largest D <= 5 whose pyramid
-// (nIni * (4^(D+1)-1)/3 counters) fits QT_PYR_CAP ints of LDS.
-#define QT_PYR_CAP 4096
-__host__ __device__ __forceinline__ int qt_pyr_off(int nIni, int d) { return nIni * (((1 << (2 * d)) - 1) / 3); }
-__host__ __device__ __forceinline__ int qt_pyr_depth(int nIni)
-{
-    int D = 5;
-    while (D > 0 && qt_pyr_off(nIni, D + 1) > QT_PYR_CAP) D--;
-    return D;
-}
 
 // Depth-D descendant of the root that holds candidate cv: index r * 4^D + path, where path is the
 // sequence of DivideNode quadrants (:481-537) a key at (x, y) falls through.  Pure geometry --
@@ -255,7 +246,7 @@ __device__ __forceinline__ int qt_build_keys(const int32_t* __restrict__ cc, con
 // BIG: the level's node arrays do not fit LDS (quota above ~1180) and live in a global slab;
 // the same code, just slower.  Each instantiation skips the levels of the other kind.
 template <bool BIG>
-__global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P, int level0, int leafOffInts)
+__global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P, int level0, int leafOffInts, int split)
 {
     __shared__ int sh[3 * QT_W + 8];
     __shared__ int pyr[QT_PYR_CAP];                       // count pyramid, later the node map
@@ -334,8 +325,20 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P, int level0
         const uint32_t* slots = P.cellCand + (int64_t)frame * P.cellCandFrame + L.cellCandOff;
         const int nleaf = nIni << (2 * D);
         for (int i = tid; i < pyrTotal; i += QT_T) pyr[i] = 0;
-        for (int i = tid; i < nleaf; i += QT_T) leafBest[i] = 0u;
+        if (!split) for (int i = tid; i < nleaf; i += QT_T) leafBest[i] = 0u;
         if (tid == 0) sh[QT_W + 2] = 0;
+        int mine = 0;                                       // records counted by this lane
+        const int lane = tid & 63;
+        if (split) {
+            // two launches: k_qt_leaves (below) has run the pass on many small workgroups; take the leaves' counts and best records
+            __syncthreads();
+            int* hDs = pyr + qt_pyr_off(nIni, D);
+            uint2* gl = P.qtLeaf + ((int64_t)frame * P.nlevels + l) * PG_QT_LEAF_CAP;
+            for (int i = tid; i < nleaf; i += QT_T) {
+                const uint2 e = gl[i];
+                hDs[i] = (int)e.x; leafBest[i] = e.y; mine += (int)e.x;
+            }
+        } else {
         // Both things the pass needs of a candidate are SEPARABLE in x and y: DivideNode splits a node at the middle of its x range
         // and of its y range independently (:483-485), so the depth-D descendant index is (root and x-path bits) | (y-path bits);
         // and the candidate-order rank ((cell row * nCols + cell col) * hCell + row in cell) * wCell + col in cell is a y term
@@ -348,29 +351,12 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P, int level0
         for (int i = tid; i < regionW + regionH; i += QT_T) {
             const bool isY = i >= regionW;
             const int c = isY ? i - regionW : i;                  // the coordinate as K2 stores it (region-relative)
-            int part, a0, a1;
-            if (isY) { part = 0; a0 = 0; a1 = regionH; }
-            else {
-                int r = (int)__fdiv_rn((float)c, hX);             // vpIniNodes[kp.pt.x/hX]  (:569)
-                r = min(max(r, 0), max(nIni, 1) - 1);
-                part = r; a0 = (int)__fmul_rn(hX, (float)r); a1 = (int)__fmul_rn(hX, (float)(r + 1));
-            }
-            for (int d = 0; d < D; d++) {
-                const int mid = a0 + ((a1 - a0 + 1) >> 1);
-                const bool q = c >= mid;
-                part = part * 4 + (q ? 1 : 0);
-                a0 = q ? mid : a0; a1 = q ? a1 : mid;
-            }
-            const uint32_t cm = (uint32_t)max(c - 3, 0);          // (order_rank's x - 3 / y - 3; K2's coordinates start at 3)
-            uint2 e;
-            if (isY) { const uint32_t ci = (cm * mH) >> 20; e = make_uint2((uint32_t)part << 1, (ci * nCols * hCell + (cm - ci * hCell)) * wCell); }
-            else { const uint32_t cj = (cm * mW) >> 20; e = make_uint2((uint32_t)part, cj * hCell * wCell + (cm - cj * wCell)); }
-            (isY ? yTab : xTab)[c] = e;
+            (isY ? yTab : xTab)[c] = qt_tab_entry(isY, c, hX, nIni, regionH, D, wCell, hCell, nCols);
         }
         __syncthreads();
         QT_TS(8);
         int* hD = pyr + qt_pyr_off(nIni, D);
-        const int lane = tid & 63, sub = lane >> 4, sl = lane & 15;
+        const int sub = lane >> 4, sl = lane & 15;
         // (the wave index as a scalar: with cb / cEnd in VGPRs the compiler made the cell loop a per-lane loop around the cross-lane
         //  shuffles below, and that build hung the kernel -- found by a timed-out run, round 4)
         const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -380,7 +366,6 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P, int level0
         // in flight -- per 16 records of the fullest cell
         const int cpw = (((ncells + QT_W - 1) / QT_W) + 31) & ~31;
         const int cBeg = wv * cpw, cEnd = min(ncells, cBeg + cpw);
-        int mine = 0;                                       // records counted by this lane
         int cntNext = (lane < 32 && cBeg + lane < cEnd) ? cc[cBeg + lane] : 0;
         for (int cb = cBeg; cb < cEnd; cb += 32) {
             const int myc = min(cntNext, cellCap);
@@ -410,6 +395,7 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P, int level0
                 }
             }
         }
+        }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
         if (lane == 0 && mine) atomicAdd(&sh[QT_W + 2], mine);
@@ -426,7 +412,7 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P, int level0
         }
         QT_TS(9);
         if (!rank24) {                                      // order ranks beyond 24 bits: the winners come from a key pass (64-bit bids)
-            qt_build_keys(cc, slots, ncells, cellCap, cellOff, sh, keys, hX, nIni, regionH, D);
+            qt_build_keys(cc, slots, ncells, L.cellCap, cellOff, sh, keys, hX, nIni, regionH, D);
             keysBuilt = true;
         }
         // counts of the shallower descendants
@@ -815,6 +801,124 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P, int level0
     QT_TS(7);
 }
 
+// K3's candidate pass as its own launch (round 4, PgPlan::qtSplit): inside k_quadtree it is ONE workgroup's walk over up to 9e4
+// candidates (27 us of a 1080p level-0 problem, ~100 us at 2160p, with the workgroup's other phases waiting behind it); here a
+// workgroup OWNS a few leaf rows of a (frame, level) problem -- a leaf row = the depth-D descendants that share their y path, a
+// band of the region ~34 px high at 1080p -- and walks the cell rows that overlap the band (about QTP_CELLS cells; a cell row that
+// straddles two bands is read by both owners, records outside the band are skipped).  Ownership means no atomics to HBM and no
+// state between batches: every leaf of the problem is written, zero or not, by exactly one workgroup.  Coordinate tables come from
+// the plan ({leaf column | row, rank part} per region column | row) and are copied to LDS: the x table whole, the y table for the band.
+#define QTP_T 512
+__global__ __launch_bounds__(QTP_T) void k_qt_leaves(const PgPlan P, int level0, int nlev)
+{
+    extern __shared__ __attribute__((aligned(16))) int qp_lds[];     // [regionW] x table, [band] y table (uint2), [rows * ncol] counts, best records
+    const int tid = threadIdx.x, frame = blockIdx.y, lane = tid & 63;
+#ifdef PGORB_QT_TIMING
+    unsigned long long qt_t0 = wall_clock64();
+#endif
+    int rem = blockIdx.x, l = level0;
+    for (int k = 0; k < nlev; k++) {
+        const PgLevel& V = P.lvl[level0 + k];
+        const int g = qt_pass_groups(V.nCols * V.nRows, qt_pyr_depth(V.nIni));
+        l = level0 + k;
+        if (rem < g) break;
+        rem -= g;
+    }
+    const PgLevel& L = P.lvl[l];
+    const int nIni = L.nIni, nCols = L.nCols, ncells = nCols * L.nRows, cellCap = L.cellCap, hCell = L.hCell;
+    const int32_t* cc = P.cellCount + (int64_t)frame * P.totalCells + L.cellBase;
+    if (nIni < 1) {                                          // no root: the reference's behaviour is undefined there (api.hip level_geometry), reported
+        if (rem == 0) {
+            int any = 0;
+            for (int i = tid; i < ncells; i += QTP_T) any |= cc[i];
+            if (any) atomicExch(P.status, PGORB_E_TOOSMALL);
+        }
+        return;
+    }
+    const int D = qt_pyr_depth(nIni), rows = 1 << D, ncol = nIni << D;
+    const int rowsPer = qt_pass_rows_per_group(ncells, D);
+    const int r0 = rem * rowsPer, r1 = min(rows, r0 + rowsPer);
+    const int regionW = L.w - 2 * PG_EDGE, regionH = L.h - 2 * PG_EDGE;
+    const uint2* gx = P.qtTab + L.qtTabOff;
+    const uint2* gy = gx + regionW;
+    const uint2* gr = gy + regionH;
+    const int ya = (int)gr[r0].x, yb = (int)gr[r1].x;        // the band, in K2's (region-relative) coordinates
+    QTP_TS(16);
+    uint2* xT = reinterpret_cast<uint2*>(qp_lds);
+    uint2* yT = xT + regionW;                                // [yb - ya], indexed y - ya
+    const int nh = (r1 - r0) * ncol;
+    int* hC = reinterpret_cast<int*>(yT + (yb - ya));        // [nh] counts + one dump bin per lane (records outside the band land there:
+    uint32_t* hB = reinterpret_cast<uint32_t*>(hC + nh + 64); //  the inner loop has no branches, so its LDS reads and atomics pipeline)
+    for (int i = tid; i < regionW; i += QTP_T) xT[i] = gx[i];
+    for (int i = tid; i < yb - ya; i += QTP_T) { uint2 e = gy[ya + i]; e.x = (e.x - (uint32_t)r0) * (uint32_t)ncol; yT[i] = e; }    // (row offset in the histogram)
+    for (int i = tid; i < 2 * (nh + 64); i += QTP_T) hC[i] = 0;
+    const uint32_t* slots = P.cellCand + (int64_t)frame * P.cellCandFrame + L.cellCandOff;
+    const bool rank24 = (long long)ncells * hCell * L.wCell <= (1 << 24);
+    // a record of cell row ci has y in [ci * hCell + 3, (ci + 1) * hCell + 3)  (K2's coordinates start at 3)
+    const int ciBeg = max(ya - 3, 0) / hCell, ciEnd = min(L.nRows - 1, max(yb - 1 - 3, 0) / hCell);
+    const int c0 = ciBeg * nCols, c1 = (yb > ya) ? (ciEnd + 1) * nCols : c0;
+    // One LANE per cell, 64 cells per wave step, steps dealt round-robin to the waves (the last, partly filled step exists once per
+    // workgroup, not once per wave): the 64 lanes of an LDS atomic belong to 64 different cells, i.e. mostly different leaves.
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cFirst = c0 + 64 * wv;
+    int cntNext = (cFirst + lane < c1) ? cc[cFirst + lane] : 0;
+    QTP_TS(17);
+    __syncthreads();
+    QTP_TS(18);
+    struct __attribute__((packed, aligned(4))) U4 { uint32_t e[4]; };
+    for (int cb = cFirst; cb < c1; cb += 64 * (QTP_T / 64)) {
+        const int myc = min(cntNext, cellCap);
+        cntNext = (cb + 64 * (QTP_T / 64) + lane < c1) ? cc[cb + 64 * (QTP_T / 64) + lane] : 0;
+        int maxn = myc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) maxn = max(maxn, __shfl_xor(maxn, d));
+        maxn = __builtin_amdgcn_readfirstlane(maxn);
+        const uint32_t* sp = slots + (int64_t)(cb + lane) * cellCap;      // (lanes past c1: myc = 0, never dereferenced)
+        // ALL loads of a round before the first use: the round is one memory round trip, not one per 8 records (that form took 5 us per
+        // step, all of it latency).  32 records per lane and round; a cell rarely holds more.
+        for (int base = 0; base < maxn; base += 32) {         // (wave-uniform trip count)
+            U4 r[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                r[j] = U4{{0u, 0u, 0u, 0u}};
+                if (base + 4 * j < myc) r[j] = *reinterpret_cast<const U4*>(sp + base + 4 * j);      // may read up to 3 slots past the count: inside the slab (+64 B)
+            }
+            const int lim = min(maxn - base, 32);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if (4 * j < lim) {                            // (wave-uniform)
+                    uint2 tx[4], ty[4];
+                    bool ok[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t v = r[j].e[k];
+                        const int ys = (int)((v >> 12) & 0xFFF);
+                        ok[k] = base + 4 * j + k < myc && ys >= ya && ys < yb;
+                        tx[k] = xT[ok[k] ? (v & 0xFFF) : 0u]; ty[k] = yT[ok[k] ? ys - ya : 0];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int hi = ok[k] ? (int)(tx[k].x + ty[k].x) : nh + lane;
+                        atomicAdd(&hC[hi], 1);
+                        if (rank24) atomicMax(&hB[hi], (r[j].e[k] & 0xFF000000u) | (0xFFFFFFu - (tx[k].y + ty[k].y)));
+                    }
+                }
+            }
+        }
+    }
+    QTP_TS(19);
+    __syncthreads();
+    QTP_TS(20);
+    uint2* gl = P.qtLeaf + ((int64_t)frame * P.nlevels + l) * PG_QT_LEAF_CAP;
+    const uint32_t cmask = (1u << D) - 1;
+    for (int i = tid; i < nh; i += QTP_T) {
+        const uint32_t rl = (uint32_t)i / (uint32_t)ncol, col = (uint32_t)i - rl * (uint32_t)ncol, row = (uint32_t)r0 + rl;
+        const uint32_t leaf = ((col >> D) << (2 * D)) + qt_spread_bits(col & cmask) + 2u * qt_spread_bits(row);
+        gl[leaf] = make_uint2((uint32_t)hC[i], hB[i]);
+    }
+    QTP_TS(21);
+}
+
 void pg_launch_quadtree(const PgPlan& P, int nframes, hipStream_t s) { pg_launch_quadtree_levels(P, nframes, 0, P.nlevels, s); }
 
 // K3 for the levels [levelBeg, levelEnd) only: a (frame, level) problem depends on nothing but K2's slots of that level
@@ -838,6 +942,34 @@ void pg_launch_quadtree_levels(const PgPlan& P, int nframes, int levelBeg, int l
     int dev = 0;
     (void)hipGetDevice(&dev);
     size_t* configured = configuredDev[dev & 63];
+    // Two launches or one?  (PgPlan::qtSplit: 0 = one, 1 = two, 2 = by this rule.)  Measured on an MI355X, K3 per step, one launch /
+    // two launches (tools/experiments/r4_split_grid.sh, profiles/r04_k3_split_grid.txt): 1080p x 1 frame 56 / 40 us, x 32 63 / 55, x 48
+    // 68 / 71, x 128 110 / 128; 2160p x 1 178 / 52, x 32 187 / 108, x 64 190 / 181; 640x480 and 720p: one launch wins at every batch.
+    // The pass kernel is a pure throughput cost (one lane per cell: ~30 % of its lanes carry a record), while inside k_quadtree the
+    // pass fills the stalls of the neighbouring workgroups' barriers -- so two launches pay when the chip is NOT full of quadtree
+    // workgroups (few frames) or when one level-0 problem is long (large frames).
+    const int cells0 = P.lvl[levelBeg].nCols * P.lvl[levelBeg].nRows;
+    const bool split = P.qtSplit == 1 || (P.qtSplit == 2 && cells0 >= 1500 && nframes <= 40 + (cells0 - 2304) * 24 / 6912);
+    if (split) {
+        int groups = 0;
+        size_t lds = 0;
+        for (int l = levelBeg; l < levelEnd; l++) {
+            const PgLevel& V = P.lvl[l];
+            const int D = qt_pyr_depth(V.nIni), ncells = V.nCols * V.nRows;
+            groups += qt_pass_groups(ncells, D);
+            // x table + (at most) the whole y table + the owned rows' counts and best records
+            lds = std::max(lds, (size_t)((V.w - 2 * PG_EDGE) + (V.h - 2 * PG_EDGE)) * 8 + (size_t)qt_pass_rows_per_group(ncells, D) * (std::max(V.nIni, 0) << D) * 8 + 2 * 64 * 4);
+        }
+        static size_t passConfigured[64] = {0};
+        int dev0 = 0;
+        (void)hipGetDevice(&dev0);
+        if (lds > 48 * 1024 && lds > passConfigured[dev0 & 63]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_qt_leaves), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            passConfigured[dev0 & 63] = lds;
+        }
+        if (groups > 0)
+            hipLaunchKernelGGL(k_qt_leaves, dim3(groups, nframes), dim3(QTP_T), lds, s, P, levelBeg, levelEnd - levelBeg);
+    }
     dim3 grid(nframes, levelEnd - levelBeg), block(QT_T);
     for (int big = 0; big < 2; big++) {
         if (!any[big]) continue;
@@ -847,7 +979,7 @@ void pg_launch_quadtree_levels(const PgPlan& P, int nframes, int levelBeg, int l
             (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             configured[big] = lds;
         }
-        if (big) hipLaunchKernelGGL(k_quadtree<true>, grid, block, lds, s, P, levelBeg, nodes[big]);
-        else hipLaunchKernelGGL(k_quadtree<false>, grid, block, lds, s, P, levelBeg, nodes[big]);
+        if (big) hipLaunchKernelGGL(k_quadtree<true>, grid, block, lds, s, P, levelBeg, nodes[big], split ? 1 : 0);
+        else hipLaunchKernelGGL(k_quadtree<false>, grid, block, lds, s, P, levelBeg, nodes[big], split ? 1 : 0);
     }
 }

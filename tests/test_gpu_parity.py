@@ -708,6 +708,51 @@ def test_options_belong_to_a_context(oracle):
     st.close()                                          # closing a stream after its extractor: a no-op (round-3 advisory)
 
 
+@pytest.mark.parametrize("split", [1, 0, 2])
+def test_quadtree_in_two_launches_and_in_one(oracle, split):
+    """K3's candidate pass as its own launch (k_qt_leaves, round 4: many small workgroups that each own a band of leaf rows, leaf
+    counts and best records handed over in HBM, tables built with the plan on the HOST; option quadtree_split 1) and inside
+    k_quadtree (0; tables built on the device); 2 = the library chooses per launch (the default).  All equal the oracle -- textured
+    frames, a deep tree (clustered corners), many roots (shallow pyramid), a batch run three times over with the frames in
+    different slots, and the tall frame without a root."""
+    import pilotguru_amd as pg
+    from pilotguru_amd._lib import PGORB_E_TOOSMALL, PgorbError
+    cases = [(640, 480, 1000, 8, synth_ride(21, 640, 480, 1)[0]), (1283, 721, 2000, 8, synth_ride(22, 1283, 721, 1)[0]),
+             (960, 540, 1500, 8, _clustered_frame(960, 540, 120, 1)), (2000, 120, 600, 2, synth_scene(77, 2000, 120))]
+    for w, h, nf, nlev, img in cases:
+        ora = oracle.OrbOracle(nf, 1.2, nlev, 20, 7)
+        okp, odesc = ora.extract(img)
+        ext = pg.ORBextractor(nf, 1.2, nlev, 20, 7, max_width=w, max_height=h)
+        ext.set_option("quadtree_split", split)
+        assert ext.get_option("quadtree_split") == split
+        for rep in range(2):
+            kp, desc = ext(img)
+            assert kp.tobytes() == okp.tobytes() and np.array_equal(desc, odesc), (w, h, rep)
+        for l in range(nlev):
+            assert ext.debug_level_keypoints(0, l) == ora.level_keypoints(l), "quadtree count level %d" % l
+        ext.close()
+    w, h, nf = 800, 600, 1200
+    ride = synth_ride(24, w, h, 6)
+    ora = oracle.OrbOracle(nf, 1.2, 8, 20, 7)
+    ext = _make(nf, w, h, batch=6)
+    ext.set_option("quadtree_split", split)
+    exp = [ora.extract(f) for f in ride]
+    for rep in range(3):
+        order = [(f + rep) % 6 for f in range(6)]                  # a different frame in every slot each time
+        res = ext.extract_batch(np.ascontiguousarray(ride[order]))
+        for (kp, desc), f in zip(res, order):
+            assert kp.tobytes() == exp[f][0].tobytes() and np.array_equal(desc, exp[f][1]), (rep, f)
+    ext.close()
+    t = pg.ORBextractor(300, 1.2, 8, 20, 7, max_width=320, max_height=720)
+    t.set_option("quadtree_split", split)
+    with pytest.raises(PgorbError) as e:                            # aspect < 0.5 WITH corners: no root (:543), raised by K3 in either form
+        t(np.ascontiguousarray(synth_ride(25, 300, 700, 1)[0]))
+    assert e.value.code == PGORB_E_TOOSMALL
+    k, d = t(np.full((700, 300), 90, np.uint8))                     # the same shape without corners: an empty result, like the reference
+    assert len(k) == 0
+    t.close()
+
+
 def test_host_frame_calls_replay_a_graph(oracle):
     """pgorb_extract (the reference's call shape: one frame per synchronous call, Frame.cc:251-257) launches its kernels directly
     the first time it sees a frame size, captures them into a HIP graph the second time and replays the graph from then on:

@@ -10,7 +10,7 @@ W, H, NF = 1920, 1080, 2000
 L = _lib.lib()
 fn = L.pgorb_debug_qt_times
 fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
-out = (ctypes.c_ulonglong * 16)()
+out = (ctypes.c_ulonglong * 24)()
 for B in (1, 128):
     ext = pg.ORBextractor(NF, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B)
     frames = torch.from_numpy(synth_ride(0, W, H, B)).cuda()
@@ -22,3 +22,4 @@ for B in (1, 128):
     names = ["pyramid sums", "roots", "generations", "node map + best", "-", "-", "(barrier)", "select", "zeroing", "candidate pass"]
     print("batch", B, "ncand", out[10], "bfs gens", out[11], "sorted gens", out[12], "total us", round(sum(t), 1))
     for nm, v in zip(names, t): print("   %-16s %7.1f us" % (nm, v))
+    print("   k_qt_leaves (frame 0, first group of level 0): level + band %.1f, loads issued %.1f, barrier %.1f, cell loop %.1f, barrier %.1f, flush %.1f us" % tuple(out[i] * 0.01 for i in range(16, 22)))

@@ -1,0 +1,19 @@
+#!/bin/bash
+# round 4 soak (final build): every fuzzer of tests/fuzzers.py with fresh seeds -> gpurun_out/r04_fuzz_soak.txt
+export TMPDIR=/tmp
+O=gpurun_out/r04_fuzz_soak.txt
+{
+echo "# tools/experiments/r4_soak.sh on one MI355X (round-4 final build): random configurations, HIP path against the oracle, bit for bit"
+for spec in "parity 5000 401" "levels 200 402" "batch_parity 1200 403" "matchers 1500 404" "ingest 500 405" "best2 3000 406"; do
+  set -- $spec
+  echo "## fuzz_$1 $2 cases, seed $3"
+  timeout 1500 python tools/experiments/fuzz_$1.py $2 $3 2>&1 | grep -v "amdgpu.ids\|^skip" | tail -4
+done
+echo "## matchers at the initialisation workload (1920x1080, 4000 features: dense windows), 40 cases, seed 407"
+timeout 900 python - <<'PY' 2>&1 | grep -v amdgpu.ids | tail -3
+import sys; sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import fuzzers
+print(fuzzers.fuzz_matchers(cases=40, seed=407, nf_range=(4000, 4001), size_range=((1920, 1921), (1080, 1081)))[1])
+PY
+} > $O 2>&1
+cat $O

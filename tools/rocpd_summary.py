@@ -3,6 +3,7 @@
 
 usage: rocpd_summary.py stats <results.db>          -> per-kernel calls / total / mean (us)
        rocpd_summary.py pmc   <results.db> [...]    -> per-kernel mean counter values
+       rocpd_summary.py bygrid <results.db> <substr> -> the kernels whose name holds <substr>, one row per launch shape
 """
 import sqlite3
 import sys
@@ -29,6 +30,19 @@ def stats(db):
             r[6], r[7], r[8]))
 
 
+def bygrid(db, sub):
+    c = sqlite3.connect(db)
+    cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
+    g = [k for k in ("grid_x", "grid_y", "grid_z", "workgroup_x") if k in cols] or [k for k in cols if k.startswith("grid")]
+    rows = list(c.execute("select name, %s, count(*), sum(duration), avg(duration), min(duration) from kernels where name like ?"
+                          " group by name, %s order by avg(duration) desc" % (", ".join(g), ", ".join(g)), ("%" + sub + "%",)))
+    print("%-40s %-28s %6s %12s %10s %10s" % ("kernel", "/".join(g), "calls", "total_us", "mean_us", "min_us"))
+    for r in rows:
+        k = len(g)
+        print("%-40s %-28s %6d %12.1f %10.1f %10.1f" % (short(r[0])[-40:], "/".join(str(int(x)) for x in r[1:1 + k]), r[1 + k],
+                                                        r[2 + k] / 1e3, r[3 + k] / 1e3, r[4 + k] / 1e3))
+
+
 def pmc(dbs):
     acc = {}
     for db in dbs:
@@ -47,5 +61,7 @@ def pmc(dbs):
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
+    elif sys.argv[1] == "bygrid":
+        bygrid(sys.argv[2], sys.argv[3])
     else:
         pmc(sys.argv[2:])

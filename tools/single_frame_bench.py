@@ -89,6 +89,41 @@ def run(width=1920, height=1080, features=2000, calls=2000, warmup=100, with_fro
             bv, fv = voc.transform(F2.mDescriptors, 4)
             if i >= 20: ts.append(time.perf_counter_ns() - t0)
         out["extract_grid_bow_transform"] = dict(_pct(ts), words=int(len(bv[0])), note="python wrappers included; BowVector / FeatureVector maps built on the host")
+        # the same two per-frame sequences through the C ABI alone, into preallocated buffers -- what a C++ caller (the adaptor of
+        # INTEGRATION.md section 1) pays; the difference from the two numbers above is the Python wrappers
+        bx = [0.0, float(width), 0.0, float(height)]             # no distortion: the image bounds (Frame.cc:461-466)
+        gs, gi = np.zeros(64 * 48 + 1, np.int32), np.zeros(cap, np.int32)
+        k1, d1, n1 = kps.copy(), desc.copy(), C.c_int(0)
+        ext._check(L.pgorb_extract(h, pf[0], width, height, width, C.c_void_p(k1.ctypes.data), C.c_void_p(d1.ctypes.data), cap, C.byref(n1)))
+        prev = np.zeros((cap, 2), np.float32); m12 = np.zeros(cap, np.int32)
+        prev0 = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
+        P = lambda a: C.c_void_p(a.ctypes.data)
+        f4 = [C.c_float(v) for v in bx]
+        ts = []
+        for i in range(max(calls // 4, 50) + 20):
+            prev[:n1.value] = prev0[:n1.value]
+            t0 = time.perf_counter_ns()
+            rc = L.pgorb_extract(h, pf[1], width, height, width, pk, pd, cap, C.byref(n))
+            rc = rc or L.pgorb_frame_grid(h, pk, n.value, *f4, P(gs), P(gi))
+            nm = L.pgorb_search_for_initialization(h, P(k1), P(d1), n1.value, pk, pd, n.value, *f4, P(prev), P(m12), 100, 0.9, 1)
+            if i >= 20: ts.append(time.perf_counter_ns() - t0)
+            if rc or nm < 0: ext._check(rc or nm)
+        out["c_abi_extract_grid_search_for_initialization"] = dict(_pct(ts), matches=int(nm))
+        word, weight, node = np.zeros(cap, np.uint32), np.zeros(cap, np.float64), np.zeros(cap, np.uint32)
+        bid, bval = np.zeros(cap + 1, np.uint32), np.zeros(cap + 1, np.float64)
+        fnode, fstart, ffeat = np.zeros(cap + 1, np.uint32), np.zeros(cap + 2, np.int32), np.zeros(cap + 1, np.uint32)
+        nb, nfv = C.c_int32(), C.c_int32()
+        ts = []
+        for i in range(max(calls // 4, 50) + 20):
+            t0 = time.perf_counter_ns()
+            rc = L.pgorb_extract(h, pf[i & 1], width, height, width, pk, pd, cap, C.byref(n))
+            rc = rc or L.pgorb_frame_grid(h, pk, n.value, *f4, P(gs), P(gi))
+            rc = rc or L.pgorb_bow_transform(h, pd, n.value, 4, P(word), P(weight), P(node))
+            rc = rc or L.pgorb_bow_vectors(n.value, P(word), P(weight), P(node), voc.scoring, voc.weighting, P(bid), P(bval), C.byref(nb),
+                                           P(fnode), P(fstart), P(ffeat), C.byref(nfv))
+            if i >= 20: ts.append(time.perf_counter_ns() - t0)
+            if rc: ext._check(rc)
+        out["c_abi_extract_grid_bow_transform"] = dict(_pct(ts), words=int(nb.value))
     ext.close()
     return out
 
