@@ -340,6 +340,29 @@ __device__ __noinline__ uint3 sfi_eval_in_place(const pgorb_keypoint kp1, float 
     return make_uint3(wkey, wave_min_u32(min(mine, (unsigned)b2)), (unsigned)bestIdx2);
 }
 
+// The long forms of a keypoint's evaluation in the sequential pass, out of line: a list longer than the fixed slots (chunk 0 = the
+// prefetched `e0`, the rest 64 entries at a time from the pair's pool), or -- the pair's pool was full -- the evaluation in place.
+// Out: smallest (distance << 16 | position), the second-smallest distance (0x7fffffff: none), the winner's i2.
+__device__ __noinline__ uint3 sfi_eval_long(int count, uint32_t e0, const uint32_t* poolRow, const pgorb_keypoint kp1, float x, float y, float r,
+                                            float minX, float minY, float invW, float invH, const uint8_t* d1, const pgorb_keypoint* K2,
+                                            const uint8_t* D2, const int32_t* start2, const int32_t* idx2, const uint16_t* matchedDist, int lane)
+{
+    if (count == (int)LIST_OVER) return sfi_eval_in_place(kp1, x, y, r, minX, minY, invW, invH, d1, K2, D2, start2, idx2, matchedDist, lane);
+    unsigned wkey = 0xFFFFFFFFu, second = 0xFFFFFFFFu;
+    int bestIdx2 = -1;
+    for (int ch = 0; ch * 64 < count; ch++) {
+        const uint32_t ee = ch == 0 ? e0 : poolRow[(uint32_t)(ch - 1) * 64u + (uint32_t)lane];
+        const int i2 = (int)(ee & 0xFFFFu), dist = (int)(ee >> 16);
+        const bool keep = ch * 64 + lane < count && !((int)matchedDist[i2] <= dist);       // :445-446
+        const unsigned key = keep ? (((unsigned)dist << 16) | (unsigned)(ch * 64 + lane)) : 0xFFFFFFFFu;
+        unsigned k1, k2;
+        wave_min2_u32(key, k1, k2);
+        if (k1 < wkey) { second = min(wkey, k2); wkey = k1; bestIdx2 = __builtin_amdgcn_readlane(i2, (int)(k1 & 63u)); }
+        else second = min(second, k1);
+    }
+    return make_uint3(wkey, second == 0xFFFFFFFFu ? 0x7fffffffu : (second >> 16), (unsigned)bestIdx2);
+}
+
 #define SFI_G 8                  // keypoints per prefetch group
 // Phase 2: the sequential pass, one wave per pair.  (Round 4 also built this pass as ROUNDS of independent keypoints -- the scheme
 // k_search_by_projection runs below -- and measured it slower here: every listed keypoint of a pair is a level-0 keypoint with a
@@ -424,26 +447,11 @@ __global__ __launch_bounds__(64) void k_search_for_initialization(
                 if (wkey == 0xFFFFFFFFu) continue;
                 bestIdx2 = __builtin_amdgcn_readlane(i2, (int)(wkey & 0xFFFFu));
                 second = (second == 0xFFFFFFFFu) ? 0x7fffffffu : (second >> 16);
-            } else if (curC[j] != (int)LIST_OVER) {
-                // a dense window: the list 64 entries at a time, continued in the pair's pool (rounds 2-3 re-evaluated such a keypoint in place)
-                wkey = 0xFFFFFFFFu; second = 0xFFFFFFFFu;
-                const uint32_t ovf = Ls.ovf[row0 + i1];
-                for (int ch = 0; ch * 64 < curC[j]; ch++) {
-                    const uint32_t ee = ch == 0 ? curE[j] : pg_list_chunk(Ls, row0 + i1, p, ovf, ch, lane);
-                    const int i2 = (int)(ee & 0xFFFFu), dist = (int)(ee >> 16);
-                    const bool keep = ch * 64 + lane < curC[j] && !((int)matchedDist[i2] <= dist);       // :445-446
-                    const unsigned key = keep ? (((unsigned)dist << 16) | (unsigned)(ch * 64 + lane)) : 0xFFFFFFFFu;
-                    unsigned k1, k2;
-                    wave_min2_u32(key, k1, k2);
-                    if (k1 < wkey) { second = min(wkey, k2); wkey = k1; bestIdx2 = __builtin_amdgcn_readlane(i2, (int)(k1 & 63u)); }
-                    else second = min(second, k1);
-                }
-                if (wkey == 0xFFFFFFFFu) continue;
-                second = (second == 0xFFFFFFFFu) ? 0x7fffffffu : (second >> 16);
             } else {
-                // more than SFI_K candidates: evaluate in place, cell by cell in the reference's order
-                const uint3 ev = sfi_eval_in_place(K1[i1], prev[2 * i1], prev[2 * i1 + 1], r, minX, minY, invW, invH, D1 + (int64_t)i1 * 32, K2, D2,
-                                                   start2, idx2, matchedDist, lane);
+                // a dense window (the list continues in the pair's pool) or a pair whose pool is full (evaluation in place): out of line, so
+                // that the eight unrolled copies of this body stay small -- inlined, the sequential wave lost 20 % to instruction fetch
+                const uint3 ev = sfi_eval_long(curC[j], curE[j], Ls.pool + (size_t)p * Ls.poolPerPair + Ls.ovf[row0 + i1], K1[i1], prev[2 * i1], prev[2 * i1 + 1], r,
+                                               minX, minY, invW, invH, D1 + (int64_t)i1 * 32, K2, D2, start2, idx2, matchedDist, lane);
                 wkey = ev.x; second = ev.y; bestIdx2 = (int)ev.z;
                 if (wkey == 0xFFFFFFFFu) continue;
             }

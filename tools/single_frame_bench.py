@@ -23,13 +23,15 @@ def _pct(ts):
             "min_us": round(float(a[0]), 1)}
 
 
-def run(width=1920, height=1080, features=2000, calls=2000, warmup=100, with_frontend=True):
+def run(width=1920, height=1080, features=2000, calls=2000, warmup=100, with_frontend=True, options=()):
     import pilotguru_amd as pg
     from pilotguru_amd.synth import synth_ride
     from pilotguru_amd import vocab as V
     ride = synth_ride(0, width, height, 2)                       # two frames of a ride: consecutive frames match
     ext = pg.ORBextractor(features, 1.2, 8, 20, 7, max_width=width, max_height=height, max_batch=1)
     L, h = ext._L, ext._h
+    for kv in options:
+        k, v = kv.split("="); ext.set_option(k, int(v))
     cap = ext.max_keypoints(width, height)
     kps = np.zeros(cap, pg.orb.KEYPOINT_DTYPE); desc = np.zeros((cap, 32), np.uint8); n = C.c_int(0)
     frames = [np.ascontiguousarray(ride[0]), np.ascontiguousarray(ride[1])]          # pageable host memory, like a cv::Mat
@@ -133,8 +135,9 @@ if __name__ == "__main__":
     ap.add_argument("--width", type=int, default=1920); ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--features", type=int, default=2000); ap.add_argument("--calls", type=int, default=2000)
     ap.add_argument("--no-frontend", action="store_true"); ap.add_argument("--out")
+    ap.add_argument("--option", action="append", default=[], help="key=value for pgorb_set_option (repeatable)")
     a = ap.parse_args()
-    r = run(a.width, a.height, a.features, a.calls, with_frontend=not a.no_frontend)
+    r = run(a.width, a.height, a.features, a.calls, with_frontend=not a.no_frontend, options=a.option)
     txt = json.dumps(r, indent=1)
     print(txt)
     if a.out: open(a.out, "w").write(txt + "\n")
