@@ -356,44 +356,93 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P, int level0
         __syncthreads();
         QT_TS(8);
         int* hD = pyr + qt_pyr_off(nIni, D);
-        const int sub = lane >> 4, sl = lane & 15;
         // (the wave index as a scalar: with cb / cEnd in VGPRs the compiler made the cell loop a per-lane loop around the cross-lane
         //  shuffles below, and that build hung the kernel -- found by a timed-out run, round 4)
         const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int cellCap = L.cellCap;
-        // a wave takes a contiguous range of cells, 32 cells (8 groups of 4) per step: their counts in one coalesced load (the
-        // next step's counts are in flight meanwhile), then one round of 16 slots per cell -- eight independent loads per lane
-        // in flight -- per 16 records of the fullest cell
-        const int cpw = (((ncells + QT_W - 1) / QT_W) + 31) & ~31;
-        const int cBeg = wv * cpw, cEnd = min(ncells, cBeg + cpw);
-        int cntNext = (lane < 32 && cBeg + lane < cEnd) ? cc[cBeg + lane] : 0;
-        for (int cb = cBeg; cb < cEnd; cb += 32) {
-            const int myc = min(cntNext, cellCap);
-            cntNext = (lane < 32 && cb + 32 + lane < cEnd) ? cc[cb + 32 + lane] : 0;
-            mine += myc;
-            int n[8];
-            int maxn = myc;
+        // One LANE per cell, 64 cells per wave step, steps dealt round-robin to the 16 waves; ALL of a cell's records (up to 32 per
+        // round; a cell rarely holds more) are in flight before the first is used, 16 bytes per load.  The first form of this pass
+        // (16 lanes per cell, 32 cells per step, one round of 16 slots per trip) spent its 27 us per level-0 problem waiting: ten
+        // dependent memory round trips per wave; this one makes three.  The 64 lanes of an LDS atomic now belong to 64 different
+        // cells -- mostly different leaves.  (A cell's slots are read up to 3 records past its count: inside the slab, api.hip.)
+        struct __attribute__((packed, aligned(4))) U4 { uint32_t e[4]; };
+        if (ncells < QT_T) {
+            // fewer cells than threads (the upper levels, small frames): 16 lanes per cell, 32 cells per wave step keeps the workgroup's
+            // lanes busy where one lane per cell would leave most of them idle (640 x 480, level 0: 300 cells) -- the round-4 form
+            const int sub = lane >> 4, sl = lane & 15;
+            const int cpw = (((ncells + QT_W - 1) / QT_W) + 31) & ~31;
+            const int cBeg = wv * cpw, cEnd = min(ncells, cBeg + cpw);
+            int cntNext = (lane < 32 && cBeg + lane < cEnd) ? cc[cBeg + lane] : 0;
+            for (int cb = cBeg; cb < cEnd; cb += 32) {
+                const int myc = min(cntNext, cellCap);
+                cntNext = (lane < 32 && cb + 32 + lane < cEnd) ? cc[cb + 32 + lane] : 0;
+                mine += myc;
+                int n[8];
+                int maxn = myc;
 #pragma unroll
-            for (int g = 0; g < 8; g++) n[g] = __shfl(myc, 4 * g + sub);
+                for (int g = 0; g < 8; g++) n[g] = __shfl(myc, 4 * g + sub);
 #pragma unroll
-            for (int d = 1; d < 32; d <<= 1) maxn = max(maxn, __shfl_xor(maxn, d));
-            maxn = __builtin_amdgcn_readfirstlane(maxn);
-            const uint32_t* sp = slots + (int64_t)(cb + sub) * cellCap + sl;
-            for (int base = 0; base < maxn; base += 16) {       // (wave-uniform trip count)
-                uint32_t v[8];
+                for (int d = 1; d < 32; d <<= 1) maxn = max(maxn, __shfl_xor(maxn, d));
+                maxn = __builtin_amdgcn_readfirstlane(maxn);
+                const uint32_t* sp = slots + (int64_t)(cb + sub) * cellCap + sl;
+                for (int base = 0; base < maxn; base += 16) {       // (wave-uniform trip count)
+                    uint32_t v[8];
 #pragma unroll
-                for (int g = 0; g < 8; g++) v[g] = (base + sl < n[g]) ? sp[(int64_t)(4 * g) * cellCap + base] : 0u;
-                QT_SETTLE4(v[0], v[1], v[2], v[3]); QT_SETTLE4(v[4], v[5], v[6], v[7]);
+                    for (int g = 0; g < 8; g++) v[g] = (base + sl < n[g]) ? sp[(int64_t)(4 * g) * cellCap + base] : 0u;
+                    QT_SETTLE4(v[0], v[1], v[2], v[3]); QT_SETTLE4(v[4], v[5], v[6], v[7]);
 #pragma unroll
-                for (int g = 0; g < 8; g++) {
-                    if (base + sl < n[g]) {
-                        const uint2 tx = xTab[v[g] & 0xFFF], ty = yTab[(v[g] >> 12) & 0xFFF];
-                        const int lf = (int)(tx.x | ty.x);
-                        atomicAdd(&hD[lf], 1);
-                        if (rank24) atomicMax(&leafBest[lf], (v[g] & 0xFF000000u) | (0xFFFFFFu - (tx.y + ty.y)));
+                    for (int g = 0; g < 8; g++) {
+                        if (base + sl < n[g]) {
+                            const uint2 tx = xTab[v[g] & 0xFFF], ty = yTab[(v[g] >> 12) & 0xFFF];
+                            const int lf = (int)(tx.x | ty.x);
+                            atomicAdd(&hD[lf], 1);
+                            if (rank24) atomicMax(&leafBest[lf], (v[g] & 0xFF000000u) | (0xFFFFFFu - (tx.y + ty.y)));
+                        }
                     }
                 }
             }
+        } else {
+        const int cFirst = 64 * wv;
+        int cntNext = (cFirst + lane < ncells) ? cc[cFirst + lane] : 0;
+        for (int cb = cFirst; cb < ncells; cb += 64 * QT_W) {
+            const int myc = min(cntNext, cellCap);
+            cntNext = (cb + 64 * QT_W + lane < ncells) ? cc[cb + 64 * QT_W + lane] : 0;
+            mine += myc;
+            int maxn = myc;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) maxn = max(maxn, __shfl_xor(maxn, d));
+            maxn = __builtin_amdgcn_readfirstlane(maxn);
+            const uint32_t* sp = slots + (int64_t)(cb + lane) * cellCap;      // (lanes past the last cell: myc = 0, never dereferenced)
+            for (int base = 0; base < maxn; base += 32) {         // (wave-uniform trip count)
+                U4 r[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    r[j] = U4{{0u, 0u, 0u, 0u}};
+                    if (base + 4 * j < myc) r[j] = *reinterpret_cast<const U4*>(sp + base + 4 * j);
+                }
+                const int lim = min(maxn - base, 32);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    if (4 * j < lim) {                            // (wave-uniform)
+                        uint2 tx[4], ty[4];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const bool ok = base + 4 * j + k < myc;
+                            const uint32_t v = ok ? r[j].e[k] : 0u;  // (a slot past the count holds anything: entry 0 of the tables instead)
+                            tx[k] = xTab[v & 0xFFF]; ty[k] = yTab[(v >> 12) & 0xFFF];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            if (base + 4 * j + k < myc) {
+                                const int lf = (int)(tx[k].x | ty[k].x);
+                                atomicAdd(&hD[lf], 1);
+                                if (rank24) atomicMax(&leafBest[lf], (r[j].e[k] & 0xFF000000u) | (0xFFFFFFu - (tx[k].y + ty[k].y)));
+                            }
+                        }
+                    }
+                }
+            }
+        }
         }
         }
 #pragma unroll
@@ -943,13 +992,13 @@ void pg_launch_quadtree_levels(const PgPlan& P, int nframes, int levelBeg, int l
     (void)hipGetDevice(&dev);
     size_t* configured = configuredDev[dev & 63];
     // Two launches or one?  (PgPlan::qtSplit: 0 = one, 1 = two, 2 = by this rule.)  Measured on an MI355X, K3 per step, one launch /
-    // two launches (tools/experiments/r4_split_grid.sh, profiles/r04_k3_split_grid.txt): 1080p x 1 frame 56 / 40 us, x 32 63 / 55, x 48
-    // 68 / 71, x 128 110 / 128; 2160p x 1 178 / 52, x 32 187 / 108, x 64 190 / 181; 640x480 and 720p: one launch wins at every batch.
-    // The pass kernel is a pure throughput cost (one lane per cell: ~30 % of its lanes carry a record), while inside k_quadtree the
-    // pass fills the stalls of the neighbouring workgroups' barriers -- so two launches pay when the chip is NOT full of quadtree
-    // workgroups (few frames) or when one level-0 problem is long (large frames).
+    // two launches (tools/experiments/r4_split_grid.sh, profiles/r04_k3_split_grid.txt): 1080p x 1 frame 45 / 40 us, x 16 47 / 46, x 32
+    // 52 / 56, x 128 100 / 129; 2160p x 1 99 / 52, x 8 100 / 61, x 32 107 / 107, x 64 139 / 184; 640x480 and 720p: one launch wins at
+    // every batch.  The pass kernel is a pure throughput cost (one lane per cell: ~30 % of its lanes carry a record), while inside
+    // k_quadtree the pass fills the stalls of the neighbouring workgroups' barriers -- so two launches pay only when the chip is NOT
+    // full of quadtree workgroups: a few frames, the more the larger they are.
     const int cells0 = P.lvl[levelBeg].nCols * P.lvl[levelBeg].nRows;
-    const bool split = P.qtSplit == 1 || (P.qtSplit == 2 && cells0 >= 1500 && nframes <= 40 + (cells0 - 2304) * 24 / 6912);
+    const bool split = P.qtSplit == 1 || (P.qtSplit == 2 && cells0 >= 1500 && nframes <= 16 + (cells0 - 2304) * 12 / 6912);
     if (split) {
         int groups = 0;
         size_t lds = 0;
