@@ -349,6 +349,8 @@ int main(int argc, char** argv)
     const auto tStart = std::chrono::steady_clock::now();
     auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count(); };
     const bool timing = getenv("PGORB_CLI_TIMING") != nullptr;
+    auto epoch = [] { return std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count(); };
+    if (timing) fprintf(stderr, "main entered at epoch %.6f\n", epoch());
     const int B = std::max(1, F.batch), DEPTH = 3;
     // the upright frame the extractor sees (the reader's rotation swaps the sides for 90 / 270)
     const bool swapSides = F.rotation == 90 || F.rotation == 270;
@@ -525,7 +527,7 @@ int main(int argc, char** argv)
     const double loopSec = std::chrono::duration<double>(std::chrono::steady_clock::now() - loopStart).count();
     fprintf(stderr, "optical_trajectories (front-end mode): %ld frames -> %s (frame loop: %.3f s, %.0f frames/s)\n", total, out.c_str(),
             loopSec, loopSec > 0 ? total / loopSec : 0.0);
-    if (timing) fprintf(stderr, "report written at %.3f s\n", since());
+    if (timing) fprintf(stderr, "report written at %.3f s, epoch %.6f\n", since(), epoch());
     if (getenv("PGORB_CLI_TEARDOWN")) {                       // orderly teardown (leak checkers): unpinning and freeing the arenas takes ~0.2 s
         if (st) pgorb_stream_destroy(st);
         delete ext;

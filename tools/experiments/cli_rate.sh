@@ -21,8 +21,10 @@ V.write_vocabulary_text('$D/voc.txt', 10, 4, d, w, p)
 d, w, p = V.synth_vocabulary_fast(10, 6, seed=7)                 # ORBvoc-sized: k = 10, L = 6, 1.1 M nodes, ~145 MB of text
 V.write_vocabulary_text_fast('$D/vocbig.txt', 10, 6, d, w, p)
 PY
-run() { t0=$(date +%s.%N); PGORB_CLI_TIMING=1 pilotguru_amd/host/optical_trajectories "$@" 2>&1 | tail -2; t1=$(date +%s.%N)
-        python -c "print('    -> %.3f s wall, %.0f frames/s including process start' % ($t1 - $t0, $N / ($t1 - $t0)))"; }
+run() { t0=$(date +%s.%N); PGORB_CLI_TIMING=1 pilotguru_amd/host/optical_trajectories "$@" > $D/run.log 2>&1; t1=$(date +%s.%N); tail -2 $D/run.log
+        # where the wall clock goes outside main(): exec + dynamic loading before it, the kernel's teardown of the process after _exit
+        m=$(grep -o "main entered at epoch [0-9.]*" $D/run.log | grep -o "[0-9.]*$"); e=$(grep -o "epoch [0-9.]*$" $D/run.log | tail -1 | grep -o "[0-9.]*$")
+        python -c "print('    -> %.3f s wall (%.3f s before main, %.3f s between the report and the shell seeing the exit), %.0f frames/s including process start' % ($t1 - $t0, $m - $t0, $t1 - $e, $N / ($t1 - $t0)))"; }
 for b in 8 32 64 128; do
   echo "grey, batch $b:"; run --vocabulary_file=$D/voc.txt --camera_settings=$D/cam.yml --in_video=$D/clip.gray --out_dir=$D --novisualize --batch=$b
 done
