@@ -531,6 +531,8 @@ int      pgorb_stream_frontend_results(pgorb_stream* s, int slot, const int32_t*
  * key "quadtree_split": K3's pass over the candidates -- 0 = inside the quadtree kernel (one launch), 1 = as a kernel of its own
  * (many small workgroups; pays for single frames and large frames), 2 = chosen per launch from the frame size and the number of
  * frames (default; the measured table is profiles/r04_k3_split_grid.txt).  PGORB_QT_SPLIT seeds it.
+ * key "quadtree_threads": threads per K3 workgroup -- 0 = chosen per launch (default: 512 when the problems of a launch queue for the
+ * chip or are small, 1024 when each has a CU to itself; profiles/r04_k3_threads_grid.txt), 256 | 512 | 1024 = that many.  PGORB_QT_THREADS seeds it.
  * key "pipeline_pyramid": 1 = the resize chain on a side stream beside K2, level by level (slower).
  * key "pipeline_levels": bit l set = a group of levels starts at level l; K3 / K4-6 of one group run on side streams beside K2
  * of the next (slower for every grouping measured).  0 = one launch per kernel (default).

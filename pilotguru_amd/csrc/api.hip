@@ -44,6 +44,7 @@ struct pgorb_ctx {
     bool planValid = false;
     // device memory
     Arena pyr, cand, sel, nodes, counters, tables, cellCand, cellCount, cellTab, cellTabBal, qtTab, qtLeaf;
+    int qtThreads = 0;                        // K3 threads per workgroup: 0 = per launch (pgorb_set_option "quadtree_threads")
     int qtSplit = 2;                          // K3's candidate pass as its own launch: 0 no, 1 yes, 2 by frame size and batch (pgorb_set_option "quadtree_split")
     int fastTilePitch = 0, fastWpb = 1;       // K2 tile-shape sweep (pgorb_set_option "fast_tile_pitch" / "fast_waves_per_block")
     // K1 beside K2 (pgorb_set_option "pipeline_pyramid"): the pyramid chain on a high-priority side stream, K2 level by
@@ -489,7 +490,7 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
         PG_HIP(c, hipMemcpy(c->qtTab.p, qt.data(), qt.size() * sizeof(uint2), hipMemcpyHostToDevice));
         const size_t leafBytes = (size_t)B * L * PG_QT_LEAF_CAP * sizeof(uint2);
         if ((rc = ensure(c, c->qtLeaf, leafBytes))) return rc;
-        P.qtTab = (const uint2*)c->qtTab.p; P.qtLeaf = (uint2*)c->qtLeaf.p; P.qtSplit = c->qtSplit;
+        P.qtTab = (const uint2*)c->qtTab.p; P.qtLeaf = (uint2*)c->qtLeaf.p; P.qtSplit = c->qtSplit; P.qtThreads = c->qtThreads;
     }
     P.fastTilePitch = c->fastTilePitch; P.fastWpb = c->fastWpb;
     P.cand = (uint32_t*)c->cand.p; P.sel = (uint32_t*)c->sel.p;
@@ -728,6 +729,7 @@ int pgorb_create(const pgorb_params* p, pgorb_ctx** out)
     if (const char* e = getenv("PGORB_EXTRACT_CHUNK_KB")) { const int kb = atoi(e); if (kb >= 16) c->chunkBytes = kb << 10; }
     c->noStage = getenv("PGORB_EXTRACT_STAGE") == nullptr;
     c->useGraph = getenv("PGORB_EXTRACT_NO_GRAPH") == nullptr;
+    if (const char* e = getenv("PGORB_QT_THREADS")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024) c->qtThreads = v; }
     if (const char* e = getenv("PGORB_QT_SPLIT")) { const int v = atoi(e); if (v >= 0 && v <= 2) c->qtSplit = v; }      // A / B switch of K3's two forms (option "quadtree_split")
     // ORBextractor.cc:415-446
     const int L = p->nlevels;
@@ -1166,6 +1168,11 @@ int pgorb_set_option(pgorb_ctx* c, const char* key, int value)
         c->fastWpb = value; c->plan.fastWpb = value;
         return 0;
     }
+    if (!strcmp(key, "quadtree_threads")) {
+        if (value != 0 && value != 256 && value != 512 && value != 1024) return fail(c, PGORB_E_ARG, "quadtree_threads must be 0 (automatic), 256, 512 or 1024");
+        c->qtThreads = value; c->plan.qtThreads = value;
+        return 0;
+    }
     if (!strcmp(key, "quadtree_split")) {
         if (value < 0 || value > 2) return fail(c, PGORB_E_ARG, "quadtree_split must be 0 (one launch), 1 (two) or 2 (automatic)");
         c->qtSplit = value; c->plan.qtSplit = value;
@@ -1183,6 +1190,7 @@ int pgorb_get_option(const pgorb_ctx* c, const char* key)
     if (!strcmp(key, "fast_tile_pitch")) return c->fastTilePitch;
     if (!strcmp(key, "fast_waves_per_block")) return c->fastWpb;
     if (!strcmp(key, "quadtree_split")) return c->qtSplit;
+    if (!strcmp(key, "quadtree_threads")) return c->qtThreads;
     if (!strcmp(key, "matcher")) return c->mx.popcount;
     if (!strcmp(key, "match_mode")) return c->mx.mode;
     if (!strcmp(key, "pipeline_pyramid")) return c->pipePyr;

@@ -546,7 +546,9 @@ __global__ __launch_bounds__(64) void k_search_for_initialization(
     if (lane == 0) nmatchesOut[p] = nmatches;
 }
 
-#define RR_T 1024
+#ifndef RR_T
+#define RR_T 1024               // threads of the rounds workgroup (one per pair); 512 in a developer build: tools/experiments/r4_rr_threads.sh
+#endif
 #define RR_W (RR_T / 64)
 // ---- SearchByProjection (local map points / last frame), src/ORBmatcher.cc:46-131, 1355-1474 ----
 // One wave per frame; queries in order.  mode 0: best + second with the same-level ratio test

@@ -127,6 +127,7 @@ struct PgPlan {
     const uint2* qtTab;       // per level: [regionW] {leaf column, rank part}, [regionH] {leaf row, rank part}, [2^D + 1] {first y of leaf row r, 0} (built with the plan)
     uint2*    qtLeaf;         // [frame][nlevels][PG_QT_LEAF_CAP] {count, (response << 24) | (0xFFFFFF - rank)}: every leaf written by k_qt_leaves in every batch
     int32_t   qtSplit;        // option "quadtree_split": 0 = the pass inside k_quadtree, 1 = two launches, 2 = chosen per launch (default; pg_launch_quadtree_levels)
+    int32_t   qtThreads;      // option "quadtree_threads": 0 = chosen per launch (default), 256 | 512 | 1024 = that many threads per K3 workgroup
     int32_t*  status;         // device status word
 };
 

@@ -43,8 +43,13 @@
 // the kernel), not bandwidth-bound.  tools/experiments/qt_timing.py prints its phases.
 #include "pgorb_internal.h"
 
-#define QT_T 1024
-#define QT_W (QT_T / 64)
+// Threads per (frame, level) workgroup: chosen per LAUNCH (pg_launch_quadtree_levels: 1 024 when every problem of the launch is resident
+// at once -- then the longest problem's latency is the kernel and it wants every wave it can get --, 512 when the problems queue for
+// the chip's slots: barriers among 8 waves are cheaper than among 16 and small problems fit four to a CU).  The kernel reads it from blockDim.
+#define QT_TMAX 1024
+#define QT_T ((int)blockDim.x)
+#define QT_SH (__builtin_ctz(blockDim.x))
+#define QT_W (QT_T >> 6)
 #define QT_POS_MASK 0x0FFFFFFFu
 
 // Wait ONCE for a batch of loads: the values become outputs of an (empty) asm statement, so the
@@ -74,7 +79,7 @@ __device__ __forceinline__ int qt_wave_incl_scan(int x)
 __device__ int qt_scan_excl(int* a, int n, int* sh)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int per = (n + QT_T - 1) / QT_T;
+    const int per = (n + QT_T - 1) >> QT_SH;
     const int b = tid * per, e = min(b + per, n);
     int sum = 0;
     for (int i = b; i < e; i++) sum += a[i];
@@ -246,9 +251,9 @@ __device__ __forceinline__ int qt_build_keys(const int32_t* __restrict__ cc, con
 // BIG: the level's node arrays do not fit LDS (quota above ~1180) and live in a global slab;
 // the same code, just slower.  Each instantiation skips the levels of the other kind.
 template <bool BIG>
-__global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P, int level0, int leafOffInts, int split)
+__global__ __launch_bounds__(QT_TMAX, 8) void k_quadtree(const PgPlan P, int level0, int leafOffInts, int split)
 {
-    __shared__ int sh[3 * QT_W + 8];
+    __shared__ int sh[3 * (QT_TMAX / 64) + 8];
     __shared__ int pyr[QT_PYR_CAP];                       // count pyramid, later the node map
     extern __shared__ __attribute__((aligned(16))) int qt_lds[];     // max(30 ints per node, cells + 1)
     const int tid = threadIdx.x;
@@ -370,7 +375,7 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P, int level0
             // fewer cells than threads (the upper levels, small frames): 16 lanes per cell, 32 cells per wave step keeps the workgroup's
             // lanes busy where one lane per cell would leave most of them idle (640 x 480, level 0: 300 cells) -- the round-4 form
             const int sub = lane >> 4, sl = lane & 15;
-            const int cpw = (((ncells + QT_W - 1) / QT_W) + 31) & ~31;
+            const int cpw = (((ncells + QT_W - 1) >> (QT_SH - 6)) + 31) & ~31;
             const int cBeg = wv * cpw, cEnd = min(ncells, cBeg + cpw);
             int cntNext = (lane < 32 && cBeg + lane < cEnd) ? cc[cBeg + lane] : 0;
             for (int cb = cBeg; cb < cEnd; cb += 32) {
@@ -550,7 +555,7 @@ __global__ __launch_bounds__(QT_T, 8) void k_quadtree(const PgPlan P, int level0
         if (!sorted_mode) {
             // ---- breadth-first generation (:606-665): processing order == list order and every
             // expandable node is split, so ONE fused scan places all children and all survivors.
-            const int per = (n + QT_T - 1) / QT_T;
+            const int per = (n + QT_T - 1) >> QT_SH;
             const int pb = tid * per, pe = min(pb + per, n);
             int se = 0, sc = 0, sx = 0;
             for (int p = pb; p < pe; p++)
@@ -1019,10 +1024,21 @@ void pg_launch_quadtree_levels(const PgPlan& P, int nframes, int levelBeg, int l
         if (groups > 0)
             hipLaunchKernelGGL(k_qt_leaves, dim3(groups, nframes), dim3(QTP_T), lds, s, P, levelBeg, levelEnd - levelBeg);
     }
-    dim3 grid(nframes, levelEnd - levelBeg), block(QT_T);
     for (int big = 0; big < 2; big++) {
         if (!any[big]) continue;
         const size_t lds = (size_t)(nodes[big] + aux[big]) * sizeof(int);
+        // Threads per workgroup (profiles/r04_k3_threads_grid.txt, K3 ms per step with 256 / 512 / 1 024 threads): 1080p x 128 frames
+        // 0.117 / 0.094 / 0.101, 640 x 480 x 512 0.166 / 0.163 / 0.259, 720p x 128 0.085 / 0.076 / 0.087 -- but one 1080p frame 77 / 52 / 46 us,
+        // 1080p x 64 0.089 / 0.066 / 0.063, 2160p x 32 0.249 / 0.152 / 0.113, 1080p / 4000 features x 128 0.219 / 0.170 / 0.164.  Barriers among 8
+        // waves are cheaper than among 16 and small problems fit three or four to a CU; a long problem that has a CU to itself wants
+        // every wave it can get.  So: 1 024 when the LDS need leaves room for one workgroup per CU anyway; otherwise 512 when the
+        // level-0 problem has fewer cells than 1 024 threads could take one each, or when the problems of the launch outnumber the
+        // 512 slots two 1 024-thread workgroups per CU give; 1 024 else.
+        const size_t ldsAll = lds + sizeof(int) * (QT_PYR_CAP + 3 * (QT_TMAX / 64) + 8);
+        int threads = QT_TMAX;
+        if (ldsAll <= 80 * 1024 && (cells0 < 1024 || (int64_t)nframes * (levelEnd - levelBeg) > 512)) threads = 512;
+        if (P.qtThreads == 256 || P.qtThreads == 512 || P.qtThreads == 1024) threads = P.qtThreads;
+        dim3 grid(nframes, levelEnd - levelBeg), block(threads);
         const void* fn = big ? reinterpret_cast<const void*>(k_quadtree<true>) : reinterpret_cast<const void*>(k_quadtree<false>);
         if (lds > configured[big]) {
             (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -55,6 +55,7 @@ def fuzz_parity(cases=200, seed=1, log=True):
             if form == 1: ext.set_option("fast_tile_pitch", int(rng.choice([48, 64, 80, 96, 112, 128])))
             if form == 2: ext.set_option("fast_waves_per_block", 4)
             ext.set_option("quadtree_split", it % 3)           # K3's pass inside the quadtree kernel / as its own launch / chosen by the library
+            ext.set_option("quadtree_threads", (0, 256, 512, 1024)[(it // 3) % 4])
             kp, d = ext(img)
         except Exception as e:
             kp = None; err = str(e)
@@ -115,6 +116,7 @@ def fuzz_batch_parity(cases=100, seed=1, log=True):
             continue                                        # (geometry the reference cannot run: covered by fuzz_parity)
         ext = pg.ORBextractor(nf, scale, nlev, ini, mn, max_width=w, max_height=h, max_batch=B)
         ext.set_option("quadtree_split", it % 3)
+        ext.set_option("quadtree_threads", (0, 256, 512, 1024)[(it // 3) % 4])
         got = ext.extract_batch(frames)
         for k in range(B):
             if got[k][0].tobytes() != want[k][0].tobytes() or not np.array_equal(got[k][1], want[k][1]):

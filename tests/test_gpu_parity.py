@@ -725,9 +725,12 @@ def test_quadtree_in_two_launches_and_in_one(oracle, split):
         ext = pg.ORBextractor(nf, 1.2, nlev, 20, 7, max_width=w, max_height=h)
         ext.set_option("quadtree_split", split)
         assert ext.get_option("quadtree_split") == split
-        for rep in range(2):
+        for threads in (0, 256, 512, 1024):                          # threads per K3 workgroup: the per-launch rule, or forced
+            ext.set_option("quadtree_threads", threads)
+            assert ext.get_option("quadtree_threads") == threads
             kp, desc = ext(img)
-            assert kp.tobytes() == okp.tobytes() and np.array_equal(desc, odesc), (w, h, rep)
+            assert kp.tobytes() == okp.tobytes() and np.array_equal(desc, odesc), (w, h, threads)
+        ext.set_option("quadtree_threads", 0)
         for l in range(nlev):
             assert ext.debug_level_keypoints(0, l) == ora.level_keypoints(l), "quadtree count level %d" % l
         ext.close()
