@@ -30,7 +30,7 @@ def _scene(rng, kind, seed, w, h):
     return img
 
 
-def fuzz_parity(cases=200, seed=1, log=True):
+def fuzz_parity(cases=200, seed=1, log=True, size_range=((90, 1000), (90, 800)), nf_range=(40, 2500)):
     """Single frames: random size, scale factor, level count, feature count, thresholds, scene kind and K2 tile shape;
     keypoints and descriptors bit for bit, and the same error state where the reference cannot run."""
     import pilotguru_amd as pg
@@ -38,9 +38,9 @@ def fuzz_parity(cases=200, seed=1, log=True):
     rng = np.random.RandomState(seed)
     bad = 0; t0 = time.time(); nkp = 0
     for it in range(cases):
-        w = int(rng.randint(90, 1000)); h = int(rng.randint(90, 800))
+        w = int(rng.randint(*size_range[0])); h = int(rng.randint(*size_range[1]))
         scale = float(rng.choice([1.2, 1.2, 1.1, 1.25, 1.33, 1.5, 1.7, 2.0]))
-        nlev = int(rng.randint(1, 9)); nf = int(rng.randint(40, 2500))
+        nlev = int(rng.randint(1, 9)); nf = int(rng.randint(*nf_range))
         ini = int(rng.choice([20, 20, 12, 30, 40, 8])); mn = min(int(rng.choice([7, 7, 5, 10, 3, 1])), ini)
         kind = int(rng.randint(0, 6))
         img = _scene(rng, kind, (2000 if kind == 5 else 1000) + it if kind != 3 else it, w, h)
@@ -92,7 +92,7 @@ def fuzz_levels(cases=80, seed=5, log=True):
     return bad, "cases %d keypoints %d mismatches %d seconds %.1f" % (cases, n, bad, time.time() - t0)
 
 
-def fuzz_batch_parity(cases=100, seed=1, log=True):
+def fuzz_batch_parity(cases=100, seed=1, log=True, size_range=((120, 900), (120, 700)), nf_range=(60, 2200)):
     """Batch paths: 2-6 frames of MIXED scene kinds through (a) pgorb_extract_batch, (b) the streamed ingest (ragged batches,
     depth 2-3) with its front-end stage (SearchForInitialization of every frame against its predecessor, random window / ratio /
     orientation check), plus the best-2 Hamming match of consecutive frames."""
@@ -101,9 +101,9 @@ def fuzz_batch_parity(cases=100, seed=1, log=True):
     rng = np.random.RandomState(seed)
     bad = 0; t0 = time.time(); nkp = 0; nframes = 0
     for it in range(cases):
-        w = int(rng.randint(120, 900)); h = int(rng.randint(120, 700))
+        w = int(rng.randint(*size_range[0])); h = int(rng.randint(*size_range[1]))
         scale = float(rng.choice([1.2, 1.2, 1.2, 1.1, 1.25, 1.5]))
-        nlev = int(rng.randint(1, 9)); nf = int(rng.randint(60, 2200))
+        nlev = int(rng.randint(1, 9)); nf = int(rng.randint(*nf_range))
         ini = int(rng.choice([20, 20, 12, 30])); mn = min(int(rng.choice([7, 7, 5, 3])), ini)
         B = int(rng.randint(2, 7))
         base = 5000 + 7 * it

@@ -17,3 +17,13 @@ print(fuzzers.fuzz_matchers(cases=40, seed=407, nf_range=(4000, 4001), size_rang
 PY
 } > $O 2>&1
 cat $O
+{
+echo "## large frames (1100..2600 x 700..1500, 500..5000 features): the levels with more cells than threads, K3 forms and thread counts rotated; fuzz_parity 160 cases seed 408, fuzz_batch_parity 40 cases seed 409"
+timeout 1500 python - <<'PY' 2>&1 | grep -v amdgpu.ids | tail -3
+import sys; sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import fuzzers
+print(fuzzers.fuzz_parity(cases=160, seed=408, size_range=((1100, 2600), (700, 1500)), nf_range=(500, 5000))[1])
+print(fuzzers.fuzz_batch_parity(cases=40, seed=409, size_range=((1100, 2000), (700, 1200)), nf_range=(500, 4000))[1])
+PY
+} >> $O 2>&1
+tail -8 $O
