@@ -490,7 +490,7 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
         PG_HIP(c, hipMemcpy(c->qtTab.p, qt.data(), qt.size() * sizeof(uint2), hipMemcpyHostToDevice));
         const size_t leafBytes = (size_t)B * L * PG_QT_LEAF_CAP * sizeof(uint2);
         if ((rc = ensure(c, c->qtLeaf, leafBytes))) return rc;
-        P.qtTab = (const uint2*)c->qtTab.p; P.qtLeaf = (uint2*)c->qtLeaf.p; P.qtSplit = c->qtSplit; P.qtThreads = c->qtThreads;
+        P.qtTab = (const uint2*)c->qtTab.p; P.qtLeaf = (uint2*)c->qtLeaf.p; P.qtSplit = c->qtSplit; P.qtThreads = c->qtThreads; P.qtWide = getenv("PGORB_QT_WIDE") ? atoi(getenv("PGORB_QT_WIDE")) != 0 : 1;
     }
     P.fastTilePitch = c->fastTilePitch; P.fastWpb = c->fastWpb;
     P.cand = (uint32_t*)c->cand.p; P.sel = (uint32_t*)c->sel.p;

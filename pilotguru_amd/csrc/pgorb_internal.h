@@ -128,6 +128,7 @@ struct PgPlan {
     uint2*    qtLeaf;         // [frame][nlevels][PG_QT_LEAF_CAP] {count, (response << 24) | (0xFFFFFF - rank)}: every leaf written by k_qt_leaves in every batch
     int32_t   qtSplit;        // option "quadtree_split": 0 = the pass inside k_quadtree, 1 = two launches, 2 = chosen per launch (default; pg_launch_quadtree_levels)
     int32_t   qtThreads;      // option "quadtree_threads": 0 = chosen per launch (default), 256 | 512 | 1024 = that many threads per K3 workgroup
+    int32_t   qtWide;         // 1 (default): 512-thread launches limited to two workgroups per CU by their LDS use the 128-VGPR instantiation (PGORB_QT_WIDE=0: never)
     int32_t*  status;         // device status word
 };
 

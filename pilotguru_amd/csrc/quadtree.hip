@@ -251,8 +251,11 @@ __device__ __forceinline__ int qt_build_keys(const int32_t* __restrict__ cc, con
 
 // BIG: the level's node arrays do not fit LDS (quota above ~1180) and live in a global slab;
 // the same code, just slower.  Each instantiation skips the levels of the other kind.
-template <bool BIG>
-__global__ __launch_bounds__(QT_TMAX, 8) void k_quadtree(const PgPlan P, int level0, int leafOffInts, int split)
+// WIDE: instantiations for launches that never have more than four waves per SIMD resident -- 512 threads with an LDS need that holds them to
+// two workgroups per CU (WIDE 1), 1 024 threads with one workgroup per CU, by LDS or because the launch has no more problems than CUs (WIDE 2):
+// 128 VGPRs instead of 64 -- the kernel wants 100 and spills 21 dwords under the cap.
+template <bool BIG, int WIDE>
+__global__ __launch_bounds__(WIDE == 1 ? 512 : QT_TMAX, WIDE ? 4 : 8) void k_quadtree(const PgPlan P, int level0, int leafOffInts, int split)
 {
     __shared__ int sh[3 * (QT_TMAX / 64) + 8];
     __shared__ int pyr[QT_PYR_CAP];                       // count pyramid, later the node map
@@ -1040,12 +1043,19 @@ void pg_launch_quadtree_levels(const PgPlan& P, int nframes, int levelBeg, int l
         if (ldsAll <= 80 * 1024 && (cells0 < 1024 || (int64_t)nframes * (levelEnd - levelBeg) > 512)) threads = 512;
         if (P.qtThreads == 256 || P.qtThreads == 512 || P.qtThreads == 1024) threads = P.qtThreads;
         dim3 grid(nframes, levelEnd - levelBeg), block(threads);
-        const void* fn = big ? reinterpret_cast<const void*>(k_quadtree<true>) : reinterpret_cast<const void*>(k_quadtree<false>);
+        const int64_t problems = (int64_t)nframes * (levelEnd - levelBeg);
+        int wide = 0;
+        if (P.qtWide && threads == 512 && ldsAll > 54 * 1024) wide = 1;
+        if (P.qtWide && threads == QT_TMAX && (ldsAll > 80 * 1024 || problems <= 256)) wide = 2;
         if (lds > configured[big]) {
-            (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#define PG_QT_ATTR(B, W) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree<B, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+            PG_QT_ATTR(true, 0); PG_QT_ATTR(true, 1); PG_QT_ATTR(true, 2); PG_QT_ATTR(false, 0); PG_QT_ATTR(false, 1); PG_QT_ATTR(false, 2);
+#undef PG_QT_ATTR
             configured[big] = lds;
         }
-        if (big) hipLaunchKernelGGL(k_quadtree<true>, grid, block, lds, s, P, levelBeg, nodes[big], split ? 1 : 0);
-        else hipLaunchKernelGGL(k_quadtree<false>, grid, block, lds, s, P, levelBeg, nodes[big], split ? 1 : 0);
+#define PG_QT_LAUNCH(B, W) hipLaunchKernelGGL((k_quadtree<B, W>), grid, block, lds, s, P, levelBeg, nodes[big], split ? 1 : 0)
+        if (big) { if (wide == 1) PG_QT_LAUNCH(true, 1); else if (wide == 2) PG_QT_LAUNCH(true, 2); else PG_QT_LAUNCH(true, 0); }
+        else { if (wide == 1) PG_QT_LAUNCH(false, 1); else if (wide == 2) PG_QT_LAUNCH(false, 2); else PG_QT_LAUNCH(false, 0); }
+#undef PG_QT_LAUNCH
     }
 }
