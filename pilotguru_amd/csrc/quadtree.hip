@@ -255,7 +255,7 @@ __device__ __forceinline__ int qt_build_keys(const int32_t* __restrict__ cc, con
 // two workgroups per CU (WIDE 1), 1 024 threads with one workgroup per CU, by LDS or because the launch has no more problems than CUs (WIDE 2):
 // 128 VGPRs instead of 64 -- the kernel wants 100 and spills 21 dwords under the cap.
 template <bool BIG, int WIDE>
-__global__ __launch_bounds__(WIDE == 1 ? 512 : QT_TMAX, WIDE ? 4 : 8) void k_quadtree(const PgPlan P, int level0, int leafOffInts, int split)
+__global__ __launch_bounds__((WIDE == 1 || WIDE == 3) ? 512 : QT_TMAX, WIDE == 3 ? 6 : (WIDE ? 4 : 8)) void k_quadtree(const PgPlan P, int level0, int leafOffInts, int split)
 {
     __shared__ int sh[3 * (QT_TMAX / 64) + 8];
     __shared__ int pyr[QT_PYR_CAP];                       // count pyramid, later the node map
@@ -1046,16 +1046,17 @@ void pg_launch_quadtree_levels(const PgPlan& P, int nframes, int levelBeg, int l
         const int64_t problems = (int64_t)nframes * (levelEnd - levelBeg);
         int wide = 0;
         if (P.qtWide && threads == 512 && ldsAll > 54 * 1024) wide = 1;
+        if (P.qtWide && threads == 512 && ldsAll > 40 * 1024 && ldsAll <= 54 * 1024) wide = 3;        // three workgroups per CU: six waves per SIMD, 80 VGPRs
         if (P.qtWide && threads == QT_TMAX && (ldsAll > 80 * 1024 || problems <= 256)) wide = 2;
         if (lds > configured[big]) {
 #define PG_QT_ATTR(B, W) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree<B, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-            PG_QT_ATTR(true, 0); PG_QT_ATTR(true, 1); PG_QT_ATTR(true, 2); PG_QT_ATTR(false, 0); PG_QT_ATTR(false, 1); PG_QT_ATTR(false, 2);
+            PG_QT_ATTR(true, 0); PG_QT_ATTR(true, 1); PG_QT_ATTR(true, 2); PG_QT_ATTR(true, 3); PG_QT_ATTR(false, 0); PG_QT_ATTR(false, 1); PG_QT_ATTR(false, 2); PG_QT_ATTR(false, 3);
 #undef PG_QT_ATTR
             configured[big] = lds;
         }
 #define PG_QT_LAUNCH(B, W) hipLaunchKernelGGL((k_quadtree<B, W>), grid, block, lds, s, P, levelBeg, nodes[big], split ? 1 : 0)
-        if (big) { if (wide == 1) PG_QT_LAUNCH(true, 1); else if (wide == 2) PG_QT_LAUNCH(true, 2); else PG_QT_LAUNCH(true, 0); }
-        else { if (wide == 1) PG_QT_LAUNCH(false, 1); else if (wide == 2) PG_QT_LAUNCH(false, 2); else PG_QT_LAUNCH(false, 0); }
+        if (big) { if (wide == 1) PG_QT_LAUNCH(true, 1); else if (wide == 2) PG_QT_LAUNCH(true, 2); else if (wide == 3) PG_QT_LAUNCH(true, 3); else PG_QT_LAUNCH(true, 0); }
+        else { if (wide == 1) PG_QT_LAUNCH(false, 1); else if (wide == 2) PG_QT_LAUNCH(false, 2); else if (wide == 3) PG_QT_LAUNCH(false, 3); else PG_QT_LAUNCH(false, 0); }
 #undef PG_QT_LAUNCH
     }
 }
