@@ -1036,11 +1036,12 @@ void pg_launch_quadtree_levels(const PgPlan& P, int nframes, int levelBeg, int l
         // 1080p x 64 0.089 / 0.066 / 0.063, 2160p x 32 0.249 / 0.152 / 0.113, 1080p / 4000 features x 128 0.219 / 0.170 / 0.164.  Barriers among 8
         // waves are cheaper than among 16 and small problems fit three or four to a CU; a long problem that has a CU to itself wants
         // every wave it can get.  So: 1 024 when the LDS need leaves room for one workgroup per CU anyway; otherwise 512 when the
-        // level-0 problem has fewer cells than 1 024 threads could take one each, or when the problems of the launch outnumber the
-        // 512 slots two 1 024-thread workgroups per CU give; 1 024 else.
+        // level-0 problem has fewer cells than 1 024 threads could take one each, or when the launch has more problems than the chip
+        // has CUs (with the 128-VGPR instantiations: 1080p x 48 frames 0.058 / 0.060 ms, x 64 0.059 / 0.063, x 96 0.076 / 0.090 for 512 /
+        // 1 024 threads); 1 024 else.
         const size_t ldsAll = lds + sizeof(int) * (QT_PYR_CAP + 3 * (QT_TMAX / 64) + 8);
         int threads = QT_TMAX;
-        if (ldsAll <= 80 * 1024 && (cells0 < 1024 || (int64_t)nframes * (levelEnd - levelBeg) > 512)) threads = 512;
+        if (ldsAll <= 80 * 1024 && (cells0 < 1024 || (int64_t)nframes * (levelEnd - levelBeg) > 256)) threads = 512;
         if (P.qtThreads == 256 || P.qtThreads == 512 || P.qtThreads == 1024) threads = P.qtThreads;
         dim3 grid(nframes, levelEnd - levelBeg), block(threads);
         const int64_t problems = (int64_t)nframes * (levelEnd - levelBeg);
