@@ -994,11 +994,27 @@ __global__ __launch_bounds__(64) void k_search_by_bow(PgBowBatch B, float nnrati
                 ang[r] = fK[idxF[r]].angle;
             }
         }
+        // The key frame's features of the node, one after the other.  Each needs its index (aFeat), then its descriptor and validity
+        // through that index: two dependent global round trips, ~2 us per feature when they sat inside the iteration -- most of this
+        // kernel's time.  They run two iterations / one iteration ahead instead (all lanes load the same addresses).
+        int idxN = a0 < a1 ? (int)aFeat[a0] : 0, idxN2 = a0 + 1 < a1 ? (int)aFeat[a0 + 1] : 0;
+        uint4 nq0 = make_uint4(0, 0, 0, 0), nq1 = nq0;
+        uint8_t nvalid = 0;
+        if (a0 < a1) {
+            nq0 = reinterpret_cast<const uint4*>(kfDesc + (int64_t)idxN * 32)[0]; nq1 = reinterpret_cast<const uint4*>(kfDesc + (int64_t)idxN * 32)[1];
+            nvalid = kfValid[idxN];
+        }
         for (int ia = a0; ia < a1; ia++) {
-            const int realIdxKF = __builtin_amdgcn_readfirstlane((int)aFeat[ia]);
-            if (!kfValid[realIdxKF]) continue;                            // !pMP || pMP->isBad() (:208-213)
-            const uint4 q0 = reinterpret_cast<const uint4*>(kfDesc + (int64_t)realIdxKF * 32)[0];
-            const uint4 q1 = reinterpret_cast<const uint4*>(kfDesc + (int64_t)realIdxKF * 32)[1];
+            const int realIdxKF = __builtin_amdgcn_readfirstlane(idxN);
+            const uint4 q0 = nq0, q1 = nq1;
+            const bool valid = nvalid != 0;
+            idxN = idxN2;
+            idxN2 = ia + 2 < a1 ? (int)aFeat[ia + 2] : 0;
+            if (ia + 1 < a1) {
+                nq0 = reinterpret_cast<const uint4*>(kfDesc + (int64_t)idxN * 32)[0]; nq1 = reinterpret_cast<const uint4*>(kfDesc + (int64_t)idxN * 32)[1];
+                nvalid = kfValid[idxN];
+            }
+            if (!valid) continue;                                         // !pMP || pMP->isBad() (:208-213)
             unsigned b1key = 0xFFFFFFFFu, b2key = 0xFFFFFFFFu;
             if (inRegs) {
 #pragma unroll
