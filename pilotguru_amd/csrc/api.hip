@@ -503,6 +503,9 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
         const size_t ob = 64 + (((size_t)B * 4 + 63) & ~(size_t)63) + (((size_t)B * selTotal * sizeof(pgorb_keypoint) + 63) & ~(size_t)63) + (size_t)B * selTotal * 32 + 64;
         if ((rc = ensure(c, c->outBlk, ob))) return rc;
         PG_HIP(c, hipMemset(c->outBlk.p, 0, 64));
+        // the memset runs on the null stream and may return before it has executed; the host-frame calls launch on a private
+        // NON-BLOCKING stream (no implicit order with stream 0), so make it land before anything can write a status
+        PG_HIP(c, hipStreamSynchronize(nullptr));
     }
     P.status = (int32_t*)c->outBlk.p;
     c->planW = w; c->planH = h; c->planBatch = B; c->planValid = true;
@@ -923,10 +926,9 @@ int pgorb_extract_batch(pgorb_ctx* c, const uint8_t* const* gray, int nframes, i
     const bool stage = frameBytes * nframes <= ((size_t)64 << 20) && !c->noStage;
     if (stage) {
         if (c->pinInBytes < frameBytes * nframes) {
-            if (c->pinIn) (void)hipHostFree(c->pinIn);
-    if (c->hg.exec) (void)hipGraphExecDestroy(c->hg.exec);
-    if (c->hg.g) (void)hipGraphDestroy(c->hg.g);
-    if (c->sHost) { (void)hipStreamSynchronize(c->sHost); (void)hipStreamDestroy(c->sHost); }
+            // an earlier call's chunk uploads out of the old buffer are complete (every call ends synchronised), but a caller
+            // that got an error return in between may have left copies queued: drain before the pages go away
+            if (c->pinIn) { (void)hipStreamSynchronize(hs); (void)hipHostFree(c->pinIn); }
             c->pinIn = nullptr; c->pinInBytes = 0;
             const size_t want = (frameBytes * std::min(nframes > 1 ? c->prm.max_batch : 1, (int)(((size_t)64 << 20) / frameBytes + 1)) + 4095) & ~(size_t)4095;
             PG_HIP(c, hipHostMalloc((void**)&c->pinIn, std::max(want, frameBytes * nframes), hipHostMallocDefault));

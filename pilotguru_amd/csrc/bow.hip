@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <fstream>
 #include <map>
+#include <new>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -281,8 +282,8 @@ int pgorb_vocab_from_blob(const void* blob, int64_t nbytes, pgorb_vocab** out)
     return 0;
 }
 
-// ORBVocabulary(text file) with a binary cache beside the text: `<path>.pgvoc` = 32-byte header (magic, version, the text
-// file's size and modification time in ns, the blob's length) + the flat blob.  A cache that matches the text file is
+// ORBVocabulary(text file) with a binary cache beside the text: `<path>.pgvoc` = 32-byte header (magic -- its last character is
+// the format version --, the text file's size and modification time in ns, the blob's length) + the flat blob.  A cache that matches the text file is
 // loaded instead of parsing 145 MB of decimals (1.2 s for ORBvoc.txt; the blob is 67 MB); anything else -- no cache, stale,
 // truncated, malformed -- parses the text and rewrites the cache (temp file + rename; failures to write are ignored).
 // *from_cache (may be NULL) tells which way it went.
@@ -295,16 +296,21 @@ int pgorb_vocab_load_cached(const char* path, pgorb_vocab** out, int* from_cache
     if (stat(path, &st) != 0) return PGORB_E_ARG;
     const int64_t srcSize = (int64_t)st.st_size, srcMtime = (int64_t)st.st_mtim.tv_sec * 1000000000ll + st.st_mtim.tv_nsec;
     const std::string cpath = std::string(path) + ".pgvoc";
-    const int64_t MAGIC = 0x31434F5647504750ll;                  // "PGPGVOC1"
+    const int64_t MAGIC = 0x32434F5647504750ll;                  // "PGPGVOC2": the trailing digit is the cache format's version word
     if (FILE* fp = fopen(cpath.c_str(), "rb")) {
         int64_t hdr[4] = {0, 0, 0, 0};
-        if (fread(hdr, 8, 4, fp) == 4 && hdr[0] == MAGIC && hdr[1] == srcSize && hdr[2] == srcMtime && hdr[3] > 64 && hdr[3] < ((int64_t)1 << 40)) {
-            std::vector<uint8_t> blob((size_t)hdr[3]);
-            if (fread(blob.data(), 1, blob.size(), fp) == blob.size() && pgorb_vocab_from_blob(blob.data(), (int64_t)blob.size(), out) == 0) {
-                fclose(fp);
-                if (from_cache) *from_cache = 1;
-                return 0;
-            }
+        struct stat cst;
+        // the blob length is bounded by what the cache file actually holds (a corrupt or hostile header must not size an allocation)
+        if (fstat(fileno(fp), &cst) == 0 && fread(hdr, 8, 4, fp) == 4 && hdr[0] == MAGIC && hdr[1] == srcSize && hdr[2] == srcMtime &&
+            hdr[3] > 64 && hdr[3] <= (int64_t)cst.st_size - 32) {
+            try {
+                std::vector<uint8_t> blob((size_t)hdr[3]);
+                if (fread(blob.data(), 1, blob.size(), fp) == blob.size() && pgorb_vocab_from_blob(blob.data(), (int64_t)blob.size(), out) == 0) {
+                    fclose(fp);
+                    if (from_cache) *from_cache = 1;
+                    return 0;
+                }
+            } catch (const std::bad_alloc&) { *out = nullptr; }   // no exception crosses the C ABI: fall back to the text parse
         }
         fclose(fp);
     }

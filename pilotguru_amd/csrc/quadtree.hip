@@ -996,10 +996,12 @@ void pg_launch_quadtree_levels(const PgPlan& P, int nframes, int levelBeg, int l
         nodes[big] = max(nodes[big], 2 * ((P.lvl[l].w - 2 * PG_EDGE) + (P.lvl[l].h - 2 * PG_EDGE)));
         if (!big) nodes[0] = max(nodes[0], P.lvl[l].nodeCap * 28);
     }
-    static size_t configuredDev[64][2] = {{0, 0}};            // (the attribute is per device)
+    // ONE running maximum per device for all eight instantiations: the attribute is set on every k_quadtree<B, W> at once, so a
+    // per-class record would let the class with the smaller need LOWER the limit the other class had just raised
+    static size_t configuredDev[64] = {0};                    // (the attribute is per device)
     int dev = 0;
     (void)hipGetDevice(&dev);
-    size_t* configured = configuredDev[dev & 63];
+    size_t& configured = configuredDev[dev & 63];
     // Two launches or one?  (PgPlan::qtSplit: 0 = one, 1 = two, 2 = by this rule.)  Measured on an MI355X, K3 per step, one launch /
     // two launches (tools/experiments/r4_split_grid.sh, profiles/r04_k3_split_grid.txt): 1080p x 1 frame 45 / 40 us, x 16 47 / 46, x 32
     // 52 / 56, x 128 100 / 129; 2160p x 1 99 / 52, x 8 100 / 61, x 32 107 / 107, x 64 139 / 184; 640x480 and 720p: one launch wins at
@@ -1049,11 +1051,11 @@ void pg_launch_quadtree_levels(const PgPlan& P, int nframes, int levelBeg, int l
         if (P.qtWide && threads == 512 && ldsAll > 54 * 1024) wide = 1;
         if (P.qtWide && threads == 512 && ldsAll > 40 * 1024 && ldsAll <= 54 * 1024) wide = 3;        // three workgroups per CU: six waves per SIMD, 80 VGPRs
         if (P.qtWide && threads == QT_TMAX && (ldsAll > 80 * 1024 || problems <= 256)) wide = 2;
-        if (lds > configured[big]) {
+        if (lds > configured) {
 #define PG_QT_ATTR(B, W) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree<B, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
             PG_QT_ATTR(true, 0); PG_QT_ATTR(true, 1); PG_QT_ATTR(true, 2); PG_QT_ATTR(true, 3); PG_QT_ATTR(false, 0); PG_QT_ATTR(false, 1); PG_QT_ATTR(false, 2); PG_QT_ATTR(false, 3);
 #undef PG_QT_ATTR
-            configured[big] = lds;
+            configured = lds;
         }
 #define PG_QT_LAUNCH(B, W) hipLaunchKernelGGL((k_quadtree<B, W>), grid, block, lds, s, P, levelBeg, nodes[big], split ? 1 : 0)
         if (big) { if (wide == 1) PG_QT_LAUNCH(true, 1); else if (wide == 2) PG_QT_LAUNCH(true, 2); else if (wide == 3) PG_QT_LAUNCH(true, 3); else PG_QT_LAUNCH(true, 0); }

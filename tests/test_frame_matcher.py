@@ -277,6 +277,34 @@ def test_log_contract_and_predict_scale(oracle):
     assert oracle.predict_scale(1.0, 0.0, lf, 8) == 0                     # ratio = inf: (int)ceil(inf) is INT_MIN on x86-64 -> 0
 
 
+def test_predict_scale_under_the_log_contract_equals_glibc_at_the_level_boundaries(oracle):
+    """`ceil(log(ratio) / mfLogScaleFactor)` (src/MapPoint.cc:524, Frame.cc:188) sits ON an integer whenever the
+    ratio is a power of the scale factor, so a 1-ulp difference between the contract's log and the platform's logf could move
+    a whole pyramid level.  Checked where it matters: ratios scaleFactor^k (the float products the reference's own tables
+    hold, k = 0..8) and every float within 300 ulps of them, for six scale factors -- the level under the contract
+    (orc_log_f == pgorb_log_f, bit-equal per the test above) equals the level glibc's logf gives in float arithmetic,
+    32 454 ratios, no mismatch.  (Away from the boundaries a 1-ulp change of the logarithm cannot cross an integer.)"""
+    import ctypes as C
+    libm = C.CDLL("libm.so.6"); libm.logf.restype = C.c_float; libm.logf.argtypes = [C.c_float]
+    total, mismatches = 0, []
+    for sfv in (1.2, 1.1, 1.3, 1.5, 2.0, 1.05):
+        sf = np.float32(sfv)
+        lf_c, lf_g = oracle.log_f(sf), np.float32(libm.logf(float(sf)))
+        assert np.float32(lf_c) == lf_g
+        r = np.float32(1.0)
+        for k in range(9):
+            for d in range(-300, 301):
+                x = (np.array([r]).view(np.int32) + d).view(np.float32)[0]
+                got = oracle.predict_scale(float(x), 1.0, lf_c, 8)
+                q = np.float32(np.float32(libm.logf(float(x))) / lf_g)
+                want = min(max(int(np.ceil(q)), 0), 7)
+                total += 1
+                if got != want:
+                    mismatches.append((sfv, k, d, got, want))
+            r = np.float32(r * sf)
+    assert total == 6 * 9 * 601 and mismatches == []
+
+
 def test_oracle_search_by_projection_keyframe_consistency(oracle):
     ride, fr = _frames(oracle, nf=1200)
     (k1, d1), (k2, d2) = fr

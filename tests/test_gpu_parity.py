@@ -873,3 +873,24 @@ def test_level_groups_beside_each_other_are_bit_exact(oracle, mask):
             okp, odesc = want[f]
             assert nh[f] == len(okp) and kps[f, :nh[f]].cpu().numpy().tobytes() == okp.tobytes()
             assert np.array_equal(desc[f, :nh[f]].cpu().numpy(), odesc)
+
+
+def test_extract_through_the_staged_upload_twice(oracle, monkeypatch):
+    """PGORB_EXTRACT_STAGE=1 (the A/B form of the host-frame upload: page-locked staging buffer in chunks) grew its
+    buffer with three stray teardown lines that destroyed the stream and the graph in use.  Two frames of one size (the second
+    call replays the captured graph), then a larger batch through the same context (the staging buffer grows while the stream
+    and the graph exist), then the first frame again: every result equals the oracle."""
+    monkeypatch.setenv("PGORB_EXTRACT_STAGE", "1")
+    w, h, nf = 640, 480, 1000
+    ride = synth_ride(2, w, h, 4)
+    ora = oracle.OrbOracle(nf, 1.2, 8, 20, 7)
+    want = [ora.extract(f) for f in ride]
+    ext = _make(nf, w, h, batch=4)
+    for i in (0, 1, 1):
+        kp, desc = ext(ride[i])
+        assert kp.tobytes() == want[i][0].tobytes() and np.array_equal(desc, want[i][1])
+    res = ext.extract_batch(list(ride))
+    for (kp, desc), (okp, odesc) in zip(res, want):
+        assert kp.tobytes() == okp.tobytes() and np.array_equal(desc, odesc)
+    kp, desc = ext(ride[0])
+    assert kp.tobytes() == want[0][0].tobytes() and np.array_equal(desc, want[0][1])
