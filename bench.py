@@ -290,8 +290,12 @@ def self_launch(n):
 
 
 def timed_steps(step, steps, dist, dev, sync):
-    """The contract's timed region: barrier + device sync on both sides of exactly `steps` steps.  Returns
-    (max-over-ranks seconds, [every rank's own seconds])."""
+    """The contract's timed region: barrier + device sync on both sides of exactly `steps` steps.  Every rank reads its
+    clock after its own device sync and BEFORE the closing barrier: the figure `value` is built on is the MAXIMUM over the
+    ranks of that interval -- the time of the slowest rank's K steps, which is what the job waits for -- and does not
+    contain the closing barrier's own latency (an RCCL barrier is 0.3-1 ms against a 28-ms window: 1-4 % of a scaling
+    efficiency that would not be kernel time).  The barrier-inclusive interval is reported beside it.
+    Returns (max-over-ranks seconds, [every rank's own seconds], max-over-ranks barrier-inclusive seconds)."""
     if dist is not None:
         dist.barrier()
     sync()
@@ -302,15 +306,16 @@ def timed_steps(step, steps, dist, dev, sync):
     t_own = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
+    t_incl = time.perf_counter() - t0
     if dist is None:
-        return elapsed, [elapsed]
+        return t_own, [t_own], t_incl
     import torch
     from pilotguru_amd import dist as pgd
     mine = torch.tensor([t_own], dtype=torch.float64, device=dev)
     allt = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
     dist.all_gather(allt, mine)
-    return pgd.max_over_ranks(elapsed, dev), [float(t.item()) for t in allt]
+    per_rank = [float(t.item()) for t in allt]
+    return max(per_rank), per_rank, pgd.max_over_ranks(t_incl, dev)
 
 
 def scaling_fields(world, frames_per_rank, elapsed, per_rank_s, n1_fps):
@@ -342,7 +347,7 @@ def launcher_test_rank(args):
     sigs = [torch.empty_like(sig) for _ in range(world)]
     dist.all_gather(sigs, sig)
     assert all(torch.equal(sigs[0], x) for x in sigs)
-    elapsed, per_rank = timed_steps(lambda: time.sleep(0.002 * (1 + rank)), args.steps, dist, dev, lambda: None)
+    elapsed, per_rank, elapsed_incl = timed_steps(lambda: time.sleep(0.002 * (1 + rank)), args.steps, dist, dev, lambda: None)
     if rank == 0:
         out = {"metric": "LAUNCHER TEST (no GPU work)", "value": world * args.batch * args.steps / elapsed, "unit": "frames/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -427,39 +432,24 @@ def main():
             torch.empty((max(B - 1, 1), cap), dtype=torch.int16, device=dev),
             torch.empty((max(B - 1, 1), cap), dtype=torch.int16, device=dev))
 
-    # the one collective of this path: broadcast the (synthetic) ORB vocabulary root -> peers
-    vocab_bytes, vocab_bcast_s = 0, None
+    # the one collective of this path: the ORB vocabulary, parsed ONCE by rank 0 from its text file, broadcast root -> peers
+    # through the C ABI (pgorb_comm_create_rank + pgorb_vocab_broadcast: librccl's ncclBroadcast straight into every context's
+    # vocabulary arena; torch.distributed only hands the 128-byte RCCL id round).  Reference: one ORBVocabulary shared by
+    # pointer, src/optical_trajectories.cc:87-94.
+    vocab_bytes, vocab_bcast_s, voc, voc_path, voc_comm = 0, None, None, None, None
     if dist is not None:
         from pilotguru_amd import dist as pgd
-        from pilotguru_amd.vocab import pack_vocabulary, synth_vocabulary_fast
-        # the size of the real ORBvoc.txt (k = 10, L = 6: 1 111 111 nodes, 66.7 MB as a blob); the file itself
-        # needs network access (fetch-vocabulary.sh:5)
-        blob = torch.from_numpy(pack_vocabulary(10, 6, *synth_vocabulary_fast(10, 6, seed=7)).copy()) if rank == 0 else None
-        torch.cuda.synchronize()
-        tb0 = time.perf_counter()
-        vocab = pgd.broadcast_vocabulary(blob, 0, dev)
-        torch.cuda.synchronize()
-        vocab_bcast_s = time.perf_counter() - tb0
-        vocab_bytes = int(vocab.numel())
-        # every rank makes the received blob resident in its context and transforms the same
-        # probe descriptors; the word ids must agree across ranks (config 4's criterion)
-        import ctypes as C
-        ext._check(ext._L.pgorb_vocab_upload_device(ext._h, C.c_void_p(vocab.data_ptr()), vocab.numel(),
-                                                    C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
-        g = torch.Generator().manual_seed(1234)
-        probe = torch.randint(0, 256, (2048, 32), generator=g, dtype=torch.uint8).to(dev)
-        pw = torch.empty(2048, dtype=torch.int32, device=dev)
-        pwt = torch.empty(2048, dtype=torch.float64, device=dev)
-        pn = torch.empty(2048, dtype=torch.int32, device=dev)
-        ext._check(ext._L.pgorb_bow_transform_device(
-            ext._h, C.c_void_p(probe.data_ptr()), 2048, 4, C.c_void_p(pw.data_ptr()), C.c_void_p(pwt.data_ptr()),
-            C.c_void_p(pn.data_ptr()), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
-        sig = torch.stack([pw.to(torch.int64).sum(), (pw.to(torch.int64) * torch.arange(2048, device=dev)).sum(),
-                           pn.to(torch.int64).sum()])
-        sigs = [torch.empty_like(sig) for _ in range(world)]
-        dist.all_gather(sigs, sig)
-        if not all(torch.equal(sigs[0], x) for x in sigs):
-            raise SystemExit("BoW words differ across ranks after the vocabulary broadcast")
+        from pilotguru_amd import vocab as V
+        if rank == 0:
+            # the size of the real ORBvoc.txt (k = 10, L = 6: 1 111 111 nodes, 146 MB of text, 66.7 MB as a blob); the file
+            # itself needs network access (fetch-vocabulary.sh:5)
+            import tempfile
+            voc_path = os.path.join(tempfile.mkdtemp(prefix="pgorb_voc_"), "orbvoc_like.txt")
+            V.write_vocabulary_text_fast(voc_path, 10, 6, *V.synth_vocabulary_fast(10, 6, seed=7))
+            voc = V.ORBVocabulary(text_file=voc_path)
+            vocab_bytes = int(voc.blob().nbytes)
+        voc_comm = pgd.VocabularyComm.from_torch_group(ext)
+        vocab_bcast_s = voc_comm.broadcast(voc, 0)
 
     def step():
         ext.extract_batch_device(frames, kps, desc, n)
@@ -473,7 +463,7 @@ def main():
     counts = n.cpu().numpy()
 
     ext.profile_begin(args.steps)
-    elapsed, per_rank_s = timed_steps(step, args.steps, dist, dev, torch.cuda.synchronize)
+    elapsed, per_rank_s, elapsed_incl = timed_steps(step, args.steps, dist, dev, torch.cuda.synchronize)
     ncalls, stage_ms = ext.profile_read()
     ext.check_async()
 
@@ -481,6 +471,33 @@ def main():
     verified = None
     if not args.no_verify and rank == 0:
         verified = verify_against_oracle(ride, kps, desc, n, mout, NF)
+
+    # config 4's criterion: every rank's BoW words -- of ITS OWN ride's first frame, through the
+    # vocabulary that reached it by the broadcast -- equal the CPU oracle's on rank 0 (words, weights and nodes themselves)
+    bow_verified = None
+    if dist is not None:
+        import ctypes as C
+        n0 = int(n[0].item())
+        pw = torch.empty(n0, dtype=torch.int32, device=dev)
+        pwt = torch.empty(n0, dtype=torch.float64, device=dev)
+        pn = torch.empty(n0, dtype=torch.int32, device=dev)
+        d0 = desc[0, :n0].contiguous()
+        ext._check(ext._L.pgorb_bow_transform_device(
+            ext._h, C.c_void_p(d0.data_ptr()), n0, 4, C.c_void_p(pw.data_ptr()), C.c_void_p(pwt.data_ptr()),
+            C.c_void_p(pn.data_ptr()), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        torch.cuda.synchronize()
+        mine = (d0.cpu().numpy(), pw.cpu().numpy(), pwt.cpu().numpy(), pn.cpu().numpy())
+        parts = [None] * world
+        dist.all_gather_object(parts, mine)
+        if rank == 0 and not args.no_verify:
+            from oracle import orb_oracle
+            ora_voc = orb_oracle.VocabOracle(voc_path)
+            for r, (dr, wr, wtr, nr) in enumerate(parts):
+                ow, owt, on = ora_voc.transform_features(dr, 4)
+                if not (np.array_equal(wr.view(np.uint32), ow) and wtr.tobytes() == owt.tobytes() and np.array_equal(nr.view(np.uint32), on)):
+                    raise SystemExit("bench verification FAILED: rank %d's BoW words differ from the oracle after the vocabulary broadcast" % r)
+            bow_verified = True
+        voc_comm.close()
 
     # sustained rate: the same step for >= --sustain-seconds (clocks and power settle; the 20-step region
     # above is only tens of milliseconds)
@@ -603,6 +620,8 @@ def main():
                        "scene": args.scene, "width": W, "height": H, "features": NF,
                        "batch": B, "keypoints_per_frame": nkp, "parallelism": "frames-sharded x%d" % world,
                        "vocab_broadcast_bytes": vocab_bytes, "vocab_broadcast_s": vocab_bcast_s,
+                       "vocab_broadcast": None if dist is None else "pgorb_vocab_broadcast (C ABI, librccl ncclBroadcast; text parsed once on rank 0)",
+                       "bow_words_equal_oracle_on_every_rank": bow_verified,
                        "matcher": matcher, "matcher_popcount_ms_per_step": popcount_ms},
             "roofline": {"bound": "hbm", "kernel": kname,
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -623,6 +642,9 @@ def main():
             "verified": verified,
         }
         out.update(scaling_fields(world, B * args.steps, elapsed, per_rank_s, args.n1_fps))
+        # `value` is built on the slowest rank's own K steps (clock read after its device sync); the same interval with the
+        # closing barrier inside, for the record
+        out["barrier_inclusive_seconds"] = elapsed_incl
         if sustained is not None:
             out["sustained_fps"] = sustained["fps"]
             out["sustained"] = sustained

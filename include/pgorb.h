@@ -365,6 +365,31 @@ void pgorb_vocab_free(pgorb_vocab* v);
  * receive buffer of the broadcast: D2D copy on `hip_stream`). */
 int  pgorb_vocab_upload(pgorb_ctx* ctx, const pgorb_vocab* v);
 int  pgorb_vocab_upload_device(pgorb_ctx* ctx, const void* d_blob, int64_t nbytes, void* hip_stream);
+/* ---- The vocabulary on every GPU of the node: ONE RCCL broadcast over xGMI --------------------------------------------
+ * Reference: the single process loads the vocabulary once and shares it with every System by pointer
+ * (src/optical_trajectories.cc:87-94, thirdparty/orb-slam2/src/ORBVocabulary.cc:7-9).  With one extractor context per
+ * GPU the pointer share becomes one ncclBroadcast of the flat blob, issued from librccl directly (csrc/comm.hip; the
+ * library is opened on first use).  It is the only collective of the path: frames / rides are sharded, nothing else
+ * is exchanged.
+ *   pgorb_comm_create_local   ONE process, one host thread per device (optical_trajectories --devices=0,1,...): the
+ *                             group's ranks are the DISTINCT devices of ctxs[0..nctx) (ncclCommInitAll); contexts
+ *                             that share a device share its rank and receive by a device-to-device copy.
+ *   pgorb_comm_unique_id /    one PROCESS per GPU (bench.py under torch.distributed.run): rank 0 makes the 128-byte
+ *   pgorb_comm_create_rank    id, the launcher's control plane hands it to the other ranks, each calls create_rank
+ *                             (ncclCommInitRank; collective over the ranks).
+ *   pgorb_vocab_broadcast     local form: `root` indexes ctxs, `v` = the parsed vocabulary.  Rank form: `root` is a
+ *                             rank, `v` is read on that rank only (NULL elsewhere; the byte count travels first).
+ *                             The receive buffer is the context's own vocabulary arena; every receiver validates
+ *                             the blob's structure on its device before the vocabulary counts as resident.
+ *                             *seconds (may be NULL): wall time of the collective alone. */
+#define PGORB_COMM_ID_BYTES 128
+typedef struct pgorb_comm pgorb_comm;
+int  pgorb_comm_unique_id(void* id /*[PGORB_COMM_ID_BYTES]*/);
+int  pgorb_comm_create_local(pgorb_ctx* const* ctxs, int nctx, pgorb_comm** out);
+int  pgorb_comm_create_rank(pgorb_ctx* ctx, int rank, int nranks, const void* id, pgorb_comm** out);
+int  pgorb_comm_ranks(const pgorb_comm* comm);
+int  pgorb_vocab_broadcast(pgorb_comm* comm, int root, const pgorb_vocab* v, double* seconds);
+void pgorb_comm_destroy(pgorb_comm* comm);
 /* Per-feature word id, word weight and the ancestor node at level L - levelsup (0 = root).
  * Host buffers / device buffers + stream. */
 int  pgorb_bow_transform(pgorb_ctx* ctx, const uint8_t* desc, int n, int levelsup,

@@ -664,6 +664,24 @@ int pg_ctx_pinned(pgorb_ctx* c, size_t bytes, void** p)
     *p = c->pinned;
     return 0;
 }
+void pg_ctx_vocab_drop(pgorb_ctx* c);
+// header checks of a vocabulary blob of `nbytes` bytes (bow.hip, blob layout): magic, version, and that the sections the
+// header implies fit; the structure itself is checked by pgorb_vocab_from_blob / the loader on the host path and by
+// k_vocab_validate on the device path
+static int vocab_header_ok(pgorb_ctx* c, const int32_t* hdr, size_t nbytes)
+{
+    if (hdr[0] != 0x43564750 || hdr[1] != 1 || hdr[4] < 2)
+        return fail(c, PGORB_E_ARG, "not a pgorb vocabulary blob");
+    const size_t n = (size_t)hdr[4];
+    auto pad = [](size_t v) { return (v + 63) / 64 * 64; };
+    size_t need = 64;
+    need = pad(need + n * 32); need = pad(need + n * 8);
+    for (int k = 0; k < 4; k++) need = pad(need + n * 4);
+    need = pad(need + (n - 1) * 4);
+    if (nbytes < need)
+        return fail(c, PGORB_E_ARG, "vocabulary blob truncated: %zu bytes, header implies %zu", nbytes, need);
+    return 0;
+}
 int pg_ctx_vocab_store(pgorb_ctx* c, const void* src, size_t nbytes, bool src_on_device, hipStream_t s)
 {
     PG_HIP(c, hipSetDevice(c->prm.device));
@@ -672,24 +690,33 @@ int pg_ctx_vocab_store(pgorb_ctx* c, const void* src, size_t nbytes, bool src_on
         PG_HIP(c, hipMemcpyAsync(hdr, src, 64, hipMemcpyDeviceToHost, s));
         PG_HIP(c, hipStreamSynchronize(s));
     } else memcpy(hdr, src, 64);
-    if (hdr[0] != 0x43564750 || hdr[1] != 1 || hdr[4] < 2)
-        return fail(c, PGORB_E_ARG, "not a pgorb vocabulary blob");
-    {
-        // the sections the header implies must fit (bow.hip, blob layout); the structure itself is checked by
-        // pgorb_vocab_from_blob / the loader on the host path and by k_vocab_validate on the device path
-        const size_t n = (size_t)hdr[4];
-        auto pad = [](size_t v) { return (v + 63) / 64 * 64; };
-        size_t need = 64;
-        need = pad(need + n * 32); need = pad(need + n * 8);
-        for (int k = 0; k < 4; k++) need = pad(need + n * 4);
-        need = pad(need + (n - 1) * 4);
-        if (nbytes < need)
-            return fail(c, PGORB_E_ARG, "vocabulary blob truncated: %zu bytes, header implies %zu", nbytes, need);
-    }
-    int rc = ensure(c, c->vocab, nbytes);
+    int rc = vocab_header_ok(c, hdr, nbytes);
     if (rc) return rc;
+    if ((rc = ensure(c, c->vocab, nbytes))) return rc;
     if (src_on_device) PG_HIP(c, hipMemcpyAsync(c->vocab.p, src, nbytes, hipMemcpyDeviceToDevice, s));
     else PG_HIP(c, hipMemcpy(c->vocab.p, src, nbytes, hipMemcpyHostToDevice));
+    c->vocabK = hdr[2]; c->vocabL = hdr[3]; c->vocabNodes = hdr[4];
+    return 0;
+}
+// The receive side of the vocabulary broadcast (comm.hip): room for `nbytes` in the context's vocabulary arena (the collective
+// writes there directly, no second copy), then -- once the bytes have landed on stream `s` -- the header checks and the fields.
+int pg_ctx_vocab_reserve(pgorb_ctx* c, size_t nbytes, void** p)
+{
+    PG_HIP(c, hipSetDevice(c->prm.device));
+    pg_ctx_vocab_drop(c);
+    int rc = ensure(c, c->vocab, nbytes);
+    if (rc) return rc;
+    *p = c->vocab.p;
+    return 0;
+}
+int pg_ctx_vocab_commit(pgorb_ctx* c, size_t nbytes, hipStream_t s)
+{
+    PG_HIP(c, hipSetDevice(c->prm.device));
+    int32_t hdr[16];
+    PG_HIP(c, hipMemcpyAsync(hdr, c->vocab.p, 64, hipMemcpyDeviceToHost, s));
+    PG_HIP(c, hipStreamSynchronize(s));
+    int rc = vocab_header_ok(c, hdr, nbytes);
+    if (rc) return rc;
     c->vocabK = hdr[2]; c->vocabL = hdr[3]; c->vocabNodes = hdr[4];
     return 0;
 }

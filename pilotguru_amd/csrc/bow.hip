@@ -348,27 +348,34 @@ int pgorb_vocab_upload(pgorb_ctx* c, const pgorb_vocab* v)
     return pg_ctx_vocab_store(c, v->blob.data(), v->blob.size(), false, 0);
 }
 
-int pgorb_vocab_upload_device(pgorb_ctx* c, const void* d_blob, int64_t nbytes, void* stream)
+// A blob that arrives on the device (a broadcast) never passed view_blob's structural checks on this rank: the same
+// checks as a kernel, so that a corrupt blob is an error code here and not a fault inside k_bow_transform
+int pg_vocab_validate_resident(pgorb_ctx* c, hipStream_t stream)
 {
-    if (!c || !d_blob || nbytes < 64) return PGORB_E_ARG;
-    int rc = pg_ctx_vocab_store(c, d_blob, (size_t)nbytes, true, (hipStream_t)stream);
-    if (rc) return rc;
-    // A blob that arrives on the device (a broadcast) never passed view_blob's structural checks on this rank:
-    // the same checks as a kernel, so that a corrupt blob is an error code here and not a fault inside k_bow_transform
     const uint8_t* blob; int k, L, nn;
-    if ((rc = pg_ctx_vocab_get(c, &blob, &k, &L, &nn))) return rc;
+    int rc = pg_ctx_vocab_get(c, &blob, &k, &L, &nn);
+    if (rc) return rc;
+    if (hipSetDevice(pg_ctx_device(c)) != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "hipSetDevice failed");
     void* flag;
     if ((rc = pg_ctx_stage(c, 2, 64, &flag))) return rc;
-    if (hipMemsetAsync(flag, 0, 4, (hipStream_t)stream) != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "hipMemsetAsync failed");
-    hipLaunchKernelGGL(k_vocab_validate, dim3((nn + 255) / 256), dim3(256), 0, (hipStream_t)stream, blob, nn, (int*)flag);
+    if (hipMemsetAsync(flag, 0, 4, stream) != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "hipMemsetAsync failed");
+    hipLaunchKernelGGL(k_vocab_validate, dim3((nn + 255) / 256), dim3(256), 0, stream, blob, nn, (int*)flag);
     int bad = 0;
-    if (hipMemcpyAsync(&bad, flag, 4, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
-        hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "vocabulary validation failed to run");
+    if (hipMemcpyAsync(&bad, flag, 4, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        hipStreamSynchronize(stream) != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "vocabulary validation failed to run");
     if (bad) {
         pg_ctx_vocab_drop(c);
         return pg_ctx_fail(c, PGORB_E_ARG, "vocabulary blob is structurally invalid (child ranges / ids out of bounds)");
     }
     return 0;
+}
+
+int pgorb_vocab_upload_device(pgorb_ctx* c, const void* d_blob, int64_t nbytes, void* stream)
+{
+    if (!c || !d_blob || nbytes < 64) return PGORB_E_ARG;
+    int rc = pg_ctx_vocab_store(c, d_blob, (size_t)nbytes, true, (hipStream_t)stream);
+    if (rc) return rc;
+    return pg_vocab_validate_resident(c, (hipStream_t)stream);
 }
 
 int pgorb_bow_transform_device(pgorb_ctx* c, const uint8_t* d_desc, int n, int levelsup, uint32_t* d_word,

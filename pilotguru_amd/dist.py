@@ -4,7 +4,10 @@ The reference is a single process.  Extraction of a frame 
 other frame, so the path shards by independent units: ride r -> rank r (config 4) with no
 data-path collective.  The only exchange is the start-up broadcast of the ORB vocabulary the
 reference loads once and shares by pointer (src/optical_trajectories.cc:87-94): root -> peers
-with torch.distributed (backend "nccl" == RCCL over xGMI on ROCm; "gloo" in CPU tests).
+through the C ABI (pgorb_comm_* / pgorb_vocab_broadcast, csrc/comm.hip: librccl's ncclBroadcast called directly, the
+receive buffer is the context's vocabulary arena).  torch.distributed is the CONTROL plane only: it starts the ranks,
+hands the 128-byte RCCL id round, and carries the barrier / max-over-ranks of the timing (gloo in the CPU tests).
+`broadcast_vocabulary` (a torch.distributed broadcast of the blob) stays for the CPU tests of the sharding logic.
 """
 import os
 
@@ -37,6 +40,71 @@ def broadcast_vocabulary(blob, root, device):
         t = torch.empty(int(n.item()), dtype=torch.uint8, device=device)
     dist.broadcast(t, root)
     return t
+
+
+class VocabularyComm:
+    """pgorb_comm: the group the vocabulary is broadcast over (include/pgorb.h).
+
+    local(extractors)          ONE process, a context per entry (contexts that share a device share a rank): the CLI's
+                               --devices form, and the one-box test of BASELINE config 4;
+    from_torch_group(ext)      one process per GPU under torch.distributed: rank 0 makes the RCCL id, the default process
+                               group hands it round (128 bytes), every rank joins with ncclCommInitRank."""
+
+    def __init__(self, handle, extractors):
+        from . import _lib
+        self._L = _lib.lib()
+        self._h = handle
+        self._ext = list(extractors)
+
+    @classmethod
+    def local(cls, extractors):
+        import ctypes as C
+        from . import _lib
+        L = _lib.lib()
+        arr = (C.c_void_p * len(extractors))(*[e._h for e in extractors])
+        h = C.c_void_p()
+        extractors[0]._check(L.pgorb_comm_create_local(arr, len(extractors), C.byref(h)))
+        return cls(h, extractors)
+
+    @classmethod
+    def from_torch_group(cls, extractor):
+        import ctypes as C
+        import torch
+        import torch.distributed as dist
+        from . import _lib
+        L = _lib.lib()
+        rank, world = dist.get_rank(), dist.get_world_size()
+        ident = (C.c_uint8 * 128)()
+        if rank == 0 and L.pgorb_comm_unique_id(ident) != 0:
+            raise RuntimeError("pgorb_comm_unique_id failed (librccl not loadable?)")
+        box = [bytes(ident)]
+        dist.broadcast_object_list(box, src=0)                     # control plane: 128 bytes
+        ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
+        h = C.c_void_p()
+        extractor._check(L.pgorb_comm_create_rank(extractor._h, rank, world, ident, C.byref(h)))
+        return cls(h, [extractor])
+
+    def ranks(self):
+        return self._L.pgorb_comm_ranks(self._h)
+
+    def broadcast(self, vocabulary, root=0):
+        """ORBVocabulary -> every member context (one ncclBroadcast).  `vocabulary` may be None on non-root ranks of the
+        per-process form.  Returns the seconds the collective itself took."""
+        import ctypes as C
+        sec = C.c_double(0.0)
+        rc = self._L.pgorb_vocab_broadcast(self._h, root, vocabulary._h if vocabulary is not None else None, C.byref(sec))
+        self._ext[0]._check(rc)
+        if vocabulary is not None:
+            vocabulary._ctx = self._ext[0]
+        return sec.value
+
+    def close(self):
+        if self._h:
+            self._L.pgorb_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
 
 
 def max_over_ranks(seconds, device):

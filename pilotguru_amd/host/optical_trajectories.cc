@@ -14,6 +14,10 @@
 // and --poses_in=<poses.txt> runs the whole tail of TrackImageSequence on poses from any back end
 // (src/slam/track_image_sequence.cc:63-109: heading smoothing, PCA plane, eigenvalue gate,
 // projected directions, turn angles, trajectory-<segment_id>.json).
+// --devices=a,b,...: one ride over several GPUs from ONE process: one host thread per device, the
+// vocabulary parsed once and broadcast with one RCCL collective behind the C ABI (pgorb_comm_create_local + pgorb_vocab_broadcast;
+// the reference shares one ORBVocabulary by pointer, src/optical_trajectories.cc:87-94), shard r of the frames on the r-th device,
+// the report merged in rank order: frontend-0.json and the --dump_features file equal the single-device run's byte for byte.
 // --shard=rank/world (with --device): one ride over several processes, one per GPU -- SURVEY.md section 8(e): contiguous
 // chunks of frames with a one-frame overlap, nothing exchanged; process `rank` writes frontend-<rank>.json (and its
 // --dump_features file) for the frames it owns, the same rule as pilotguru_amd/dist.py frame_chunk_for_rank.
@@ -30,6 +34,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <map>
 #include <sstream>
 #include <string>
@@ -56,6 +61,7 @@ struct Flags {
     int device = 0, batch = 64, max_frames = -1, segment_id = 0, rotation = 0;
     int copy_threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));     // slot filling and the per-frame BoW maps
     int shard_rank = 0, shard_world = 1;          // --shard=rank/world: this process takes its chunk of the ride
+    std::vector<int> devices;                     // --devices=a,b,...: one process, one host thread per device, shard r on device r of the list
 };
 
 [[noreturn]] void check_failed(const char* what)
@@ -96,8 +102,19 @@ bool parse_flags(int argc, char** argv, Flags& F)
             if (sscanf(val.c_str(), "%d/%d", &F.shard_rank, &F.shard_world) != 2 || F.shard_world < 1 || F.shard_rank < 0 ||
                 F.shard_rank >= F.shard_world) { fprintf(stderr, "ERROR: --shard wants rank/world with 0 <= rank < world\n"); return false; }
         }
+        else if (name == "devices") {
+            F.devices.clear();
+            std::stringstream ss(val); std::string tok;
+            while (std::getline(ss, tok, ',')) {
+                char* e = nullptr; const long d = strtol(tok.c_str(), &e, 10);
+                if (tok.empty() || *e || d < 0 || d > 1023) { fprintf(stderr, "ERROR: --devices wants a comma-separated list of device ordinals\n"); return false; }
+                F.devices.push_back((int)d);
+            }
+            if (F.devices.empty()) { fprintf(stderr, "ERROR: --devices wants at least one device\n"); return false; }
+        }
         else { fprintf(stderr, "ERROR: unknown command line flag '%s'\n", name.c_str()); return false; }
     }
+    if (!F.devices.empty() && F.shard_world > 1) { fprintf(stderr, "ERROR: --devices (one process, every shard) and --shard (one process per shard) exclude each other\n"); return false; }
     return true;
 }
 
@@ -318,6 +335,195 @@ int write_trajectory_from_poses(const Flags& F)
     return EXIT_SUCCESS;
 }
 
+// Extractor parameters of the ride (underscore keys of this fork, Tracking.cc:131-135; defaults as written by calibrate.cc:518-532)
+struct RideParams {
+    int nFeatures = 2000, nLevels = 8, iniTh = 20, minTh = 7, camW = 0, camH = 0, rgb = 0;
+    float scaleFactor = 1.2f;
+    double fps = 30.0;
+};
+
+// One shard of the ride on one device: the whole single-device run is the shard 0 / 1.  With --shard=r/N the process runs
+// shard r; with --devices=a,b,... the process runs every shard, one host thread per device.
+// Frames [firstExtracted, stop) are read, frames from firstOwned on are reported (the frame before firstOwned is extracted
+// only as the predecessor of the first owned match) -- the same rule as pilotguru_amd/dist.py frame_chunk_for_rank.
+struct Shard {
+    const Flags& F;
+    const RideParams& R;
+    int device, rank, world;
+    FrameSource src;
+    pgorb::ORBextractor* ext = nullptr;
+    pgorb_stream* st = nullptr;
+    std::string devError;
+    double tCtx = 0, tStream = 0;
+    long firstOwned = 0, maxFrames = -1, total = 0;
+    std::vector<uint8_t> frame0;                              // the first frame tells the size
+    long long t0 = 0, id0 = 0;
+    bool frame0Read = false, haveSize = false;
+    int upW = 0, upH = 0;                                     // the upright frame the extractor sees
+    std::string frames;                                       // the "frames" entries of the report, comma separated
+    std::string dumpBuf;                                      // --dump_features records when several shards share one file
+    FILE* dump = nullptr;                                     //   ... or the file itself (one shard)
+    double loopSec = 0;
+
+    Shard(const Flags& f, const RideParams& r, int dev, int rk, int wd) : F(f), R(r), device(dev), rank(rk), world(wd) {}
+
+    void open_source()
+    {
+        if (!src.open(F.in_video, R.camW, R.camH, R.fps))
+            check_failed("input video opens (y4m, PGM pattern or .gray + Camera_width/Camera_height)");
+        maxFrames = F.max_frames;
+        if (world > 1) {
+            long nframes = src.count();
+            if (F.max_frames >= 0) nframes = std::min<long>(nframes, F.max_frames);
+            const long per = nframes / world, extra = nframes % world;
+            const long first = rank * per + std::min<long>(rank, extra), stop = first + per + (rank < extra ? 1 : 0);
+            const long firstExtracted = stop > first ? std::max<long>(first - 1, 0) : first;
+            firstOwned = first;
+            if (!src.skip(firstExtracted)) check_failed("input video holds the frames of this shard");
+            maxFrames = stop - firstExtracted;
+        }
+        // (a printf pattern of PGM / PPM files only knows its frame size once the first file is read: read it first then)
+        if (src.w <= 0 || src.h <= 0) {
+            if (!((maxFrames < 0 || maxFrames > 0) && src.next(frame0, &t0, &id0))) frame0.clear();
+            frame0Read = true;
+        }
+        const bool swapSides = F.rotation == 90 || F.rotation == 270;        // the reader's rotation swaps the sides
+        upW = swapSides ? src.h : src.w; upH = swapSides ? src.w : src.h;
+        haveSize = src.w > 0 && src.h > 0;                    // (false: an empty pattern source / an empty shard of one -- nothing to extract)
+    }
+
+    // HIP runtime start, the context's arenas, the stream's page-locked slots (beside the vocabulary load)
+    void create_device(const std::function<double()>& since)
+    {
+        if (!haveSize) return;
+        const int B = std::max(1, F.batch), DEPTH = 3;
+        try { ext = new pgorb::ORBextractor(R.nFeatures, R.scaleFactor, R.nLevels, R.iniTh, R.minTh, upW, upH, B, device); }
+        catch (const std::exception& e) { devError = e.what(); return; }
+        tCtx = since();
+        if (pgorb_max_keypoints(ext->context(), upW, upH) < 0) { devError = "frame size usable for the ORB cell grid"; return; }
+        // frames as read; rotation, flips and the grey conversion on the device (Camera_RGB: 1 = RGB, 0 = BGR; Tracking.cc:247-260).
+        // A settings file without the key means BGR: `int nRGB = fSettings["Camera_RGB"]` reads 0 from an empty cv::FileNode (Tracking.cc:102)
+        if (pgorb_stream_create_ingest(ext->context(), src.w, src.h, src.channels, R.rgb != 0, F.rotation,
+                                       F.vertical_flip, F.horizontal_flip, B, DEPTH, &st) != PGORB_OK) { devError = pgorb_last_error(ext->context()); return; }
+        tStream = since();
+    }
+
+    // The frame loop of TrackImageSequence (src/slam/track_image_sequence.cc:43-52) as a stream of batches
+    // (include/pgorb.h, pgorb_stream_*): the source writes every frame straight into a page-locked slot; upload,
+    // kernels and result download of up to DEPTH batches overlap.  The per-frame work of the tracking thread --
+    // Frame::ComputeBoW's transform and MonocularInitialization's SearchForInitialization(previous, current) -- runs on
+    // the device for the whole batch as the stream's front-end stage (pgorb_stream_frontend); the host only folds the
+    // per-feature words into BowVector / FeatureVector and writes the report.  The vocabulary is resident in the context.
+    void run(int vs, int vwt, int copyThreads)
+    {
+        const int B = std::max(1, F.batch), DEPTH = 3;
+        if (!frame0Read && !((maxFrames < 0 || maxFrames > 0) && src.next(frame0, &t0, &id0))) frame0.clear();
+        if (ext) {
+            // Frame::ComputeImageBounds without distortion: [0, cols] x [0, rows] (Frame.cc:462-466); ORBmatcher(0.9, true)
+            // .SearchForInitialization(mInitialFrame, mCurrentFrame, mvbPrevMatched, mvIniMatches, 100) (Tracking.cc:596-597);
+            // transform(..., 4) (Frame.cc:404)
+            if (pgorb_stream_frontend(st, 0.f, (float)upW, 0.f, (float)upH, 100, 0.9f, 1, 4) != PGORB_OK) check_failed(pgorb_last_error(ext->context()));
+        }
+        const size_t fbytes = src.frame_bytes();
+        std::vector<std::vector<long long>> tusS(DEPTH, std::vector<long long>(B)), idsS(DEPTH, std::vector<long long>(B));
+        std::ostringstream js;
+        long read = 0; bool first = true, firstOfRide = true;
+        int submitted = 0, collected = 0; bool more = !frame0.empty();
+        const auto loopStart = std::chrono::steady_clock::now();
+        std::vector<int> nbowB, nfvB;
+        while (more || collected < submitted) {
+            // keep DEPTH batches in flight: fill and submit the next slot while there are frames
+            while (more && submitted - collected < DEPTH) {
+                const int slot = submitted % DEPTH;
+                uint8_t* in = pgorb_stream_input(st, slot);
+                int nb = 0;
+                std::vector<uint8_t> tmp;
+                // a mapped file's frames are copied into the page-locked slot by several threads at once (one thread moves
+                // ~6-9 GB/s out of the page cache: 3 000 grey / 1 400 RGB24 1080p frames per second, a third of the link)
+                std::vector<std::pair<const uint8_t*, uint8_t*>> copies;
+                while (nb < B && (maxFrames < 0 || read < maxFrames)) {
+                    if (read == 0) { memcpy(in, frame0.data(), fbytes); tusS[slot][0] = t0; idsS[slot][0] = id0; }
+                    else if (src.map) {
+                        if (!src.next(tmp, &tusS[slot][nb], &idsS[slot][nb], nullptr, false)) { more = false; break; }
+                        copies.emplace_back(src.lastPtr, in + (size_t)nb * fbytes);
+                    } else {
+                        if (!src.next(tmp, &tusS[slot][nb], &idsS[slot][nb], in + (size_t)nb * fbytes)) { more = false; break; }
+                    }
+                    nb++; read++;
+                }
+                if (!copies.empty()) {
+                    const int nthreads = (int)std::min<size_t>(copies.size(), (size_t)std::max(1, copyThreads));
+                    std::vector<std::thread> pool;
+                    for (int t = 1; t < nthreads; t++)
+                        pool.emplace_back([&, t] { for (size_t k = t; k < copies.size(); k += nthreads) memcpy(copies[k].second, copies[k].first, fbytes); });
+                    for (size_t k = 0; k < copies.size(); k += nthreads) memcpy(copies[k].second, copies[k].first, fbytes);
+                    for (auto& th : pool) th.join();
+                }
+                if (maxFrames >= 0 && read >= maxFrames) more = false;
+                if (!nb) break;
+                if (pgorb_stream_submit(st, slot, nb) != PGORB_OK) check_failed(pgorb_last_error(ext->context()));
+                submitted++;
+            }
+            if (collected >= submitted) break;
+            const int slot = collected % DEPTH;
+            const int32_t* n = nullptr; const pgorb_keypoint* kps = nullptr; const uint8_t* desc = nullptr; int cap = 0;
+            const int nb = pgorb_stream_wait(st, slot, &n, &kps, &desc, nullptr, nullptr, nullptr, &cap);
+            if (nb < 0) check_failed(pgorb_last_error(ext->context()));
+            const int32_t* nmatch = nullptr; const uint32_t *word = nullptr, *node = nullptr; const double* wt = nullptr;
+            if (pgorb_stream_frontend_results(st, slot, nullptr, &nmatch, &word, &wt, &node) != PGORB_OK) check_failed(pgorb_last_error(ext->context()));
+            collected++;
+            const std::vector<long long>&tus = tusS[slot], &ids = idsS[slot];
+            // Frame::ComputeBoW: BowVector / FeatureVector of transform(descriptors, ..., 4)  (Frame.cc:399-406): the per-feature words
+            // come from the device, the two ordered maps are built on the host -- ~0.1 ms per frame, so the frames of a batch are
+            // shared out over the copy threads (one thread held the whole loop to ~5 000 frames/s)
+            nbowB.assign(nb, 0); nfvB.assign(nb, 0);
+            {
+                const int nthreads = std::max(1, std::min(nb, copyThreads));
+                auto work = [&](int t) {
+                    std::vector<uint32_t> bid, fnode, ffeat; std::vector<double> bval; std::vector<int32_t> fstart;
+                    for (int i = t; i < nb; i += nthreads) {
+                        if (ids[i] < firstOwned || !n[i]) continue;
+                        const size_t o = (size_t)i * cap;
+                        bid.resize(n[i] + 1); bval.resize(n[i] + 1); fnode.resize(n[i] + 1); ffeat.resize(n[i] + 1); fstart.resize(n[i] + 2);
+                        pgorb_bow_vectors(n[i], word + o, wt + o, node + o, vs, vwt, bid.data(), bval.data(), &nbowB[i],
+                                          fnode.data(), fstart.data(), ffeat.data(), &nfvB[i]);
+                    }
+                };
+                std::vector<std::thread> pool;
+                for (int t = 1; t < nthreads; t++) pool.emplace_back(work, t);
+                work(0);
+                for (auto& th : pool) th.join();
+            }
+            for (int i = 0; i < nb; i++) {
+                const bool hadPrev = !firstOfRide;
+                firstOfRide = false;
+                if (ids[i] < firstOwned) continue;               // the overlap frame of a shard: only a predecessor
+                const size_t o = (size_t)i * cap;
+                const int nbow = nbowB[i], nfv = nfvB[i];
+                const int nmatches = hadPrev ? nmatch[i] : -1;   // MonocularInitialization's matcher call (Tracking.cc:596-597)
+                js << (first ? "" : ",\n") << "    {\"frame_id\": " << ids[i] << ", \"time_usec\": " << tus[i] << ", \"n_keypoints\": " << n[i]
+                   << ", \"n_bow_words\": " << nbow << ", \"n_feature_nodes\": " << nfv << ", \"n_matches_prev\": " << nmatches << "}";
+                first = false;
+                if (dump || !F.dump_features.empty()) {
+                    const int32_t hdr[2] = {(int32_t)ids[i], n[i]};
+                    if (dump) {
+                        fwrite(hdr, 4, 2, dump);
+                        fwrite(kps + o, sizeof(pgorb_keypoint), n[i], dump);
+                        fwrite(desc + o * 32, 32, n[i], dump);
+                    } else {
+                        dumpBuf.append((const char*)hdr, 8);
+                        dumpBuf.append((const char*)(kps + o), sizeof(pgorb_keypoint) * (size_t)n[i]);
+                        dumpBuf.append((const char*)(desc + o * 32), (size_t)32 * n[i]);
+                    }
+                }
+            }
+            for (int i = 0; i < nb; i++) total += ids[i] >= firstOwned;      // (a shard's overlap frame is not one of its frames)
+        }
+        frames = js.str();
+        loopSec = std::chrono::duration<double>(std::chrono::steady_clock::now() - loopStart).count();
+    }
+};
+
 }  // namespace
 
 int main(int argc, char** argv)
@@ -332,205 +538,109 @@ int main(int argc, char** argv)
 
     std::map<std::string, double> S = read_settings(F.camera_settings);
     auto get = [&](const char* k, double d) { return S.count(k) ? S[k] : d; };
-    // underscore keys of this fork (Tracking.cc:131-135); defaults as written by calibrate.cc:518-532
+    RideParams R;
     // mpIniORBextractor: 2 * nFeatures while the tracker is NOT_INITIALIZED / NO_IMAGES_YET (Tracking.cc:137-143, :262-264) --
     // the frames MonocularInitialization runs SearchForInitialization on (:596-597)
-    const int nFeatures = (int)get("ORBextractor_nFeatures", 2000) * (F.init_extractor ? 2 : 1), nLevels = (int)get("ORBextractor_nLevels", 8);
-    const float scaleFactor = (float)get("ORBextractor_scaleFactor", 1.2);
-    const int iniTh = (int)get("ORBextractor_iniThFAST", 20), minTh = (int)get("ORBextractor_minThFAST", 7);
-
-    FrameSource src;
-    if (!src.open(F.in_video, (int)get("Camera_width", 0), (int)get("Camera_height", 0), get("Camera_fps", 30.0)))
-        check_failed("input video opens (y4m, PGM pattern or .gray + Camera_width/Camera_height)");
+    R.nFeatures = (int)get("ORBextractor_nFeatures", 2000) * (F.init_extractor ? 2 : 1); R.nLevels = (int)get("ORBextractor_nLevels", 8);
+    R.scaleFactor = (float)get("ORBextractor_scaleFactor", 1.2);
+    R.iniTh = (int)get("ORBextractor_iniThFAST", 20); R.minTh = (int)get("ORBextractor_minThFAST", 7);
+    R.camW = (int)get("Camera_width", 0); R.camH = (int)get("Camera_height", 0); R.fps = get("Camera_fps", 30.0);
+    R.rgb = (int)get("Camera_RGB", 0);
 
     // Start-up (round 4): creating the device context -- HIP runtime start, the context's arenas, the stream's page-locked slots --
-    // was 0.45 s of a 0.56-s run on a 2 048-frame clip, one thing after the other.  Now a second thread creates context and stream
-    // while this one loads the vocabulary (from its binary cache beside the text file when there is one) and reads the first frame.
+    // was 0.45 s of a 0.56-s run on a 2 048-frame clip, one thing after the other.  Now a second thread (one per device) creates
+    // context and stream while this one loads the vocabulary (from its binary cache beside the text file when there is one).
     const auto tStart = std::chrono::steady_clock::now();
-    auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count(); };
+    std::function<double()> since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count(); };
     const bool timing = getenv("PGORB_CLI_TIMING") != nullptr;
     auto epoch = [] { return std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count(); };
     if (timing) fprintf(stderr, "main entered at epoch %.6f\n", epoch());
-    const int B = std::max(1, F.batch), DEPTH = 3;
-    // the upright frame the extractor sees (the reader's rotation swaps the sides for 90 / 270)
-    const bool swapSides = F.rotation == 90 || F.rotation == 270;
-    pgorb::ORBextractor* ext = nullptr;
-    pgorb_stream* st = nullptr;
-    std::string devError;
-    double tCtx = 0, tStream = 0;
-    // --shard: frames [firstExtracted, stop) are read, frames from firstOwned on are reported (the frame before
-    // firstOwned is extracted only as the predecessor of the first owned match)
-    long firstOwned = 0;
-    if (F.shard_world > 1) {
-        long nframes = src.count();
-        if (F.max_frames >= 0) nframes = std::min<long>(nframes, F.max_frames);
-        const long per = nframes / F.shard_world, extra = nframes % F.shard_world;
-        const long first = F.shard_rank * per + std::min<long>(F.shard_rank, extra), stop = first + per + (F.shard_rank < extra ? 1 : 0);
-        const long firstExtracted = stop > first ? std::max<long>(first - 1, 0) : first;
-        firstOwned = first;
-        if (!src.skip(firstExtracted)) check_failed("input video holds the frames of this shard");
-        F.max_frames = (int)(stop - firstExtracted);
-    }
-    // (a printf pattern of PGM / PPM files only knows its frame size once the first file is read: read it first then)
-    std::vector<uint8_t> frame0;                              // the first frame tells the size
-    long long t0 = 0, id0 = 0;
-    bool frame0Read = false;
-    if (src.w <= 0 || src.h <= 0) {
-        if (!((F.max_frames < 0 || F.max_frames > 0) && src.next(frame0, &t0, &id0))) frame0.clear();
-        frame0Read = true;
-    }
-    const int upW2 = swapSides ? src.h : src.w, upH2 = swapSides ? src.w : src.h;
-    const bool haveSize = src.w > 0 && src.h > 0;            // (false: an empty pattern source / an empty shard of one -- nothing to extract)
-    std::thread devThread([&] {
-        if (!haveSize) return;
-        try { ext = new pgorb::ORBextractor(nFeatures, scaleFactor, nLevels, iniTh, minTh, upW2, upH2, B, F.device); }
-        catch (const std::exception& e) { devError = e.what(); return; }
-        tCtx = since();
-        if (pgorb_max_keypoints(ext->context(), upW2, upH2) < 0) { devError = "frame size usable for the ORB cell grid"; return; }
-        // frames as read; rotation, flips and the grey conversion on the device (Camera_RGB: 1 = RGB, 0 = BGR; Tracking.cc:247-260).
-        // A settings file without the key means BGR: `int nRGB = fSettings["Camera_RGB"]` reads 0 from an empty cv::FileNode (Tracking.cc:102)
-        if (pgorb_stream_create_ingest(ext->context(), src.w, src.h, src.channels, (int)get("Camera_RGB", 0) != 0, F.rotation,
-                                       F.vertical_flip, F.horizontal_flip, B, DEPTH, &st) != PGORB_OK) { devError = pgorb_last_error(ext->context()); return; }
-        tStream = since();
-    });
+
+    // --devices=a,b,...: ONE process, one host thread per listed device, shard r of the ride on device r of the list; the
+    // vocabulary is parsed ONCE and reaches every device with one RCCL broadcast (pgorb_vocab_broadcast); the shards' entries
+    // are merged in rank order, so frontend-0.json and the --dump_features file equal the single-device run's byte for byte.
+    // --shard=r/N (one process per GPU, started by a launcher): this process is shard r and writes frontend-<r>.json.
+    const bool multi = !F.devices.empty();
+    std::vector<Shard*> shards;
+    if (multi) for (size_t r = 0; r < F.devices.size(); r++) shards.push_back(new Shard(F, R, F.devices[r], (int)r, (int)F.devices.size()));
+    else shards.push_back(new Shard(F, R, F.device, F.shard_rank, F.shard_world));
+    for (Shard* sh : shards) sh->open_source();
+    std::vector<std::thread> devThreads;
+    for (Shard* sh : shards) devThreads.emplace_back([sh, &since] { sh->create_device(since); });
 
     pgorb_vocab* voc = nullptr;
     int vocFromCache = 0;
     if ((F.vocabulary_cache ? pgorb_vocab_load_cached(F.vocabulary_file.c_str(), &voc, &vocFromCache)
                             : pgorb_vocab_load_text(F.vocabulary_file.c_str(), &voc)) != PGORB_OK) {           // ORBVocabulary.cc:8 CHECK
-        devThread.join();
+        for (auto& t : devThreads) t.join();
         check_failed("vocabulary loads (ORB vocabulary text file)");
     }
     int vk, vL, vn, vw, vs, vwt; pgorb_vocab_info(voc, &vk, &vL, &vn, &vw, &vs, &vwt);
     const double tVoc = since();
+    for (auto& t : devThreads) t.join();
+    for (Shard* sh : shards) if (!sh->devError.empty()) check_failed(sh->devError.c_str());
 
-    // The frame loop of TrackImageSequence (src/slam/track_image_sequence.cc:43-52) as a stream of batches
-    // (include/pgorb.h, pgorb_stream_*): the source writes every frame straight into a page-locked slot; upload,
-    // kernels and result download of up to DEPTH batches overlap.  The per-frame work of the tracking thread --
-    // Frame::ComputeBoW's transform and MonocularInitialization's SearchForInitialization(previous, current) -- runs on
-    // the device for the whole batch as the stream's front-end stage (pgorb_stream_frontend); the host only folds the
-    // per-feature words into BowVector / FeatureVector and writes the report.
-    if (!frame0Read && !((F.max_frames < 0 || F.max_frames > 0) && src.next(frame0, &t0, &id0))) frame0.clear();
-    devThread.join();
-    if (!devError.empty()) check_failed(devError.c_str());
-    if (ext) {
-    if (pgorb_vocab_upload(ext->context(), voc) != PGORB_OK) check_failed("vocabulary upload");
-    // Frame::ComputeImageBounds without distortion: [0, cols] x [0, rows] (Frame.cc:462-466); ORBmatcher(0.9, true)
-    // .SearchForInitialization(mInitialFrame, mCurrentFrame, mvbPrevMatched, mvIniMatches, 100) (Tracking.cc:596-597);
-    // transform(..., 4) (Frame.cc:404)
-    if (pgorb_stream_frontend(st, 0.f, (float)upW2, 0.f, (float)upH2, 100, 0.9f, 1, 4) != PGORB_OK) check_failed(pgorb_last_error(ext->context()));
+    // one vocabulary for every System (src/optical_trajectories.cc:87-94): a plain upload for one context, ONE broadcast for several
+    double tBcast = 0;
+    if (!multi) { if (shards[0]->ext && pgorb_vocab_upload(shards[0]->ext->context(), voc) != PGORB_OK) check_failed("vocabulary upload"); }
+    else {
+        std::vector<pgorb_ctx*> ctxs;
+        for (Shard* sh : shards) if (sh->ext) ctxs.push_back(sh->ext->context());
+        if (!ctxs.empty()) {
+            pgorb_comm* comm = nullptr;
+            if (pgorb_comm_create_local(ctxs.data(), (int)ctxs.size(), &comm) != PGORB_OK) check_failed(pgorb_last_error(ctxs[0]));
+            if (pgorb_vocab_broadcast(comm, 0, voc, &tBcast) != PGORB_OK) check_failed(pgorb_last_error(ctxs[0]));
+            fprintf(stderr, "vocabulary: %d nodes parsed once, broadcast to %d context(s) on %d device(s) over RCCL in %.3f ms\n",
+                    vn, (int)ctxs.size(), pgorb_comm_ranks(comm), tBcast * 1e3);
+            pgorb_comm_destroy(comm);
+        }
     }
     if (timing)
-        fprintf(stderr, "start-up: vocabulary %s at %.3f s, context at %.3f s, stream at %.3f s, front-end stage ready at %.3f s\n",
-                vocFromCache ? "(from its cache)" : "(text parsed)", tVoc, tCtx, tStream, since());
-    const size_t fbytes = src.frame_bytes();
-    std::vector<std::vector<long long>> tusS(DEPTH, std::vector<long long>(B)), idsS(DEPTH, std::vector<long long>(B));
+        fprintf(stderr, "start-up: vocabulary %s at %.3f s, context at %.3f s, stream at %.3f s, vocabulary resident at %.3f s\n",
+                vocFromCache ? "(from its cache)" : "(text parsed)", tVoc, shards[0]->tCtx, shards[0]->tStream, since());
+
+    FILE* dump = F.dump_features.empty() ? nullptr : fopen(F.dump_features.c_str(), "wb");
+    if (!multi) shards[0]->dump = dump;
+    const auto loopStart = std::chrono::steady_clock::now();
+    {
+        // the copy threads (slot filling, the per-frame BoW maps) are shared out over the device threads
+        const int perShard = std::max(1, F.copy_threads / (int)shards.size());
+        std::vector<std::thread> run;
+        for (size_t r = 1; r < shards.size(); r++) run.emplace_back([&, r] { shards[r]->run(vs, vwt, perShard); });
+        shards[0]->run(vs, vwt, perShard);
+        for (auto& t : run) t.join();
+    }
+    long total = 0;
     std::ostringstream js;
     js << "{\n  \"frames\": [";
-    FILE* dump = F.dump_features.empty() ? nullptr : fopen(F.dump_features.c_str(), "wb");
-    long total = 0, read = 0; bool first = true, firstOfRide = true;
-    int submitted = 0, collected = 0; bool more = !frame0.empty();
-    const auto loopStart = std::chrono::steady_clock::now();
-    std::vector<int> nbowB, nfvB;
-    while (more || collected < submitted) {
-        // keep DEPTH batches in flight: fill and submit the next slot while there are frames
-        while (more && submitted - collected < DEPTH) {
-            const int slot = submitted % DEPTH;
-            uint8_t* in = pgorb_stream_input(st, slot);
-            int nb = 0;
-            std::vector<uint8_t> tmp;
-            // a mapped file's frames are copied into the page-locked slot by several threads at once (one thread moves
-            // ~6-9 GB/s out of the page cache: 3 000 grey / 1 400 RGB24 1080p frames per second, a third of the link)
-            std::vector<std::pair<const uint8_t*, uint8_t*>> copies;
-            while (nb < B && (F.max_frames < 0 || read < F.max_frames)) {
-                if (read == 0) { memcpy(in, frame0.data(), fbytes); tusS[slot][0] = t0; idsS[slot][0] = id0; }
-                else if (src.map) {
-                    if (!src.next(tmp, &tusS[slot][nb], &idsS[slot][nb], nullptr, false)) { more = false; break; }
-                    copies.emplace_back(src.lastPtr, in + (size_t)nb * fbytes);
-                } else {
-                    if (!src.next(tmp, &tusS[slot][nb], &idsS[slot][nb], in + (size_t)nb * fbytes)) { more = false; break; }
-                }
-                nb++; read++;
-            }
-            if (!copies.empty()) {
-                const int nthreads = (int)std::min<size_t>(copies.size(), (size_t)std::max(1, F.copy_threads));
-                std::vector<std::thread> pool;
-                for (int t = 1; t < nthreads; t++)
-                    pool.emplace_back([&, t] { for (size_t k = t; k < copies.size(); k += nthreads) memcpy(copies[k].second, copies[k].first, fbytes); });
-                for (size_t k = 0; k < copies.size(); k += nthreads) memcpy(copies[k].second, copies[k].first, fbytes);
-                for (auto& th : pool) th.join();
-            }
-            if (F.max_frames >= 0 && read >= F.max_frames) more = false;
-            if (!nb) break;
-            if (pgorb_stream_submit(st, slot, nb) != PGORB_OK) check_failed(pgorb_last_error(ext->context()));
-            submitted++;
-        }
-        if (collected >= submitted) break;
-        const int slot = collected % DEPTH;
-        const int32_t* n = nullptr; const pgorb_keypoint* kps = nullptr; const uint8_t* desc = nullptr; int cap = 0;
-        const int nb = pgorb_stream_wait(st, slot, &n, &kps, &desc, nullptr, nullptr, nullptr, &cap);
-        if (nb < 0) check_failed(pgorb_last_error(ext->context()));
-        const int32_t* nmatch = nullptr; const uint32_t *word = nullptr, *node = nullptr; const double* wt = nullptr;
-        if (pgorb_stream_frontend_results(st, slot, nullptr, &nmatch, &word, &wt, &node) != PGORB_OK) check_failed(pgorb_last_error(ext->context()));
-        collected++;
-        const std::vector<long long>&tus = tusS[slot], &ids = idsS[slot];
-        // Frame::ComputeBoW: BowVector / FeatureVector of transform(descriptors, ..., 4)  (Frame.cc:399-406): the per-feature words
-        // come from the device, the two ordered maps are built on the host -- ~0.1 ms per frame, so the frames of a batch are
-        // shared out over the copy threads (one thread held the whole loop to ~5 000 frames/s)
-        nbowB.assign(nb, 0); nfvB.assign(nb, 0);
-        {
-            const int nthreads = std::max(1, std::min(nb, F.copy_threads));
-            auto work = [&](int t) {
-                std::vector<uint32_t> bid, fnode, ffeat; std::vector<double> bval; std::vector<int32_t> fstart;
-                for (int i = t; i < nb; i += nthreads) {
-                    if (ids[i] < firstOwned || !n[i]) continue;
-                    const size_t o = (size_t)i * cap;
-                    bid.resize(n[i] + 1); bval.resize(n[i] + 1); fnode.resize(n[i] + 1); ffeat.resize(n[i] + 1); fstart.resize(n[i] + 2);
-                    pgorb_bow_vectors(n[i], word + o, wt + o, node + o, vs, vwt, bid.data(), bval.data(), &nbowB[i],
-                                      fnode.data(), fstart.data(), ffeat.data(), &nfvB[i]);
-                }
-            };
-            std::vector<std::thread> pool;
-            for (int t = 1; t < nthreads; t++) pool.emplace_back(work, t);
-            work(0);
-            for (auto& th : pool) th.join();
-        }
-        for (int i = 0; i < nb; i++) {
-            const bool hadPrev = !firstOfRide;
-            firstOfRide = false;
-            if (ids[i] < firstOwned) continue;               // the overlap frame of a shard: only a predecessor
-            const size_t o = (size_t)i * cap;
-            const int nbow = nbowB[i], nfv = nfvB[i];
-            const int nmatches = hadPrev ? nmatch[i] : -1;   // MonocularInitialization's matcher call (Tracking.cc:596-597)
-            js << (first ? "\n" : ",\n") << "    {\"frame_id\": " << ids[i] << ", \"time_usec\": " << tus[i] << ", \"n_keypoints\": " << n[i]
-               << ", \"n_bow_words\": " << nbow << ", \"n_feature_nodes\": " << nfv << ", \"n_matches_prev\": " << nmatches << "}";
-            first = false;
-            if (dump) {
-                const int32_t hdr[2] = {(int32_t)ids[i], n[i]};
-                fwrite(hdr, 4, 2, dump);
-                fwrite(kps + o, sizeof(pgorb_keypoint), n[i], dump);
-                fwrite(desc + o * 32, 32, n[i], dump);
-            }
-        }
-        for (int i = 0; i < nb; i++) total += ids[i] >= firstOwned;      // (a shard's overlap frame is not one of its frames)
+    bool first = true;
+    for (Shard* sh : shards) {
+        total += sh->total;
+        if (sh->frames.empty()) continue;
+        js << (first ? "\n" : ",\n") << sh->frames;
+        first = false;
+        if (multi && dump) fwrite(sh->dumpBuf.data(), 1, sh->dumpBuf.size(), dump);
     }
-    js << "\n  ],\n  \"orb\": {\"nFeatures\": " << nFeatures << ", \"nLevels\": " << nLevels << ", \"iniThFAST\": " << iniTh
-       << ", \"minThFAST\": " << minTh << "},\n  \"vocabulary\": {\"k\": " << vk << ", \"L\": " << vL << ", \"nodes\": " << vn << ", \"words\": " << vw
+    js << "\n  ],\n  \"orb\": {\"nFeatures\": " << R.nFeatures << ", \"nLevels\": " << R.nLevels << ", \"iniThFAST\": " << R.iniTh
+       << ", \"minThFAST\": " << R.minTh << "},\n  \"vocabulary\": {\"k\": " << vk << ", \"L\": " << vL << ", \"nodes\": " << vn << ", \"words\": " << vw
        << "}\n}";
     if (dump) fclose(dump);
-    const std::string out = (F.out_dir.empty() ? std::string(".") : F.out_dir) + "/frontend-" + std::to_string(F.shard_world > 1 ? F.shard_rank : 0) + ".json";
+    const std::string out = (F.out_dir.empty() ? std::string(".") : F.out_dir) + "/frontend-" + std::to_string(!multi && F.shard_world > 1 ? F.shard_rank : 0) + ".json";
     {
         std::ofstream o(out);
         if (!o.good()) check_failed("out_dir is writable");
         o << js.str() << std::endl;
     }
     const double loopSec = std::chrono::duration<double>(std::chrono::steady_clock::now() - loopStart).count();
-    fprintf(stderr, "optical_trajectories (front-end mode): %ld frames -> %s (frame loop: %.3f s, %.0f frames/s)\n", total, out.c_str(),
-            loopSec, loopSec > 0 ? total / loopSec : 0.0);
+    fprintf(stderr, "optical_trajectories (front-end mode): %ld frames -> %s (frame loop: %.3f s, %.0f frames/s%s)\n", total, out.c_str(),
+            loopSec, loopSec > 0 ? total / loopSec : 0.0, multi ? (", " + std::to_string(shards.size()) + " device threads").c_str() : "");
     if (timing) fprintf(stderr, "report written at %.3f s, epoch %.6f\n", since(), epoch());
     if (getenv("PGORB_CLI_TEARDOWN")) {                       // orderly teardown (leak checkers): unpinning and freeing the arenas takes ~0.2 s
-        if (st) pgorb_stream_destroy(st);
-        delete ext;
+        for (Shard* sh : shards) {
+            if (sh->st) pgorb_stream_destroy(sh->st);
+            delete sh->ext;
+            delete sh;
+        }
         pgorb_vocab_free(voc);
         return EXIT_SUCCESS;
     }

@@ -127,9 +127,11 @@ def test_single_ride_split_over_two_contexts():
 
 
 def test_multi_gpu_code_path_on_one_gpu():
-    """bench.py's N > 1 branch as a one-rank job under torch.distributed.run: init_process_group("nccl")
-    (RCCL), broadcast_vocabulary, pgorb_vocab_upload_device, the BoW transform on every rank and the
-    all_gather of its signature, the barriers and the max-over-ranks timing."""
+    """bench.py's N > 1 branch as a one-rank job under torch.distributed.run: init_process_group("nccl") (RCCL) as the
+    control plane, the ORBvoc-sized vocabulary parsed from text on rank 0 and broadcast through the C ABI
+    (pgorb_comm_unique_id / pgorb_comm_create_rank / pgorb_vocab_broadcast: librccl called directly), the BoW transform
+    of the rank's own first frame gathered to rank 0 and compared with the oracle's words / weights / nodes, the barriers
+    and the max-over-ranks timing (closing barrier outside the interval `value` is built on)."""
     env = dict(os.environ, PGORB_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
            "--master-addr", "127.0.0.1", "--master-port", "29631", os.path.join(ROOT, "bench.py"),
@@ -141,6 +143,8 @@ def test_multi_gpu_code_path_on_one_gpu():
     out = json.loads(line)
     assert out["config"]["vocab_broadcast_bytes"] > 60 << 20         # the ORBvoc-sized blob (k=10, L=6) went through RCCL
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["verified"] is True
+    assert out["config"]["bow_words_equal_oracle_on_every_rank"] is True and out["config"]["vocab_broadcast_s"] > 0
+    assert out["barrier_inclusive_seconds"] >= out["max_rank_seconds"]
 
 
 @pytest.mark.parametrize("w,h,nf,total,batch,depth", [(640, 480, 1000, 23, 8, 3), (1920, 1080, 2000, 20, 8, 2)])

@@ -318,6 +318,18 @@ def test_cli_shard_reproduces_the_unsharded_ride(tmp_path, kind):
         dump += open(os.path.join(od, "feat.bin"), "rb").read()
     assert got == want
     assert dump == open(os.path.join(whole, "feat.bin"), "rb").read()
+    # --devices: the same shards as host threads of ONE process, the vocabulary parsed once and broadcast over RCCL behind
+    # the C ABI (one rank per distinct device; contexts sharing a device copy from the rank's buffer) -- the merged report
+    # and dump ARE the unsharded run's.  "0" = a one-device RCCL group; "0,0,0" = three contexts on the one GPU a test box has
+    for devs, nctx in (("0", 1), ("0,0,0", 3), ("0,0,0,0,0", 5)):
+        od = os.path.join(d, "dev" + str(nctx)); os.mkdir(od)
+        r = _cli(*common, "--out_dir=" + od, "--devices=" + devs, "--dump_features=" + os.path.join(od, "feat.bin"))
+        assert r.returncode == 0, r.stderr
+        assert "parsed once, broadcast to %d context(s) on 1 device(s) over RCCL" % nctx in r.stderr, r.stderr
+        assert open(os.path.join(od, "frontend-0.json")).read() == open(os.path.join(whole, "frontend-0.json")).read()
+        assert open(os.path.join(od, "feat.bin"), "rb").read() == open(os.path.join(whole, "feat.bin"), "rb").read()
+    assert _cli(*common, "--out_dir=" + od, "--devices=0,0", "--shard=0/2").returncode != 0      # one or the other
+    assert _cli(*common, "--out_dir=" + od, "--devices=").returncode != 0
     # more shards than frames: the surplus ranks own nothing and say so
     od = os.path.join(d, "empty"); os.mkdir(od)
     r = _cli(*common, "--out_dir=" + od, "--shard=12/13")
