@@ -263,6 +263,51 @@ def upload_leg(pg, ext, ride, NF, W, H, B, seconds=2.0, depth=3, frontend=False,
                     "three HIP streams (pgorb_stream_*); PCIe-inclusive, not the headline value"}
 
 
+def live_pmc(args, kname):
+    """HBM traffic (and VALU instructions) of kernel `kname`, measured by THIS run: three short child runs of this very
+    command under `rocprofv3 --kernel-trace --pmc <one counter group>` (separate passes, as MI355X_MICROARCH.md's HBM
+    section prescribes: FETCH_SIZE and WRITE_SIZE do not fit one pass), 1 warm-up + 3 steps each, every other leg off.
+    Returns {"fetch_kb", "write_kb", "sq_insts_valu", "seconds"} per launch, or None when rocprofv3 is not usable here
+    (the caller then cites the newest committed profile and says so)."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    t0 = time.perf_counter()
+    base = tempfile.mkdtemp(prefix="pgorb_pmc_")
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--batch", str(args.batch),
+             "--width", str(args.width), "--height", str(args.height), "--features", str(args.features), "--scene", args.scene,
+             "--no-cpu-baseline", "--no-verify", "--sustain-seconds", "0", "--no-upload-leg", "--no-overlap-leg",
+             "--no-single-frame-leg", "--no-traffic-leg"]
+    env = dict(os.environ, TMPDIR="/tmp", PGORB_BENCH_CHILD="1")
+    out = {}
+    try:
+        for tag, group in (("fetch_kb", ["FETCH_SIZE"]), ("write_kb", ["WRITE_SIZE"]), ("sq_insts_valu", ["SQ_INSTS_VALU", "SQ_INSTS_SALU"])):
+            d = os.path.join(base, tag)
+            r = subprocess.run([exe, "--kernel-trace", "--pmc"] + group + ["-d", d, "--"] + child, env=env, cwd="/tmp",
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
+            if r.returncode != 0 or not dbs:
+                return None
+            con = sqlite3.connect(dbs[0])
+            for counter in group:
+                row = con.execute("select avg(value), count(*) from counters_collection where counter_name = ? and kernel_name like ?",
+                                  (counter, "%" + kname + "%")).fetchone()
+                if not row or row[0] is None:
+                    return None
+                out[tag if counter == group[0] else counter.lower()] = float(row[0])
+            con.close()
+    except (OSError, subprocess.SubprocessError, sqlite3.Error):
+        return None
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+    out["seconds"] = time.perf_counter() - t0
+    return out
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -382,6 +427,8 @@ def main():
     ap.add_argument("--no-upload-leg", action="store_true")
     ap.add_argument("--no-single-frame-leg", action="store_true",
                     help="skip the one-frame-per-synchronous-call leg (the reference's call shape, tools/single_frame_bench.py)")
+    ap.add_argument("--no-traffic-leg", action="store_true",
+                    help="do not re-measure roofline.traffic with rocprofv3 PMC child runs after the timed region (cite the newest committed profile instead)")
     ap.add_argument("--n1-fps", type=float, default=None,
                     help="the N = 1 frames/s of the same configuration; adds scaling_efficiency to the line")
     args = ap.parse_args()
@@ -515,43 +562,45 @@ def main():
         ext.check_async()
         sustained = {"fps": ksteps * B / (te - ts), "seconds": te - ts, "steps": ksteps}
 
-    # two batches in flight: a second context on a second HIP stream takes every other batch, so that kernels with
-    # different bottlenecks (K1 HBM, K2 / K4-6 VALU issue, K3 latency, K7 matrix pipe) of neighbouring batches share the
-    # chip.  Same work per batch; reported next to `value`, not as it (the kernels' own durations stretch when they share
-    # the GPU, so `roofline` and the stage times stay those of the one-batch-at-a-time loop above).
+    # two batches in flight INSIDE the library (round 5: pgorb_stream_create_device, one context, two lanes): the caller submits
+    # resident batches without blocking, the stream runs consecutive batches on two sibling working sets and HIP streams, so
+    # that kernels with different bottlenecks (K1 HBM, K2 / K4-6 VALU issue, K3 latency, K7 matrix pipe) of neighbouring
+    # batches share the chip; the match of a batch's first frame against the previous batch's last is chained in submission
+    # order.  Same work per batch plus that one extra pair; reported next to `value`, not as it (the kernels' own durations
+    # stretch when they share the GPU, so `roofline` and the stage times stay those of the one-batch-at-a-time loop above).
     inflight2 = None
     if not args.no_overlap_leg and dist is None and B > 1:
-        ext2 = pg.ORBextractor(NF, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B, device=local_rank)
-        outs2 = (torch.empty_like(kps), torch.empty_like(desc), torch.empty_like(n))
-        mout2 = tuple(torch.empty_like(t) for t in mout)
-        sA, sB = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-
-        def step2(k):
-            if k & 1:
-                ext2.extract_batch_device(frames, *outs2, stream=sB.cuda_stream)
-                ext2.match_batch_device(outs2[1], outs2[2], pq, pt, mout2, stream=sB.cuda_stream)
-            else:
-                ext.extract_batch_device(frames, kps, desc, n, stream=sA.cuda_stream)
-                ext.match_batch_device(desc, n, pq, pt, mout, stream=sA.cuda_stream)
+        st2 = pg.DeviceFrameStream(ext, W, H, B, depth=2, lanes=2)
         torch.cuda.synchronize()
         for k in range(4):
-            step2(k)
+            if k >= 2:
+                st2.wait(k & 1, on_host=False)
+            st2.submit(k & 1, frames)
+        r0, r1 = st2.wait(0), st2.wait(1)
         torch.cuda.synchronize()
         ts = time.perf_counter(); ksteps = 0
+        st2.submit(0, frames); st2.submit(1, frames)
         while time.perf_counter() - ts < 1.5:
             for k in range(40):
-                step2(k)
-            torch.cuda.synchronize()
-            ksteps += 40
+                st2.wait(k & 1, on_host=False)              # (orders the slot's reuse on the caller's stream; the host does not block)
+                st2.submit(k & 1, frames)
+            st2.wait(0); st2.submit(0, frames)                # the host joins the queue once per 40 batches
+            ksteps += 41
+        r0, r1 = st2.wait(0), st2.wait(1)
+        torch.cuda.synchronize()
         te = time.perf_counter()
-        ext.check_async(); ext2.check_async()
+        ksteps += 2
+        ext.check_async()
         nh2 = n.cpu().tolist()
-        same = torch.equal(n, outs2[2]) and all(torch.equal(desc[f, :nh2[f]], outs2[1][f, :nh2[f]]) and
-                                                torch.equal(kps[f, :nh2[f]].view(torch.int32), outs2[0][f, :nh2[f]].view(torch.int32)) for f in range(B))
-        inflight2 = {"fps": ksteps * B / (te - ts), "seconds": te - ts, "steps": ksteps, "contexts": 2, "streams": 2,
-                     "second_context_equal": bool(same),
-                     "note": "two contexts on two HIP streams take alternate batches of the same size; nothing else changes"}
-        del ext2
+        same = all(torch.equal(r[0], n) and all(torch.equal(desc[f, :nh2[f]], r[2][f, :nh2[f]]) and
+                                                 torch.equal(kps[f, :nh2[f]].view(torch.int32), r[1][f, :nh2[f]].view(torch.int32)) and
+                                                 (f == 0 or torch.equal(mout[0][f - 1, :nh2[f]], r[3][f, :nh2[f]])) for f in range(B))
+                   for r in (r0, r1))
+        inflight2 = {"fps": ksteps * B / (te - ts), "seconds": te - ts, "steps": ksteps, "contexts": 1, "lanes": 2,
+                     "every_frame_of_both_in_flight_batches_equals_the_one_batch_loop": bool(same),
+                     "note": "pgorb_stream_create_device / _submit_device: resident batches submitted without blocking, two lanes (sibling "
+                             "working sets on two internal HIP streams) inside ONE context; matches chained across batches"}
+        st2.close()
 
     # the matcher the north star describes (ballot / popcount), timed on the same descriptors
     matcher = ext.matcher_name(cap)
@@ -594,20 +643,34 @@ def main():
         ach = (abytes[rk] * B / launches) / (stage_ms[rk] / launches * 1e-3) / 1e9
         kname = {"pyramid": "k_pyr_resize_rows4_lds", "fast": ext.fast_kernel_name(), "describe": "k_describe",
                  "match": "k_match_mfma"}[rk]
-        traffic, traffic_src, valu_insts = None, None, None   # HBM bytes / VALU instructions per launch from the committed PMC passes
-        try:
-            import glob
-            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):   # newest round first
-                tr = json.load(open(path))
-                if tr["workload"] == {"width": W, "height": H, "features": NF, "batch": B} and kname in tr["kernels"] \
-                        and tr.get("scene", "textured") == args.scene:
-                    k = tr["kernels"][kname]
-                    traffic = (2.0 * k["fetch_kb"] + k["write_kb"]) * 1024.0
-                    traffic_src = "profiles/" + os.path.basename(path)
-                    valu_insts = k.get("sq_insts_valu")
-                    break
-        except (OSError, KeyError, ValueError):
-            pass
+        # HBM bytes / VALU instructions per launch of that kernel: measured by this run (three rocprofv3 PMC child runs of this
+        # command, after the timed region) -- or, when rocprofv3 cannot run here, cited from the newest committed profile
+        traffic, traffic_src, valu_insts, valu_src, traffic_live = None, None, None, None, False
+        if not args.no_traffic_leg and world == 1 and not os.environ.get("PGORB_BENCH_CHILD"):
+            live = live_pmc(args, kname)
+            if live is not None:
+                traffic = (2.0 * live["fetch_kb"] + live["write_kb"]) * 1024.0
+                valu_insts = live.get("sq_insts_valu")
+                traffic_live = True
+                traffic_src = ("measured by this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE child runs of this command "
+                               "(1 + 3 steps each, %.0f s), bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB per launch (gfx950 FETCH_SIZE correction)"
+                               % live["seconds"])
+                valu_src = "SQ_INSTS_VALU of a third child run, per launch"
+        if traffic is None:
+            try:
+                import glob
+                for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):   # newest round first
+                    tr = json.load(open(path))
+                    if tr["workload"] == {"width": W, "height": H, "features": NF, "batch": B} and kname in tr["kernels"] \
+                            and tr.get("scene", "textured") == args.scene:
+                        k = tr["kernels"][kname]
+                        traffic = (2.0 * k["fetch_kb"] + k["write_kb"]) * 1024.0
+                        traffic_src = "CITED, not measured by this run: profiles/" + os.path.basename(path) + " (rocprofv3 PMC passes of this command on an earlier run)"
+                        valu_insts = k.get("sq_insts_valu")
+                        valu_src = "profiles/" + os.path.basename(path) + " (SQ_INSTS_VALU of an earlier profiled run, per launch)"
+                        break
+            except (OSError, KeyError, ValueError):
+                pass
         out = {
             "metric": "frames/sec ORB extract+match, 1080p @ 2000 kp/frame",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -626,14 +689,14 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kname,
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": (traffic_src + " (rocprofv3 PMC passes of this command on an earlier run; "
-                                            "not re-measured by this process)") if traffic_src else None,
+                         "traffic_measured_by_this_run": traffic_live, "traffic_source": traffic_src,
+                         "traffic_over_algorithmic": (traffic / (abytes[rk] * B / launches)) if traffic else None,
                          "algorithmic_bytes_per_launch": abytes[rk] * B / launches,
                          "launch_ms": stage_ms[rk] / launches},
             # the resource that actually binds this path: wave-level VALU instructions of the same kernel
             # against what the chip's 1024 SIMDs can issue at the guide's 2 cycles per wave64 instruction
             "roofline_valu": None if not valu_insts else {
-                "kernel": kname, "insts": valu_insts, "insts_source": traffic_src + " (SQ_INSTS_VALU of an earlier profiled run, per launch)",
+                "kernel": kname, "insts": valu_insts, "insts_source": valu_src,
                 "cycles_per_inst_peak": 2, "simds": 1024, "clock_ghz": 2.4,
                 "min_ms_at_peak": valu_insts * 2 / 1024 / 2.4e9 * 1e3, "launch_ms": stage_ms[rk] / launches,
                 "frac": (valu_insts * 2 / 1024 / 2.4e9 * 1e3) / (stage_ms[rk] / launches)},

@@ -524,6 +524,31 @@ int      pgorb_stream_reset(pgorb_stream* s);                    /* the next bat
 int      pgorb_stream_submit(pgorb_stream* s, int slot, int nframes);
 int      pgorb_stream_wait(pgorb_stream* s, int slot, const int32_t** n, const pgorb_keypoint** kps, const uint8_t** desc,
                            const int32_t** best_idx, const uint16_t** best, const uint16_t** second, int* cap);
+/* The same stream for frames that are ALREADY RESIDENT on the device, with several batches in flight INSIDE the library
+ * (round 5).  The reference's loop hands the extractor one frame after the other (Frame.cc:251-257); a caller with
+ * resident frames submits batch after batch without blocking and the stream runs consecutive batches on `lanes`
+ * (1..depth; 2 is what pays on an MI355X) independent extractor working sets -- lane 0 is the context itself, the others
+ * are private siblings with the same parameters and options -- each on its own internal HIP stream, so that kernels of
+ * neighbouring batches with different bottlenecks share the chip: K1 (HBM) beside K2 / K4-6 (VALU issue), K3 (latency),
+ * K7 (matrix pipe).  Slot k runs on lane k % lanes.  Results are exactly those of the one-batch-at-a-time calls: K1..K6
+ * of a batch depend on nothing outside it; what crosses batches (frame 0's match against the last frame of the
+ * previously SUBMITTED batch, the front-end stage's state) is one section at the end of each batch's queue, chained in
+ * submission order by an event.
+ *   pgorb_stream_submit_device   d_frames: nframes grey planes (row pitch `stride`, `frame_stride` bytes apart), ready
+ *                                where `hip_stream` (the caller's; NULL = the null stream) stands at the call; they
+ *                                must stay valid until the slot's batch is complete (level 0 may alias them).
+ *   pgorb_stream_wait_device     wait_on_host != 0 (or hip_stream NULL): blocks until the slot's batch is complete and
+ *                                checks its status word; otherwise makes `hip_stream` wait for it and returns at once.
+ *                                DEVICE pointers, laid out as pgorb_stream_wait's, valid until the slot is submitted
+ *                                again; with the front-end stage on, pgorb_stream_frontend_results hands out device
+ *                                pointers as well.  Returns the number of frames of the batch. */
+int      pgorb_stream_create_device(pgorb_ctx* ctx, int w, int h, int batch, int depth, int lanes, pgorb_stream** out);
+int      pgorb_stream_submit_device(pgorb_stream* s, int slot, const uint8_t* d_frames, int nframes, int stride,
+                                    int64_t frame_stride, void* hip_stream);
+int      pgorb_stream_wait_device(pgorb_stream* s, int slot, int wait_on_host, void* hip_stream, const int32_t** d_n,
+                                  const pgorb_keypoint** d_kps, const uint8_t** d_desc, const int32_t** d_best_idx,
+                                  const uint16_t** d_best, const uint16_t** d_second, int* cap);
+int      pgorb_stream_lanes(const pgorb_stream* s);
 /* Optional front-end stage of the stream: what the reference's tracking thread does with every fresh Frame, run on
  * the device for the whole batch behind K7 -- Frame::AssignFeaturesToGrid with the given image bounds
  * (src/Frame.cc:234-249), ORBmatcher(nnratio, check_orientation).SearchForInitialization(previous frame, frame,

@@ -1335,6 +1335,17 @@ struct pgorb_stream {
     size_t inBytes = 0;                                       // bytes per input frame
     bool dead = false;                                        // a submit failed half way: the stream only accepts destroy
     hipStream_t sIn = nullptr, sRun = nullptr, sOut = nullptr;
+    // Device-resident form (pgorb_stream_create_device, round 5): frames come from the caller's device memory, results stay
+    // on the device, and consecutive batches run on `lanes` independent extractor working sets (lane 0 = the context itself,
+    // the others private sibling contexts with the same parameters and options), each on its own HIP stream -- two batches
+    // in flight let K1 (HBM), K2 / K4-6 (VALU issue), K3 (latency) and K7 (matrix pipe) of neighbouring batches share the chip.
+    // Slot k runs on lane k % lanes.  What crosses batches -- the previous batch's last frame for the first match, the
+    // front-end stage's state -- is one section per batch at the END of its lane's queue, chained by an event.
+    bool device = false;
+    std::vector<pgorb_ctx*> lane;          // [0] = c
+    std::vector<hipStream_t> sLane;        // [0] = sRun
+    hipEvent_t evChain = nullptr; bool chainArmed = false;
+    int32_t* hStatus = nullptr;            // pinned, one word per slot (device form: the batch's status word)
     struct Slot {
         uint8_t* hIn = nullptr;            // pinned [B][srcH][srcW][ch]
         uint8_t* dIn = nullptr;            // device copy of it
@@ -1356,7 +1367,8 @@ struct pgorb_stream {
     int32_t *dGridStart = nullptr, *dGridIdx = nullptr; float* dPrevMatched = nullptr;     // device scratch, [B+1] frames
 };
 
-static int stream_submit_queue(pgorb_stream* s, pgorb_stream::Slot& sl, int nframes);
+static int stream_submit_queue(pgorb_stream* s, pgorb_stream::Slot& sl, int nframes, int slotIndex = 0, const uint8_t* d_frames = nullptr,
+                               int stride = 0, int64_t frame_stride = 0, hipStream_t caller = nullptr);
 
 // result-block layout for the stream's current settings (kps and desc hold B+1 frames: index 0 = the previous batch's last frame)
 static void stream_layout(pgorb_stream* s)
@@ -1439,6 +1451,60 @@ int pgorb_stream_create_ingest(pgorb_ctx* c, int src_w, int src_h, int channels,
     ok = ok && hipMemcpy(s->dPt, pt.data(), B * 4, hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && ensure(c, c->xdesc, pg_match_scratch_bytes(c->mx, s->cap, batch) + 16) == 0;
     if (!ok) { pgorb_stream_destroy(s); return fail(c, PGORB_E_HIP, "pgorb_stream_create: allocation failed"); }
+    s->lane.assign(1, c); s->sLane.assign(1, s->sRun);
+    c->streams.push_back(s);
+    *out = s;
+    return 0;
+}
+
+// The device-resident form: `lanes` extractor working sets behind one stream object (include/pgorb.h).
+int pgorb_stream_create_device(pgorb_ctx* c, int w, int h, int batch, int depth, int lanes, pgorb_stream** out)
+{
+    if (!c || !out) return PGORB_E_ARG;
+    *out = nullptr;
+    if (batch < 1 || batch > c->prm.max_batch || depth < 2 || depth > 8 || lanes < 1 || lanes > depth || w < 1 || h < 1)
+        return fail(c, PGORB_E_ARG, "pgorb_stream_create_device: batch 1..max_batch, depth 2..8, lanes 1..depth");
+    PG_HIP(c, hipSetDevice(c->prm.device));
+    int rc = make_plan(c, w, h, batch);
+    if (rc) return rc;
+    pgorb_stream* s = new pgorb_stream();
+    s->c = c; s->w = w; s->h = h; s->B = batch; s->depth = depth; s->cap = c->plan.selTotal;
+    s->srcW = w; s->srcH = h; s->ch = 1; s->device = true;
+    s->inBytes = (size_t)w * h;
+    const size_t cap = (size_t)s->cap, B = (size_t)batch;
+    stream_layout(s);
+    s->lane.assign(1, c);
+    bool ok = hipStreamCreateWithFlags(&s->sRun, hipStreamNonBlocking) == hipSuccess;
+    s->sLane.assign(1, s->sRun);
+    for (int l = 1; l < lanes && ok; l++) {
+        // a sibling context: the same extractor (parameters, options), its own pyramid / candidate / selection arenas and plan
+        pgorb_ctx* lc = nullptr;
+        hipStream_t ls = nullptr;
+        ok = pgorb_create(&c->prm, &lc) == PGORB_OK;
+        if (ok) {
+            lc->mx = c->mx; lc->qtThreads = c->qtThreads; lc->qtSplit = c->qtSplit; lc->fastTilePitch = c->fastTilePitch; lc->fastWpb = c->fastWpb;
+            s->lane.push_back(lc);
+            ok = make_plan(lc, w, h, batch) == 0 && hipStreamCreateWithFlags(&ls, hipStreamNonBlocking) == hipSuccess;
+            s->sLane.push_back(ls);
+        }
+    }
+    s->slot.resize(depth);
+    ok = ok && hipHostMalloc((void**)&s->hStatus, 64 * sizeof(int32_t), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&s->evChain, hipEventDisableTiming) == hipSuccess;
+    for (auto& sl : s->slot) {
+        ok = ok && hipMalloc((void**)&sl.dOut, s->outBytes + 256) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&sl.evIn, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&sl.evRun, hipEventDisableTiming) == hipSuccess;
+    }
+    std::vector<int32_t> pq(batch), pt(batch);
+    for (int f = 0; f < batch; f++) { pq[f] = f + 1; pt[f] = f; }
+    ok = ok && hipMalloc((void**)&s->dPq, B * 4) == hipSuccess && hipMalloc((void**)&s->dPt, B * 4) == hipSuccess;
+    ok = ok && hipMalloc((void**)&s->dPrevDesc, cap * 32) == hipSuccess && hipMalloc((void**)&s->dPrevN, 4) == hipSuccess;
+    ok = ok && hipMalloc((void**)&s->dPrevKps, cap * sizeof(pgorb_keypoint)) == hipSuccess;
+    ok = ok && hipMemcpy(s->dPq, pq.data(), B * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(s->dPt, pt.data(), B * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && ensure(c, c->xdesc, pg_match_scratch_bytes(c->mx, s->cap, batch) + 16) == 0;
+    if (!ok) { pgorb_stream_destroy(s); return fail(c, PGORB_E_HIP, "pgorb_stream_create_device: allocation failed"); }
     c->streams.push_back(s);
     *out = s;
     return 0;
@@ -1460,6 +1526,10 @@ void pgorb_stream_destroy(pgorb_stream* s)
     if (s->sIn) (void)hipStreamSynchronize(s->sIn);
     if (s->sRun) (void)hipStreamSynchronize(s->sRun);
     if (s->sOut) (void)hipStreamSynchronize(s->sOut);
+    for (size_t l = 1; l < s->sLane.size(); l++) if (s->sLane[l]) { (void)hipStreamSynchronize(s->sLane[l]); (void)hipStreamDestroy(s->sLane[l]); }
+    for (size_t l = 1; l < s->lane.size(); l++) pgorb_destroy(s->lane[l]);      // the private sibling contexts
+    if (s->evChain) (void)hipEventDestroy(s->evChain);
+    if (s->hStatus) (void)hipHostFree(s->hStatus);
     for (auto& sl : s->slot) {
         if (sl.hIn) (void)hipHostFree(sl.hIn);
         if (sl.dIn) (void)hipFree(sl.dIn);
@@ -1495,12 +1565,15 @@ int pgorb_stream_reset(pgorb_stream* s)                  // a new ride: the next
     return 0;
 }
 
+int pgorb_stream_lanes(const pgorb_stream* s) { return s ? (int)s->lane.size() : PGORB_E_ARG; }
+
 int pgorb_stream_submit(pgorb_stream* s, int slot, int nframes)
 {
     if (!s || slot < 0 || slot >= s->depth) return PGORB_E_ARG;
     pgorb_ctx* c = s->c;
     if (nframes < 1 || nframes > s->B) return fail(c, PGORB_E_ARG, "pgorb_stream_submit: 1..batch frames");
     if (s->dead) return fail(c, PGORB_E_HIP, "pgorb_stream_submit: an earlier submit failed half way; destroy the stream");
+    if (s->device) return fail(c, PGORB_E_ARG, "pgorb_stream_submit: a device-resident stream takes pgorb_stream_submit_device");
     pgorb_stream::Slot& sl = s->slot[slot];
     if (sl.busy) return fail(c, PGORB_E_ARG, "pgorb_stream_submit: slot %d not collected with pgorb_stream_wait", slot);
     PG_HIP(c, hipSetDevice(c->prm.device));
@@ -1518,71 +1591,115 @@ int pgorb_stream_submit(pgorb_stream* s, int slot, int nframes)
     return 0;
 }
 
+int pgorb_stream_submit_device(pgorb_stream* s, int slot, const uint8_t* d_frames, int nframes, int stride, int64_t frame_stride,
+                               void* hip_stream)
+{
+    if (!s || slot < 0 || slot >= s->depth) return PGORB_E_ARG;
+    pgorb_ctx* c = s->c;
+    if (!s->device) return fail(c, PGORB_E_ARG, "pgorb_stream_submit_device: the stream was created for host frames");
+    if (nframes < 1 || nframes > s->B || !d_frames || stride < s->w) return fail(c, PGORB_E_ARG, "pgorb_stream_submit_device: 1..batch frames, stride >= width");
+    if (s->dead) return fail(c, PGORB_E_HIP, "pgorb_stream_submit_device: an earlier submit failed half way; destroy the stream");
+    pgorb_stream::Slot& sl = s->slot[slot];
+    if (sl.busy) return fail(c, PGORB_E_ARG, "pgorb_stream_submit_device: slot %d not collected with pgorb_stream_wait_device", slot);
+    PG_HIP(c, hipSetDevice(c->prm.device));
+    pgorb_ctx* lc = s->lane[slot % (int)s->lane.size()];
+    int rc = make_plan(lc, s->w, s->h, nframes);
+    if (rc) { if (lc != c) c->err = lc->err; return rc; }
+    rc = stream_submit_queue(s, sl, nframes, slot, d_frames, stride, frame_stride, (hipStream_t)hip_stream);
+    if (rc) {
+        for (hipStream_t q : s->sLane) (void)hipStreamSynchronize(q);
+        s->dead = true;
+        return rc;
+    }
+    sl.frames = nframes; sl.busy = true;
+    return 0;
+}
+
 }  // extern "C"
 
-static int stream_submit_queue(pgorb_stream* s, pgorb_stream::Slot& sl, int nframes)
+static int stream_submit_queue(pgorb_stream* s, pgorb_stream::Slot& sl, int nframes, int slotIndex, const uint8_t* d_frames,
+                               int stride, int64_t frame_stride, hipStream_t caller)
 {
-    pgorb_ctx* c = s->c;
+    pgorb_ctx* c = s->c;                                       // errors, the vocabulary and the matchers' scratch live here
+    const int laneIx = s->device ? slotIndex % (int)s->lane.size() : 0;
+    pgorb_ctx* lc = s->lane[laneIx];                           // the extractor working set this batch runs on
+    hipStream_t sr = s->sLane[laneIx];
     int rc;
     const size_t fbytes = s->inBytes, cap = (size_t)s->cap;
-    // copy-in: after the kernels of this slot's previous batch have read its device frames
-    PG_HIP(c, hipStreamWaitEvent(s->sIn, sl.evRun, 0));
-    PG_HIP(c, hipMemcpyAsync(sl.dIn, sl.hIn, fbytes * nframes, hipMemcpyHostToDevice, s->sIn));
-    PG_HIP(c, hipEventRecord(sl.evIn, s->sIn));
-    // compute: after the upload, and after the previous download of this slot's result block
-    PG_HIP(c, hipStreamWaitEvent(s->sRun, sl.evIn, 0));
-    PG_HIP(c, hipStreamWaitEvent(s->sRun, sl.evOut, 0));
+    if (!s->device) {
+        // copy-in: after the kernels of this slot's previous batch have read its device frames
+        PG_HIP(c, hipStreamWaitEvent(s->sIn, sl.evRun, 0));
+        PG_HIP(c, hipMemcpyAsync(sl.dIn, sl.hIn, fbytes * nframes, hipMemcpyHostToDevice, s->sIn));
+        PG_HIP(c, hipEventRecord(sl.evIn, s->sIn));
+        // compute: after the upload, and after the previous download of this slot's result block
+        PG_HIP(c, hipStreamWaitEvent(sr, sl.evIn, 0));
+        PG_HIP(c, hipStreamWaitEvent(sr, sl.evOut, 0));
+    } else {
+        // the caller's frames are ready where the caller's stream stands now
+        PG_HIP(c, hipEventRecord(sl.evIn, caller));
+        PG_HIP(c, hipStreamWaitEvent(sr, sl.evIn, 0));
+    }
     int32_t* dN = (int32_t*)(sl.dOut + s->offN);
     pgorb_keypoint* dK = (pgorb_keypoint*)(sl.dOut + s->offK);
     uint8_t* dD = sl.dOut + s->offD;
-    if (s->havePrev) {
-        PG_HIP(c, hipMemcpyAsync(dD, s->dPrevDesc, cap * 32, hipMemcpyDeviceToDevice, s->sRun));
-        PG_HIP(c, hipMemcpyAsync(dN, s->dPrevN, 4, hipMemcpyDeviceToDevice, s->sRun));
-        if (s->fe) PG_HIP(c, hipMemcpyAsync(dK, s->dPrevKps, cap * sizeof(pgorb_keypoint), hipMemcpyDeviceToDevice, s->sRun));
-    } else {
-        PG_HIP(c, hipMemsetAsync(dN, 0, 4, s->sRun));
-    }
-    if (s->ingest) {
+    // ---- extraction: K1..K6 of this batch alone (nothing here looks at another batch) ----
+    if (s->device) {
+        rc = run_batch(lc, d_frames, false, nframes, s->w, s->h, stride, frame_stride, dK + cap, dD + cap * 32, s->cap, dN + 1, sr);
+        if (rc && lc != c) c->err = lc->err;
+    } else if (s->ingest) {
         // frames as decoded: rotation / flips / cvtColor on the device into level 0 (image_sequence_reader.cc:53-58,186-205;
         // Tracking.cc:247-260), then the extractor on the upright grey planes
         pg_launch_ingest(c->plan, sl.dIn, s->srcW * s->ch, (int64_t)fbytes, s->srcW, s->srcH, s->ch, s->rgbOrder, s->rot,
-                         s->vflip != 0, s->hflip != 0, nframes, s->sRun);
-        rc = run_batch(c, nullptr, true, nframes, s->w, s->h, s->w, 0, dK + cap, dD + cap * 32, s->cap, dN + 1, s->sRun);
+                         s->vflip != 0, s->hflip != 0, nframes, sr);
+        rc = run_batch(c, nullptr, true, nframes, s->w, s->h, s->w, 0, dK + cap, dD + cap * 32, s->cap, dN + 1, sr);
     } else {
-        rc = run_batch(c, sl.dIn, false, nframes, s->w, s->h, s->w, (int64_t)fbytes, dK + cap, dD + cap * 32, s->cap, dN + 1, s->sRun);
+        rc = run_batch(c, sl.dIn, false, nframes, s->w, s->h, s->w, (int64_t)fbytes, dK + cap, dD + cap * 32, s->cap, dN + 1, sr);
     }
     if (rc) return rc;
+    // ---- the section that crosses batches: behind the previous batch's section, whatever lane that ran on ----
+    if (s->chainArmed && s->lane.size() > 1) PG_HIP(c, hipStreamWaitEvent(sr, s->evChain, 0));
+    if (s->havePrev) {
+        PG_HIP(c, hipMemcpyAsync(dD, s->dPrevDesc, cap * 32, hipMemcpyDeviceToDevice, sr));
+        PG_HIP(c, hipMemcpyAsync(dN, s->dPrevN, 4, hipMemcpyDeviceToDevice, sr));
+        if (s->fe) PG_HIP(c, hipMemcpyAsync(dK, s->dPrevKps, cap * sizeof(pgorb_keypoint), hipMemcpyDeviceToDevice, sr));
+    } else {
+        PG_HIP(c, hipMemsetAsync(dN, 0, 4, sr));
+    }
     // the slab form (match_mode 0) may have been selected after the stream was created: size its arena for THIS launch
     // (ensure() only ever grows; hipFree of the old arena waits for the work that still uses it)
     if ((rc = ensure(c, c->xdesc, pg_match_scratch_bytes(c->mx, s->cap, nframes) + 16))) return rc;
     pg_launch_match_batch(c->mx, dD, dN, s->cap, s->dPq, s->dPt, nframes, (uint8_t*)c->xdesc.p, (int32_t*)(sl.dOut + s->offI),
-                          (uint16_t*)(sl.dOut + s->offB1), (uint16_t*)(sl.dOut + s->offB2), s->sRun);
+                          (uint16_t*)(sl.dOut + s->offB1), (uint16_t*)(sl.dOut + s->offB2), sr);
     if (s->fe) {
         // what the tracking thread does with a fresh Frame, for the whole batch: the 64x48 grid of every frame
         // (Frame.cc:234-249), SearchForInitialization(previous, current) with vbPrevMatched = the previous frame's
         // keypoints (Tracking.cc:583-597), ORBVocabulary::transform of every descriptor (Frame.cc:399-406)
         const float* b = s->feBounds;
         if ((rc = pgorb_frame_grid_batch_device(c, dK + cap, dN + 1, nframes, s->cap, b[0], b[1], b[2], b[3],
-                                                s->dGridStart + (PGORB_GRID_CELLS + 1), s->dGridIdx + cap, s->sRun))) return rc;
-        pg_launch_prev_matched_init(dK, (int64_t)nframes * cap, s->dPrevMatched, s->sRun);
+                                                s->dGridStart + (PGORB_GRID_CELLS + 1), s->dGridIdx + cap, sr))) return rc;
+        pg_launch_prev_matched_init(dK, (int64_t)nframes * cap, s->dPrevMatched, sr);
         if ((rc = pgorb_search_for_initialization_batch_device(c, dK, dD, dN, s->cap, s->dGridStart, s->dGridIdx, s->dPt, s->dPq, nframes,
                                                                b[0], b[1], b[2], b[3], s->dPrevMatched, (int32_t*)(sl.dOut + s->offM12),
-                                                               (int32_t*)(sl.dOut + s->offNM), s->feWindow, s->feRatio, s->feCheckOri, s->sRun))) return rc;
+                                                               (int32_t*)(sl.dOut + s->offNM), s->feWindow, s->feRatio, s->feCheckOri, sr))) return rc;
         if (s->feLevelsUp >= 0 &&
             (rc = pgorb_bow_transform_device(c, dD + cap * 32, nframes * s->cap, s->feLevelsUp, (uint32_t*)(sl.dOut + s->offW),
-                                             (double*)(sl.dOut + s->offWt), (uint32_t*)(sl.dOut + s->offNd), s->sRun))) return rc;
-        PG_HIP(c, hipMemcpyAsync(s->dPrevKps, dK + (size_t)nframes * cap, cap * sizeof(pgorb_keypoint), hipMemcpyDeviceToDevice, s->sRun));
+                                             (double*)(sl.dOut + s->offWt), (uint32_t*)(sl.dOut + s->offNd), sr))) return rc;
+        PG_HIP(c, hipMemcpyAsync(s->dPrevKps, dK + (size_t)nframes * cap, cap * sizeof(pgorb_keypoint), hipMemcpyDeviceToDevice, sr));
     }
-    PG_HIP(c, hipMemcpyAsync(s->dPrevDesc, dD + (size_t)nframes * cap * 32, cap * 32, hipMemcpyDeviceToDevice, s->sRun));
-    PG_HIP(c, hipMemcpyAsync(s->dPrevN, dN + nframes, 4, hipMemcpyDeviceToDevice, s->sRun));
+    PG_HIP(c, hipMemcpyAsync(s->dPrevDesc, dD + (size_t)nframes * cap * 32, cap * 32, hipMemcpyDeviceToDevice, sr));
+    PG_HIP(c, hipMemcpyAsync(s->dPrevN, dN + nframes, 4, hipMemcpyDeviceToDevice, sr));
     // the batch's device status word travels inside the result block (the next batch resets the word)
-    PG_HIP(c, hipMemcpyAsync(sl.dOut + s->outBytes, c->plan.status, 4, hipMemcpyDeviceToDevice, s->sRun));
-    PG_HIP(c, hipEventRecord(sl.evRun, s->sRun));
+    PG_HIP(c, hipMemcpyAsync(sl.dOut + s->outBytes, lc->plan.status, 4, hipMemcpyDeviceToDevice, sr));
+    if (s->device) PG_HIP(c, hipMemcpyAsync(s->hStatus + slotIndex, lc->plan.status, 4, hipMemcpyDeviceToHost, sr));
+    PG_HIP(c, hipEventRecord(sl.evRun, sr));
+    if (s->lane.size() > 1) { PG_HIP(c, hipEventRecord(s->evChain, sr)); s->chainArmed = true; }
     s->havePrev = true;
-    // copy-out
-    PG_HIP(c, hipStreamWaitEvent(s->sOut, sl.evRun, 0));
-    PG_HIP(c, hipMemcpyAsync(sl.hOut, sl.dOut, s->outBytes + 4, hipMemcpyDeviceToHost, s->sOut));
-    PG_HIP(c, hipEventRecord(sl.evOut, s->sOut));
+    if (!s->device) {
+        // copy-out
+        PG_HIP(c, hipStreamWaitEvent(s->sOut, sl.evRun, 0));
+        PG_HIP(c, hipMemcpyAsync(sl.hOut, sl.dOut, s->outBytes + 4, hipMemcpyDeviceToHost, s->sOut));
+        PG_HIP(c, hipEventRecord(sl.evOut, s->sOut));
+    }
     PG_HIP(c, hipGetLastError());
     return 0;
 }
@@ -1595,6 +1712,7 @@ int pgorb_stream_wait(pgorb_stream* s, int slot, const int32_t** n, const pgorb_
     if (!s || slot < 0 || slot >= s->depth) return PGORB_E_ARG;
     pgorb_ctx* c = s->c;
     pgorb_stream::Slot& sl = s->slot[slot];
+    if (s->device) return fail(c, PGORB_E_ARG, "pgorb_stream_wait: a device-resident stream takes pgorb_stream_wait_device");
     if (!sl.busy) return fail(c, PGORB_E_ARG, "pgorb_stream_wait: slot %d has no batch in flight", slot);
     PG_HIP(c, hipSetDevice(c->prm.device));
     PG_HIP(c, hipEventSynchronize(sl.evOut));
@@ -1607,6 +1725,36 @@ int pgorb_stream_wait(pgorb_stream* s, int slot, const int32_t** n, const pgorb_
     if (best_idx) *best_idx = (const int32_t*)(sl.hOut + s->offI);
     if (best) *best = (const uint16_t*)(sl.hOut + s->offB1);
     if (second) *second = (const uint16_t*)(sl.hOut + s->offB2);
+    if (cap) *cap = s->cap;
+    return sl.frames;
+}
+
+// Device-resident form: the slot's batch is complete (host blocks on the batch's event, or -- hip_stream != NULL with
+// wait_on_host == 0 -- that stream is made to wait for it and the call returns at once); DEVICE pointers into the slot's
+// result block, valid until the slot is submitted again.
+int pgorb_stream_wait_device(pgorb_stream* s, int slot, int wait_on_host, void* hip_stream, const int32_t** d_n, const pgorb_keypoint** d_kps,
+                             const uint8_t** d_desc, const int32_t** d_best_idx, const uint16_t** d_best, const uint16_t** d_second, int* cap)
+{
+    if (!s || slot < 0 || slot >= s->depth) return PGORB_E_ARG;
+    pgorb_ctx* c = s->c;
+    if (!s->device) return fail(c, PGORB_E_ARG, "pgorb_stream_wait_device: the stream was created for host frames");
+    pgorb_stream::Slot& sl = s->slot[slot];
+    if (!sl.busy) return fail(c, PGORB_E_ARG, "pgorb_stream_wait_device: slot %d has no batch in flight", slot);
+    PG_HIP(c, hipSetDevice(c->prm.device));
+    if (wait_on_host || !hip_stream) {
+        PG_HIP(c, hipEventSynchronize(sl.evRun));
+        const int32_t st = s->hStatus[slot];
+        if (st) { sl.busy = false; return fail(c, st, "device reported status %d", st); }
+    } else {
+        PG_HIP(c, hipStreamWaitEvent((hipStream_t)hip_stream, sl.evRun, 0));        // (the status word: pgorb_check_async of the caller's choice)
+    }
+    sl.busy = false;
+    if (d_n) *d_n = (const int32_t*)(sl.dOut + s->offN) + 1;
+    if (d_kps) *d_kps = (const pgorb_keypoint*)(sl.dOut + s->offK) + s->cap;
+    if (d_desc) *d_desc = sl.dOut + s->offD + (size_t)s->cap * 32;
+    if (d_best_idx) *d_best_idx = (const int32_t*)(sl.dOut + s->offI);
+    if (d_best) *d_best = (const uint16_t*)(sl.dOut + s->offB1);
+    if (d_second) *d_second = (const uint16_t*)(sl.dOut + s->offB2);
     if (cap) *cap = s->cap;
     return sl.frames;
 }
@@ -1636,7 +1784,7 @@ int pgorb_stream_frontend(pgorb_stream* s, float min_x, float max_x, float min_y
     bool ok = true;
     for (size_t i = 0; i < s->slot.size(); i++) {
         ok = ok && hipMalloc((void**)&nd[i], t.outBytes + 256) == hipSuccess;
-        ok = ok && hipHostMalloc((void**)&nh[i], t.outBytes + 256, hipHostMallocDefault) == hipSuccess;
+        ok = ok && (s->device || hipHostMalloc((void**)&nh[i], t.outBytes + 256, hipHostMallocDefault) == hipSuccess);
     }
     if (!s->dGridStart) {
         gs = nullptr; gi = nullptr; pm = nullptr;
@@ -1651,7 +1799,8 @@ int pgorb_stream_frontend(pgorb_stream* s, float min_x, float max_x, float min_y
         return fail(c, PGORB_E_HIP, "pgorb_stream_frontend: allocation failed (the stream is unchanged)");
     }
     for (size_t i = 0; i < s->slot.size(); i++) {
-        (void)hipFree(s->slot[i].dOut); (void)hipHostFree(s->slot[i].hOut);
+        (void)hipFree(s->slot[i].dOut);
+        if (s->slot[i].hOut) (void)hipHostFree(s->slot[i].hOut);
         s->slot[i].dOut = nd[i]; s->slot[i].hOut = nh[i];
     }
     s->dGridStart = gs; s->dGridIdx = gi; s->dPrevMatched = pm;
@@ -1670,12 +1819,13 @@ int pgorb_stream_frontend_results(pgorb_stream* s, int slot, const int32_t** mat
     pgorb_stream::Slot& sl = s->slot[slot];
     if (!s->fe) return fail(c, PGORB_E_ARG, "pgorb_stream_frontend_results: the front-end stage is not enabled");
     if (sl.busy) return fail(c, PGORB_E_ARG, "pgorb_stream_frontend_results: collect slot %d with pgorb_stream_wait first", slot);
-    if (matches12) *matches12 = (const int32_t*)(sl.hOut + s->offM12);
-    if (nmatches) *nmatches = (const int32_t*)(sl.hOut + s->offNM);
+    const uint8_t* base = s->device ? sl.dOut : sl.hOut;      // (a device-resident stream hands out DEVICE pointers here as well)
+    if (matches12) *matches12 = (const int32_t*)(base + s->offM12);
+    if (nmatches) *nmatches = (const int32_t*)(base + s->offNM);
     const bool bow = s->feLevelsUp >= 0;
-    if (word) *word = bow ? (const uint32_t*)(sl.hOut + s->offW) : nullptr;
-    if (weight) *weight = bow ? (const double*)(sl.hOut + s->offWt) : nullptr;
-    if (node) *node = bow ? (const uint32_t*)(sl.hOut + s->offNd) : nullptr;
+    if (word) *word = bow ? (const uint32_t*)(base + s->offW) : nullptr;
+    if (weight) *weight = bow ? (const double*)(base + s->offWt) : nullptr;
+    if (node) *node = bow ? (const uint32_t*)(base + s->offNd) : nullptr;
     return 0;
 }
 

@@ -368,6 +368,9 @@ __device__ __forceinline__ int quick_pass_b(const uint8_t* tile, int IW, int IH,
 #undef PG_RING
     acc &= V.acc;                                                     // validity (pg_lane_valid)
     acc2 &= V.acc2;
+#if defined(PGORB_FAST_STOP) && PGORB_FAST_STOP == 2
+    return (__ballot((acc | acc2) != 0) != 0ull) ? 1 : 0;
+#endif
     const int cnt = __popc(acc) + __popc(acc2);
     const int incl = wave_incl_scan(cnt);
     const int nlist = __builtin_amdgcn_readlane(incl, 63);
@@ -520,12 +523,21 @@ __device__ __forceinline__ int fast_pass(int32_t* status, const uint8_t* tile, i
     const int nlist = NARROW ? quick_pass_b<STRONG>(tile, IW, IH, t, list, lane, V)
                     : (IW <= 32) ? quick_pass<8, STRONG>(tile, TP, IW, 0, IH, t, list, lane)
                                  : quick_pass<16, STRONG>(tile, TP, IW, 0, IH, t, list, lane);
+#if defined(PGORB_FAST_STOP) && PGORB_FAST_STOP == 3        // developer builds (tools/experiments/r5_k2_stages.sh): stop behind a stage,
+    return nlist > 0 ? 0x40000000 | nlist : 0;              // with the stage's result kept alive
+#endif
+#if defined(PGORB_FAST_STOP) && PGORB_FAST_STOP == 2
+    return nlist;
+#endif
     if (nlist < 0)                                         // list would overflow: chunked slow path
         return fast_pass_chunked(tile, TP, smap, mapPitch, mapRows, IW, IH, t, list, out, cellCap, xoff, yoff, lane);
     PG_WAVE_SYNC();
     // (3) exact scores for the compacted pixels
     score_list<NARROW>(tile, TP, smap, mapPitch, list, nlist, t, lane);
     PG_WAVE_SYNC();
+#if defined(PGORB_FAST_STOP) && PGORB_FAST_STOP == 4
+    return 0x40000000 | (nlist ? list[lane % nlist] : 0);
+#endif
     // (4) NMS (strictly greater than all 8 neighbours; outside the interior = 0); survivors go
     // straight into this cell's slots
     int total = 0;
@@ -680,6 +692,10 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgPlan P, int 
     }
     PG_WAVE_SYNC();
     FT_TS(2);
+#if defined(PGORB_FAST_STOP) && PGORB_FAST_STOP == 1       // window staged, nothing else
+    if (lane == 0) *cellCnt = reinterpret_cast<const uint32_t*>(tile)[17] & 1;
+    return;
+#endif
 
     uint32_t* out = cellCandBase + ((uint64_t)frame * cellCandFrame + rec[7]);
     const PgCellValid cv = {rec[8], rec[9], rec[10], rec[11], rec[12], rec[13], rec[14], rec[15]};
@@ -689,8 +705,8 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgPlan P, int 
     // The two detector passes written out (round 3): as a `for (pass)` loop the compiler merged the two bodies and paid for it
     // with scalar flag juggling around every phase.
     int total = fast_pass<TPC, MPC, NARROW, false>(statusPtr, tile, TP, smap, mapPitch, mapRows, IW, IH, iniTh, list, out, cellCap, xoff, yoff, lane, valid);
-#if defined(PGORB_FAST_SKIP)                               // timing experiments: no minTh retry
-    if (lane == 0) *cellCnt = min(total, cellCap);
+#if defined(PGORB_FAST_SKIP) || defined(PGORB_FAST_STOP)   // timing experiments: no minTh retry
+    if (lane == 0) *cellCnt = min(total & 0xFFFF, cellCap);
     return;
 #endif
     if (total == 0) {

@@ -34,6 +34,7 @@ class ORBextractor:
         self.nfeatures, self.nlevels = int(nfeatures), int(nlevels)
         self.scaleFactor = float(scaleFactor)
         self.max_batch = int(max_batch)
+        self.device = int(device)
         prm = _lib.PgorbParams(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST,
                                max_width, max_height, max_batch, device, blur_tie_mode)
         h = C.c_void_p()
@@ -511,3 +512,77 @@ class FrameStream:
             return self._view(p.value, dtype, shape)
         return (view(ptr[0], np.int32, (nf,)), view(ptr[1], KEYPOINT_DTYPE, (nf, cap)), view(ptr[2], np.uint8, (nf, cap, 32)),
                 view(ptr[3], np.int32, (nf, cap)), view(ptr[4], np.uint16, (nf, cap)), view(ptr[5], np.uint16, (nf, cap)))
+
+
+class DeviceFrameStream:
+    """The device-resident form of the stream (include/pgorb.h, pgorb_stream_create_device): frames are torch CUDA(HIP)
+    uint8 tensors [B, H, W], results stay on the device, and `lanes` batches are in flight INSIDE the library (slot k
+    runs on lane k % lanes, each lane an independent extractor working set on its own HIP stream).  Results equal the
+    one-batch-at-a-time calls, including the match of a batch's first frame against the previous batch's last."""
+
+    def __init__(self, extractor, w, h, batch, depth=2, lanes=2):
+        self.ext, self.w, self.h, self.batch, self.depth = extractor, int(w), int(h), int(batch), int(depth)
+        self._L = extractor._L
+        hs = C.c_void_p()
+        extractor._check(self._L.pgorb_stream_create_device(extractor._h, self.w, self.h, self.batch, self.depth, int(lanes), C.byref(hs)))
+        self._s = hs
+        self._keep = [None] * self.depth              # the submitted frame tensors (level 0 may alias them)
+        extractor._streams.add(self)
+
+    def close(self):
+        if getattr(self, "_s", None):
+            self._L.pgorb_stream_destroy(self._s)
+            self._s = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def lanes(self):
+        return self._L.pgorb_stream_lanes(self._s)
+
+    def reset(self):
+        self.ext._check(self._L.pgorb_stream_reset(self._s))
+
+    def frontend(self, bounds, window_size=100, nnratio=0.9, check_orientation=True, bow_levelsup=-1):
+        self.ext._check(self._L.pgorb_stream_frontend(self._s, *[float(b) for b in bounds], int(window_size), float(nnratio),
+                                                      int(bool(check_orientation)), int(bow_levelsup)))
+
+    def submit(self, slot, frames_u8, stream=None):
+        """Queue one batch; returns at once.  `frames_u8` must be ready on `stream` (default: torch's current stream)."""
+        import torch
+        nb, h, w = frames_u8.shape
+        s = stream if stream is not None else torch.cuda.current_stream(frames_u8.device).cuda_stream
+        self.ext._check(self._L.pgorb_stream_submit_device(self._s, slot, C.c_void_p(frames_u8.data_ptr()), nb, frames_u8.stride(1),
+                                                           frames_u8.stride(0), C.c_void_p(s)))
+        self._keep[slot] = frames_u8
+
+    def wait(self, slot, on_host=True, stream=None):
+        """(n[frames], kps[frames, cap, 7] f32 view, desc[frames, cap, 32], best_idx, best, second [frames, cap]) as torch
+        tensors that ALIAS the slot's device result block (valid until the slot is submitted again)."""
+        import torch
+        ptr = [C.c_void_p() for _ in range(6)]
+        cap = C.c_int32()
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        nf = self.ext._check(self._L.pgorb_stream_wait_device(self._s, slot, int(bool(on_host)), C.c_void_p(s),
+                                                              *[C.byref(p) for p in ptr], C.byref(cap)))
+        cap = cap.value
+        dev = torch.device("cuda", self.ext.device)
+
+        def view(p, dtype, shape, itemsize):
+            return _device_tensor(p.value, int(np.prod(shape)) * itemsize, dev).view(dtype).reshape(shape)
+        return (view(ptr[0], torch.int32, (nf,), 4), view(ptr[1], torch.float32, (nf, cap, 7), 4), view(ptr[2], torch.uint8, (nf, cap, 32), 1),
+                view(ptr[3], torch.int32, (nf, cap), 4), view(ptr[4], torch.int16, (nf, cap), 2), view(ptr[5], torch.int16, (nf, cap), 2))
+
+
+def _device_tensor(address, nbytes, device):
+    """A torch uint8 tensor over `nbytes` of device memory the library owns (no copy): through the CUDA array interface."""
+    import torch
+
+    class _Raw:
+        pass
+    r = _Raw()
+    r.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(address), False), "version": 2}
+    return torch.as_tensor(r, device=device)

@@ -353,3 +353,110 @@ def test_stream_error_paths():
     with pytest.raises(Exception):
         pg.FrameStream(ext, w, h, batch + 1, 2)                 # more than max_batch
     st.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,nf,total,batch,depth,lanes", [
+    (640, 480, 1000, 29, 8, 3, 2), (640, 480, 1000, 13, 4, 4, 3), (1920, 1080, 2000, 20, 8, 2, 2), (640, 480, 1000, 9, 4, 2, 1)])
+def test_device_resident_stream_with_batches_in_flight(w, h, nf, total, batch, depth, lanes):
+    """pgorb_stream_create_device / _submit_device / _wait_device (round 5): resident frames, `lanes` batches in flight
+    inside the library on sibling working sets, results on the device.  Every frame's keypoints and descriptors and every
+    frame's best-2 match against its predecessor -- ACROSS the border between two batches that ran concurrently on
+    different lanes -- against the oracle; a ragged last batch; slots reused (more batches than slots)."""
+    import torch
+    import pilotguru_amd as pg
+    from _oracle_pool import oracle_ride
+    ride = synth_ride(41, w, h, total)
+    oext, omatch = oracle_ride(list(ride), (nf, 1.2, 8, 20, 7))
+    ext = pg.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=batch)
+    st = pg.DeviceFrameStream(ext, w, h, batch, depth, lanes)
+    assert st.lanes() == lanes
+    frames = torch.from_numpy(ride).cuda()
+    chunks = [(b0, min(batch, total - b0)) for b0 in range(0, total, batch)]
+    results, inflight = {}, []
+
+    def collect(j, slot):
+        results[j] = [t.cpu().numpy() for t in st.wait(slot)]
+    for i, (b0, nb) in enumerate(chunks):
+        slot = i % depth
+        if len(inflight) == depth:
+            collect(*inflight.pop(0))
+        st.submit(slot, frames[b0:b0 + nb])
+        inflight.append((i, slot))
+    for j, slot in inflight:
+        collect(j, slot)
+    st.close()
+    for i, (b0, nb) in enumerate(chunks):
+        n, kps, desc, bi, b1, b2 = results[i]
+        assert len(n) == nb
+        for k in range(nb):
+            f = b0 + k
+            okp, odesc = oext[f]
+            assert n[k] * 28 == len(okp) and kps[k, :n[k]].tobytes() == okp and desc[k, :n[k]].tobytes() == odesc, "frame %d" % f
+            if f == 0:
+                assert np.all(bi[k, :n[k]] == -1)
+            else:
+                obi, ob1, ob2 = omatch[f - 1]
+                assert bi[k, :n[k]].tobytes() == obi and b1[k, :n[k]].view(np.uint16).tobytes() == ob1 and \
+                    b2[k, :n[k]].view(np.uint16).tobytes() == ob2, "match of frame %d vs %d" % (f, f - 1)
+
+
+@pytest.mark.gpu
+def test_device_resident_stream_front_end_stage_equals_the_host_stream():
+    """The front-end stage (grid, SearchForInitialization of every frame against its predecessor, BoW transform) behind a
+    device-resident stream with two lanes equals the host-frame stream's (which tests/test_frame_matcher.py and
+    test_streamed_front_end_stage_against_the_oracle hold to the oracle): the stage's cross-batch state -- the previous
+    frame's keypoints, vbPrevMatched -- is chained in submission order although the batches extract concurrently."""
+    import torch
+    import pilotguru_amd as pg
+    from pilotguru_amd import vocab as V
+    w, h, nf, total, batch = 640, 480, 1000, 19, 6
+    ride = synth_ride(5, w, h, total, dx=3, dy=1)
+    chunks = [(b0, min(batch, total - b0)) for b0 in range(0, total, batch)]
+
+    def run(device_form):
+        ext = pg.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=batch)
+        V.ORBVocabulary(blob=V.synth_vocabulary_blob(8, 4, seed=3)).upload(ext)
+        st = pg.DeviceFrameStream(ext, w, h, batch, 2, 2) if device_form else pg.FrameStream(ext, w, h, batch, 2)
+        st.frontend((0.0, float(w), 0.0, float(h)), 100, 0.9, True, 3)
+        frames = torch.from_numpy(ride).cuda() if device_form else None
+        out = []
+        pending = []
+
+        def collect(slot, nb):
+            res = st.wait(slot)
+            cap = res[1].shape[1]
+            if device_form:
+                ptr = [pg.orb.C.c_void_p() for _ in range(5)]
+                ext._check(ext._L.pgorb_stream_frontend_results(st._s, slot, *[pg.orb.C.byref(p) for p in ptr]))
+                dev = torch.device("cuda", 0)
+                m12 = pg.orb._device_tensor(ptr[0].value, nb * cap * 4, dev).view(torch.int32).reshape(nb, cap).cpu().numpy()
+                nm = pg.orb._device_tensor(ptr[1].value, nb * 4, dev).view(torch.int32).cpu().numpy()
+                word = pg.orb._device_tensor(ptr[2].value, nb * cap * 4, dev).view(torch.int32).reshape(nb, cap).cpu().numpy().view(np.uint32)
+                n = res[0].cpu().numpy()
+            else:
+                m12, nm, word, _, _ = st.frontend_results(slot, nb, cap)
+                n = np.array(res[0])
+            for k in range(nb):
+                out.append((int(n[k]), int(nm[k]), m12[k, :n[k]].copy() if len(out) else None, word[k, :n[k]].copy()))
+        for i, (b0, nb) in enumerate(chunks):
+            slot = i % 2
+            if len(pending) == 2:
+                collect(*pending.pop(0))
+            if device_form:
+                st.submit(slot, frames[b0:b0 + nb])
+            else:
+                st.input(slot)[:nb] = ride[b0:b0 + nb]
+                st.submit(slot, nb)
+            pending.append((slot, nb))
+        for p in pending:
+            collect(*p)
+        st.close()
+        return out
+    host, dev = run(False), run(True)
+    assert len(host) == len(dev) == total
+    for f, (a, b) in enumerate(zip(host, dev)):
+        assert a[0] == b[0] and np.array_equal(a[3], b[3]), "frame %d: keypoint count / BoW words" % f
+        if f:
+            assert a[1] == b[1] and np.array_equal(a[2], b[2]), "frame %d: SearchForInitialization against its predecessor" % f
+    assert sum(a[1] for a in host[1:]) > 100
