@@ -55,6 +55,9 @@ struct pgorb_ctx {
     // K3 / K4-6 of a group of levels beside K2 of the next group (pgorb_set_option "pipeline_levels", bit l = a group
     // starts at level l): K3 is one workgroup's critical path per (frame, level) and leaves the chip mostly idle
     int pipeLev = 0, pipeLevPrio = 0;
+    // a device-resident stream's lanes (pgorb_stream_create_device): recorded behind the batch's last pyramid launch / behind K2,
+    // so that the NEXT batch (on another lane) can be held back until this one has reached that point (stagger)
+    hipEvent_t evPyrEnd = nullptr, evFastEnd = nullptr;
     hipStream_t sQt = nullptr, sDesc = nullptr;
     hipEvent_t evGrpFast[PG_MAXL] = {}, evGrpQt[PG_MAXL] = {}, evDescDone = nullptr;
     Arena stageA, stageB, stageOut, stageSfi, vocab;
@@ -607,8 +610,10 @@ int run_batch(pgorb_ctx* c, const uint8_t* d_gray, bool resident_in_level0, int 
         for (int l = 1; l < P.nlevels; l++)
             if (!pg_launch_pyramid_level(P, l, nframes, s, l == 1 ? P.status : nullptr) && l == 1) PG_HIP(c, hipMemsetAsync(P.status, 0, 16, s));
         if (ev) PG_HIP(c, hipEventRecord(ev[1], s));
+        if (c->evPyrEnd) PG_HIP(c, hipEventRecord(c->evPyrEnd, s));
         pg_launch_fast(P, nframes, s);
         if (ev) PG_HIP(c, hipEventRecord(ev[2], s));
+        if (c->evFastEnd) PG_HIP(c, hipEventRecord(c->evFastEnd, s));
     }
     pg_launch_quadtree(P, nframes, s);
     if (ev) PG_HIP(c, hipEventRecord(ev[3], s));
@@ -791,6 +796,8 @@ void pgorb_destroy(pgorb_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->prm.device);
     while (!c->streams.empty()) pgorb_stream_destroy(c->streams.back());      // a stream holds a pointer to its context
+    if (c->evPyrEnd) (void)hipEventDestroy(c->evPyrEnd);
+    if (c->evFastEnd) (void)hipEventDestroy(c->evFastEnd);
     Arena* all[] = {&c->cellTab, &c->cellTabBal, &c->cellCand, &c->cellCount, &c->pyr, &c->cand, &c->sel, &c->nodes, &c->counters, &c->tables, &c->qtTab, &c->qtLeaf,
                     &c->outBlk, &c->stageA, &c->stageB, &c->stageOut, &c->stageSfi, &c->vocab, &c->xdesc};
     for (Arena* a : all) if (a->p) (void)hipFree(a->p);
@@ -1340,18 +1347,24 @@ struct pgorb_stream {
     // the others private sibling contexts with the same parameters and options), each on its own HIP stream -- two batches
     // in flight let K1 (HBM), K2 / K4-6 (VALU issue), K3 (latency) and K7 (matrix pipe) of neighbouring batches share the chip.
     // Slot k runs on lane k % lanes.  What crosses batches -- the previous batch's last frame for the first match, the
-    // front-end stage's state -- is one section per batch at the END of its lane's queue, chained by an event.
+    // front-end stage's state -- is one short section per batch; the sections run in submission order on a stream of their
+    // own (sChain), each behind its batch's K1..K6, so the lanes never wait for each other: they drift apart and kernels of
+    // DIFFERENT kinds end up side by side (a first build queued the section at the end of the lane's own stream, chained by
+    // an event: the lanes then ran in lockstep, K1 beside K1 and K2 beside K2, and gained nothing -- 98.1 k against 98.3 k).
     bool device = false;
     std::vector<pgorb_ctx*> lane;          // [0] = c
     std::vector<hipStream_t> sLane;        // [0] = sRun
-    hipEvent_t evChain = nullptr; bool chainArmed = false;
+    int stagger = 0;                       // 0: lanes start their batches as soon as they can; 1: a batch's K1 starts when the previously
+                                           // submitted batch has finished ITS K1 (its K2 is starting); 2: ... has finished its K2
+    int lastLane = -1;                     // the lane the previously submitted batch runs on
+    hipStream_t sChain = nullptr;          // the sections that cross batches, in submission order (several lanes: a stream of its own)
     int32_t* hStatus = nullptr;            // pinned, one word per slot (device form: the batch's status word)
     struct Slot {
         uint8_t* hIn = nullptr;            // pinned [B][srcH][srcW][ch]
         uint8_t* dIn = nullptr;            // device copy of it
         uint8_t* dOut = nullptr;           // device result block (layout below)
         uint8_t* hOut = nullptr;           // pinned copy of it
-        hipEvent_t evIn = nullptr, evRun = nullptr, evOut = nullptr;
+        hipEvent_t evIn = nullptr, evRun = nullptr, evOut = nullptr, evExt = nullptr;   // evExt: K1..K6 of the slot's batch done (device form)
         int frames = 0; bool busy = false;
     };
     std::vector<Slot> slot;
@@ -1451,7 +1464,7 @@ int pgorb_stream_create_ingest(pgorb_ctx* c, int src_w, int src_h, int channels,
     ok = ok && hipMemcpy(s->dPt, pt.data(), B * 4, hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && ensure(c, c->xdesc, pg_match_scratch_bytes(c->mx, s->cap, batch) + 16) == 0;
     if (!ok) { pgorb_stream_destroy(s); return fail(c, PGORB_E_HIP, "pgorb_stream_create: allocation failed"); }
-    s->lane.assign(1, c); s->sLane.assign(1, s->sRun);
+    s->lane.assign(1, c); s->sLane.assign(1, s->sRun); s->sChain = s->sRun;
     c->streams.push_back(s);
     *out = s;
     return 0;
@@ -1490,11 +1503,19 @@ int pgorb_stream_create_device(pgorb_ctx* c, int w, int h, int batch, int depth,
     }
     s->slot.resize(depth);
     ok = ok && hipHostMalloc((void**)&s->hStatus, 64 * sizeof(int32_t), hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&s->evChain, hipEventDisableTiming) == hipSuccess;
+    if (lanes > 1) ok = ok && hipStreamCreateWithFlags(&s->sChain, hipStreamNonBlocking) == hipSuccess;
+    else s->sChain = s->sRun;
+    if (const char* e = getenv("PGORB_STREAM_STAGGER")) s->stagger = atoi(e);
+    if (lanes > 1)
+        for (pgorb_ctx* lc : s->lane) {
+            if (!lc->evPyrEnd) ok = ok && hipEventCreateWithFlags(&lc->evPyrEnd, hipEventDisableTiming) == hipSuccess;
+            if (!lc->evFastEnd) ok = ok && hipEventCreateWithFlags(&lc->evFastEnd, hipEventDisableTiming) == hipSuccess;
+        }
     for (auto& sl : s->slot) {
         ok = ok && hipMalloc((void**)&sl.dOut, s->outBytes + 256) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&sl.evIn, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&sl.evRun, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&sl.evExt, hipEventDisableTiming) == hipSuccess;
     }
     std::vector<int32_t> pq(batch), pt(batch);
     for (int f = 0; f < batch; f++) { pq[f] = f + 1; pt[f] = f; }
@@ -1528,7 +1549,7 @@ void pgorb_stream_destroy(pgorb_stream* s)
     if (s->sOut) (void)hipStreamSynchronize(s->sOut);
     for (size_t l = 1; l < s->sLane.size(); l++) if (s->sLane[l]) { (void)hipStreamSynchronize(s->sLane[l]); (void)hipStreamDestroy(s->sLane[l]); }
     for (size_t l = 1; l < s->lane.size(); l++) pgorb_destroy(s->lane[l]);      // the private sibling contexts
-    if (s->evChain) (void)hipEventDestroy(s->evChain);
+    if (s->sChain && s->lane.size() > 1) { (void)hipStreamSynchronize(s->sChain); (void)hipStreamDestroy(s->sChain); }
     if (s->hStatus) (void)hipHostFree(s->hStatus);
     for (auto& sl : s->slot) {
         if (sl.hIn) (void)hipHostFree(sl.hIn);
@@ -1538,6 +1559,7 @@ void pgorb_stream_destroy(pgorb_stream* s)
         if (sl.evIn) (void)hipEventDestroy(sl.evIn);
         if (sl.evRun) (void)hipEventDestroy(sl.evRun);
         if (sl.evOut) (void)hipEventDestroy(sl.evOut);
+        if (sl.evExt) (void)hipEventDestroy(sl.evExt);
     }
     if (s->dPq) (void)hipFree(s->dPq);
     if (s->dPt) (void)hipFree(s->dPt);
@@ -1608,6 +1630,7 @@ int pgorb_stream_submit_device(pgorb_stream* s, int slot, const uint8_t* d_frame
     rc = stream_submit_queue(s, sl, nframes, slot, d_frames, stride, frame_stride, (hipStream_t)hip_stream);
     if (rc) {
         for (hipStream_t q : s->sLane) (void)hipStreamSynchronize(q);
+        (void)hipStreamSynchronize(s->sChain);
         s->dead = true;
         return rc;
     }
@@ -1635,9 +1658,21 @@ static int stream_submit_queue(pgorb_stream* s, pgorb_stream::Slot& sl, int nfra
         PG_HIP(c, hipStreamWaitEvent(sr, sl.evIn, 0));
         PG_HIP(c, hipStreamWaitEvent(sr, sl.evOut, 0));
     } else {
-        // the caller's frames are ready where the caller's stream stands now
+        // the caller's frames are ready where the caller's stream stands now; the slot's result block is free once the
+        // section of the batch that used it last is done (a never-recorded event does not wait)
         PG_HIP(c, hipEventRecord(sl.evIn, caller));
         PG_HIP(c, hipStreamWaitEvent(sr, sl.evIn, 0));
+        PG_HIP(c, hipStreamWaitEvent(sr, sl.evRun, 0));
+        // stagger (PGORB_STREAM_STAGGER=1|2 at stream creation; off by default): hold a batch back until the previously submitted
+        // one (another lane) is past its pyramid (or past K2).  Measured on an MI355X (tools/experiments/r5_lanes.py,
+        // profiles/r05_lanes.txt; 1080p / 2000, batch 128): one lane 94-96 k frames/s, two lanes 101.3 k without stagger, 101.1 k /
+        // 99.0 k with 1 / 2, three lanes 99.0 k -- the hardware interleaves the lanes' kernels at workgroup granularity whatever
+        // the start offsets, and K2's one-wave workgroups take every wave slot they can get.  A never-recorded event does not wait.
+        if (s->stagger && s->lastLane >= 0 && s->lastLane != laneIx) {
+            pgorb_ctx* pl = s->lane[s->lastLane];
+            PG_HIP(c, hipStreamWaitEvent(sr, s->stagger == 2 ? pl->evFastEnd : pl->evPyrEnd, 0));
+        }
+        s->lastLane = laneIx;
     }
     int32_t* dN = (int32_t*)(sl.dOut + s->offN);
     pgorb_keypoint* dK = (pgorb_keypoint*)(sl.dOut + s->offK);
@@ -1656,8 +1691,15 @@ static int stream_submit_queue(pgorb_stream* s, pgorb_stream::Slot& sl, int nfra
         rc = run_batch(c, sl.dIn, false, nframes, s->w, s->h, s->w, (int64_t)fbytes, dK + cap, dD + cap * 32, s->cap, dN + 1, sr);
     }
     if (rc) return rc;
-    // ---- the section that crosses batches: behind the previous batch's section, whatever lane that ran on ----
-    if (s->chainArmed && s->lane.size() > 1) PG_HIP(c, hipStreamWaitEvent(sr, s->evChain, 0));
+    // the batch's device status word travels inside the result block (the lane's next batch resets the word)
+    PG_HIP(c, hipMemcpyAsync(sl.dOut + s->outBytes, lc->plan.status, 4, hipMemcpyDeviceToDevice, sr));
+    if (s->device) PG_HIP(c, hipMemcpyAsync(s->hStatus + slotIndex, lc->plan.status, 4, hipMemcpyDeviceToHost, sr));
+    // ---- the section that crosses batches: in submission order on sChain, behind this batch's K1..K6 ----
+    if (s->sChain != sr) {
+        PG_HIP(c, hipEventRecord(sl.evExt, sr));
+        PG_HIP(c, hipStreamWaitEvent(s->sChain, sl.evExt, 0));
+        sr = s->sChain;
+    }
     if (s->havePrev) {
         PG_HIP(c, hipMemcpyAsync(dD, s->dPrevDesc, cap * 32, hipMemcpyDeviceToDevice, sr));
         PG_HIP(c, hipMemcpyAsync(dN, s->dPrevN, 4, hipMemcpyDeviceToDevice, sr));
@@ -1688,11 +1730,7 @@ static int stream_submit_queue(pgorb_stream* s, pgorb_stream::Slot& sl, int nfra
     }
     PG_HIP(c, hipMemcpyAsync(s->dPrevDesc, dD + (size_t)nframes * cap * 32, cap * 32, hipMemcpyDeviceToDevice, sr));
     PG_HIP(c, hipMemcpyAsync(s->dPrevN, dN + nframes, 4, hipMemcpyDeviceToDevice, sr));
-    // the batch's device status word travels inside the result block (the next batch resets the word)
-    PG_HIP(c, hipMemcpyAsync(sl.dOut + s->outBytes, lc->plan.status, 4, hipMemcpyDeviceToDevice, sr));
-    if (s->device) PG_HIP(c, hipMemcpyAsync(s->hStatus + slotIndex, lc->plan.status, 4, hipMemcpyDeviceToHost, sr));
     PG_HIP(c, hipEventRecord(sl.evRun, sr));
-    if (s->lane.size() > 1) { PG_HIP(c, hipEventRecord(s->evChain, sr)); s->chainArmed = true; }
     s->havePrev = true;
     if (!s->device) {
         // copy-out
