@@ -300,6 +300,10 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
     }
     PG_WAVE_SYNC();
     DT_TS(1);
+#if defined(PGORB_DESC_STOP) && PGORB_DESC_STOP == 1        // developer builds (tools/experiments/r5_k46_stages.sh): stop behind a stage, its result kept alive
+    if (lane == 0 && idx < cap_per_frame) kps[(int64_t)frame * cap_per_frame + idx].octave = raw[17 * DW_PITCH + 5];
+    return;
+#endif
 
     // ---- IC_Angle: integer moments over the radius-15 disc (:77-104) -------------------
     // One task = one aligned dword (4 pixels) of one disc row; v_dot4_u32_u8 against the
@@ -322,6 +326,10 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
     DT_TS(2);
 #endif
     const float angle = pg_fast_atan2((float)m01, (float)m10);
+#if defined(PGORB_DESC_STOP) && PGORB_DESC_STOP == 2
+    if (lane == 0 && idx < cap_per_frame) kps[(int64_t)frame * cap_per_frame + idx].angle = angle;
+    return;
+#endif
 #ifdef PGORB_DESC_TIMING
     asm volatile("" :: "v"(angle));
     DT_TS(3);
@@ -362,6 +370,10 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
     }
     PG_WAVE_SYNC();
     DT_TS(4);
+#if defined(PGORB_DESC_STOP) && PGORB_DESC_STOP == 3
+    if (lane == 0 && idx < cap_per_frame) { kps[(int64_t)frame * cap_per_frame + idx].angle = angle; kps[(int64_t)frame * cap_per_frame + idx].octave = (int)hT[5 * DH_PITCH + 7]; }
+    return;
+#endif
     // column pass: on demand.  Only the 512 rotated tap positions of the 37x37 blurred tile are
     // ever read, so each lane blurs its own 8 taps from the row-pass sums (4 LDS dwords, 3
     // v_dot2_u32_u16 each) instead of the wave producing all 1369 pixels.
@@ -374,6 +386,10 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     float a, b;
     pg_sincos_f(__fmul_rn(angle, factorPI), &b, &a);
+#if defined(PGORB_DESC_STOP) && PGORB_DESC_STOP == 4
+    if (lane == 0 && idx < cap_per_frame) { kps[(int64_t)frame * cap_per_frame + idx].angle = a; kps[(int64_t)frame * cap_per_frame + idx].x = b; kps[(int64_t)frame * cap_per_frame + idx].octave = (int)hT[5 * DH_PITCH + 7]; }
+    return;
+#endif
 #ifdef PGORB_DESC_TIMING
     asm volatile("" :: "v"(a), "v"(b));
     DT_TS(5);
