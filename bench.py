@@ -419,7 +419,7 @@ def main():
                     help="textured = SURVEY.md 8d's scene (the headline workload); road = sky / asphalt / texture band")
     ap.add_argument("--no-overlap-leg", action="store_true", help="skip the two-batches-in-flight leg (second context)")
     ap.add_argument("--sustain-seconds", type=float, default=3.0,
-                    help="after the timed steps, keep stepping for this long and report sustained_fps (0 = skip)")
+                    help="BEFORE the warm-up and timed steps, step for this long and report sustained_fps (0 = skip): the GPU is in its working state when the timed region starts")
     ap.add_argument("--pipeline-pyramid", type=int, default=None,
                     help="1 / 0: run the pyramid chain beside K2 on a side stream (library default when omitted)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -503,6 +503,27 @@ def main():
         if B > 1:
             ext.match_batch_device(desc, n, pq, pt, mout)
 
+    # The sustained leg runs FIRST (round 5): the same step for >= --sustain-seconds, every rank.  It is a measurement of its own
+    # (`sustained_fps`, N = 1) -- and it is what brings the GPU to the state it works in: after the seconds of host-side set-up
+    # above the clocks are down, and the first ~30 steps of a cold start run 1.60 ... 1.38 ms (tools/experiments/r3_ramp.py), so the
+    # driver's 5 + 20 steps used to be timed on a clock ramp (`value` sat 5-7 % under `sustained_fps`).  The contract's W warm-up
+    # steps and K timed steps follow unchanged.
+    sustained = None
+    if args.sustain_seconds > 0:
+        step(); torch.cuda.synchronize()
+        t1 = time.perf_counter(); step(); torch.cuda.synchronize()
+        k_chunk = max(10, int(0.25 / max(time.perf_counter() - t1, 1e-6)))
+        ts = time.perf_counter(); ksteps = 0
+        while time.perf_counter() - ts < args.sustain_seconds:
+            for _ in range(k_chunk):
+                step()
+            torch.cuda.synchronize()
+            ksteps += k_chunk
+        te = time.perf_counter()
+        ext.check_async()
+        sustained = {"fps": ksteps * B / (te - ts), "seconds": te - ts, "steps": ksteps,
+                     "note": "this rank's own rate; runs before the warm-up and timed steps"}
+
     for _ in range(args.warmup):
         step()
     ext.check_async()
@@ -545,22 +566,6 @@ def main():
                     raise SystemExit("bench verification FAILED: rank %d's BoW words differ from the oracle after the vocabulary broadcast" % r)
             bow_verified = True
         voc_comm.close()
-
-    # sustained rate: the same step for >= --sustain-seconds (clocks and power settle; the 20-step region
-    # above is only tens of milliseconds)
-    sustained = None
-    if args.sustain_seconds > 0 and dist is None:
-        k_chunk = max(10, int(0.25 / max(elapsed / args.steps, 1e-6)))
-        torch.cuda.synchronize()
-        ts = time.perf_counter(); ksteps = 0
-        while time.perf_counter() - ts < args.sustain_seconds:
-            for _ in range(k_chunk):
-                step()
-            torch.cuda.synchronize()
-            ksteps += k_chunk
-        te = time.perf_counter()
-        ext.check_async()
-        sustained = {"fps": ksteps * B / (te - ts), "seconds": te - ts, "steps": ksteps}
 
     # two batches in flight INSIDE the library (round 5: pgorb_stream_create_device, one context, two lanes): the caller submits
     # resident batches without blocking, the stream runs consecutive batches on two sibling working sets and HIP streams, so
