@@ -26,7 +26,6 @@
 //       the bins are computed after the loop, in parallel.
 // All per-pair state (vMatchedDistance, vnMatches21, vnMatches12) lives in LDS.
 #include "pgorb_internal.h"
-#include <rocprim/block/block_radix_sort.hpp>
 #include <algorithm>
 #include <string.h>
 #include <vector>
@@ -1144,46 +1143,82 @@ __global__ __launch_bounds__(1024) void k_feature_vectors(const uint32_t* __rest
     if (tid == 0) { fvStart[scan[1024]] = n; nfv[f] = scan[1024]; }
 }
 
-// The same CSR by SORTING (round 4): the features' keys node id << 13 | feature index are unique, so the FeatureVector is their
-// ascending order.  One workgroup per frame sorts up to FV_T * FV_IPT = 8 192 keys with rocPRIM's block radix sort (the one library
-// primitive in this file: a stable multi-pass digit ranking is ~400 lines of its own and this is not a hot kernel) over exactly
-// the bits in use; the counting form above is O(n^2) -- 0.17 ms for 128 frames of 2 000 features, 0.65 ms at 4 000, a third of
-// it one thread's scan over 1 024 partial sums -- and stays for frames beyond 8 192 features.
+// The same CSR by SORTING (round 4; round 5: the sort is this file's own): the features' keys node id << 13 | feature index are
+// unique, the features arrive in index order, so the FeatureVector is a STABLE sort by node id.  One workgroup per frame holds up to
+// FV_T * FV_IPT = 8 192 keys in LDS and runs least-significant-digit passes of 2 bits over exactly the bits the largest node id uses
+// (ORBvoc at levelsup 4: 11 bits, six passes): a thread owns 8 CONSECUTIVE positions (stability), counts its four digits in two
+// packed 16 + 16-bit words (a count never exceeds 8 192), one DPP wave scan per word + sixteen wave totals give every thread the
+// number of equal digits in front of it, and the keys are scattered into the second buffer.  (Round 4 called rocPRIM's
+// block_radix_sort here; the counting form above is O(n^2) -- 0.17 ms for 128 frames of 2 000 features, 0.65 ms at 4 000 -- and stays
+// for frames beyond 8 192 features.)
 #define FV_T 1024
 #define FV_IPT 8
-typedef rocprim::block_radix_sort<unsigned long long, FV_T, FV_IPT> pg_fv_sort_t;
 __global__ __launch_bounds__(FV_T) void k_feature_vectors_sorted(const uint32_t* __restrict__ node, const int32_t* __restrict__ nIn, int cap,
                                                                  uint32_t* __restrict__ fvNode, int32_t* __restrict__ fvStart,
                                                                  uint32_t* __restrict__ fvFeat, int32_t* __restrict__ nfv)
 {
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = min(nIn[f], cap);
-    pg_fv_sort_t::storage_type& storage = *reinterpret_cast<pg_fv_sort_t::storage_type*>(pg_sfi_smem);
-    uint32_t* snode = reinterpret_cast<uint32_t*>(pg_sfi_smem + sizeof(pg_fv_sort_t::storage_type));      // [FV_T * FV_IPT] sorted node ids
-    int* wsum = reinterpret_cast<int*>(snode + FV_T * FV_IPT);                                             // [FV_T / 64 + 1]
+    unsigned long long* bufA = reinterpret_cast<unsigned long long*>(pg_sfi_smem);                      // [FV_T * FV_IPT] keys
+    unsigned long long* bufB = bufA + FV_T * FV_IPT;
+    uint32_t* snode = reinterpret_cast<uint32_t*>(bufB);                                                  // the sorted node ids end up here
+    int* wsum = reinterpret_cast<int*>(bufB + FV_T * FV_IPT);                                             // [2 * FV_T / 64 + 2]
     node += (int64_t)f * cap; fvNode += (int64_t)f * cap; fvFeat += (int64_t)f * cap; fvStart += (int64_t)f * (cap + 1);
-    unsigned long long keys[FV_IPT];
     uint32_t mx = 0;
 #pragma unroll
     for (int k = 0; k < FV_IPT; k++) {
         const int i = tid * FV_IPT + k;
         const uint32_t nd = i < n ? node[i] : 0u;
         mx = max(mx, nd);
-        keys[k] = i < n ? (((unsigned long long)nd << 13) | (unsigned long long)i) : 0xFFFFFFFFFFFFFFFFull;
+        bufA[i] = i < n ? (((unsigned long long)nd << 13) | (unsigned long long)i) : 0xFFFFFFFFFFFFFFFFull;      // padding: all ones, stays last
     }
-    // the bits in use: 13 of the index + those of the largest node id (+ 1: the padding keys, all ones, must stay last)
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d));
     if (lane == 0) wsum[wv] = (int)mx;
     __syncthreads();
     for (int w = 0; w < FV_T / 64; w++) mx = max(mx, (uint32_t)wsum[w]);
     __syncthreads();
-    const unsigned endBit = min(64u, 13u + (32u - (unsigned)__clz(mx | 1u)) + 1u);
-    pg_fv_sort_t().sort(keys, storage, 0u, endBit);
+    const int nbits = 32 - __clz(mx | 1u);                      // bits of the largest node id
+    unsigned long long *src = bufA, *dst = bufB;
+    for (int shift = 13; shift < 13 + nbits; shift += 2) {
+        unsigned long long key[FV_IPT];
+        uint32_t c01 = 0u, c23 = 0u, before[FV_IPT];            // packed digit counts of this thread: (digit 0 | digit 1 << 16), (2 | 3 << 16)
+#pragma unroll
+        for (int k = 0; k < FV_IPT; k++) {
+            key[k] = src[tid * FV_IPT + k];
+            const uint32_t d = (uint32_t)(key[k] >> shift) & 3u, fld = (d & 1u) << 4;
+            const uint32_t word = (d & 2u) ? c23 : c01;
+            before[k] = (word >> fld) & 0xFFFFu;                // equal digits of this thread in front of key k
+            if (d & 2u) c23 += 1u << fld; else c01 += 1u << fld;
+        }
+        const uint32_t i01 = (uint32_t)wave_incl_scan((int)c01, lane), i23 = (uint32_t)wave_incl_scan((int)c23, lane);
+        if (lane == 63) { wsum[2 * wv] = (int)i01; wsum[2 * wv + 1] = (int)i23; }
+        __syncthreads();
+        uint32_t b01 = 0u, b23 = 0u, t01 = 0u, t23 = 0u;        // digits in the waves in front of this one / in the whole block
+        for (int w = 0; w < FV_T / 64; w++) {
+            const uint32_t v01 = (uint32_t)wsum[2 * w], v23 = (uint32_t)wsum[2 * w + 1];
+            if (w < wv) { b01 += v01; b23 += v23; }
+            t01 += v01; t23 += v23;
+        }
+        const uint32_t e01 = b01 + i01 - c01, e23 = b23 + i23 - c23;             // exclusive over the threads, still packed
+        const uint32_t base1 = t01 & 0xFFFFu, base2 = base1 + (t01 >> 16), base3 = base2 + (t23 & 0xFFFFu);
+#pragma unroll
+        for (int k = 0; k < FV_IPT; k++) {
+            const uint32_t d = (uint32_t)(key[k] >> shift) & 3u, fld = (d & 1u) << 4;
+            const uint32_t ex = (((d & 2u) ? e23 : e01) >> fld) & 0xFFFFu;
+            const uint32_t base = d == 0u ? 0u : d == 1u ? base1 : d == 2u ? base2 : base3;
+            dst[base + ex + before[k]] = key[k];
+        }
+        __syncthreads();
+        unsigned long long* t = src; src = dst; dst = t;
+    }
+    unsigned long long skey[FV_IPT];
+#pragma unroll
+    for (int k = 0; k < FV_IPT; k++) skey[k] = src[tid * FV_IPT + k];
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < FV_IPT; k++) {
         const int r = tid * FV_IPT + k;
-        if (r < n) { snode[r] = (uint32_t)(keys[k] >> 13); fvFeat[r] = (uint32_t)(keys[k] & 8191ull); }
+        if (r < n) { snode[r] = (uint32_t)(skey[k] >> 13); fvFeat[r] = (uint32_t)(skey[k] & 8191ull); }
     }
     __syncthreads();
     // group heads: position r starts a group when its node differs from its predecessor's; exclusive scan of the counts over the threads
@@ -1340,7 +1375,7 @@ int pgorb_feature_vectors_batch_device(pgorb_ctx* c, const uint32_t* d_node, con
     if (hipSetDevice(pg_ctx_device(c)) != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "hipSetDevice failed");
     static const bool counting = getenv("PGORB_FV_COUNTING") != nullptr;      // (A / B switch: the O(n^2) counting form for every size)
     if (cap <= FV_T * FV_IPT && !counting) {
-        const size_t ldsS = sizeof(pg_fv_sort_t::storage_type) + (size_t)FV_T * FV_IPT * 4 + (FV_T / 64 + 1) * 4;
+        const size_t ldsS = (size_t)2 * FV_T * FV_IPT * 8 + (2 * FV_T / 64 + 2) * 4;       // two key buffers + the wave totals
         if (!pg_raise_lds(c, reinterpret_cast<const void*>(k_feature_vectors_sorted), 6, ldsS)) return pg_ctx_fail(c, PGORB_E_LIMIT, "feature vector scratch exceeds the LDS");
         hipLaunchKernelGGL(k_feature_vectors_sorted, dim3(nframes), dim3(FV_T), ldsS, (hipStream_t)stream, d_node, d_n, cap, d_fv_node, d_fv_start, d_fv_feat, d_nfv);
         if (hipGetLastError() != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "k_feature_vectors_sorted launch failed");

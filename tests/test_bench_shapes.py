@@ -438,7 +438,9 @@ def test_device_resident_stream_front_end_stage_equals_the_host_stream():
                 m12, nm, word, _, _ = st.frontend_results(slot, nb, cap)
                 n = np.array(res[0])
             for k in range(nb):
-                out.append((int(n[k]), int(nm[k]), m12[k, :n[k]].copy() if len(out) else None, word[k, :n[k]].copy()))
+                # matches12 of the pair (previous frame, frame k) is indexed by the PREVIOUS frame's keypoints
+                nprev = out[-1][0] if out else 0
+                out.append((int(n[k]), int(nm[k]), m12[k, :nprev].copy() if out else None, word[k, :n[k]].copy()))
         for i, (b0, nb) in enumerate(chunks):
             slot = i % 2
             if len(pending) == 2:

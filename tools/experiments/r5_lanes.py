@@ -7,8 +7,9 @@ from pilotguru_amd.synth import synth_ride
 W, H, NF, B = 1920, 1080, 2000, 128
 ext = pg.ORBextractor(NF, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B)
 frames = torch.from_numpy(synth_ride(0, W, H, B)).cuda()
-def run(lanes, depth, stagger, secs=2.0):
+def run(lanes, depth, stagger, secs=2.0, ahead=0):
     os.environ["PGORB_STREAM_STAGGER"] = str(stagger)
+    os.environ["PGORB_STREAM_K1_AHEAD"] = str(ahead)
     st = pg.DeviceFrameStream(ext, W, H, B, depth=depth, lanes=lanes)
     for k in range(2 * depth):
         if k >= depth: st.wait(k % depth, on_host=False)
@@ -26,5 +27,9 @@ def run(lanes, depth, stagger, secs=2.0):
     dt = time.perf_counter() - t0
     st.close()
     return (n + depth) * B / dt
+if len(sys.argv) > 1 and sys.argv[1] == "ahead":
+    for lanes, depth, ah in ((2, 2, 0), (2, 2, 1), (2, 4, 1), (3, 3, 1), (2, 2, 0), (2, 2, 1)):
+        print("lanes %d depth %d K1-ahead %d: %.0f frames/s" % (lanes, depth, ah, run(lanes, depth, 0, ahead=ah)), flush=True)
+    sys.exit(0)
 for lanes, depth, stg in ((1, 2, 0), (2, 2, 0), (2, 2, 1), (2, 2, 2), (2, 4, 1), (2, 4, 2), (3, 3, 1), (3, 6, 1), (2, 2, 1), (1, 2, 0)):
     print("lanes %d depth %d stagger %d: %.0f frames/s" % (lanes, depth, stg, run(lanes, depth, stg)), flush=True)
