@@ -58,10 +58,6 @@ struct pgorb_ctx {
     // a device-resident stream's lanes (pgorb_stream_create_device): recorded behind the batch's last pyramid launch / behind K2,
     // so that the NEXT batch (on another lane) can be held back until this one has reached that point (stagger)
     hipEvent_t evPyrEnd = nullptr, evFastEnd = nullptr;
-    // ... and the pyramid of a lane's batch on ANOTHER stream (sAhead: the stream's high-priority pyramid queue), one-wave workgroups;
-    // K2.. on the lane's own stream behind evAheadPyr; evLaneDone: the lane's previous batch has left its arenas
-    hipStream_t sAhead = nullptr;
-    hipEvent_t evAheadPyr = nullptr, evLaneDone = nullptr;
     hipStream_t sQt = nullptr, sDesc = nullptr;
     hipEvent_t evGrpFast[PG_MAXL] = {}, evGrpQt[PG_MAXL] = {}, evDescDone = nullptr;
     Arena stageA, stageB, stageOut, stageSfi, vocab;
@@ -541,12 +537,6 @@ int run_batch(pgorb_ctx* c, const uint8_t* d_gray, bool resident_in_level0, int 
     // by a memset otherwise
     const bool foldClear = !c->pipePyr && P.nlevels > 1;
     if (!foldClear) PG_HIP(c, hipMemsetAsync(P.status, 0, 16, s));
-    if (c->sAhead && P.nlevels > 1 && !c->pipePyr && !c->pipeLev) {
-        // the high-priority pyramid queue may run as soon as (i) the frames are where the lane's stream stands now (its wait on the
-        // caller's event is queued) and (ii) the lane's previous batch is out of its arenas
-        PG_HIP(c, hipEventRecord(c->evPyrEnd, s));
-        PG_HIP(c, hipStreamWaitEvent(c->sAhead, c->evPyrEnd, 0));
-    }
     hipEvent_t* ev = (c->profExtract < c->profMax) ? &c->evExtract[5 * (size_t)c->profExtract] : nullptr;
     if (ev) PG_HIP(c, hipEventRecord(ev[0], s));
     if (c->pipePyr && P.nlevels > 1) {
@@ -616,15 +606,6 @@ int run_batch(pgorb_ctx* c, const uint8_t* d_gray, bool resident_in_level0, int 
         PG_HIP(c, hipGetLastError());
         c->lastFrames = nframes;
         return 0;
-    } else if (c->sAhead && P.nlevels > 1) {
-        // the pyramid on the stream's high-priority queue (one-wave workgroups), everything else here behind it
-        for (int l = 1; l < P.nlevels; l++)
-            if (!pg_launch_pyramid_level(P, l, nframes, c->sAhead, l == 1 ? P.status : nullptr, 1) && l == 1) PG_HIP(c, hipMemsetAsync(P.status, 0, 16, c->sAhead));
-        PG_HIP(c, hipEventRecord(c->evAheadPyr, c->sAhead));
-        PG_HIP(c, hipStreamWaitEvent(s, c->evAheadPyr, 0));
-        if (ev) PG_HIP(c, hipEventRecord(ev[1], s));
-        pg_launch_fast(P, nframes, s);
-        if (ev) PG_HIP(c, hipEventRecord(ev[2], s));
     } else {
         for (int l = 1; l < P.nlevels; l++)
             if (!pg_launch_pyramid_level(P, l, nframes, s, l == 1 ? P.status : nullptr) && l == 1) PG_HIP(c, hipMemsetAsync(P.status, 0, 16, s));
@@ -817,8 +798,6 @@ void pgorb_destroy(pgorb_ctx* c)
     while (!c->streams.empty()) pgorb_stream_destroy(c->streams.back());      // a stream holds a pointer to its context
     if (c->evPyrEnd) (void)hipEventDestroy(c->evPyrEnd);
     if (c->evFastEnd) (void)hipEventDestroy(c->evFastEnd);
-    if (c->evAheadPyr) (void)hipEventDestroy(c->evAheadPyr);
-    if (c->evLaneDone) (void)hipEventDestroy(c->evLaneDone);
     Arena* all[] = {&c->cellTab, &c->cellTabBal, &c->cellCand, &c->cellCount, &c->pyr, &c->cand, &c->sel, &c->nodes, &c->counters, &c->tables, &c->qtTab, &c->qtLeaf,
                     &c->outBlk, &c->stageA, &c->stageB, &c->stageOut, &c->stageSfi, &c->vocab, &c->xdesc};
     for (Arena* a : all) if (a->p) (void)hipFree(a->p);
@@ -1378,7 +1357,6 @@ struct pgorb_stream {
     int stagger = 0;                       // 0: lanes start their batches as soon as they can; 1: a batch's K1 starts when the previously
                                            // submitted batch has finished ITS K1 (its K2 is starting); 2: ... has finished its K2
     int lastLane = -1;                     // the lane the previously submitted batch runs on
-    hipStream_t sAhead = nullptr;          // PGORB_STREAM_K1_AHEAD: the lanes' pyramids on ONE high-priority queue (see run_batch)
     hipStream_t sChain = nullptr;          // the sections that cross batches, in submission order (several lanes: a stream of its own)
     int32_t* hStatus = nullptr;            // pinned, one word per slot (device form: the batch's status word)
     struct Slot {
@@ -1528,20 +1506,10 @@ int pgorb_stream_create_device(pgorb_ctx* c, int w, int h, int batch, int depth,
     if (lanes > 1) ok = ok && hipStreamCreateWithFlags(&s->sChain, hipStreamNonBlocking) == hipSuccess;
     else s->sChain = s->sRun;
     if (const char* e = getenv("PGORB_STREAM_STAGGER")) s->stagger = atoi(e);
-    const bool ahead = lanes > 1 && getenv("PGORB_STREAM_K1_AHEAD") && atoi(getenv("PGORB_STREAM_K1_AHEAD")) != 0;
-    if (ahead) {
-        int lo = 0, hi = 0;
-        ok = ok && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hipStreamCreateWithPriority(&s->sAhead, hipStreamNonBlocking, hi) == hipSuccess;
-        s->stagger = 0;
-    }
     if (lanes > 1)
         for (pgorb_ctx* lc : s->lane) {
             if (!lc->evPyrEnd) ok = ok && hipEventCreateWithFlags(&lc->evPyrEnd, hipEventDisableTiming) == hipSuccess;
             if (!lc->evFastEnd) ok = ok && hipEventCreateWithFlags(&lc->evFastEnd, hipEventDisableTiming) == hipSuccess;
-            if (ahead) {
-                if (!lc->evAheadPyr) ok = ok && hipEventCreateWithFlags(&lc->evAheadPyr, hipEventDisableTiming) == hipSuccess;
-                lc->sAhead = s->sAhead;
-            }
         }
     for (auto& sl : s->slot) {
         ok = ok && hipMalloc((void**)&sl.dOut, s->outBytes + 256) == hipSuccess;
@@ -1579,11 +1547,6 @@ void pgorb_stream_destroy(pgorb_stream* s)
     if (s->sIn) (void)hipStreamSynchronize(s->sIn);
     if (s->sRun) (void)hipStreamSynchronize(s->sRun);
     if (s->sOut) (void)hipStreamSynchronize(s->sOut);
-    if (s->sAhead) {
-        (void)hipStreamSynchronize(s->sAhead);
-        for (pgorb_ctx* lc : s->lane) lc->sAhead = nullptr;
-        (void)hipStreamDestroy(s->sAhead);
-    }
     for (size_t l = 1; l < s->sLane.size(); l++) if (s->sLane[l]) { (void)hipStreamSynchronize(s->sLane[l]); (void)hipStreamDestroy(s->sLane[l]); }
     for (size_t l = 1; l < s->lane.size(); l++) pgorb_destroy(s->lane[l]);      // the private sibling contexts
     if (s->sChain && s->lane.size() > 1) { (void)hipStreamSynchronize(s->sChain); (void)hipStreamDestroy(s->sChain); }

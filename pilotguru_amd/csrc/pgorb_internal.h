@@ -247,7 +247,7 @@ void pg_launch_ingest(const PgPlan& P, const uint8_t* src, int stride, int64_t f
                       int rgb_order, int rot, int vflip, int hflip, int nframes, hipStream_t s);
 void pg_launch_color_to_gray(const PgPlan& P, const uint8_t* src, int stride, int64_t fstride, int channels,
                              int rgb_order, int nframes, hipStream_t s);
-bool pg_launch_pyramid_level(const PgPlan& P, int level, int nframes, hipStream_t s, int32_t* clearWord = nullptr, int oneWave = 0);
+bool pg_launch_pyramid_level(const PgPlan& P, int level, int nframes, hipStream_t s, int32_t* clearWord = nullptr);
 void pg_launch_fast(const PgPlan& P, int nframes, hipStream_t s);
 void pg_launch_fast_levels(const PgPlan& P, int nframes, int levelBeg, int levelEnd, hipStream_t s);
 void pg_launch_quadtree(const PgPlan& P, int nframes, hipStream_t s);

@@ -355,17 +355,14 @@ __device__ __forceinline__ PgRowGrp pyr_unpack_group(const uint32_t (&rr)[8])
 __global__ __launch_bounds__(256) void k_pyr_resize_rows4(
     const uint8_t* __restrict__ src, int spitch, int64_t sfstride, int sh,
     uint8_t* __restrict__ dst, int dpitch, int64_t dfstride, int dw, int dh,
-    const PgQuadTab2* __restrict__ qtab, const PgRowGrp* __restrict__ rowgrp, int nx, uint32_t nxMagic, int wavesY)
+    const PgQuadTab2* __restrict__ qtab, const PgRowGrp* __restrict__ rowgrp, int nx, uint32_t nxMagic)
 {
-    // wavesY = blockDim.y: 4 (a 256 x 32 tile per workgroup) or 1 -- one-wave workgroups of 256 x 8, for the pyramid that runs one
-    // batch AHEAD on a high-priority stream beside K2 of the batch before (api.hip, device-resident stream): a one-wave workgroup
-    // fits into ANY wave slot a retiring K2 wave leaves, a four-wave workgroup with LDS waits for a whole CU to drain
     asm volatile("" :: "s"(src), "s"(spitch), "s"(sfstride), "s"(sh), "s"(dst), "s"(dpitch), "s"(dfstride),
-                 "s"(dw), "s"(dh), "s"(qtab), "s"(rowgrp), "s"(nx), "s"(nxMagic), "s"(wavesY));
+                 "s"(dw), "s"(dh), "s"(qtab), "s"(rowgrp), "s"(nx), "s"(nxMagic));
     const int t = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const int ty = (nx == 1) ? t : (int)__umulhi((uint32_t)t, nxMagic), tx = t - ty * nx;      // t / nx, t % nx
     const int quad = tx * 64 + threadIdx.x;
-    const int grp = (ty * wavesY + __builtin_amdgcn_readfirstlane(threadIdx.y)) * 2;      // groups grp, grp + 1
+    const int grp = (ty * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y)) * 2;      // groups grp, grp + 1
     const int dy0 = grp * 4;
     const int ngrp = (dh + 3) >> 2;
     const PgRowGrp* rp = rowgrp + min(grp, ngrp - 1);                 // (the table has one record of slack)
@@ -487,20 +484,11 @@ __global__ __launch_bounds__(256) void k_pyr_resize_rows4_lds(
 }
 
 // clearWord: a device word this launch sets to zero (or null).  Returns false when the kernel variant taken cannot do that.
-bool pg_launch_pyramid_level(const PgPlan& P, int level, int nframes, hipStream_t s, int32_t* clearWord, int oneWave)
+bool pg_launch_pyramid_level(const PgPlan& P, int level, int nframes, hipStream_t s, int32_t* clearWord)
 {
     const PgLevel& S = P.lvl[level - 1];
     const PgLevel& D = P.lvl[level];
     static const bool noLds = getenv("PGORB_PYR_NO_LDS") != nullptr;
-    if (oneWave && D.qtab2 && D.yrel) {
-        const int nx = (D.w + 255) / 256, ny = (D.h + 7) / 8;
-        const int tiles = (nx * ny + 7) & ~7;
-        const uint32_t nxMagic = nx > 1 ? (uint32_t)(((1ull << 32) / (uint64_t)nx) + 1ull) : 0u;
-        dim3 block(64, 1), grid(tiles, 1, nframes);
-        hipLaunchKernelGGL(k_pyr_resize_rows4, grid, block, 0, s, S.img, S.pitch, S.fstride, S.h,
-                           D.img, D.pitch, D.fstride, D.w, D.h, D.qtab2, D.rowgrp, nx, nxMagic, 1);
-        return false;
-    }
     if (D.qtab2 && D.yrel && D.pyrCpr > 0 && S.pitch % 16 == 0 && !noLds) {
         const int tileRows = 16 * D.pyrGpw;
         const int nx = (D.w + 255) / 256, ny = (D.h + tileRows - 1) / tileRows;
@@ -521,7 +509,7 @@ bool pg_launch_pyramid_level(const PgPlan& P, int level, int nframes, hipStream_
         const uint32_t nxMagic = nx > 1 ? (uint32_t)(((1ull << 32) / (uint64_t)nx) + 1ull) : 0u;   // exact: tiles * nx < 2^32
         dim3 block(64, 4), grid(tiles, 1, nframes);
         hipLaunchKernelGGL(k_pyr_resize_rows4, grid, block, 0, s, S.img, S.pitch, S.fstride, S.h,
-                           D.img, D.pitch, D.fstride, D.w, D.h, D.qtab2, D.rowgrp, nx, nxMagic, 4);
+                           D.img, D.pitch, D.fstride, D.w, D.h, D.qtab2, D.rowgrp, nx, nxMagic);
         return false;
     }
     if (D.qtab) {
