@@ -45,6 +45,8 @@
 #include <stdlib.h>
 
 extern __shared__ __attribute__((aligned(16))) uint8_t pg_fast_smem[];
+typedef __attribute__((address_space(1))) const void* pg_gptr_t;
+typedef __attribute__((address_space(3))) void* pg_lptr_t;
 
 // v_min3_i32 / v_max3_i32 as opaque instructions: written as min(min(a, b), c) the optimiser re-associates the
 // sliding-window chains of the exact score, shares two-input pairs between neighbouring windows and ends up with MORE
@@ -400,6 +402,9 @@ __device__ __forceinline__ int quick_pass_b(const uint8_t* tile, int IW, int IH,
 // polarities cost 16 + 80.  Entries whose pixel is not a corner at t are overwritten with 0xFFFF: NMS skips them
 // without touching the score map, and of a pixel's two entries (both polarities passed) at most one survives.
 #define FAST_DEAD 0xFFFFu
+#ifndef PG_FAST_SCORE_I32          // developer A/B build (make EXTRA=-DPG_FAST_SCORE_I32=1): the 32-bit integer form of rounds 2-4 everywhere
+#define PG_FAST_SCORE_I32 0
+#endif
 template <bool BFMT>     // entry format: quick_pass_b's (lane, bit position) or the older (polarity << 15) | (iy << 8) | ix
 __device__ __forceinline__ void score_list(const uint8_t* tile, int TP, uint8_t* smap, int mapPitch,
                                            uint16_t* list, int nlist, int t, int lane)
@@ -441,6 +446,82 @@ __device__ __forceinline__ void score_list(const uint8_t* tile, int TP, uint8_t*
             else if (!corner) list[i] = (uint16_t)FAST_DEAD;
         }
     }
+}
+
+// (3') round 5: the exact score on PACKED f16 pairs -- 21 three-input operations per candidate instead of 16 + 40.
+// A FAST score only ORDERS ring pixels, so the differences never have to be formed: with x_k = sgn * (1024 + ring_k) (f16: the
+// bit pattern 0x6400 | byte IS 1024 + byte, the sign bit negates -- one v_bitop3_b32 per register, no conversion)
+//     max over the 16 arcs of (min over the arc of sgn * (v - ring))  =  sgn * (1024 + v)  -  min over the arcs of (max over the arc of x),
+// for the darker ring (sgn = +1) and the brighter ring (sgn = -1) alike.  Ring positions k and k + 8 share a register
+// (low / high half: the arcs that start at k and at k + 8 are computed by the same v_pk_maximum3_f16), and the positions past 7
+// of the sliding windows are the SAME registers with their halves exchanged -- op_sel / op_sel_hi of the packed instruction, no
+// operation.  8 + 8 v_pk_maximum3_f16 (windows of 3, then 3 + 3 + 3), 5 v_pk_minimum3_f16 over the 16 arcs and
+// across the halves.  All values are integers below 2048 in magnitude: exact in f16.  The high halves come from ds_read_u8_d16_hi (on this
+// part -- sramecc -- a d16 load ZEROES the other half of its destination, tools/ubench/valu_rate5.hip), the low halves from plain
+// byte loads, and the bitop3 that applies bias and sign also merges the two.
+#define PG_PK3(OP, d, a, b, c, SEL) asm(OP " %0, %1, %2, %3" SEL : "=v"(d) : "v"(a), "v"(b), "v"(c))
+#define PG_SW_NONE ""
+#define PG_SW_C " op_sel:[0,0,1] op_sel_hi:[1,1,0]"        // halves of the third source exchanged
+#define PG_SW_BC " op_sel:[0,1,1] op_sel_hi:[1,0,0]"       // ... of the second and third
+template <bool BFMT>
+__device__ __forceinline__ void score_list_pk(const uint8_t* tile, uint8_t* smap, uint16_t* list, int nlist, int t, int lane)
+{
+    constexpr int TP = 48, MP = 40;
+#define PG_RO(dx, dy) ((3 + (dy)) * TP + 3 + (dx))               // byte offset of ring pixel (dx, dy) from (x - 3, y - 3)
+    const _Float16 th = (_Float16)t;
+    for (int base = 0; base < nlist; base += 64) {
+        const int i = base + lane;
+        if (i < nlist) {
+            const int e = list[i];
+            int iy, ix, bright;
+            if (BFMT) bfmt_decode(e, iy, ix, bright);
+            else { iy = (e >> 8) & 0x7F; ix = e & 0xFF; bright = e >> 15; }
+            const uint8_t* rb = tile + iy * TP + 1 + ix;             // (x - 3, y - 3) of the candidate
+            // ring positions 0..7 (OpenCV's order: (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)) -> low halves
+            const uint32_t l0 = rb[PG_RO(0, 3)], l1 = rb[PG_RO(1, 3)], l2 = rb[PG_RO(2, 2)], l3 = rb[PG_RO(3, 1)];
+            const uint32_t l4 = rb[PG_RO(3, 0)], l5 = rb[PG_RO(3, -1)], l6 = rb[PG_RO(2, -2)], l7 = rb[PG_RO(1, -3)];
+            const uint32_t v = rb[PG_RO(0, 0)];
+            // ... 8..15 ((0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)) -> high halves
+            uint32_t h0, h1, h2, h3, h4, h5, h6, h7;
+            const uint32_t la = (uint32_t)(uintptr_t)(pg_lptr_t)rb;
+            asm volatile("ds_read_u8_d16_hi %0, %8 offset:%9\n\tds_read_u8_d16_hi %1, %8 offset:%10\n\tds_read_u8_d16_hi %2, %8 offset:%11\n\t"
+                         "ds_read_u8_d16_hi %3, %8 offset:%12\n\tds_read_u8_d16_hi %4, %8 offset:%13\n\tds_read_u8_d16_hi %5, %8 offset:%14\n\t"
+                         "ds_read_u8_d16_hi %6, %8 offset:%15\n\tds_read_u8_d16_hi %7, %8 offset:%16\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3), "=&v"(h4), "=&v"(h5), "=&v"(h6), "=&v"(h7)
+                         : "v"(la), "n"(PG_RO(0, -3)), "n"(PG_RO(-1, -3)), "n"(PG_RO(-2, -2)), "n"(PG_RO(-3, -1)), "n"(PG_RO(-3, 0)),
+                           "n"(PG_RO(-3, 1)), "n"(PG_RO(-2, 2)), "n"(PG_RO(-1, 3)));
+            const uint32_t K = bright ? 0xE400E400u : 0x64006400u;   // 1024 + byte, negated for the brighter ring
+            // (lo | hi) ^ K:  bitop3 0x56
+            const uint32_t A0 = __builtin_amdgcn_bitop3_b32(l0, h0, K, 0x56), A1 = __builtin_amdgcn_bitop3_b32(l1, h1, K, 0x56);
+            const uint32_t A2 = __builtin_amdgcn_bitop3_b32(l2, h2, K, 0x56), A3 = __builtin_amdgcn_bitop3_b32(l3, h3, K, 0x56);
+            const uint32_t A4 = __builtin_amdgcn_bitop3_b32(l4, h4, K, 0x56), A5 = __builtin_amdgcn_bitop3_b32(l5, h5, K, 0x56);
+            const uint32_t A6 = __builtin_amdgcn_bitop3_b32(l6, h6, K, 0x56), A7 = __builtin_amdgcn_bitop3_b32(l7, h7, K, 0x56);
+            // windows of 3: T_k = (max x[k..k+2], max x[k+8..k+10]); A_8 = A_0 with its halves exchanged, A_9 = A_1 ...
+            uint32_t T0, T1, T2, T3, T4, T5, T6, T7;
+            PG_PK3("v_pk_maximum3_f16", T0, A0, A1, A2, PG_SW_NONE); PG_PK3("v_pk_maximum3_f16", T1, A1, A2, A3, PG_SW_NONE);
+            PG_PK3("v_pk_maximum3_f16", T2, A2, A3, A4, PG_SW_NONE); PG_PK3("v_pk_maximum3_f16", T3, A3, A4, A5, PG_SW_NONE);
+            PG_PK3("v_pk_maximum3_f16", T4, A4, A5, A6, PG_SW_NONE); PG_PK3("v_pk_maximum3_f16", T5, A5, A6, A7, PG_SW_NONE);
+            PG_PK3("v_pk_maximum3_f16", T6, A6, A7, A0, PG_SW_C);    PG_PK3("v_pk_maximum3_f16", T7, A7, A0, A1, PG_SW_BC);
+            // windows of 9: N_k = max(T_k, T_k+3, T_k+6)
+            uint32_t N0, N1, N2, N3, N4, N5, N6, N7;
+            PG_PK3("v_pk_maximum3_f16", N0, T0, T3, T6, PG_SW_NONE); PG_PK3("v_pk_maximum3_f16", N1, T1, T4, T7, PG_SW_NONE);
+            PG_PK3("v_pk_maximum3_f16", N2, T2, T5, T0, PG_SW_C);    PG_PK3("v_pk_maximum3_f16", N3, T3, T6, T1, PG_SW_C);
+            PG_PK3("v_pk_maximum3_f16", N4, T4, T7, T2, PG_SW_C);    PG_PK3("v_pk_maximum3_f16", N5, T5, T0, T3, PG_SW_BC);
+            PG_PK3("v_pk_maximum3_f16", N6, T6, T1, T4, PG_SW_BC);   PG_PK3("v_pk_maximum3_f16", N7, T7, T2, T5, PG_SW_BC);
+            uint32_t r1, r2, r3, r4, M;
+            PG_PK3("v_pk_minimum3_f16", r1, N0, N1, N2, PG_SW_NONE); PG_PK3("v_pk_minimum3_f16", r2, N3, N4, N5, PG_SW_NONE);
+            PG_PK3("v_pk_minimum3_f16", r3, N6, N7, r1, PG_SW_NONE); PG_PK3("v_pk_minimum3_f16", r4, r2, r3, r3, PG_SW_NONE);
+            PG_PK3("v_pk_minimum3_f16", M, r4, r4, r4, PG_SW_C);     // low half: min(low, high)  (the unpacked v_min3_f16 issues at half the rate)
+            // sgn * (1024 + v) - 1 as f16 bits: 1023 + v = 0x63FF + v;  -(1025 + v) = 0xE401 + v
+            const uint32_t ccb = v + (bright ? 0xE401u : 0x63FFu);
+            const _Float16 sh = __builtin_bit_cast(_Float16, (uint16_t)ccb) - __builtin_bit_cast(_Float16, (uint16_t)M);   // the score (OpenCV: arc minimum - 1)
+            const bool corner = sh >= th;
+            if (corner) smap[(iy + 1) * MP + ix + 1] = (uint8_t)(int)sh;
+            if (BFMT) list[i] = corner ? (uint16_t)((iy << 8) | ix) : (uint16_t)FAST_DEAD;
+            else if (!corner) list[i] = (uint16_t)FAST_DEAD;
+        }
+    }
+#undef PG_RO
 }
 
 // 3x3 strict NMS of one pixel on the score map (outside the interior = 0); returns its score or 0
@@ -494,8 +575,6 @@ __device__ __noinline__ int fast_pass_chunked(const uint8_t* tile, int TP, uint8
     return done;
 }
 
-typedef __attribute__((address_space(1))) const void* pg_gptr_t;
-typedef __attribute__((address_space(3))) void* pg_lptr_t;
 
 #ifdef PGORB_FAST_TIMING
 // developer build only (make EXTRA=-DPGORB_FAST_TIMING): 10 ns ticks per phase of every wave (no
@@ -507,8 +586,12 @@ extern "C" int pgorb_debug_fast_times(unsigned int* out, int nwaves)
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(pg_ft_log), sizeof(unsigned) * 8 * (size_t)nwaves) == hipSuccess ? 0 : -1;
 }
+#define FT_PARAMS , unsigned long long& ft_t0, const int ft_id
+#define FT_ARGS , ft_t0, ft_id
 #else
 #define FT_TS(k) do {} while (0)
+#define FT_PARAMS
+#define FT_ARGS
 #endif
 
 // One detector pass at threshold t over the staged window == cv::FAST(window, t, true): necessary test + compaction,
@@ -517,7 +600,7 @@ extern "C" int pgorb_debug_fast_times(unsigned int* out, int nwaves)
 template <int TPC, int MPC, bool NARROW, bool STRONG>
 __device__ __forceinline__ int fast_pass(int32_t* status, const uint8_t* tile, int TP, uint8_t* smap, int mapPitch, int mapRows,
                                          int IW, int IH, int t, uint16_t* list, uint32_t* out, int cellCap, int xoff, int yoff, int lane,
-                                         const PgLaneValid& V)
+                                         const PgLaneValid& V FT_PARAMS)
 {
     // (2) necessary test + compaction
     const int nlist = NARROW ? quick_pass_b<STRONG>(tile, IW, IH, t, list, lane, V)
@@ -532,9 +615,12 @@ __device__ __forceinline__ int fast_pass(int32_t* status, const uint8_t* tile, i
     if (nlist < 0)                                         // list would overflow: chunked slow path
         return fast_pass_chunked(tile, TP, smap, mapPitch, mapRows, IW, IH, t, list, out, cellCap, xoff, yoff, lane);
     PG_WAVE_SYNC();
+    if (!STRONG) FT_TS(5);
     // (3) exact scores for the compacted pixels
-    score_list<NARROW>(tile, TP, smap, mapPitch, list, nlist, t, lane);
+    if (TPC == 48 && MPC == 40 && !PG_FAST_SCORE_I32) score_list_pk<NARROW>(tile, smap, list, nlist, t, lane);
+    else score_list<NARROW>(tile, TP, smap, mapPitch, list, nlist, t, lane);
     PG_WAVE_SYNC();
+    if (!STRONG) FT_TS(6);
 #if defined(PGORB_FAST_STOP) && PGORB_FAST_STOP == 4
     return 0x40000000 | (nlist ? list[lane % nlist] : 0);
 #endif
@@ -692,6 +778,30 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgPlan P, int 
     }
     PG_WAVE_SYNC();
     FT_TS(2);
+    // developer builds (tools/experiments/r5_k2_sensitivity.sh): what one more unit of each resource costs the launch -- n extra
+    // fast-class VALU instructions, n scalar instructions, n conflict-free LDS reads or n x 64 cycles of sleep per cell
+#ifdef PGORB_FAST_PAD_VALU
+    { uint32_t z = lane;
+#pragma unroll
+      for (int i = 0; i < PGORB_FAST_PAD_VALU; i++) asm volatile("v_add_u32_e32 %0, %0, %0" : "+v"(z));
+      asm volatile("" :: "v"(z)); }
+#endif
+#ifdef PGORB_FAST_PAD_SALU
+    { uint32_t z = (uint32_t)cell;
+#pragma unroll
+      for (int i = 0; i < PGORB_FAST_PAD_SALU; i++) asm volatile("s_add_u32 %0, %0, %0" : "+s"(z) :: "scc");
+      asm volatile("" :: "s"(z)); }
+#endif
+#ifdef PGORB_FAST_PAD_LDS
+    { uint32_t z = 0; const uint32_t* tw = reinterpret_cast<const uint32_t*>(tile) + lane;
+#pragma unroll
+      for (int i = 0; i < PGORB_FAST_PAD_LDS; i++) z += tw[(i & 7) * 64];
+      asm volatile("" :: "v"(z)); }
+#endif
+#ifdef PGORB_FAST_PAD_SLEEP
+#pragma unroll
+    for (int i = 0; i < PGORB_FAST_PAD_SLEEP; i++) __builtin_amdgcn_s_sleep(1);
+#endif
 #if defined(PGORB_FAST_STOP) && PGORB_FAST_STOP == 1       // window staged, nothing else
     if (lane == 0) *cellCnt = reinterpret_cast<const uint32_t*>(tile)[17] & 1;
     return;
@@ -704,7 +814,8 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgPlan P, int 
 
     // The two detector passes written out (round 3): as a `for (pass)` loop the compiler merged the two bodies and paid for it
     // with scalar flag juggling around every phase.
-    int total = fast_pass<TPC, MPC, NARROW, false>(statusPtr, tile, TP, smap, mapPitch, mapRows, IW, IH, iniTh, list, out, cellCap, xoff, yoff, lane, valid);
+    int total = fast_pass<TPC, MPC, NARROW, false>(statusPtr, tile, TP, smap, mapPitch, mapRows, IW, IH, iniTh, list, out, cellCap, xoff, yoff, lane, valid FT_ARGS);
+    FT_TS(7);
 #if defined(PGORB_FAST_SKIP) || defined(PGORB_FAST_STOP)   // timing experiments: no minTh retry
     if (lane == 0) *cellCnt = min(total & 0xFFFF, cellCap);
     return;
@@ -714,7 +825,7 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgPlan P, int 
         // not depend on the threshold and every corner at iniThFAST is a candidate of the retry again (an "empty" cell
         // can hold corners -- equal neighbouring maxima that strict NMS removed)
         PG_WAVE_SYNC();
-        total = fast_pass<TPC, MPC, NARROW, true>(statusPtr, tile, TP, smap, mapPitch, mapRows, IW, IH, minTh, list, out, cellCap, xoff, yoff, lane, valid);
+        total = fast_pass<TPC, MPC, NARROW, true>(statusPtr, tile, TP, smap, mapPitch, mapRows, IW, IH, minTh, list, out, cellCap, xoff, yoff, lane, valid FT_ARGS);
     }
     if (lane == 0) *cellCnt = min(total, cellCap);
     FT_TS(3);

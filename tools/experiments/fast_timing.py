@@ -22,7 +22,7 @@ fn(log.ctypes.data, n)
 log = log[(log[:, 2] > 0) & (log[:, 3] > 0)]              # waves that ran a full cell
 print("waves", len(log))
 names = {0: "start -> cell record", 4: "-> addresses ready", 1: "-> window loads issued", 2: "-> window in LDS",
-         5: "-> iniTh test + compaction", 6: "-> iniTh scores", 3: "-> done (NMS, emission, retry)"}
+         5: "-> iniTh test + compaction", 6: "-> iniTh scores", 7: "-> iniTh NMS + emission", 3: "-> done (the minTh retry)"}
 for i, nm in names.items():
     v = log[:, i] * 0.01
     print("   %-28s mean %6.2f us   median %6.2f   p90 %6.2f" % (nm, v.mean(), np.median(v), np.percentile(v, 90)))
