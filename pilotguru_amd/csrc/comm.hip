@@ -90,6 +90,13 @@ struct pgorb_comm {
 
 namespace {
 
+// the calling thread's current device is put back when a group call returns (the calls walk the group's devices)
+struct DeviceRestore {
+    int dev = -1;
+    DeviceRestore() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+    ~DeviceRestore() { if (dev >= 0) (void)hipSetDevice(dev); }
+};
+
 int comm_fail(pgorb_comm* cm, int code, const std::string& msg)
 {
     return pg_ctx_fail(cm->ctxs.empty() ? nullptr : cm->ctxs[0], code, msg.c_str());
@@ -123,6 +130,7 @@ int pgorb_comm_create_local(pgorb_ctx* const* ctxs, int nctx, pgorb_comm** out)
     for (int i = 0; i < nctx; i++) if (!ctxs[i]) return PGORB_E_ARG;
     Rccl* R = rccl();
     if (!R->error.empty()) return pg_ctx_fail(ctxs[0], PGORB_E_HIP, R->error.c_str());
+    DeviceRestore keep;
     pgorb_comm* cm = new pgorb_comm();
     cm->local = true;
     for (int i = 0; i < nctx; i++) {
@@ -156,6 +164,7 @@ int pgorb_comm_create_rank(pgorb_ctx* ctx, int rank, int nranks, const void* id,
     *out = nullptr;
     Rccl* R = rccl();
     if (!R->error.empty()) return pg_ctx_fail(ctx, PGORB_E_HIP, R->error.c_str());
+    DeviceRestore keep;
     pgorb_comm* cm = new pgorb_comm();
     cm->local = false; cm->myRank = rank; cm->nranks = nranks;
     cm->ctxs.push_back(ctx); cm->rankOfCtx.push_back(0); cm->leaderOfRank.push_back(0);
@@ -181,6 +190,7 @@ int pgorb_comm_create_rank(pgorb_ctx* ctx, int rank, int nranks, const void* id,
 void pgorb_comm_destroy(pgorb_comm* cm)
 {
     if (!cm) return;
+    DeviceRestore keep;
     Rccl* R = rccl();
     for (size_t k = 0; k < cm->streams.size(); k++) {
         (void)hipSetDevice(cm->devices[k]);
@@ -203,6 +213,7 @@ int pgorb_vocab_broadcast(pgorb_comm* cm, int root, const pgorb_vocab* v, double
 {
     if (!cm) return PGORB_E_ARG;
     if (seconds) *seconds = 0.0;
+    DeviceRestore keep;
     Rccl* R = rccl();
     const int nctx = (int)cm->ctxs.size();
     if (cm->local ? (root < 0 || root >= nctx) : (root < 0 || root >= cm->nranks)) return comm_fail(cm, PGORB_E_ARG, "broadcast root out of range");
