@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 O=gpurun_out/r05_fuzz_soak.txt
 {
-echo "# tools/experiments/r4_soak.sh on one MI355X (round-5 build: the exact score on packed f16 pairs): random configurations, HIP path against the oracle, bit for bit"
+echo "# tools/experiments/r5_soak.sh on one MI355X (round-5 build: the exact score on packed f16 pairs): random configurations, HIP path against the oracle, bit for bit"
 for spec in "parity 5000 501" "levels 200 502" "batch_parity 1200 503" "matchers 1500 504" "ingest 500 505" "best2 3000 506"; do
   set -- $spec
   echo "## fuzz_$1 $2 cases, seed $3"
