@@ -338,7 +338,10 @@ __device__ __forceinline__ int quick_pass_b(const uint8_t* tile, int IW, int IH,
                             const uint32_t A = (E & M7) + KA, Q = (E & M7) + KQ
 #pragma unroll
     for (int s = 0; s < 5; s++) {
-        if (8 * s >= IH) break;                                       // wave-uniform
+        // steps 0-3 run whatever the interior's height (their rows lie inside the LDS allocation: row 8 s + lr + 6 <= 37; what they
+        // see past the interior is masked by V): no scalar branch between the steps, so the four steps are ONE basic block and
+        // their LDS reads can all be in flight before the first lerp.  Only the fifth step (interiors taller than 32 rows) is optional.
+        if (s == 4 && IH <= 32) break;                                // wave-uniform
         const uint32_t* ru = b0 + (8 * s) * (TP / 4);
         const uint32_t* rc = b0 + (8 * s + 3) * (TP / 4);
         const uint32_t* rd = b0 + (8 * s + 6) * (TP / 4);
