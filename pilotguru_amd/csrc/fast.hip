@@ -405,6 +405,12 @@ __device__ __forceinline__ int quick_pass_b(const uint8_t* tile, int IW, int IH,
 // polarities cost 16 + 80.  Entries whose pixel is not a corner at t are overwritten with 0xFFFF: NMS skips them
 // without touching the score map, and of a pixel's two entries (both polarities passed) at most one survives.
 #define FAST_DEAD 0xFFFFu
+#ifndef PG_FAST_NO_FUSED           // developer A/B builds of two round-5 changes (tools/experiments/r5_k2_ab.sh)
+#define PG_FAST_NO_FUSED 0
+#endif
+#ifndef PG_FAST_NO_CLAMP
+#define PG_FAST_NO_CLAMP 0
+#endif
 #ifndef PG_FAST_SCORE_I32          // developer A/B build (make EXTRA=-DPG_FAST_SCORE_I32=1): the 32-bit integer form of rounds 2-4 everywhere
 #define PG_FAST_SCORE_I32 0
 #endif
@@ -466,65 +472,75 @@ __device__ __forceinline__ void score_list(const uint8_t* tile, int TP, uint8_t*
 #define PG_SW_NONE ""
 #define PG_SW_C " op_sel:[0,0,1] op_sel_hi:[1,1,0]"        // halves of the third source exchanged
 #define PG_SW_BC " op_sel:[0,1,1] op_sel_hi:[1,0,0]"       // ... of the second and third
+// the exact score of ONE list entry: returns the score when the pixel is a corner at t (score >= t), 0 otherwise; (iy, ix) = its
+// interior coordinates
+template <bool BFMT>
+__device__ __forceinline__ int pk_score_entry(const uint8_t* tile, int e, _Float16 th, int& iy, int& ix)
+{
+    constexpr int TP = 48;
+#define PG_RO(dx, dy) ((3 + (dy)) * TP + 3 + (dx))               // byte offset of ring pixel (dx, dy) from (x - 3, y - 3)
+    int bright;
+    if (BFMT) bfmt_decode(e, iy, ix, bright);
+    else { iy = (e >> 8) & 0x7F; ix = e & 0xFF; bright = e >> 15; }
+    const uint8_t* rb = tile + iy * TP + 1 + ix;             // (x - 3, y - 3) of the candidate
+    // ring positions 0..7 (OpenCV's order: (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)) -> low halves
+    const uint32_t l0 = rb[PG_RO(0, 3)], l1 = rb[PG_RO(1, 3)], l2 = rb[PG_RO(2, 2)], l3 = rb[PG_RO(3, 1)];
+    const uint32_t l4 = rb[PG_RO(3, 0)], l5 = rb[PG_RO(3, -1)], l6 = rb[PG_RO(2, -2)], l7 = rb[PG_RO(1, -3)];
+    const uint32_t v = rb[PG_RO(0, 0)];
+    // ... 8..15 ((0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)) -> high halves
+    uint32_t h0, h1, h2, h3, h4, h5, h6, h7;
+    const uint32_t la = (uint32_t)(uintptr_t)(pg_lptr_t)rb;
+    asm volatile("ds_read_u8_d16_hi %0, %8 offset:%9\n\tds_read_u8_d16_hi %1, %8 offset:%10\n\tds_read_u8_d16_hi %2, %8 offset:%11\n\t"
+                 "ds_read_u8_d16_hi %3, %8 offset:%12\n\tds_read_u8_d16_hi %4, %8 offset:%13\n\tds_read_u8_d16_hi %5, %8 offset:%14\n\t"
+                 "ds_read_u8_d16_hi %6, %8 offset:%15\n\tds_read_u8_d16_hi %7, %8 offset:%16\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3), "=&v"(h4), "=&v"(h5), "=&v"(h6), "=&v"(h7)
+                 : "v"(la), "n"(PG_RO(0, -3)), "n"(PG_RO(-1, -3)), "n"(PG_RO(-2, -2)), "n"(PG_RO(-3, -1)), "n"(PG_RO(-3, 0)),
+                   "n"(PG_RO(-3, 1)), "n"(PG_RO(-2, 2)), "n"(PG_RO(-1, 3)));
+    const uint32_t K = bright ? 0xE400E400u : 0x64006400u;   // 1024 + byte, negated for the brighter ring
+    // (lo | hi) ^ K:  bitop3 0x56
+    const uint32_t A0 = __builtin_amdgcn_bitop3_b32(l0, h0, K, 0x56), A1 = __builtin_amdgcn_bitop3_b32(l1, h1, K, 0x56);
+    const uint32_t A2 = __builtin_amdgcn_bitop3_b32(l2, h2, K, 0x56), A3 = __builtin_amdgcn_bitop3_b32(l3, h3, K, 0x56);
+    const uint32_t A4 = __builtin_amdgcn_bitop3_b32(l4, h4, K, 0x56), A5 = __builtin_amdgcn_bitop3_b32(l5, h5, K, 0x56);
+    const uint32_t A6 = __builtin_amdgcn_bitop3_b32(l6, h6, K, 0x56), A7 = __builtin_amdgcn_bitop3_b32(l7, h7, K, 0x56);
+    // windows of 3: T_k = (max x[k..k+2], max x[k+8..k+10]); A_8 = A_0 with its halves exchanged, A_9 = A_1 ...
+    uint32_t T0, T1, T2, T3, T4, T5, T6, T7;
+    PG_PK3("v_pk_maximum3_f16", T0, A0, A1, A2, PG_SW_NONE); PG_PK3("v_pk_maximum3_f16", T1, A1, A2, A3, PG_SW_NONE);
+    PG_PK3("v_pk_maximum3_f16", T2, A2, A3, A4, PG_SW_NONE); PG_PK3("v_pk_maximum3_f16", T3, A3, A4, A5, PG_SW_NONE);
+    PG_PK3("v_pk_maximum3_f16", T4, A4, A5, A6, PG_SW_NONE); PG_PK3("v_pk_maximum3_f16", T5, A5, A6, A7, PG_SW_NONE);
+    PG_PK3("v_pk_maximum3_f16", T6, A6, A7, A0, PG_SW_C);    PG_PK3("v_pk_maximum3_f16", T7, A7, A0, A1, PG_SW_BC);
+    // windows of 9: N_k = max(T_k, T_k+3, T_k+6)
+    uint32_t N0, N1, N2, N3, N4, N5, N6, N7;
+    PG_PK3("v_pk_maximum3_f16", N0, T0, T3, T6, PG_SW_NONE); PG_PK3("v_pk_maximum3_f16", N1, T1, T4, T7, PG_SW_NONE);
+    PG_PK3("v_pk_maximum3_f16", N2, T2, T5, T0, PG_SW_C);    PG_PK3("v_pk_maximum3_f16", N3, T3, T6, T1, PG_SW_C);
+    PG_PK3("v_pk_maximum3_f16", N4, T4, T7, T2, PG_SW_C);    PG_PK3("v_pk_maximum3_f16", N5, T5, T0, T3, PG_SW_BC);
+    PG_PK3("v_pk_maximum3_f16", N6, T6, T1, T4, PG_SW_BC);   PG_PK3("v_pk_maximum3_f16", N7, T7, T2, T5, PG_SW_BC);
+    uint32_t r1, r2, r3, r4, M;
+    PG_PK3("v_pk_minimum3_f16", r1, N0, N1, N2, PG_SW_NONE); PG_PK3("v_pk_minimum3_f16", r2, N3, N4, N5, PG_SW_NONE);
+    PG_PK3("v_pk_minimum3_f16", r3, N6, N7, r1, PG_SW_NONE); PG_PK3("v_pk_minimum3_f16", r4, r2, r3, r3, PG_SW_NONE);
+    PG_PK3("v_pk_minimum3_f16", M, r4, r4, r4, PG_SW_C);     // low half: min(low, high)  (the unpacked v_min3_f16 issues at half the rate)
+    // sgn * (1024 + v) - 1 as f16 bits: 1023 + v = 0x63FF + v;  -(1025 + v) = 0xE401 + v
+    const uint32_t ccb = v + (bright ? 0xE401u : 0x63FFu);
+    const _Float16 sh = __builtin_bit_cast(_Float16, (uint16_t)ccb) - __builtin_bit_cast(_Float16, (uint16_t)M);   // the score (OpenCV: arc minimum - 1)
+    return sh >= th ? (int)sh : 0;
+#undef PG_RO
+}
+
 template <bool BFMT>
 __device__ __forceinline__ void score_list_pk(const uint8_t* tile, uint8_t* smap, uint16_t* list, int nlist, int t, int lane)
 {
-    constexpr int TP = 48, MP = 40;
-#define PG_RO(dx, dy) ((3 + (dy)) * TP + 3 + (dx))               // byte offset of ring pixel (dx, dy) from (x - 3, y - 3)
+    constexpr int MP = 40;
     const _Float16 th = (_Float16)t;
     for (int base = 0; base < nlist; base += 64) {
         const int i = base + lane;
         if (i < nlist) {
-            const int e = list[i];
-            int iy, ix, bright;
-            if (BFMT) bfmt_decode(e, iy, ix, bright);
-            else { iy = (e >> 8) & 0x7F; ix = e & 0xFF; bright = e >> 15; }
-            const uint8_t* rb = tile + iy * TP + 1 + ix;             // (x - 3, y - 3) of the candidate
-            // ring positions 0..7 (OpenCV's order: (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)) -> low halves
-            const uint32_t l0 = rb[PG_RO(0, 3)], l1 = rb[PG_RO(1, 3)], l2 = rb[PG_RO(2, 2)], l3 = rb[PG_RO(3, 1)];
-            const uint32_t l4 = rb[PG_RO(3, 0)], l5 = rb[PG_RO(3, -1)], l6 = rb[PG_RO(2, -2)], l7 = rb[PG_RO(1, -3)];
-            const uint32_t v = rb[PG_RO(0, 0)];
-            // ... 8..15 ((0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)) -> high halves
-            uint32_t h0, h1, h2, h3, h4, h5, h6, h7;
-            const uint32_t la = (uint32_t)(uintptr_t)(pg_lptr_t)rb;
-            asm volatile("ds_read_u8_d16_hi %0, %8 offset:%9\n\tds_read_u8_d16_hi %1, %8 offset:%10\n\tds_read_u8_d16_hi %2, %8 offset:%11\n\t"
-                         "ds_read_u8_d16_hi %3, %8 offset:%12\n\tds_read_u8_d16_hi %4, %8 offset:%13\n\tds_read_u8_d16_hi %5, %8 offset:%14\n\t"
-                         "ds_read_u8_d16_hi %6, %8 offset:%15\n\tds_read_u8_d16_hi %7, %8 offset:%16\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3), "=&v"(h4), "=&v"(h5), "=&v"(h6), "=&v"(h7)
-                         : "v"(la), "n"(PG_RO(0, -3)), "n"(PG_RO(-1, -3)), "n"(PG_RO(-2, -2)), "n"(PG_RO(-3, -1)), "n"(PG_RO(-3, 0)),
-                           "n"(PG_RO(-3, 1)), "n"(PG_RO(-2, 2)), "n"(PG_RO(-1, 3)));
-            const uint32_t K = bright ? 0xE400E400u : 0x64006400u;   // 1024 + byte, negated for the brighter ring
-            // (lo | hi) ^ K:  bitop3 0x56
-            const uint32_t A0 = __builtin_amdgcn_bitop3_b32(l0, h0, K, 0x56), A1 = __builtin_amdgcn_bitop3_b32(l1, h1, K, 0x56);
-            const uint32_t A2 = __builtin_amdgcn_bitop3_b32(l2, h2, K, 0x56), A3 = __builtin_amdgcn_bitop3_b32(l3, h3, K, 0x56);
-            const uint32_t A4 = __builtin_amdgcn_bitop3_b32(l4, h4, K, 0x56), A5 = __builtin_amdgcn_bitop3_b32(l5, h5, K, 0x56);
-            const uint32_t A6 = __builtin_amdgcn_bitop3_b32(l6, h6, K, 0x56), A7 = __builtin_amdgcn_bitop3_b32(l7, h7, K, 0x56);
-            // windows of 3: T_k = (max x[k..k+2], max x[k+8..k+10]); A_8 = A_0 with its halves exchanged, A_9 = A_1 ...
-            uint32_t T0, T1, T2, T3, T4, T5, T6, T7;
-            PG_PK3("v_pk_maximum3_f16", T0, A0, A1, A2, PG_SW_NONE); PG_PK3("v_pk_maximum3_f16", T1, A1, A2, A3, PG_SW_NONE);
-            PG_PK3("v_pk_maximum3_f16", T2, A2, A3, A4, PG_SW_NONE); PG_PK3("v_pk_maximum3_f16", T3, A3, A4, A5, PG_SW_NONE);
-            PG_PK3("v_pk_maximum3_f16", T4, A4, A5, A6, PG_SW_NONE); PG_PK3("v_pk_maximum3_f16", T5, A5, A6, A7, PG_SW_NONE);
-            PG_PK3("v_pk_maximum3_f16", T6, A6, A7, A0, PG_SW_C);    PG_PK3("v_pk_maximum3_f16", T7, A7, A0, A1, PG_SW_BC);
-            // windows of 9: N_k = max(T_k, T_k+3, T_k+6)
-            uint32_t N0, N1, N2, N3, N4, N5, N6, N7;
-            PG_PK3("v_pk_maximum3_f16", N0, T0, T3, T6, PG_SW_NONE); PG_PK3("v_pk_maximum3_f16", N1, T1, T4, T7, PG_SW_NONE);
-            PG_PK3("v_pk_maximum3_f16", N2, T2, T5, T0, PG_SW_C);    PG_PK3("v_pk_maximum3_f16", N3, T3, T6, T1, PG_SW_C);
-            PG_PK3("v_pk_maximum3_f16", N4, T4, T7, T2, PG_SW_C);    PG_PK3("v_pk_maximum3_f16", N5, T5, T0, T3, PG_SW_BC);
-            PG_PK3("v_pk_maximum3_f16", N6, T6, T1, T4, PG_SW_BC);   PG_PK3("v_pk_maximum3_f16", N7, T7, T2, T5, PG_SW_BC);
-            uint32_t r1, r2, r3, r4, M;
-            PG_PK3("v_pk_minimum3_f16", r1, N0, N1, N2, PG_SW_NONE); PG_PK3("v_pk_minimum3_f16", r2, N3, N4, N5, PG_SW_NONE);
-            PG_PK3("v_pk_minimum3_f16", r3, N6, N7, r1, PG_SW_NONE); PG_PK3("v_pk_minimum3_f16", r4, r2, r3, r3, PG_SW_NONE);
-            PG_PK3("v_pk_minimum3_f16", M, r4, r4, r4, PG_SW_C);     // low half: min(low, high)  (the unpacked v_min3_f16 issues at half the rate)
-            // sgn * (1024 + v) - 1 as f16 bits: 1023 + v = 0x63FF + v;  -(1025 + v) = 0xE401 + v
-            const uint32_t ccb = v + (bright ? 0xE401u : 0x63FFu);
-            const _Float16 sh = __builtin_bit_cast(_Float16, (uint16_t)ccb) - __builtin_bit_cast(_Float16, (uint16_t)M);   // the score (OpenCV: arc minimum - 1)
-            const bool corner = sh >= th;
-            if (corner) smap[(iy + 1) * MP + ix + 1] = (uint8_t)(int)sh;
+            int iy, ix;
+            const int sc = pk_score_entry<BFMT>(tile, list[i], th, iy, ix);
+            const bool corner = sc != 0;
+            if (corner) smap[(iy + 1) * MP + ix + 1] = (uint8_t)sc;
             if (BFMT) list[i] = corner ? (uint16_t)((iy << 8) | ix) : (uint16_t)FAST_DEAD;
             else if (!corner) list[i] = (uint16_t)FAST_DEAD;
         }
     }
-#undef PG_RO
 }
 
 // 3x3 strict NMS of one pixel on the score map (outside the interior = 0); returns its score or 0
@@ -619,6 +635,34 @@ __device__ __forceinline__ int fast_pass(int32_t* status, const uint8_t* tile, i
         return fast_pass_chunked(tile, TP, smap, mapPitch, mapRows, IW, IH, t, list, out, cellCap, xoff, yoff, lane);
     PG_WAVE_SYNC();
     if (!STRONG) FT_TS(5);
+    if (TPC == 48 && MPC == 40 && !PG_FAST_SCORE_I32 && !PG_FAST_NO_FUSED && nlist <= 64) {
+        // ONE round (most cells at iniThFAST): the lane that scored an entry also suppresses and emits it -- the score stays in its
+        // register, so NMS starts at the neighbour reads: no re-filed list entry, no list read, no centre read (two dependent LDS
+        // round trips and a dozen instructions of a wave whose life is its instruction count)
+        int sc = 0, iy = 0, ix = 0;
+        if (lane < nlist) {
+            sc = pk_score_entry<NARROW>(tile, list[lane], (_Float16)t, iy, ix);
+            if (sc) smap[(iy + 1) * 40 + ix + 1] = (uint8_t)sc;
+        }
+        PG_WAVE_SYNC();
+        if (!STRONG) FT_TS(6);
+        if (sc) {
+            const uint8_t* m = smap + (iy + 1) * 40 + ix + 1;
+            const int a = imax3(m[-41], m[-40], m[-39]);
+            const int b = imax3(m[39], m[40], m[41]);
+            const int c = imax3(m[-1], m[1], max(a, b));
+            sc = sc > c ? sc : 0;
+        }
+        const unsigned long long mk = __ballot(sc != 0);
+        if (sc) {
+            const uint32_t pos = (uint32_t)wave_prefix(mk);
+            if (pos < (uint32_t)cellCap)
+                out[pos] = (uint32_t)(ix + xoff) | ((uint32_t)(iy + yoff) << 12) | ((uint32_t)sc << 24);
+            else
+                atomicExch(status, PGORB_E_OVERFLOW);            // cannot happen (see header)
+        }
+        return __popcll(mk);
+    }
     // (3) exact scores for the compacted pixels
     if (TPC == 48 && MPC == 40 && !PG_FAST_SCORE_I32) score_list_pk<NARROW>(tile, smap, list, nlist, t, lane);
     else score_list<NARROW>(tile, TP, smap, mapPitch, list, nlist, t, lane);
@@ -738,30 +782,38 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgPlan P, int 
         asm volatile("" :: "v"(voff));
         FT_TS(4);
 #endif
-        // the score map is cleared FIRST (16 B per lane and step; the map starts 16-byte aligned and the candidate list
-        // behind it absorbs the last partial step): behind the window loads the compiler waits for the DMA before every
-        // ds_write (it cannot tell the two LDS targets apart), which put the clearing after the landing instead of under it
         const int nz = (mapRows * mapPitch + 15) >> 4;
-        if (MPC == 40 && NARROW) {                                 // <= 42 rows of 40 bytes: two unconditional steps of 1 KiB -- what
-            (void)nz;                                              // they clear past the map is the candidate list, written later (the
-            const uint4 z = make_uint4(0u, 0u, 0u, 0u);            // launcher keeps map + list >= 2 KiB)
-            reinterpret_cast<uint4*>(smap)[lane] = z;
-            reinterpret_cast<uint4*>(smap)[lane + 64] = z;
-        } else {
+        const bool laneOn = r0 < rowsPer;
+        // Round 5: in the common geometry the first TWO loads (rows 0-20, 21-41) are issued by every lane with a chunk, whatever the
+        // window's height: a row past the window is CLAMPED to its last row (a duplicate read of a line that is being fetched anyway), so
+        // there is no guard per instruction -- three of them cost 36 scalar instructions and three exec round trips on a wave whose life
+        // is its instruction count.  Rows 37-41 of a 37-row window land in the first bytes of the score map, which is therefore cleared
+        // AFTER the landing now (below); a third load only exists for windows taller than 42 rows (wave-uniform branch).
+        constexpr bool CLAMPED = TPC == 48 && MPC == 40 && NARROW && !PG_FAST_NO_CLAMP;
+        if (!CLAMPED) {
+            // the score map is cleared FIRST (16 B per lane and step; the map starts 16-byte aligned and the candidate list
+            // behind it absorbs the last partial step): behind the window loads the compiler waits for the DMA before every
+            // ds_write (it cannot tell the two LDS targets apart), which put the clearing after the landing instead of under it
             for (int i = lane; i < nz; i += 64) reinterpret_cast<uint4*>(smap)[i] = make_uint4(0u, 0u, 0u, 0u);
         }
-        const bool laneOn = r0 < rowsPer;
         if (TPC == 48) {
-            // 3 chunks per row, 21 rows per instruction; the narrow geometry's windows have at most 46 rows: at most three
-            // instructions, straight line (the loop form compiled into a 4 x unrolled loop with a remainder loop and a division
-            // for the trip count), written out so that the address is SGPR base + 32-bit VGPR offset (the builtin takes a flat
-            // 64-bit VGPR address).  A 36-px-wide cell of a level with ONE cell row can be up to 59 px tall (65 window rows):
-            // the wide instantiation unrolls six guarded steps (126 rows).  (Round 3's first version stopped at three for
+            // 3 chunks per row, 21 rows per instruction, written out so that the address is SGPR base + 32-bit VGPR offset (the
+            // builtin takes a flat 64-bit VGPR address).  A 36-px-wide cell of a level with ONE cell row can be up to 59 px tall (65
+            // window rows): the wide instantiation unrolls six guarded steps (126 rows).  (Round 3's first version stopped at three for
             // both and lost the bottom rows of such cells -- found by the fuzz soak, tests/test_gpu_parity.py has the case now.)
             const uint32_t ldsTile = (uint32_t)(uintptr_t)(pg_lptr_t)tile;
             constexpr int KMAX = NARROW ? 3 : 6;
+            if (CLAMPED) {
+                const uint32_t chOff = (uint32_t)(ch * 16);
+                const uint32_t v0 = (uint32_t)imad24(min(r0, H - 1), pitch, (int)chOff);          // (rows < 64, pitch < 2^23: one v_mad_i32_i24)
+                const uint32_t v1 = (uint32_t)imad24(min(r0 + 21, H - 1), pitch, (int)chOff);
+                if (laneOn) {
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(v0), "s"(win), "s"(ldsTile) : "memory");
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(v1), "s"(win), "s"(ldsTile + 21 * 48) : "memory");
+                }
+            }
 #pragma unroll
-            for (int k = 0; k < KMAX; k++) {
+            for (int k = CLAMPED ? 2 : 0; k < KMAX; k++) {
                 if (k * 21 < H) {                                          // wave-uniform
                     const uint8_t* gk = win + (int64_t)(k * 21) * pitch;   // scalar
                     if (laneOn && r0 + k * 21 < H)
@@ -778,6 +830,11 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgPlan P, int 
         }
         FT_TS(1);
         __builtin_amdgcn_s_waitcnt(0);                     // vmcnt(0): the DMA has landed
+        if (CLAMPED) {                                     // <= 42 rows of 40 bytes: two unconditional steps of 1 KiB -- what they clear
+            const uint4 z = make_uint4(0u, 0u, 0u, 0u);    // past the map is the candidate list, written later (the launcher keeps
+            reinterpret_cast<uint4*>(smap)[lane] = z;      // map + list >= 2 KiB)
+            reinterpret_cast<uint4*>(smap)[lane + 64] = z;
+        }
     }
     PG_WAVE_SYNC();
     FT_TS(2);
