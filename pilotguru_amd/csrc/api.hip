@@ -46,7 +46,7 @@ struct pgorb_ctx {
     Arena pyr, cand, sel, nodes, counters, tables, cellCand, cellCount, cellTab, cellTabBal, qtTab, qtLeaf;
     int qtThreads = 0;                        // K3 threads per workgroup: 0 = per launch (pgorb_set_option "quadtree_threads")
     int qtSplit = 2;                          // K3's candidate pass as its own launch: 0 no, 1 yes, 2 by frame size and batch (pgorb_set_option "quadtree_split")
-    int fastTilePitch = 0, fastWpb = 1;       // K2 tile-shape sweep (pgorb_set_option "fast_tile_pitch" / "fast_waves_per_block")
+    int fastTilePitch = 0, fastWpb = 1, fastCpw = PG_FAST_CPW_DEFAULT;       // K2 tile-shape sweep (pgorb_set_option "fast_tile_pitch" / "fast_waves_per_block")
     // K1 beside K2 (pgorb_set_option "pipeline_pyramid"): the pyramid chain on a high-priority side stream, K2 level by
     // level on a second one as the levels appear
     int pipePyr = 0;
@@ -495,7 +495,7 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
         if ((rc = ensure(c, c->qtLeaf, leafBytes))) return rc;
         P.qtTab = (const uint2*)c->qtTab.p; P.qtLeaf = (uint2*)c->qtLeaf.p; P.qtSplit = c->qtSplit; P.qtThreads = c->qtThreads; P.qtWide = getenv("PGORB_QT_WIDE") ? atoi(getenv("PGORB_QT_WIDE")) != 0 : 1;
     }
-    P.fastTilePitch = c->fastTilePitch; P.fastWpb = c->fastWpb;
+    P.fastTilePitch = c->fastTilePitch; P.fastWpb = c->fastWpb; P.fastCpw = c->fastCpw;
     P.cand = (uint32_t*)c->cand.p; P.sel = (uint32_t*)c->sel.p;
     P.nodeScratch = (int32_t*)c->nodes.p;
     P.candCount = (int32_t*)c->counters.p;
@@ -1204,6 +1204,11 @@ int pgorb_set_option(pgorb_ctx* c, const char* key, int value)
         c->fastWpb = value; c->plan.fastWpb = value;
         return 0;
     }
+    if (!strcmp(key, "fast_cells_per_wave")) {
+        if (value < 1 || value > 64) return fail(c, PGORB_E_ARG, "fast_cells_per_wave must be 1 ... 64");
+        c->fastCpw = value; c->plan.fastCpw = value;
+        return 0;
+    }
     if (!strcmp(key, "quadtree_threads")) {
         if (value != 0 && value != 256 && value != 512 && value != 1024) return fail(c, PGORB_E_ARG, "quadtree_threads must be 0 (automatic), 256, 512 or 1024");
         c->qtThreads = value; c->plan.qtThreads = value;
@@ -1225,6 +1230,7 @@ int pgorb_get_option(const pgorb_ctx* c, const char* key)
     if (!key || !c) return PGORB_OPTION_UNKNOWN;
     if (!strcmp(key, "fast_tile_pitch")) return c->fastTilePitch;
     if (!strcmp(key, "fast_waves_per_block")) return c->fastWpb;
+    if (!strcmp(key, "fast_cells_per_wave")) return c->fastCpw;
     if (!strcmp(key, "quadtree_split")) return c->qtSplit;
     if (!strcmp(key, "quadtree_threads")) return c->qtThreads;
     if (!strcmp(key, "matcher")) return c->mx.popcount;
@@ -1495,7 +1501,7 @@ int pgorb_stream_create_device(pgorb_ctx* c, int w, int h, int batch, int depth,
         hipStream_t ls = nullptr;
         ok = pgorb_create(&c->prm, &lc) == PGORB_OK;
         if (ok) {
-            lc->mx = c->mx; lc->qtThreads = c->qtThreads; lc->qtSplit = c->qtSplit; lc->fastTilePitch = c->fastTilePitch; lc->fastWpb = c->fastWpb;
+            lc->mx = c->mx; lc->qtThreads = c->qtThreads; lc->qtSplit = c->qtSplit; lc->fastTilePitch = c->fastTilePitch; lc->fastWpb = c->fastWpb; lc->fastCpw = c->fastCpw;
             s->lane.push_back(lc);
             ok = make_plan(lc, w, h, batch) == 0 && hipStreamCreateWithFlags(&ls, hipStreamNonBlocking) == hipSuccess;
             s->sLane.push_back(ls);

@@ -43,6 +43,7 @@
 // algorithmic bytes per frame = sum_l w_l*h_l.
 #include "pgorb_internal.h"
 #include <stdlib.h>
+#include <string.h>
 
 extern __shared__ __attribute__((aligned(16))) uint8_t pg_fast_smem[];
 typedef __attribute__((address_space(1))) const void* pg_gptr_t;
@@ -341,7 +342,8 @@ __device__ __forceinline__ int quick_pass_b(const uint8_t* tile, int IW, int IH,
         // steps 0-3 run whatever the interior's height (their rows lie inside the LDS allocation: row 8 s + lr + 6 <= 37; what they
         // see past the interior is masked by V): no scalar branch between the steps, so the four steps are ONE basic block and
         // their LDS reads can all be in flight before the first lerp.  Only the fifth step (interiors taller than 32 rows) is optional.
-        if (s == 4 && IH <= 32) break;                                // wave-uniform
+        // (the four-pair form of the retry keeps its steps apart: 44 reads in flight at once do not fit the 64 registers)
+        if (STRONG ? 8 * s >= IH : (s == 4 && IH <= 32)) break;       // wave-uniform
         const uint32_t* ru = b0 + (8 * s) * (TP / 4);
         const uint32_t* rc = b0 + (8 * s + 3) * (TP / 4);
         const uint32_t* rd = b0 + (8 * s + 6) * (TP / 4);
@@ -702,50 +704,68 @@ __device__ __forceinline__ int fast_pass(int32_t* status, const uint8_t* tile, i
 // necessary test and its per-lane set-up are compiled out (true for 1080p / 2160p / 480p: wCell <= 32).
 // WPB waves per workgroup, each wave an independent cell (no workgroup barrier anywhere: the waves only share the
 // launch and the LDS allocation, 4 x fewer workgroups for the dispatcher).
+// Everything a K2 wave reads from its argument block: 128 bytes = two s_load_dwordx16.  The wave (re)loads them at the start of
+// EVERY cell it walks, by explicit scalar loads: nothing but the loop counter is alive from one cell to the next, so the cell body
+// compiles like the one-cell kernel (kept in SGPRs across the body, the arguments cost ~20 spills into VGPR lanes and scratch,
+// and the launch ran 36 % slower -- round 3 had met the same wall).
+struct PgFastArgs {
+    const uint8_t* l0img;  int64_t l0fstride;  const uint8_t* pyrBase;  int32_t* cellCount;                       // dwords 0-7
+    uint32_t* cellCand;  int32_t* status;  const uint32_t* tab;  int32_t l0pitch, totalCells;                       // 8-15
+    uint32_t cellCandFrame;  int32_t iniTh, minTh, TPr, tileRows, MPr, mapRows, cellsPerXcd;                        // 16-23
+    int32_t chunkInv, cell0, cellEnd, waveLds, cpw, pad0, pad1, pad2;                                               // 24-31
+};
+static_assert(sizeof(PgFastArgs) == 128, "two s_load_dwordx16");
+typedef uint32_t pg_u32x16 __attribute__((ext_vector_type(16)));
+
 template <int TPC, int MPC, bool NARROW, int WPB>
-__global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgPlan P, int TPr, int tileRows,
-                                                       int MPr, int mapRows, int cellsPerXcd,
-                                                       int chunkInv, int cell0, int cellEnd, const uint32_t* tab, int waveLds)
+__global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgFastArgs KA)
 {
-    const int TP = TPC ? TPC : TPr, mapPitch = MPC ? MPC : MPr;
-    const int lane = threadIdx.x & 63;
-    const int wv = (WPB > 1) ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
-    const uint32_t frame = blockIdx.y;                             // (unsigned: 32 x 32 -> 64-bit scalar multiplies, two instructions each)
     // Records [cell0, cellEnd) of `tab`.  The default table is in a BALANCED dispatch order (api.hip): XCD x -- the
     // dispatcher deals consecutive workgroups to consecutive XCDs -- gets the x-th eighth of EVERY level's cells, a
     // contiguous band per level, so neighbours still share L2 lines and every XCD sees the same mix of cheap cells
     // (level 0: ~15 candidates) and expensive ones (upper levels: 40..170 candidates, several score rounds).  In plain
     // cell order XCD 7 held only upper-level cells and the launch waited for it while XCDs 0-2 idled.
     // The canonical-order table serves one level per launch when the pyramid chain runs beside K2.
-    const int cell = cell0 + (blockIdx.x & 7) * cellsPerXcd + (blockIdx.x >> 3) * WPB + wv;      // position in the table
+    // cpw CONSECUTIVE records per wave (round 5; option "fast_cells_per_wave"): a one-wave workgroup's slot stands empty for ~0.7 us
+    // between two waves (SQ_WAVE_CYCLES against slots x time: 88 % occupancy at one cell per wave) -- a wave that walks several
+    // records pays that once.  No prefetch: the cells run one after the other on the same LDS.
+    auto one_cell = [&](const int j) {
+    // (the lane id through an opaque copy per cell: what depends on the lane alone is recomputed per cell instead of being hoisted
+    //  out of the loop, where a dozen per-lane constants alive across the cell body push it into scratch)
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int wv = (WPB > 1) ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
+    // Two scalar round trips to the window address: (1) the argument block, including what level 0 needs when it aliases the
+    // caller's buffer, (2) ONE s_load_dwordx16 of the cell's record (pgorb_internal.h, PgPlan::cellTab).
+    pg_u32x16 a0, a1;
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(a0), "=&s"(a1) : "s"(__builtin_amdgcn_kernarg_segment_ptr()) : "memory");
+#define PG_A64(T, v, k) reinterpret_cast<T>((uintptr_t)(((uint64_t)(v)[(k) + 1] << 32) | (v)[k]))
+    const uint8_t* l0img = PG_A64(const uint8_t*, a0, 0);
+    const int64_t l0fstride = (int64_t)(((uint64_t)a0[3] << 32) | a0[2]);
+    const uint8_t* pyrBase = PG_A64(const uint8_t*, a0, 4);
+    int32_t* const cellCountBase = PG_A64(int32_t*, a0, 6);
+    uint32_t* const cellCandBase = PG_A64(uint32_t*, a0, 8);
+    int32_t* const statusPtr = PG_A64(int32_t*, a0, 10);
+    const uint32_t* tab = PG_A64(const uint32_t*, a0, 12);
+#undef PG_A64
+    const int l0pitch = (int)a0[14], totalCells = (int)a0[15];
+    const uint32_t cellCandFrame = a1[0];                          // u32 slots per frame: < 2^32 (make_plan)
+    const int iniTh = (int)a1[1], minTh = (int)a1[2], TPr = (int)a1[3], tileRows = (int)a1[4], MPr = (int)a1[5], mapRows = (int)a1[6];
+    const int cellsPerXcd = (int)a1[7], chunkInv = (int)a1[8], cell0 = (int)a1[9], cellEnd = (int)a1[10], waveLds = (int)a1[11], cpw = (int)a1[12];
+    const int TP = TPC ? TPC : TPr, mapPitch = MPC ? MPC : MPr;
+    const uint32_t frame = blockIdx.y;                             // (unsigned: 32 x 32 -> 64-bit scalar multiplies, two instructions each)
+    const int slot = ((int)(blockIdx.x >> 3) * WPB + wv) * cpw + j;           // within this XCD's run of records
+    const int cell = cell0 + (int)(blockIdx.x & 7) * cellsPerXcd + slot;      // position in the table
 #ifdef PGORB_FAST_TIMING
     unsigned long long ft_t0 = wall_clock64();
-    const int ft_id = (int)frame * P.totalCells + cell;
+    const int ft_id = (int)frame * totalCells + cell;
 #endif
-    // Two scalar round trips to the window address: (1) the kernel arguments, including what level
-    // 0 needs when it aliases the caller's buffer, (2) ONE s_load_dwordx8 of the cell's record
-    // (pgorb_internal.h, PgPlan::cellTab).  Left to itself the compiler spreads this over four to
-    // five dependent loads (vector loads + readfirstlane, level-0 fields fetched on demand).
-    const uint8_t* l0img = P.lvl[0].img;
-    const int l0pitch = P.lvl[0].pitch;
-    const int64_t l0fstride = P.lvl[0].fstride;
-    const uint8_t* pyrBase = P.pyrBase;
     const uint32_t* recp = tab + 16 * (int64_t)cell;               // (the tables have 8 records of slack)
-    const int totalCells = P.totalCells;
-    // (everything else the wave will need from the argument block rides in the same batch of scalar loads: a field
-    //  fetched where it is first used costs the wave one more trip to the scalar cache in the middle of its prologue)
-    int32_t* const cellCountBase = P.cellCount;
-    uint32_t* const cellCandBase = P.cellCand;
-    const uint32_t cellCandFrame = (uint32_t)P.cellCandFrame;     // u32 slots per frame: < 2^32 (make_plan)
-    const int iniTh = P.iniTh, minTh = P.minTh;
-    int32_t* const statusPtr = P.status;
-    asm volatile("" :: "s"(statusPtr), "s"(l0img), "s"(l0pitch), "s"(l0fstride), "s"(pyrBase), "s"(totalCells), "s"(cellCountBase),
-                 "s"(cellCandBase), "s"(cellCandFrame), "s"(iniTh), "s"(minTh), "s"(TPr), "s"(tileRows), "s"(MPr), "s"(mapRows),
-                 "s"(chunkInv), "s"(waveLds));
-    typedef uint32_t pg_u32x16 __attribute__((ext_vector_type(16)));
     pg_u32x16 rec;
     asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rec) : "s"(recp) : "memory");
-    if (cell >= cellEnd || (int)(blockIdx.x >> 3) * WPB + wv >= cellsPerXcd) return;
+    if (cell >= cellEnd || slot >= cellsPerXcd) return;
     const int iniX = rec[1] & 0xFFFF, iniY = rec[1] >> 16;
     const int W = rec[2] & 0xFF, H = (rec[2] >> 8) & 0xFF, cellCap = rec[2] >> 17;
     int32_t* cellCnt = cellCountBase + ((uint64_t)frame * (uint32_t)totalCells + (rec[0] >> 4));     // the record names its cell
@@ -889,6 +909,13 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgPlan P, int 
     }
     if (lane == 0) *cellCnt = min(total, cellCap);
     FT_TS(3);
+    };      // one_cell
+    const int ncell = KA.cpw;
+#pragma unroll 1
+    for (int j = 0; j < ncell; j++) {
+        if (j) PG_WAVE_SYNC();
+        one_cell(j);
+    }
 }
 
 void pg_launch_fast_cells(const PgPlan& P, int nframes, hipStream_t s, int levelBeg, int levelEnd);
@@ -932,9 +959,18 @@ void pg_launch_fast_cells(const PgPlan& P, int nframes, hipStream_t s, int level
     const bool narrow = maxW - 6 <= 32 && maxH - 6 <= 40;      // 8 quads per row, at most 5 steps of 8 rows (quick_pass_b)
     const int wpb = (P.fastWpb == 4) ? 4 : 1;                  // 4 independent waves per workgroup measured 13 % slower
     const int waveLds = (int)((smem + 15) & ~(size_t)15);
-    dim3 grid(((cellsPerXcd + wpb - 1) / wpb) * 8, nframes), block(64 * wpb);
-#define PG_LAUNCH_CELLS(TPC, MPC, NAR, W) hipLaunchKernelGGL((k_fast_cells<TPC, MPC, NAR, W>), grid, block, (size_t)waveLds * W, s, P, TP, \
-        tileRows, mapPitch, mapRows, cellsPerXcd, chunkInv, cell0, cellEnd, tab, waveLds)
+    int cpw = P.fastCpw > 0 ? P.fastCpw : 1;                   // records per wave (option "fast_cells_per_wave"; PGORB_FAST_CPW overrides)
+    if (const char* e = getenv("PGORB_FAST_CPW")) cpw = atoi(e);
+    cpw = cpw < 1 ? 1 : (cpw > 64 ? 64 : cpw);
+    dim3 grid(((cellsPerXcd + wpb * cpw - 1) / (wpb * cpw)) * 8, nframes), block(64 * wpb);
+    PgFastArgs KA;
+    memset(&KA, 0, sizeof KA);
+    KA.l0img = P.lvl[0].img; KA.l0fstride = P.lvl[0].fstride; KA.pyrBase = P.pyrBase; KA.cellCount = P.cellCount;
+    KA.cellCand = P.cellCand; KA.status = P.status; KA.tab = tab; KA.l0pitch = P.lvl[0].pitch; KA.totalCells = P.totalCells;
+    KA.cellCandFrame = (uint32_t)P.cellCandFrame; KA.iniTh = P.iniTh; KA.minTh = P.minTh; KA.TPr = TP; KA.tileRows = tileRows;
+    KA.MPr = mapPitch; KA.mapRows = mapRows; KA.cellsPerXcd = cellsPerXcd; KA.chunkInv = chunkInv; KA.cell0 = cell0; KA.cellEnd = cellEnd;
+    KA.waveLds = waveLds; KA.cpw = cpw;
+#define PG_LAUNCH_CELLS(TPC, MPC, NAR, W) hipLaunchKernelGGL((k_fast_cells<TPC, MPC, NAR, W>), grid, block, (size_t)waveLds * W, s, KA)
     if (wpb == 4) {
         if (common && narrow) PG_LAUNCH_CELLS(48, 40, true, 4);
         else if (common) PG_LAUNCH_CELLS(48, 40, false, 4);

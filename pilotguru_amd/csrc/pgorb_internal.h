@@ -89,6 +89,7 @@ struct PgSelRec {
 };
 static_assert(sizeof(PgSelRec) == 32, "one s_load_dwordx8");
 
+#define PG_FAST_CPW_DEFAULT 1  // K2 cell records per wave
 #define PG_QT_LEAF_CAP 4096   // >= the leaves of any count pyramid (quadtree.hip, QT_PYR_CAP)
 struct PgPlan {
     PgLevel  lvl[PG_MAXL];
@@ -116,6 +117,7 @@ struct PgPlan {
     int32_t  cellsPerXcdBal;
     int32_t  fastTilePitch;   // K2 tile-shape sweep: 0 = automatic, else the LDS window pitch in bytes (run-time-pitch instantiation)
     int32_t  fastWpb;         // K2 waves (= independent cells) per workgroup: 1 (default) or 4
+    int32_t  fastCpw;         // K2 consecutive cell records per wave (option "fast_cells_per_wave"): PG_FAST_CPW_DEFAULT
     const uint8_t*  pyrBase;  // pyramid arena
     uint32_t* cand;           // K3: dense uint2 key records (2 u32 per key)
     uint32_t* sel;
