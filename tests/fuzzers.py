@@ -54,6 +54,7 @@ def fuzz_parity(cases=200, seed=1, log=True, size_range=((90, 1000), (90, 800)),
             form = int(rng.randint(0, 4))                    # K2 tile shape: shipped, or a random LDS pitch / 4 cells per workgroup
             if form == 1: ext.set_option("fast_tile_pitch", int(rng.choice([48, 64, 80, 96, 112, 128])))
             if form == 2: ext.set_option("fast_waves_per_block", 4)
+            if form == 3: ext.set_option("fast_cells_per_wave", int(rng.choice([2, 3, 7])))
             ext.set_option("quadtree_split", it % 3)           # K3's pass inside the quadtree kernel / as its own launch / chosen by the library
             ext.set_option("quadtree_threads", (0, 256, 512, 1024)[(it // 3) % 4])
             kp, d = ext(img)

@@ -616,11 +616,13 @@ def test_levels_with_one_tall_cell_row(oracle, w, h, scale, nlev, nf):
     assert len(kp) == len(okp) > 0 and kp.tobytes() == okp.tobytes() and np.array_equal(desc, odesc)
 
 
-@pytest.mark.parametrize("pitch,wpb", [(0, 1), (48, 1), (64, 1), (80, 1), (96, 1), (128, 1), (0, 4), (64, 4)])
-def test_fast_every_tile_shape_bit_exact(oracle, pitch, wpb):
+@pytest.mark.parametrize("pitch,wpb,cpw", [(0, 1, 1), (48, 1, 1), (64, 1, 1), (80, 1, 1), (96, 1, 1), (128, 1, 1), (0, 4, 1), (64, 4, 1),
+                                           (0, 1, 2), (0, 1, 5), (0, 4, 3), (80, 1, 4), (0, 1, 64)])
+def test_fast_every_tile_shape_bit_exact(oracle, pitch, wpb, cpw):
     """BASELINE.json configs[2]: "LDS tile-size sweep ... bit-exact at every tile size".  K2's LDS window pitch
     (pgorb_set_option "fast_tile_pitch": 0 = the shipped 48-byte pitch with immediate offsets, 48 ... 128 = the same window in
-    an LDS row of that many bytes, run-time pitch) x waves per workgroup (1 | 4), on the hard scenes: textured, driving-like
+    an LDS row of that many bytes, run-time pitch) x waves per workgroup (1 | 4) x consecutive cell records per wave (round 5,
+    "fast_cells_per_wave": the cells of a wave run one after the other on the same LDS), on the hard scenes: textured, driving-like
     (minThFAST retry per cell), pure noise (candidate list overflow -> row-chunked passes) and panoramic frames (cells up to
     59 px).  Candidate sets and the final output against the oracle.  (Rounds 1-3 swept a block form -- one workgroup
     per block of cells -- that lost on every shape and left the tree in round 4; profiles/r04_k2_tile_sweep_2160p.txt times these.)"""
@@ -637,7 +639,9 @@ def test_fast_every_tile_shape_bit_exact(oracle, pitch, wpb):
         ext = pg.ORBextractor(nf, 1.2, nlevels, 20, 7, max_width=w, max_height=h)
         ext.set_option("fast_tile_pitch", pitch)
         ext.set_option("fast_waves_per_block", wpb)
+        ext.set_option("fast_cells_per_wave", cpw)
         assert ext.get_option("fast_tile_pitch") == pitch and ext.get_option("fast_waves_per_block") == wpb
+        assert ext.get_option("fast_cells_per_wave") == cpw
         kp, desc = ext(img)
         for l in range(nlevels):
             x, y, r = ext.debug_level_candidates(0, l)
