@@ -342,7 +342,8 @@ __device__ __forceinline__ int quick_pass_b(const uint8_t* tile, int IW, int IH,
         // steps 0-3 run whatever the interior's height (their rows lie inside the LDS allocation: row 8 s + lr + 6 <= 37; what they
         // see past the interior is masked by V): no scalar branch between the steps, so the four steps are ONE basic block and
         // their LDS reads can all be in flight before the first lerp.  Only the fifth step (interiors taller than 32 rows) is optional.
-        // (the four-pair form of the retry keeps its steps apart: 44 reads in flight at once do not fit the 64 registers)
+        // (the four-pair form of the retry keeps its steps apart: 44 reads in flight at once do not fit the 64 registers; a
+        //  sched_barrier between step pairs did not hold the reads back either)
         if (STRONG ? 8 * s >= IH : (s == 4 && IH <= 32)) break;       // wave-uniform
         const uint32_t* ru = b0 + (8 * s) * (TP / 4);
         const uint32_t* rc = b0 + (8 * s + 3) * (TP / 4);
@@ -729,7 +730,7 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgFastArgs KA)
     // cpw CONSECUTIVE records per wave (round 5; option "fast_cells_per_wave"): a one-wave workgroup's slot stands empty for ~0.7 us
     // between two waves (SQ_WAVE_CYCLES against slots x time: 88 % occupancy at one cell per wave) -- a wave that walks several
     // records pays that once.  No prefetch: the cells run one after the other on the same LDS.
-    auto one_cell = [&](const int j) {
+    auto one_cell = [&](const int j) -> int {
     // (the lane id through an opaque copy per cell: what depends on the lane alone is recomputed per cell instead of being hoisted
     //  out of the loop, where a dozen per-lane constants alive across the cell body push it into scratch)
     int tid = (int)threadIdx.x;
@@ -765,14 +766,14 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgFastArgs KA)
     const uint32_t* recp = tab + 16 * (int64_t)cell;               // (the tables have 8 records of slack)
     pg_u32x16 rec;
     asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rec) : "s"(recp) : "memory");
-    if (cell >= cellEnd || slot >= cellsPerXcd) return;
+    if (cell >= cellEnd || slot >= cellsPerXcd) return cpw;
     const int iniX = rec[1] & 0xFFFF, iniY = rec[1] >> 16;
     const int W = rec[2] & 0xFF, H = (rec[2] >> 8) & 0xFF, cellCap = rec[2] >> 17;
     int32_t* cellCnt = cellCountBase + ((uint64_t)frame * (uint32_t)totalCells + (rec[0] >> 4));     // the record names its cell
     FT_TS(0);
     if (rec[2] & 0x10000u) {                             // skipped cell (or a padding position of the balanced table)
         if (lane == 0 && (rec[0] >> 4) != 0x0FFFFFFFu) *cellCnt = 0;
-        return;
+        return cpw;
     }
     const int IW = W - 6, IH = H - 6;
     // window start (iniY, iniX - 1) of this frame; level 0 may be the caller's buffer
@@ -781,7 +782,11 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgFastArgs KA)
     const uint8_t* win = l0 ? l0img + (int64_t)frame * l0fstride + (int64_t)iniY * l0pitch + (iniX - 1)
                             : pyrBase + (((uint64_t)rec[5] << 32) | rec[4]) + (uint64_t)frame * rec[6];
 
-    uint8_t* tile = pg_fast_smem + wv * waveLds;                   // [tileRows][TP], this wave's slice
+    // (the LDS base through an opaque zero per cell: as a loop invariant it and the offsets derived from it were kept in SGPRs
+    //  across the cell body and spilled into VGPR lanes -- a v_readlane in front of every m0 write)
+    int ldsZero = 0;
+    asm volatile("" : "+s"(ldsZero));
+    uint8_t* tile = pg_fast_smem + ldsZero + wv * waveLds;         // [tileRows][TP], this wave's slice
     uint8_t* smap = tile + tileRows * TP;                          // [mapRows][mapPitch], 1-px zero rim
     uint16_t* list = reinterpret_cast<uint16_t*>(smap + mapRows * mapPitch);   // [FAST_LIST_CAP]
 
@@ -836,7 +841,9 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgFastArgs KA)
             for (int k = CLAMPED ? 2 : 0; k < KMAX; k++) {
                 if (k * 21 < H) {                                          // wave-uniform
                     const uint8_t* gk = win + (int64_t)(k * 21) * pitch;   // scalar
-                    if (laneOn && r0 + k * 21 < H)
+                    int rk = r0;
+                    if (CLAMPED) asm volatile("" : "+v"(rk));              // (the lane's guard is computed INSIDE the branch: windows taller than 42 rows are rare)
+                    if (laneOn && rk + k * 21 < H)
                         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                                      :: "v"(voff), "s"(gk), "s"(ldsTile + k * 21 * 48) : "memory");      // (m0 is reserved: the compiler never keeps a value in it across statements, and this instantiation has no other user)
                 }
@@ -884,7 +891,7 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgFastArgs KA)
 #endif
 #if defined(PGORB_FAST_STOP) && PGORB_FAST_STOP == 1       // window staged, nothing else
     if (lane == 0) *cellCnt = reinterpret_cast<const uint32_t*>(tile)[17] & 1;
-    return;
+    return cpw;
 #endif
 
     uint32_t* out = cellCandBase + ((uint64_t)frame * cellCandFrame + rec[7]);
@@ -898,7 +905,7 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgFastArgs KA)
     FT_TS(7);
 #if defined(PGORB_FAST_SKIP) || defined(PGORB_FAST_STOP)   // timing experiments: no minTh retry
     if (lane == 0) *cellCnt = min(total & 0xFFFF, cellCap);
-    return;
+    return cpw;
 #endif
     if (total == 0) {
         // vKeysCell.empty() -> retry at minThFAST (:812-816).  The score map keeps what the first pass wrote: a FAST score does
@@ -909,13 +916,16 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgFastArgs KA)
     }
     if (lane == 0) *cellCnt = min(total, cellCap);
     FT_TS(3);
+    return cpw;
     };      // one_cell
-    const int ncell = KA.cpw;
+    // (the number of records comes out of the first cell's argument load: a load of its own in front would be a third scalar
+    //  round trip on every wave)
+    int j = 0, ncell;
 #pragma unroll 1
-    for (int j = 0; j < ncell; j++) {
+    do {
         if (j) PG_WAVE_SYNC();
-        one_cell(j);
-    }
+        ncell = one_cell(j);
+    } while (++j < ncell);
 }
 
 void pg_launch_fast_cells(const PgPlan& P, int nframes, hipStream_t s, int levelBeg, int levelEnd);
