@@ -495,8 +495,34 @@ def main():
             V.write_vocabulary_text_fast(voc_path, 10, 6, *V.synth_vocabulary_fast(10, 6, seed=7))
             voc = V.ORBVocabulary(text_file=voc_path)
             vocab_bytes = int(voc.blob().nbytes)
-        voc_comm = pgd.VocabularyComm.from_torch_group(ext)
-        vocab_bcast_s = voc_comm.broadcast(voc, 0)
+        # The C-ABI group has only ever run as ONE rank on the boxes this was written on.  If it cannot be formed on some rank
+        # (librccl not loadable from the library, a unique-id mismatch ...) every rank learns it from one all_reduce and all of
+        # them take the round-2..4 path instead -- torch.distributed's own RCCL broadcast of the blob + pgorb_vocab_upload_device --
+        # so that a multi-GPU run still produces its line; `vocab_broadcast` in the line says which path ran.
+        vocab_path_used = "pgorb_vocab_broadcast (C ABI, librccl ncclBroadcast; text parsed once on rank 0)"
+        ok = 1
+        try:
+            voc_comm = pgd.VocabularyComm.from_torch_group(ext)
+        except Exception as e:                                    # noqa: BLE001 -- any failure takes the fallback, on every rank
+            sys.stderr.write("rank %d: pgorb_comm_create_rank failed (%s); falling back to torch.distributed's broadcast\n" % (rank, e))
+            ok, voc_comm = 0, None
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            vocab_bcast_s = voc_comm.broadcast(voc, 0)
+        else:
+            if voc_comm is not None:
+                voc_comm.close(); voc_comm = None
+            import ctypes as C
+            blob_t = torch.from_numpy(np.ascontiguousarray(voc.blob()).copy()) if rank == 0 else None
+            torch.cuda.synchronize(); tb0 = time.perf_counter()
+            vt = pgd.broadcast_vocabulary(blob_t, 0, dev)
+            torch.cuda.synchronize(); vocab_bcast_s = time.perf_counter() - tb0
+            vocab_bytes = int(vt.numel())
+            ext._check(ext._L.pgorb_vocab_upload_device(ext._h, C.c_void_p(vt.data_ptr()), vt.numel(),
+                                                        C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+            torch.cuda.synchronize()
+            vocab_path_used = "torch.distributed broadcast (RCCL) + pgorb_vocab_upload_device: the C-ABI group could not be formed"
 
     def step():
         ext.extract_batch_device(frames, kps, desc, n)
@@ -565,7 +591,8 @@ def main():
                 if not (np.array_equal(wr.view(np.uint32), ow) and wtr.tobytes() == owt.tobytes() and np.array_equal(nr.view(np.uint32), on)):
                     raise SystemExit("bench verification FAILED: rank %d's BoW words differ from the oracle after the vocabulary broadcast" % r)
             bow_verified = True
-        voc_comm.close()
+        if voc_comm is not None:
+            voc_comm.close()
 
     # two batches in flight INSIDE the library (round 5: pgorb_stream_create_device, one context, two lanes): the caller submits
     # resident batches without blocking, the stream runs consecutive batches on two sibling working sets and HIP streams, so
@@ -688,7 +715,7 @@ def main():
                        "scene": args.scene, "width": W, "height": H, "features": NF,
                        "batch": B, "keypoints_per_frame": nkp, "parallelism": "frames-sharded x%d" % world,
                        "vocab_broadcast_bytes": vocab_bytes, "vocab_broadcast_s": vocab_bcast_s,
-                       "vocab_broadcast": None if dist is None else "pgorb_vocab_broadcast (C ABI, librccl ncclBroadcast; text parsed once on rank 0)",
+                       "vocab_broadcast": None if dist is None else vocab_path_used,
                        "bow_words_equal_oracle_on_every_rank": bow_verified,
                        "matcher": matcher, "matcher_popcount_ms_per_step": popcount_ms},
             "roofline": {"bound": "hbm", "kernel": kname,

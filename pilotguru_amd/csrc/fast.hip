@@ -337,18 +337,38 @@ __device__ __forceinline__ int quick_pass_b(const uint8_t* tile, int IW, int IH,
     uint32_t acc = 0u, acc2 = 0u;
 #define PG_RING(R, E, A, Q) const uint32_t E = __builtin_amdgcn_lerp(R, nC, ONES); \
                             const uint32_t A = (E & M7) + KA, Q = (E & M7) + KQ
+    // the eleven dwords a step reads (five for the two-pair form); the retry's four-pair form loads them ONE STEP AHEAD (below)
+    struct Rows { uint32_t C, Lw, Rw, U, D, Pc, Pl, Pr, Mc, Ml, Mr; };
+    auto load_rows = [&](const int s) {
+        Rows r;
+        const uint32_t* ru = b0 + (8 * s) * (TP / 4);
+        const uint32_t* rc = b0 + (8 * s + 3) * (TP / 4);
+        const uint32_t* rd = b0 + (8 * s + 6) * (TP / 4);
+        r.C = rc[0]; r.Lw = rc[-1]; r.Rw = rc[1]; r.U = ru[0]; r.D = rd[0];
+        if (STRONG) {
+            // diagonals: rows y+2 / y-2 at x+2 / x-2 -- rings 2 (+2,+2), 14 (-2,+2), 6 (+2,-2), 10 (-2,-2); opposite pairs (2,10), (6,14)
+            const uint32_t* rp = b0 + (8 * s + 5) * (TP / 4);
+            const uint32_t* rm = b0 + (8 * s + 1) * (TP / 4);
+            r.Pc = rp[0]; r.Pl = rp[-1]; r.Pr = rp[1]; r.Mc = rm[0]; r.Ml = rm[-1]; r.Mr = rm[1];
+        } else { r.Pc = r.Pl = r.Pr = r.Mc = r.Ml = r.Mr = 0u; }
+        return r;
+    };
+    constexpr bool SPF = STRONG;
+    Rows nxt = SPF ? load_rows(0) : Rows{};
 #pragma unroll
     for (int s = 0; s < 5; s++) {
         // steps 0-3 run whatever the interior's height (their rows lie inside the LDS allocation: row 8 s + lr + 6 <= 37; what they
         // see past the interior is masked by V): no scalar branch between the steps, so the four steps are ONE basic block and
         // their LDS reads can all be in flight before the first lerp.  Only the fifth step (interiors taller than 32 rows) is optional.
-        // (the four-pair form of the retry keeps its steps apart: 44 reads in flight at once do not fit the 64 registers; a
-        //  sched_barrier between step pairs did not hold the reads back either)
+        // (The four-pair form of the retry keeps its steps apart -- 44 reads in flight at once do not fit the 64 registers, and a
+        //  sched_barrier between step pairs did not hold the reads back -- and has the NEXT step's eleven reads in flight while it
+        //  computes this one's: one exposed LDS round trip per cell instead of four.)
         if (STRONG ? 8 * s >= IH : (s == 4 && IH <= 32)) break;       // wave-uniform
-        const uint32_t* ru = b0 + (8 * s) * (TP / 4);
-        const uint32_t* rc = b0 + (8 * s + 3) * (TP / 4);
-        const uint32_t* rd = b0 + (8 * s + 6) * (TP / 4);
-        const uint32_t C = rc[0], Lw = rc[-1], Rw = rc[1], U = ru[0], D = rd[0];
+        const Rows R = SPF ? nxt : load_rows(s);
+        if (SPF && s < 3) nxt = load_rows(s + 1);                     // (rows of steps <= 3 are always inside the allocation)
+        else if (SPF && s == 3 && IH > 32) nxt = load_rows(4);        // wave-uniform
+        if (SPF) PG_WAVE_SYNC();                                   // (compiler-only: keeps the reads HERE -- left alone they are sunk to their uses in the next step's block)
+        const uint32_t C = R.C, Lw = R.Lw, Rw = R.Rw, U = R.U, D = R.D;
         const uint32_t nC = ~C;
         const uint32_t W12 = __builtin_amdgcn_alignbyte(C, Lw, 1);    // pixels x-3 of the quad: (Lw.b1, Lw.b2, Lw.b3, C.b0)
         const uint32_t W4 = __builtin_amdgcn_alignbyte(Rw, C, 3);     // pixels x+3: (C.b3, Rw.b0, Rw.b1, Rw.b2)
@@ -358,10 +378,7 @@ __device__ __forceinline__ int quick_pass_b(const uint8_t* tile, int IW, int IH,
         // NOT darker in a pair: (E | Q) of both members; darker in every pair <=> no pair's bit set.   0xE0 = a & (b | c)
         uint32_t nd = __builtin_amdgcn_bitop3_b32(eU | qU, eD, qD, 0xE0) | __builtin_amdgcn_bitop3_b32(eL | qL, eR, qR, 0xE0);
         if (STRONG) {
-            // diagonals: rows y+2 / y-2 at x+2 / x-2 -- rings 2 (+2,+2), 14 (-2,+2), 6 (+2,-2), 10 (-2,-2); opposite pairs (2,10), (6,14)
-            const uint32_t* rp = b0 + (8 * s + 5) * (TP / 4);
-            const uint32_t* rm = b0 + (8 * s + 1) * (TP / 4);
-            const uint32_t Pc = rp[0], Pl = rp[-1], Pr = rp[1], Mc = rm[0], Ml = rm[-1], Mr = rm[1];
+            const uint32_t Pc = R.Pc, Pl = R.Pl, Pr = R.Pr, Mc = R.Mc, Ml = R.Ml, Mr = R.Mr;
             const uint32_t r2 = __builtin_amdgcn_alignbyte(Pr, Pc, 2), r14 = __builtin_amdgcn_alignbyte(Pc, Pl, 2);
             const uint32_t r6 = __builtin_amdgcn_alignbyte(Mr, Mc, 2), r10 = __builtin_amdgcn_alignbyte(Mc, Ml, 2);
             PG_RING(r2, e2, a2, q2); PG_RING(r10, e10, a10, q10); PG_RING(r6, e6, a6, q6); PG_RING(r14, e14, a14, q14);
@@ -533,6 +550,7 @@ __device__ __forceinline__ void score_list_pk(const uint8_t* tile, uint8_t* smap
 {
     constexpr int MP = 40;
     const _Float16 th = (_Float16)t;
+    // (reading the NEXT round's entry a round ahead measured 0.6 % slower: profiles/r05_k2_ab.txt)
     for (int base = 0; base < nlist; base += 64) {
         const int i = base + lane;
         if (i < nlist) {
@@ -556,6 +574,17 @@ __device__ __forceinline__ int nms_score(const uint8_t* smap, int mapPitch, int 
     // trips per wave, not by LDS throughput); corners read their eight neighbours at once and reduce them with
     // three v_max3 + one v_max instead of eight compare-and-branch steps.
     if (!s) return 0;
+    const int a = imax3(m[-mapPitch - 1], m[-mapPitch], m[-mapPitch + 1]);
+    const int b = imax3(m[mapPitch - 1], m[mapPitch], m[mapPitch + 1]);
+    const int c = imax3(m[-1], m[1], max(a, b));
+    return s > c ? s : 0;
+}
+
+// ... of a pixel known to be a corner: the nine bytes in one batch
+__device__ __forceinline__ int nms_corner(const uint8_t* smap, int mapPitch, int iy, int ix)
+{
+    const uint8_t* m = smap + (iy + 1) * mapPitch + ix + 1;
+    const int s = m[0];
     const int a = imax3(m[-mapPitch - 1], m[-mapPitch], m[-mapPitch + 1]);
     const int b = imax3(m[mapPitch - 1], m[mapPitch], m[mapPitch + 1]);
     const int c = imax3(m[-1], m[1], max(a, b));
@@ -682,7 +711,10 @@ __device__ __forceinline__ int fast_pass(int32_t* status, const uint8_t* tile, i
         int sc = 0, p = 0;
         if (i < nlist) {
             p = list[i];
-            if (p != (int)FAST_DEAD) sc = nms_score(smap, mapPitch, (p >> 8) & 0x7F, p & 0xFF);   // (dead: not a corner at t)
+            // (dead: not a corner at t.)  Every entry that is still alive IS a corner -- the scoring round marked the others -- so its
+            // own score and its eight neighbours are read in ONE batch: the short circuit on the centre byte that nms_score
+            // keeps for the row-chunked path would be a dependent LDS round trip per round here
+            if (p != (int)FAST_DEAD) sc = nms_corner(smap, mapPitch, (p >> 8) & 0x7F, p & 0xFF);
         }
         const unsigned long long m = __ballot(sc != 0);
         if (sc) {
