@@ -577,7 +577,7 @@ int      pgorb_stream_frontend_results(pgorb_stream* s, int slot, const int32_t*
  * key "fast_tile_pitch": K2's LDS window pitch in bytes, the tile-size sweep of BASELINE.json configs[2] -- 0 = automatic
  * (48 with compile-time offsets for cells up to 36 px: the shipped shape), 48 | 64 | ... | 128 = that pitch through the
  * run-time-pitch instantiation (values below what the plan's cells need are ignored).
- * key "fast_waves_per_block": 1 (default) | 4 independent cells (waves) per K2 workgroup.
+ * key "fast_waves_per_block": 1 (default) | 2 | 4 independent cells (waves) per K2 workgroup (measured 7 % / 15 % slower, round 5).
  * key "fast_cells_per_wave": 1 (default) ... 64 consecutive cell records a K2 wave walks, one after the other (round 5; measured
  *     slower from 2 on, profiles/r05_k2_cells_per_wave.txt: a sweep knob like the two above).
  * key "quadtree_split": K3's pass over the candidates -- 0 = inside the quadtree kernel (one launch), 1 = as a kernel of its own

@@ -1200,7 +1200,7 @@ int pgorb_set_option(pgorb_ctx* c, const char* key, int value)
         return 0;
     }
     if (!strcmp(key, "fast_waves_per_block")) {
-        if (value != 1 && value != 4) return fail(c, PGORB_E_ARG, "fast_waves_per_block must be 1 or 4");
+        if (value != 1 && value != 2 && value != 4) return fail(c, PGORB_E_ARG, "fast_waves_per_block must be 1, 2 or 4");
         c->fastWpb = value; c->plan.fastWpb = value;
         return 0;
     }

@@ -999,7 +999,8 @@ void pg_launch_fast_cells(const PgPlan& P, int nframes, hipStream_t s, int level
     const int cellEnd = all ? 8 * P.cellsPerXcdBal : (levelEnd < P.nlevels) ? P.lvl[levelEnd].cellBase : P.totalCells;
     const int cellsPerXcd = all ? P.cellsPerXcdBal : (cellEnd - cell0 + 7) / 8;
     const bool narrow = maxW - 6 <= 32 && maxH - 6 <= 40;      // 8 quads per row, at most 5 steps of 8 rows (quick_pass_b)
-    const int wpb = (P.fastWpb == 4) ? 4 : 1;                  // 4 independent waves per workgroup measured 13 % slower
+    int wpb = (P.fastWpb == 4) ? 4 : (P.fastWpb == 2) ? 2 : 1; // 4 independent waves per workgroup measured 13 % slower (round 2), 2: round 5
+    if (const char* e = getenv("PGORB_FAST_WPB")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) wpb = v; }
     const int waveLds = (int)((smem + 15) & ~(size_t)15);
     int cpw = P.fastCpw > 0 ? P.fastCpw : 1;                   // records per wave (option "fast_cells_per_wave"; PGORB_FAST_CPW overrides)
     if (const char* e = getenv("PGORB_FAST_CPW")) cpw = atoi(e);
@@ -1013,7 +1014,11 @@ void pg_launch_fast_cells(const PgPlan& P, int nframes, hipStream_t s, int level
     KA.MPr = mapPitch; KA.mapRows = mapRows; KA.cellsPerXcd = cellsPerXcd; KA.chunkInv = chunkInv; KA.cell0 = cell0; KA.cellEnd = cellEnd;
     KA.waveLds = waveLds; KA.cpw = cpw;
 #define PG_LAUNCH_CELLS(TPC, MPC, NAR, W) hipLaunchKernelGGL((k_fast_cells<TPC, MPC, NAR, W>), grid, block, (size_t)waveLds * W, s, KA)
-    if (wpb == 4) {
+    if (wpb == 2) {
+        if (common && narrow) PG_LAUNCH_CELLS(48, 40, true, 2);
+        else if (common) PG_LAUNCH_CELLS(48, 40, false, 2);
+        else PG_LAUNCH_CELLS(0, 0, false, 2);
+    } else if (wpb == 4) {
         if (common && narrow) PG_LAUNCH_CELLS(48, 40, true, 4);
         else if (common) PG_LAUNCH_CELLS(48, 40, false, 4);
         else PG_LAUNCH_CELLS(0, 0, false, 4);

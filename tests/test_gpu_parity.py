@@ -617,7 +617,7 @@ def test_levels_with_one_tall_cell_row(oracle, w, h, scale, nlev, nf):
 
 
 @pytest.mark.parametrize("pitch,wpb,cpw", [(0, 1, 1), (48, 1, 1), (64, 1, 1), (80, 1, 1), (96, 1, 1), (128, 1, 1), (0, 4, 1), (64, 4, 1),
-                                           (0, 1, 2), (0, 1, 5), (0, 4, 3), (80, 1, 4), (0, 1, 64)])
+                                           (0, 1, 2), (0, 1, 5), (0, 4, 3), (80, 1, 4), (0, 1, 64), (0, 2, 1), (64, 2, 2)])
 def test_fast_every_tile_shape_bit_exact(oracle, pitch, wpb, cpw):
     """BASELINE.json configs[2]: "LDS tile-size sweep ... bit-exact at every tile size".  K2's LDS window pitch
     (pgorb_set_option "fast_tile_pitch": 0 = the shipped 48-byte pitch with immediate offsets, 48 ... 128 = the same window in
