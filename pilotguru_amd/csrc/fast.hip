@@ -140,6 +140,9 @@ __device__ __forceinline__ int wave_prefix(unsigned long long m)
 // tile layout: row r at tile + r*TP; window column c at byte 1 + c, so interior column 0
 // (window column 3) is at byte 4.
 #define FAST_LIST_CAP 768          // compacted candidates held in LDS (u16 each)
+#ifndef PG_FAST_COMPACT_BALLOT      // developer A/B (tools/experiments/r5_k2_ab.sh): 1 = compaction by per-trip ballots, 0 = DPP prefix scan + per-lane runs
+#define PG_FAST_COMPACT_BALLOT 1
+#endif
 
 typedef unsigned short pg_us2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pg_pkmin(uint32_t a, uint32_t b)
@@ -396,6 +399,41 @@ __device__ __forceinline__ int quick_pass_b(const uint8_t* tile, int IW, int IH,
 #if defined(PGORB_FAST_STOP) && PGORB_FAST_STOP == 2
     return (__ballot((acc | acc2) != 0) != 0ull) ? 1 : 0;
 #endif
+#if PG_FAST_COMPACT_BALLOT
+    // Compaction by ballots, one per trip (round 5): trip k files the k-th hit of every lane that has one -- position = hits filed so
+    // far (a scalar) + the lane's rank among the lanes of this trip (v_mbcnt of the ballot).  No prefix scan in front (six dependent
+    // DPP steps and their wait states), no popcounts; the list comes out trip-major, so a lane's own hits -- rows 8 apart at the
+    // 48-byte pitch: the same LDS bank -- no longer sit next to each other in a score round.
+    const int base = bfmt_lane_base(lane);
+    int nlist = 0;                                                    // wave-uniform
+    uint32_t bits = acc;
+    for (;;) {
+        const unsigned long long m = __ballot(bits != 0);
+        if (!m) break;
+        if (bits) {
+            const int bpos = __ffs((int)bits) - 1;
+            bits &= bits - 1;
+            const int pos = nlist + wave_prefix(m);
+            if (pos < FAST_LIST_CAP) list[pos] = (uint16_t)(base | bpos);
+        }
+        nlist += __popcll(m);
+    }
+    if (IH > 32) {                                                    // wave-uniform
+        bits = acc2;
+        for (;;) {
+            const unsigned long long m = __ballot(bits != 0);
+            if (!m) break;
+            if (bits) {
+                const int bpos = __ffs((int)bits) - 1;
+                bits &= bits - 1;
+                const int pos = nlist + wave_prefix(m);
+                if (pos < FAST_LIST_CAP) list[pos] = (uint16_t)(base | BFMT_FIFTH | bpos);
+            }
+            nlist += __popcll(m);
+        }
+    }
+    return nlist > FAST_LIST_CAP ? -1 : nlist;
+#else
     const int cnt = __popc(acc) + __popc(acc2);
     const int incl = wave_incl_scan(cnt);
     const int nlist = __builtin_amdgcn_readlane(incl, 63);
@@ -417,6 +455,7 @@ __device__ __forceinline__ int quick_pass_b(const uint8_t* tile, int IW, int IH,
         }
     }
     return nlist;
+#endif
 }
 
 // (3) exact scores for the compacted pixels -> score map.  An entry names the polarity its pixel passed the necessary
