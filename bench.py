@@ -288,7 +288,7 @@ def live_pmc(args, kname):
         for tag, group in (("fetch_kb", ["FETCH_SIZE"]), ("write_kb", ["WRITE_SIZE"]), ("sq_insts_valu", ["SQ_INSTS_VALU", "SQ_INSTS_SALU"])):
             d = os.path.join(base, tag)
             r = subprocess.run([exe, "--kernel-trace", "--pmc"] + group + ["-d", d, "--"] + child, env=env, cwd="/tmp",
-                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=90)
             dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
             if r.returncode != 0 or not dbs:
                 return None
@@ -601,7 +601,8 @@ def main():
     # order.  Same work per batch plus that one extra pair; reported next to `value`, not as it (the kernels' own durations
     # stretch when they share the GPU, so `roofline` and the stage times stay those of the one-batch-at-a-time loop above).
     inflight2 = None
-    if not args.no_overlap_leg and dist is None and B > 1:
+    leg_errors = {}                                              # a LEG that fails is reported in the line; it never takes the line with it
+    def _inflight_leg():
         st2 = pg.DeviceFrameStream(ext, W, H, B, depth=2, lanes=2)
         torch.cuda.synchronize()
         for k in range(4):
@@ -628,37 +629,50 @@ def main():
                                                  torch.equal(kps[f, :nh2[f]].view(torch.int32), r[1][f, :nh2[f]].view(torch.int32)) and
                                                  (f == 0 or torch.equal(mout[0][f - 1, :nh2[f]], r[3][f, :nh2[f]])) for f in range(B))
                    for r in (r0, r1))
-        inflight2 = {"fps": ksteps * B / (te - ts), "seconds": te - ts, "steps": ksteps, "contexts": 1, "lanes": 2,
+        res = {"fps": ksteps * B / (te - ts), "seconds": te - ts, "steps": ksteps, "contexts": 1, "lanes": 2,
                      "every_frame_of_both_in_flight_batches_equals_the_one_batch_loop": bool(same),
                      "note": "pgorb_stream_create_device / _submit_device: resident batches submitted without blocking, two lanes (sibling "
                              "working sets on two internal HIP streams) inside ONE context; matches chained across batches"}
         st2.close()
+        return res
+    if not args.no_overlap_leg and dist is None and B > 1:
+        try:
+            inflight2 = _inflight_leg()
+        except Exception as e:                                   # noqa: BLE001
+            leg_errors["two_batches_in_flight"] = str(e)[:300]
 
     # the matcher the north star describes (ballot / popcount), timed on the same descriptors
     matcher = ext.matcher_name(cap)
     popcount_ms = None
     if dist is None and B > 1:
-        ext.set_option("matcher", 1)
-        for _ in range(2):
-            ext.match_batch_device(desc, n, pq, pt, mout)
-        torch.cuda.synchronize()
-        tp = time.perf_counter()
-        for _ in range(5):
-            ext.match_batch_device(desc, n, pq, pt, mout)
-        torch.cuda.synchronize()
-        popcount_ms = (time.perf_counter() - tp) / 5 * 1e3
-        ext.set_option("matcher", 0)
+        try:
+            ext.set_option("matcher", 1)
+            for _ in range(2):
+                ext.match_batch_device(desc, n, pq, pt, mout)
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            for _ in range(5):
+                ext.match_batch_device(desc, n, pq, pt, mout)
+            torch.cuda.synchronize()
+            popcount_ms = (time.perf_counter() - tp) / 5 * 1e3
+        except Exception as e:                                   # noqa: BLE001
+            leg_errors["matcher_popcount"] = str(e)[:300]
+        finally:
+            ext.set_option("matcher", 0)
 
     # frames that start in HOST memory: the streamed path (pinned double buffers, copies overlapped with
     # the kernels of the neighbouring batches) -- PCIe-inclusive, reported next to `value`, never as it
     uploaded = None
     if not args.no_upload_leg and dist is None:
-        uploaded = upload_leg(pg, ext, ride, NF, W, H, B, seconds=2.0)
-        uploaded["with_front_end_stage"] = upload_leg(pg, ext, ride, NF, W, H, B, seconds=1.5, frontend=True, link=False)
-        rgb = upload_leg(pg, ext, ride, NF, W, H, B, seconds=1.5, link=False, channels=3)
-        rgb["link_bound_fps"] = uploaded["link_bound_fps"] / 3.0
-        rgb["fraction_of_link"] = rgb["value"] / rgb["link_bound_fps"]
-        uploaded["rgb24"] = rgb
+        try:
+            uploaded = upload_leg(pg, ext, ride, NF, W, H, B, seconds=2.0)
+            uploaded["with_front_end_stage"] = upload_leg(pg, ext, ride, NF, W, H, B, seconds=1.5, frontend=True, link=False)
+            rgb = upload_leg(pg, ext, ride, NF, W, H, B, seconds=1.5, link=False, channels=3)
+            rgb["link_bound_fps"] = uploaded["link_bound_fps"] / 3.0
+            rgb["fraction_of_link"] = rgb["value"] / rgb["link_bound_fps"]
+            uploaded["rgb24"] = rgb
+        except Exception as e:                                   # noqa: BLE001
+            leg_errors["frames_uploaded"] = str(e)[:300]
 
     if rank == 0:
         frames_total = world * B * args.steps
@@ -757,9 +771,14 @@ def main():
             except Exception as e:                             # (a leg, not the measurement: report and go on)
                 out["single_frame"] = {"error": str(e)[:200]}
         if not args.no_cpu_baseline and world == 1:            # rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(W, H, NF, args.scene)
-            out["speedup_vs_cpu_all_cores"] = fps / out["cpu_baseline"]["value"]
-            out["speedup_vs_cpu_one_thread"] = fps / out["cpu_baseline"]["one_thread"]["value"]
+            try:
+                out["cpu_baseline"] = cpu_baseline(W, H, NF, args.scene)
+                out["speedup_vs_cpu_all_cores"] = fps / out["cpu_baseline"]["value"]
+                out["speedup_vs_cpu_one_thread"] = fps / out["cpu_baseline"]["one_thread"]["value"]
+            except Exception as e:                               # noqa: BLE001 -- the CPU leg must not take the GPU line with it
+                leg_errors["cpu_baseline"] = str(e)[:300]
+        if leg_errors:
+            out["leg_errors"] = leg_errors
         line = json.dumps(out)
     else:
         line = None
