@@ -36,12 +36,13 @@ def level_sizes(ext, w, h):
             for l in range(ext.nlevels)]
 
 
-def algorithmic_bytes(sizes, nkp):
-    """Per-frame algorithmic bytes of each kernel group."""
+def algorithmic_bytes(sizes, nkp, fused=False):
+    """Per-frame algorithmic bytes of each kernel group.  fused: the launch that resizes
+    level l -> l + 1 also detects level l (csrc/fused.hip) -- every level is read ONCE, K2 is left with the last level."""
     px = [a * b for a, b in sizes]
     return {
         "pyramid": sum(px[:-1]) + sum(px[1:]),          # reads of levels 0..L-2 + writes of 1..L-1
-        "fast": sum(px),                                # one detection read of every level
+        "fast": px[-1] if fused else sum(px),           # one detection read of every level (fused: of the last level)
         "quadtree": 0,
         "describe": nkp * (43 * 43 + 60),               # raw window + keypoint/descriptor out
         "match": 2 * nkp * 32 + nkp * 8,
@@ -281,7 +282,7 @@ def live_pmc(args, kname):
     child = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--batch", str(args.batch),
              "--width", str(args.width), "--height", str(args.height), "--features", str(args.features), "--scene", args.scene,
              "--no-cpu-baseline", "--no-verify", "--sustain-seconds", "0", "--no-upload-leg", "--no-overlap-leg",
-             "--no-single-frame-leg", "--no-traffic-leg"]
+             "--no-single-frame-leg", "--no-traffic-leg"] + (["--fused-levels", str(args.fused_levels)] if args.fused_levels is not None else [])
     env = dict(os.environ, TMPDIR="/tmp", PGORB_BENCH_CHILD="1")
     out = {}
     try:
@@ -422,6 +423,8 @@ def main():
                     help="BEFORE the warm-up and timed steps, step for this long and report sustained_fps (0 = skip): the GPU is in its working state when the timed region starts")
     ap.add_argument("--pipeline-pyramid", type=int, default=None,
                     help="1 / 0: run the pyramid chain beside K2 on a side stream (library default when omitted)")
+    ap.add_argument("--fused-levels", type=int, default=None,
+                    help="1 / 0: resize level l -> l + 1 and detect level l in one launch (csrc/fused.hip; library default when omitted)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-upload-leg", action="store_true")
@@ -464,6 +467,8 @@ def main():
 
     if args.pipeline_pyramid is not None:
         ext.set_option("pipeline_pyramid", args.pipeline_pyramid)
+    if args.fused_levels is not None:
+        ext.set_option("fused_levels", args.fused_levels)
     # one ride per rank (ride id = rank): B consecutive frames, resident in HBM
     from pilotguru_amd import dist as pgd0
     make_ride = synth_ride_road if args.scene == "road" else synth_ride
@@ -508,6 +513,12 @@ def main():
             ok, voc_comm = 0, None
         flag = torch.tensor([ok], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        # which librccl the library resolved, and how many the process maps (one process must never run two RCCLs: the id of
+        # one would be handed to the other)
+        lib_path, lib_pre = pgd.VocabularyComm.library()
+        with open("/proc/self/maps") as mf:
+            mapped = sorted({ln.split()[-1] for ln in mf if "librccl.so" in ln.rsplit("/", 1)[-1]})
+        rccl_info = {"path": lib_path, "held_by_process_before": lib_pre, "mapped": mapped}
         if int(flag.item()) == 1:
             vocab_bcast_s = voc_comm.broadcast(voc, 0)
         else:
@@ -679,7 +690,8 @@ def main():
         fps = frames_total / elapsed
         sizes = level_sizes(ext, W, H)
         nkp = float(counts.mean())
-        abytes = algorithmic_bytes(sizes, nkp)
+        fused = ext.get_option("fused_levels") == 1
+        abytes = algorithmic_bytes(sizes, nkp, fused)
         dom = max(("pyramid", "fast", "quadtree", "describe", "match"), key=lambda s: stage_ms[s])
         # the roofline object describes the dominant HBM-streaming kernel; the quadtree moves
         # no image bytes, so when it dominates wall time the image kernel with most time is used
@@ -687,7 +699,7 @@ def main():
         rk = max(cands, key=lambda s: stage_ms[s])
         launches = 7 if rk == "pyramid" else 1
         ach = (abytes[rk] * B / launches) / (stage_ms[rk] / launches * 1e-3) / 1e9
-        kname = {"pyramid": "k_pyr_resize_rows4_lds", "fast": ext.fast_kernel_name(), "describe": "k_describe",
+        kname = {"pyramid": "k_pyr_fast" if fused else "k_pyr_resize_rows4_lds", "fast": ext.fast_kernel_name(), "describe": "k_describe",
                  "match": "k_match_mfma"}[rk]
         # HBM bytes / VALU instructions per launch of that kernel: measured by this run (three rocprofv3 PMC child runs of this
         # command, after the timed region) -- or, when rocprofv3 cannot run here, cited from the newest committed profile
@@ -727,9 +739,11 @@ def main():
                                    "resident in HBM, extract + best-2 Hamming match vs previous frame"
                                    % (W, H, NF, B),
                        "scene": args.scene, "width": W, "height": H, "features": NF,
+                       "fused_levels": fused,
                        "batch": B, "keypoints_per_frame": nkp, "parallelism": "frames-sharded x%d" % world,
                        "vocab_broadcast_bytes": vocab_bytes, "vocab_broadcast_s": vocab_bcast_s,
                        "vocab_broadcast": None if dist is None else vocab_path_used,
+                       "vocab_broadcast_librccl": None if dist is None else rccl_info,
                        "bow_words_equal_oracle_on_every_rank": bow_verified,
                        "matcher": matcher, "matcher_popcount_ms_per_step": popcount_ms},
             "roofline": {"bound": "hbm", "kernel": kname,

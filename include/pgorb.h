@@ -381,9 +381,15 @@ int  pgorb_vocab_upload_device(pgorb_ctx* ctx, const void* d_blob, int64_t nbyte
  *                             rank, `v` is read on that rank only (NULL elsewhere; the byte count travels first).
  *                             The receive buffer is the context's own vocabulary arena; every receiver validates
  *                             the blob's structure on its device before the vocabulary counts as resident.
- *                             *seconds (may be NULL): wall time of the collective alone. */
+ *                             *seconds (may be NULL): wall time of the collective alone.
+ *   pgorb_comm_library        which librccl the library resolved (the file ncclGetUniqueId lives in).  The library asks
+ *                             the loader for a librccl the PROCESS already holds first (RTLD_NOLOAD: under
+ *                             torch.distributed that is torch's bundled copy) and loads one by name only when there is
+ *                             none, so that one process never runs two RCCLs.  *preloaded (may be NULL) = 1 when it was
+ *                             already mapped.  Returns 0, or PGORB_E_HIP with the loader's message in `path`. */
 #define PGORB_COMM_ID_BYTES 128
 typedef struct pgorb_comm pgorb_comm;
+int  pgorb_comm_library(char* path, int cap, int* preloaded);
 int  pgorb_comm_unique_id(void* id /*[PGORB_COMM_ID_BYTES]*/);
 int  pgorb_comm_create_local(pgorb_ctx* const* ctxs, int nctx, pgorb_comm** out);
 int  pgorb_comm_create_rank(pgorb_ctx* ctx, int rank, int nranks, const void* id, pgorb_comm** out);
@@ -537,8 +543,9 @@ int      pgorb_stream_wait(pgorb_stream* s, int slot, const int32_t** n, const p
  *   pgorb_stream_submit_device   d_frames: nframes grey planes (row pitch `stride`, `frame_stride` bytes apart), ready
  *                                where `hip_stream` (the caller's; NULL = the null stream) stands at the call; they
  *                                must stay valid until the slot's batch is complete (level 0 may alias them).
- *   pgorb_stream_wait_device     wait_on_host != 0 (or hip_stream NULL): blocks until the slot's batch is complete and
- *                                checks its status word; otherwise makes `hip_stream` wait for it and returns at once.
+ *   pgorb_stream_wait_device     wait_on_host != 0: blocks until the slot's batch is complete and checks its status
+ *                                word; otherwise makes `hip_stream` (NULL = the null stream, as in submit) wait for it
+ *                                and returns at once.
  *                                DEVICE pointers, laid out as pgorb_stream_wait's, valid until the slot is submitted
  *                                again; with the front-end stage on, pgorb_stream_frontend_results hands out device
  *                                pointers as well.  Returns the number of frames of the batch. */

@@ -38,7 +38,7 @@ SYMBOLS = (
     "pgorb_smooth_heading_directions", "pgorb_smooth_time_series", "pgorb_trajectory_pca",
     "pgorb_project_directions", "pgorb_project_translations", "pgorb_turn_angles",
     "pgorb_principal_rotation_axes", "pgorb_angular_velocities_around_axis",
-    "pgorb_comm_unique_id", "pgorb_comm_create_local", "pgorb_comm_create_rank", "pgorb_comm_ranks", "pgorb_vocab_broadcast", "pgorb_comm_destroy",
+    "pgorb_comm_library", "pgorb_comm_unique_id", "pgorb_comm_create_local", "pgorb_comm_create_rank", "pgorb_comm_ranks", "pgorb_vocab_broadcast", "pgorb_comm_destroy",
     "pgorb_kahan_sum", "pgorb_fit_num_windows", "pgorb_fit_velocity_windows", "pgorb_calibrator_eval", "pgorb_fit_motion_velocities",
 )
 
@@ -182,6 +182,7 @@ def lib():
     L.pgorb_bow_transform.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp]
     L.pgorb_bow_transform_device.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     L.pgorb_bow_vectors.argtypes = [C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, vp, i32p, vp, vp, vp, i32p]
+    L.pgorb_comm_library.argtypes = [C.c_char_p, C.c_int, i32p]
     L.pgorb_comm_unique_id.argtypes = [vp]
     L.pgorb_comm_create_local.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(vp)]
     L.pgorb_comm_create_rank.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]

@@ -46,6 +46,8 @@ struct pgorb_ctx {
     Arena pyr, cand, sel, nodes, counters, tables, cellCand, cellCount, cellTab, cellTabBal, qtTab, qtLeaf;
     int qtThreads = 0;                        // K3 threads per workgroup: 0 = per launch (pgorb_set_option "quadtree_threads")
     int qtSplit = 2;                          // K3's candidate pass as its own launch: 0 no, 1 yes, 2 by frame size and batch (pgorb_set_option "quadtree_split")
+    PgFusePlan fuse;                          // tables of the fused launches (make_plan)
+    int fused = 1;                            // pgorb_set_option "fused_levels": resize + detect in one launch per level (fused.hip)
     int fastTilePitch = 0, fastWpb = 1, fastCpw = PG_FAST_CPW_DEFAULT;       // K2 tile-shape sweep (pgorb_set_option "fast_tile_pitch" / "fast_waves_per_block")
     // K1 beside K2 (pgorb_set_option "pipeline_pyramid"): the pyramid chain on a high-priority side stream, K2 level by
     // level on a second one as the levels appear
@@ -209,12 +211,14 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
     PG_HIP(c, hipDeviceSynchronize());
     PgPlan& P = c->plan;
     memset(&P, 0, sizeof(P));
+    memset(&c->fuse, 0, sizeof(c->fuse));
     P.nlevels = L; P.iniTh = c->prm.ini_th_fast; P.minTh = c->prm.min_th_fast;
     P.tieMode = c->prm.blur_tie_mode;
 
     // --- resize tables ---
     std::vector<uint8_t> tab;
-    struct TabOff { size_t xofs, xofs1, xalpha, yofs, ybeta, qtab, yrel, qtab2, rowgrp, tilex; int cpr, prows; bool hasQ, hasY, hasQ2; } toff[PG_MAXL];
+    struct TabOff { size_t xofs, xofs1, xalpha, yofs, ybeta, qtab, yrel, qtab2, rowgrp, tilex, fbands, fcols; int cpr, prows, fnb, fntx, fcpr, frows; bool hasQ, hasY, hasQ2; } toff[PG_MAXL];
+    for (int l = 0; l < PG_MAXL; l++) toff[l].fnb = 0;
     int pyrGpw = 2;                                                   // 4-row groups per wave of the LDS-staged resize
     if (const char* e = getenv("PGORB_PYR_TILE_ROWS")) { const int r = atoi(e); if (r == 16 || r == 32 || r == 64) pyrGpw = r / 16; }
     for (int l = 1; l < L; l++) {
@@ -317,6 +321,68 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
             }
             toff[l].tilex = put(tx0.data(), tx0.size() * 4);
         }
+        // fused resize + detect (fused.hip) with level l - 1 as the source: bands = the source level's cell rows (hCell + 6 staged
+        // rows from row 16 + i hCell) between an edge band above (rows 0 ...) and below; a band owns the 4-row groups of level l whose
+        // first source row lies in [its first row, the next band's first row), so that the six source rows of every group are staged;
+        // tile columns = NS cells, a column owns the quads whose window starts in [15 + first cell * wCell, ... of the next column).
+        toff[l].fnb = 0;
+        {
+            const LevelGeom& S = g[l - 1];
+            const int ngrp = (g[l].h + 3) / 4, rowsB = S.hCell + 6;
+            bool fok = ok2 && oky && S.wCell <= 32 && S.hCell <= 40 && S.hCell >= 16 && S.wCell >= 16;
+            std::vector<int32_t> bands, cols;
+            int nb = 0, ntx = 0, cprF = 0;
+            if (fok) {
+                const int maxS = rg[ngrp - 1].sFirst;
+                std::vector<int> Y{0};
+                for (int i = 0; i < S.nRows || PG_EDGE + i * S.hCell <= maxS; i++) Y.push_back(PG_EDGE + i * S.hCell);
+                int gi = 0;
+                for (size_t b = 0; b < Y.size(); b++) {
+                    const int yNext = b + 1 < Y.size() ? Y[b + 1] : INT32_MAX;
+                    const int g0 = gi;
+                    while (gi < ngrp && rg[gi].sFirst < yNext) {
+                        if (rg[gi].sFirst < Y[b] || rg[gi].sFirst + 5 - Y[b] > rowsB - 1) fok = false;
+                        gi++;
+                    }
+                    const int cellRow = (b >= 1 && (int)b - 1 < S.nRows) ? (int)b - 1 : -1;
+                    if (gi == g0 && cellRow < 0) continue;              // an edge band without destination rows
+                    bands.insert(bands.end(), {Y[b], g0, gi, cellRow});
+                    nb++;
+                }
+                if (gi != ngrp) fok = false;
+            }
+            if (fok) {
+                // the widest tile column whose quads fit one wave (64 lanes)
+                for (int NS = 12; NS >= 1 && ntx == 0; NS--) {
+                    const int nt = (S.nCols + NS - 1) / NS;
+                    std::vector<int32_t> cc;
+                    int qi = 0, span = 0;
+                    bool fits = true;
+                    for (int tx = 0; tx < nt && fits; tx++) {
+                        const int xNext = tx + 1 < nt ? PG_EDGE - 1 + (tx + 1) * NS * S.wCell : INT32_MAX;
+                        const int q0 = qi;
+                        while (qi < nq && q2[qi].xb < xNext) qi++;
+                        const int c0 = tx * NS, nc = std::min(NS, S.nCols - c0);
+                        const int firstWin = PG_EDGE + c0 * S.wCell - 1, lastWin = PG_EDGE + (c0 + nc - 1) * S.wCell - 1;
+                        const int x0a = std::min(tx == 0 ? 0 : firstWin, qi > q0 ? q2[q0].xb : firstWin) & ~15;
+                        const int xEnd = std::max(lastWin + 48 + 4, qi > q0 ? q2[qi - 1].xb + 8 + 4 : 0);
+                        if (qi - q0 > 64 || x0a < 0) fits = false;
+                        span = std::max(span, xEnd - x0a);
+                        cc.insert(cc.end(), {x0a, q0, qi, c0, nc, 0, 0, 0});
+                    }
+                    if (!fits || qi != nq) continue;
+                    const int cpr = (span + 15) / 16;
+                    if (cpr > 32) continue;
+                    ntx = nt; cprF = cpr; cols = cc;
+                }
+                if (ntx == 0) fok = false;
+            }
+            if (fok) {
+                toff[l].fbands = put(bands.data(), bands.size() * 4);
+                toff[l].fcols = put(cols.data(), cols.size() * 4);
+                toff[l].fnb = nb; toff[l].fntx = ntx; toff[l].fcpr = cprF; toff[l].frows = rowsB;
+            }
+        }
     }
     if ((rc = ensure(c, c->tables, tab.size() + 16))) return rc;
     if (!tab.empty()) PG_HIP(c, hipMemcpy(c->tables.p, tab.data(), tab.size(), hipMemcpyHostToDevice));
@@ -396,6 +462,11 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
             V.tilex = (const int32_t*)(t + toff[l].tilex);
             V.pyrCpr = toff[l].cpr; V.pyrRows = toff[l].prows; V.pyrGpw = pyrGpw;
             V.qtab2 = toff[l].hasQ2 ? (const PgQuadTab2*)(t + toff[l].qtab2) : nullptr;
+            if (toff[l].fnb > 0) {                          // the fused tables belong to the SOURCE level l - 1
+                PgFuseLevel& SV = c->fuse.lvl[l - 1];
+                SV.bands = (const int32_t*)(t + toff[l].fbands); SV.cols = (const int32_t*)(t + toff[l].fcols);
+                SV.nBands = toff[l].fnb; SV.nTx = toff[l].fntx; SV.cpr = toff[l].fcpr; SV.rows = toff[l].frows;
+            }
         }
     }
     P.cellCand = (uint32_t*)c->cellCand.p; P.cellCount = (int32_t*)c->cellCount.p;
@@ -495,7 +566,7 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
         if ((rc = ensure(c, c->qtLeaf, leafBytes))) return rc;
         P.qtTab = (const uint2*)c->qtTab.p; P.qtLeaf = (uint2*)c->qtLeaf.p; P.qtSplit = c->qtSplit; P.qtThreads = c->qtThreads; P.qtWide = getenv("PGORB_QT_WIDE") ? atoi(getenv("PGORB_QT_WIDE")) != 0 : 1;
     }
-    P.fastTilePitch = c->fastTilePitch; P.fastWpb = c->fastWpb; P.fastCpw = c->fastCpw;
+    P.fastTilePitch = c->fastTilePitch; P.fastWpb = c->fastWpb; P.fastCpw = c->fastCpw; c->fuse.enabled = c->fused;
     P.cand = (uint32_t*)c->cand.p; P.sel = (uint32_t*)c->sel.p;
     P.nodeScratch = (int32_t*)c->nodes.p;
     P.candCount = (int32_t*)c->counters.p;
@@ -535,7 +606,8 @@ int run_batch(pgorb_ctx* c, const uint8_t* d_gray, bool resident_in_level0, int 
     }
     // the device status word is per batch: cleared by the first pyramid launch (pyramid.hip) where the order of the kernels allows it,
     // by a memset otherwise
-    const bool foldClear = !c->pipePyr && P.nlevels > 1;
+    const bool fusedPath = c->fuse.enabled && !c->pipePyr && !c->pipeLev && P.nlevels > 1;
+    const bool foldClear = !c->pipePyr && P.nlevels > 1 && !fusedPath;
     if (!foldClear) PG_HIP(c, hipMemsetAsync(P.status, 0, 16, s));
     hipEvent_t* ev = (c->profExtract < c->profMax) ? &c->evExtract[5 * (size_t)c->profExtract] : nullptr;
     if (ev) PG_HIP(c, hipEventRecord(ev[0], s));
@@ -606,6 +678,25 @@ int run_batch(pgorb_ctx* c, const uint8_t* d_gray, bool resident_in_level0, int 
         PG_HIP(c, hipGetLastError());
         c->lastFrames = nframes;
         return 0;
+    } else if (c->fuse.enabled && P.nlevels > 1) {
+        // Every level read ONCE (fused.hip): the launch that resizes level l -> l + 1 detects level l; a level without fused tables
+        // takes K1 + its own K2; the last level is detected by K2.  (Stage events: "pyramid" = the chain of fused launches, i.e. the
+        // whole pyramid AND the detection of levels 0 .. L-2; "fast" = what is left for K2.)
+        PG_HIP(c, hipMemsetAsync(P.status, 0, 16, s));        // (K2's part of the first launch may report: the word is cleared in front of it)
+        int pending = -1;                                     // first level of a run of levels still waiting for K2
+        for (int l = 0; l + 1 < P.nlevels; l++) {
+            if (pg_launch_pyr_fast(P, c->fuse, l, nframes, s)) {
+                if (pending >= 0) { pg_launch_fast_levels(P, nframes, pending, l, s); pending = -1; }
+            } else {
+                pg_launch_pyramid_level(P, l + 1, nframes, s);
+                if (pending < 0) pending = l;
+            }
+        }
+        if (ev) PG_HIP(c, hipEventRecord(ev[1], s));
+        if (c->evPyrEnd) PG_HIP(c, hipEventRecord(c->evPyrEnd, s));
+        pg_launch_fast_levels(P, nframes, pending >= 0 ? pending : P.nlevels - 1, P.nlevels, s);
+        if (ev) PG_HIP(c, hipEventRecord(ev[2], s));
+        if (c->evFastEnd) PG_HIP(c, hipEventRecord(c->evFastEnd, s));
     } else {
         for (int l = 1; l < P.nlevels; l++)
             if (!pg_launch_pyramid_level(P, l, nframes, s, l == 1 ? P.status : nullptr) && l == 1) PG_HIP(c, hipMemsetAsync(P.status, 0, 16, s));
@@ -627,6 +718,7 @@ int run_batch(pgorb_ctx* c, const uint8_t* d_gray, bool resident_in_level0, int 
 }  // namespace
 
 // ---- helpers used by bow.hip ---------------------------------------------------------------
+extern "C" void pg_forward_option_to_lanes(pgorb_ctx* c, const char* key, int value);      // (defined behind pgorb_stream)
 int pg_ctx_fail(pgorb_ctx* c, int code, const char* msg) { return fail(c, code, "%s", msg); }
 int pg_ctx_device(pgorb_ctx* c) { return c->prm.device; }
 int pg_ctx_stage(pgorb_ctx* c, int which, size_t bytes, void** p)
@@ -1187,6 +1279,7 @@ int pgorb_set_option(pgorb_ctx* c, const char* key, int value)
 {
     if (!key) return PGORB_E_ARG;
     if (!c) return PGORB_E_ARG;                               // every option belongs to a context (round 4: no process-wide state)
+    pg_forward_option_to_lanes(c, key, value);                // the sibling contexts of live multi-lane device streams follow
     c->planEpoch++;                                            // (a captured graph of the host-frame path holds the old settings)
     if (!strcmp(key, "matcher")) { c->mx.popcount = value ? 1 : pg_match_default_opts().popcount; return 0; }     // 0 = what the environment says
     if (!strcmp(key, "match_mode")) {
@@ -1219,6 +1312,7 @@ int pgorb_set_option(pgorb_ctx* c, const char* key, int value)
         c->qtSplit = value; c->plan.qtSplit = value;
         return 0;
     }
+    if (!strcmp(key, "fused_levels")) { c->fused = value ? 1 : 0; c->fuse.enabled = c->fused; return 0; }
     if (!strcmp(key, "pipeline_pyramid")) { c->pipePyr = value ? 1 : 0; return 0; }
     if (!strcmp(key, "pipeline_levels")) { c->pipeLev = value & ((1 << PG_MAXL) - 2); return 0; }
     if (!strcmp(key, "pipeline_levels_priority")) { c->pipeLevPrio = value ? 1 : 0; return 0; }
@@ -1235,6 +1329,7 @@ int pgorb_get_option(const pgorb_ctx* c, const char* key)
     if (!strcmp(key, "quadtree_threads")) return c->qtThreads;
     if (!strcmp(key, "matcher")) return c->mx.popcount;
     if (!strcmp(key, "match_mode")) return c->mx.mode;
+    if (!strcmp(key, "fused_levels")) return c->fused;
     if (!strcmp(key, "pipeline_pyramid")) return c->pipePyr;
     if (!strcmp(key, "pipeline_levels")) return c->pipeLev;
     if (!strcmp(key, "pipeline_levels_priority")) return c->pipeLevPrio;
@@ -1477,6 +1572,22 @@ int pgorb_stream_create_ingest(pgorb_ctx* c, int src_w, int src_h, int channels,
 }
 
 // The device-resident form: `lanes` extractor working sets behind one stream object (include/pgorb.h).
+void pg_forward_option_to_lanes(pgorb_ctx* c, const char* key, int value)
+{
+    for (pgorb_stream* st : c->streams)
+        for (size_t l = 1; l < st->lane.size(); l++)
+            if (st->lane[l] && st->lane[l] != c) (void)pgorb_set_option(st->lane[l], key, value);
+}
+
+// every tunable of a context (pgorb_set_option), for the sibling contexts of a multi-lane device stream: "same parameters and
+// options" (pgorb.h) -- one list, used at lane creation; pgorb_set_option forwards later changes to the lanes of live streams
+static void copy_tunables(pgorb_ctx* dst, const pgorb_ctx* src)
+{
+    dst->mx = src->mx; dst->qtThreads = src->qtThreads; dst->qtSplit = src->qtSplit; dst->fastTilePitch = src->fastTilePitch;
+    dst->fastWpb = src->fastWpb; dst->fastCpw = src->fastCpw; dst->fused = src->fused; dst->pipePyr = src->pipePyr; dst->pipeLev = src->pipeLev;
+    dst->pipeLevPrio = src->pipeLevPrio;
+}
+
 int pgorb_stream_create_device(pgorb_ctx* c, int w, int h, int batch, int depth, int lanes, pgorb_stream** out)
 {
     if (!c || !out) return PGORB_E_ARG;
@@ -1501,7 +1612,7 @@ int pgorb_stream_create_device(pgorb_ctx* c, int w, int h, int batch, int depth,
         hipStream_t ls = nullptr;
         ok = pgorb_create(&c->prm, &lc) == PGORB_OK;
         if (ok) {
-            lc->mx = c->mx; lc->qtThreads = c->qtThreads; lc->qtSplit = c->qtSplit; lc->fastTilePitch = c->fastTilePitch; lc->fastWpb = c->fastWpb; lc->fastCpw = c->fastCpw;
+            copy_tunables(lc, c);
             s->lane.push_back(lc);
             ok = make_plan(lc, w, h, batch) == 0 && hipStreamCreateWithFlags(&ls, hipStreamNonBlocking) == hipSuccess;
             s->sLane.push_back(ls);
@@ -1785,7 +1896,7 @@ int pgorb_stream_wait_device(pgorb_stream* s, int slot, int wait_on_host, void* 
     pgorb_stream::Slot& sl = s->slot[slot];
     if (!sl.busy) return fail(c, PGORB_E_ARG, "pgorb_stream_wait_device: slot %d has no batch in flight", slot);
     PG_HIP(c, hipSetDevice(c->prm.device));
-    if (wait_on_host || !hip_stream) {
+    if (wait_on_host) {                                       // (hip_stream == NULL is the legacy null stream, as in pgorb_stream_submit_device)
         PG_HIP(c, hipEventSynchronize(sl.evRun));
         const int32_t st = s->hStatus[slot];
         if (st) { sl.busy = false; return fail(c, st, "device reported status %d", st); }

@@ -23,6 +23,7 @@
 #include "pgorb_internal.h"
 #include <rccl/rccl.h>
 #include <dlfcn.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -52,23 +53,63 @@ struct Rccl {
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     std::string error;
+    std::string path;         // the file ncclGetUniqueId resolved into (dladdr)
+    bool preloaded = false;   // the process had it mapped before the library asked
 };
+
+// The RCCL the library calls must be the one the PROCESS already has: under torch.distributed the process holds torch's
+// bundled torch/lib/librccl.so, and a second build loaded by name would hand the 128-byte ncclUniqueId of one RCCL to the
+// other.  So: first ask the loader for a librccl that is ALREADY mapped (RTLD_NOLOAD, by soname and by the path
+// /proc/self/maps shows), and only when the process has none load one by name.
+void* rccl_already_mapped(std::string* path)
+{
+    const char* sonames[] = {"librccl.so.1", "librccl.so"};
+    for (const char* n : sonames)
+        if (void* h = dlopen(n, RTLD_NOW | RTLD_NOLOAD)) { *path = n; return h; }
+    // a copy loaded by path whose soname the loader does not index under these names (torch/lib/librccl.so)
+    if (FILE* f = fopen("/proc/self/maps", "r")) {
+        char line[4096];
+        void* h = nullptr;
+        while (!h && fgets(line, sizeof line, f)) {
+            const char* p = strchr(line, '/');
+            if (!p) continue;
+            std::string file(p);
+            while (!file.empty() && (file.back() == '\n' || file.back() == ' ')) file.pop_back();
+            const size_t base = file.rfind('/');
+            if (file.compare(base + 1, 10, "librccl.so") != 0) continue;
+            if ((h = dlopen(file.c_str(), RTLD_NOW | RTLD_NOLOAD))) *path = file;
+        }
+        fclose(f);
+        return h;
+    }
+    return nullptr;
+}
 
 Rccl* rccl()
 {
     static Rccl R;
     static std::once_flag once;
     std::call_once(once, [] {
-        const char* names[] = {getenv("PGORB_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char* n : names) {
-            if (!n || !*n) continue;
-            if ((R.so = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+        std::string lastErr;
+        if (const char* forced = getenv("PGORB_RCCL_LIBRARY"); forced && *forced) {
+            if (!(R.so = dlopen(forced, RTLD_NOW | RTLD_LOCAL))) { const char* e = dlerror(); lastErr = e ? e : "dlopen failed"; }
         }
-        if (!R.so) { R.error = std::string("librccl.so not found (") + (dlerror() ? dlerror() : "dlopen failed") + ")"; return; }
+        if (!R.so && (R.so = rccl_already_mapped(&R.path))) R.preloaded = true;
+        if (!R.so) {
+            const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+            for (const char* n : names) {
+                if ((R.so = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+                const char* e = dlerror();                             // (dlerror() clears the message: read it ONCE per failure)
+                lastErr = e ? e : "dlopen failed";
+            }
+        }
+        if (!R.so) { R.error = "librccl.so not found (" + lastErr + ")"; return; }
 #define PG_SYM(f) if (!(R.f = reinterpret_cast<decltype(R.f)>(dlsym(R.so, "nccl" #f)))) R.error = "librccl lacks nccl" #f
         PG_SYM(GetUniqueId); PG_SYM(CommInitRank); PG_SYM(CommInitAll); PG_SYM(CommDestroy); PG_SYM(Broadcast);
         PG_SYM(GroupStart); PG_SYM(GroupEnd); PG_SYM(GetErrorString);
 #undef PG_SYM
+        Dl_info info;
+        if (R.GetUniqueId && dladdr(reinterpret_cast<void*>(R.GetUniqueId), &info) && info.dli_fname) R.path = info.dli_fname;
     });
     return &R;
 }
@@ -110,6 +151,18 @@ int nccl_fail(pgorb_comm* cm, const char* what, ncclResult_t r)
 }  // namespace
 
 extern "C" {
+
+// Which librccl the library resolved (the file ncclGetUniqueId lives in), for diagnostics: bench.py prints it, the tests
+// assert it is the one the process already held.  Returns 0, or PGORB_E_HIP when no librccl could be opened (the text is
+// then the loader's message).  *preloaded (may be NULL): 1 when the process had it mapped before libpgorb asked.
+int pgorb_comm_library(char* path, int cap, int* preloaded)
+{
+    Rccl* R = rccl();
+    const std::string& t = R->error.empty() ? R->path : R->error;
+    if (path && cap > 0) { strncpy(path, t.c_str(), (size_t)cap - 1); path[cap - 1] = 0; }
+    if (preloaded) *preloaded = R->preloaded ? 1 : 0;
+    return R->error.empty() ? 0 : PGORB_E_HIP;
+}
 
 int pgorb_comm_unique_id(void* id)
 {
@@ -173,14 +226,14 @@ int pgorb_comm_create_rank(pgorb_ctx* ctx, int rank, int nranks, const void* id,
     ncclUniqueId u;
     memcpy(&u, id, sizeof u);
     hipStream_t s = nullptr;
-    if (hipSetDevice(cm->devices[0]) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc(&cm->d_count, 64) != hipSuccess) {
+    bool ok = hipSetDevice(cm->devices[0]) == hipSuccess && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess;
+    if (ok) cm->streams.push_back(s);                                  // (owned by the group from here on: destroy releases it)
+    if (!ok || hipMalloc(&cm->d_count, 64) != hipSuccess) {
         const int rc = comm_fail(cm, PGORB_E_HIP, "stream for the broadcast");
         cm->comms.clear();
         pgorb_comm_destroy(cm);
         return rc;
     }
-    cm->streams.push_back(s);
     const ncclResult_t r = R->CommInitRank(&cm->comms[0], nranks, u, rank);
     if (r != ncclSuccess) { const int rc = nccl_fail(cm, "ncclCommInitRank", r); cm->comms.clear(); pgorb_comm_destroy(cm); return rc; }
     *out = cm;
@@ -237,11 +290,13 @@ int pgorb_vocab_broadcast(pgorb_comm* cm, int root, const pgorb_vocab* v, double
         const auto t0 = std::chrono::steady_clock::now();
         ncclResult_t r = R->GroupStart();
         if (r != ncclSuccess) return nccl_fail(cm, "ncclGroupStart", r);
+        bool devFail = false;
         for (int k = 0; k < cm->nranks && r == ncclSuccess; k++) {
-            if (hipSetDevice(cm->devices[k]) != hipSuccess) return comm_fail(cm, PGORB_E_HIP, "hipSetDevice failed");
+            if (hipSetDevice(cm->devices[k]) != hipSuccess) { devFail = true; break; }      // (the group is ended below, whatever happened)
             r = R->Broadcast(buf[rootRank], buf[k], (size_t)nbytes, ncclUint8, rootRank, cm->comms[k], cm->streams[k]);
         }
         const ncclResult_t re = R->GroupEnd();
+        if (devFail) return comm_fail(cm, PGORB_E_HIP, "hipSetDevice failed");
         if (r != ncclSuccess) return nccl_fail(cm, "ncclBroadcast", r);
         if (re != ncclSuccess) return nccl_fail(cm, "ncclGroupEnd", re);
         for (int k = 0; k < cm->nranks; k++) {

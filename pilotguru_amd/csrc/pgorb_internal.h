@@ -89,6 +89,19 @@ struct PgSelRec {
 };
 static_assert(sizeof(PgSelRec) == 32, "one s_load_dwordx8");
 
+// Fused resize + detect launch (fused.hip) with level l as the SOURCE: tiles = bands (the level's cell rows + the edge bands above and
+// below) x columns of NS cells.  bands == null when the level does not take it (no next level, cells wider than 32 px, a generic
+// scale factor).  Host-side only (not part of PgPlan, which travels to kernels by value).
+struct PgFuseLevel {
+    const int32_t* bands;     // [nBands] {first staged source row, first 4-row group of level + 1, end group, cell row or -1}
+    const int32_t* cols;      // [nTx] {first staged column (16-aligned), first quad of level + 1, end quad, first cell column, cells, 0, 0, 0}
+    int32_t  nBands, nTx, cpr, rows;      // 16-byte chunks per staged row; staged rows per band (hCell + 6)
+};
+struct PgFusePlan {
+    PgFuseLevel lvl[PG_MAXL];
+    int32_t  enabled;         // option "fused_levels": 1 (default) = levels with fused tables take fused.hip's launch, 0 = K1 + K2
+};
+
 #define PG_FAST_CPW_DEFAULT 1  // K2 cell records per wave
 #define PG_QT_LEAF_CAP 4096   // >= the leaves of any count pyramid (quadtree.hip, QT_PYR_CAP)
 struct PgPlan {
@@ -250,6 +263,7 @@ void pg_launch_ingest(const PgPlan& P, const uint8_t* src, int stride, int64_t f
 void pg_launch_color_to_gray(const PgPlan& P, const uint8_t* src, int stride, int64_t fstride, int channels,
                              int rgb_order, int nframes, hipStream_t s);
 bool pg_launch_pyramid_level(const PgPlan& P, int level, int nframes, hipStream_t s, int32_t* clearWord = nullptr);
+bool pg_launch_pyr_fast(const PgPlan& P, const PgFusePlan& F, int level, int nframes, hipStream_t s);          // fused.hip
 void pg_launch_fast(const PgPlan& P, int nframes, hipStream_t s);
 void pg_launch_fast_levels(const PgPlan& P, int nframes, int levelBeg, int levelEnd, hipStream_t s);
 void pg_launch_quadtree(const PgPlan& P, int nframes, hipStream_t s);

@@ -274,76 +274,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize_quads(
 //    v_dot2_u32_u16 against the packed 11-bit coefficients is HResizeLinear -- 2 instructions
 //    per pixel and row.
 //  * The vertical blend picks its two rows with wave-uniform branches (4 patterns).
-typedef unsigned short pg_us2 __attribute__((ext_vector_type(2)));
-struct __attribute__((packed, aligned(1))) PgU2 { uint32_t x, y; };
-
-// (a[23:0] * b[23:0]) >> 32
-__device__ __forceinline__ uint32_t pg_mulhi_u24(uint32_t a, uint32_t b)
-{
-    uint32_t r;
-    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
-// VResizeLinear (OpenCV 2.4 imgproc/imgwarp.cpp): ((b0 * S0) >> 16) + ((b1 * S1) >> 16) + 2) >> 2
-// with S = horizontal sum >> 4.  H holds S << 4 (the horizontal sum with its low 4 bits cleared)
-// and b arrives << 12, so each product-and-shift is one v_mul_hi_u32_u24:
-// (S * 16) * (b * 4096) >> 32 == (S * b) >> 16 (S < 2^15, b <= 2^11: both factors fit 24 bits).
-template <int D, int F>
-__device__ __forceinline__ uint32_t pyr_vrow(const uint32_t (&H)[6][4], uint32_t b0s, uint32_t b1s)
-{
-    constexpr int iA = D + (F & 1), iB = iA + ((F >> 1) & 1);
-    uint32_t out = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const uint32_t v = (pg_mulhi_u24(H[iA][j], b0s) + pg_mulhi_u24(H[iB][j], b1s) + 2u) >> 2;   // <= 255
-        out |= v << (8 * j);
-    }
-    return out;
-}
-
-template <int D>
-__device__ __forceinline__ void pyr_store_row(const uint32_t (&H)[6][4], int dy, int dh, const PgRowGrp& R,
-                                              uint8_t* dbase, int dpitch)
-{
-    if (dy >= dh) return;
-    const int f = (R.yrel4 >> (8 * D)) & 3;                            // wave-uniform
-    const uint32_t b0s = (uint32_t)R.ybeta[2 * D] << 12, b1s = (uint32_t)R.ybeta[2 * D + 1] << 12;
-    uint32_t out;
-    if (f == 0) out = pyr_vrow<D, 0>(H, b0s, b1s);
-    else if (f == 1) out = pyr_vrow<D, 1>(H, b0s, b1s);
-    else if (f == 2) out = pyr_vrow<D, 2>(H, b0s, b1s);
-    else out = pyr_vrow<D, 3>(H, b0s, b1s);
-    *reinterpret_cast<uint32_t*>(dbase + (int64_t)dy * dpitch) = out;
-}
-
-// horizontal pass of the 6 source rows of one 4-row group + the 4 destination rows
-__device__ __forceinline__ void pyr_group(const PgU2 (&w)[6], const PgQuadTab2& T, const PgRowGrp& R, int dy0, int dh,
-                                          uint8_t* dbase, int dpitch)
-{
-    uint32_t H[6][4];                                                  // (horizontal sum >> 4) << 4
-#pragma unroll
-    for (int k = 0; k < 6; k++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t taps = __builtin_amdgcn_perm(w[k].y, w[k].x, T.sel[j]);      // tap0 | tap1 << 16
-            H[k][j] = __builtin_amdgcn_udot2(__builtin_bit_cast(pg_us2, taps),
-                                             __builtin_bit_cast(pg_us2, T.coef[j]), 0u, false) & ~15u;
-        }
-    pyr_store_row<0>(H, dy0 + 0, dh, R, dbase, dpitch);
-    pyr_store_row<1>(H, dy0 + 1, dh, R, dbase, dpitch);
-    pyr_store_row<2>(H, dy0 + 2, dh, R, dbase, dpitch);
-    pyr_store_row<3>(H, dy0 + 3, dh, R, dbase, dpitch);
-}
-
-__device__ __forceinline__ PgRowGrp pyr_unpack_group(const uint32_t (&rr)[8])
-{
-    PgRowGrp R;
-    R.sFirst = (int)rr[0]; R.yrel4 = rr[1];
-#pragma unroll
-    for (int k = 0; k < 4; k++) { R.ybeta[2 * k] = (int16_t)(rr[2 + k] & 0xFFFF); R.ybeta[2 * k + 1] = (int16_t)(rr[2 + k] >> 16); }
-    return R;
-}
+#include "pyramid_rows4.inc"
 
 // grid (tiles per frame rounded up to a multiple of 8, 1, frames), block (64, 4): a tile is 256
 // columns x 32 rows, a wave (one threadIdx.y) makes two groups of 4 rows.  Workgroup b lands on

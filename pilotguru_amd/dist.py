@@ -74,15 +74,36 @@ class VocabularyComm:
         from . import _lib
         L = _lib.lib()
         rank, world = dist.get_rank(), dist.get_world_size()
+        # EVERY rank takes part in the id broadcast, whatever happened on rank 0: it sends (ok, id), and when ok == 0 all ranks
+        # raise together AFTER the collective -- a rank that raised before it would leave its peers blocked in the broadcast
+        # while it moves on to the caller's next collective (mismatched collectives: the job hangs)
         ident = (C.c_uint8 * 128)()
+        ok = 1
         if rank == 0 and L.pgorb_comm_unique_id(ident) != 0:
-            raise RuntimeError("pgorb_comm_unique_id failed (librccl not loadable?)")
-        box = [bytes(ident)]
+            ok = 0
+        box = [(ok, bytes(ident))]
         dist.broadcast_object_list(box, src=0)                     # control plane: 128 bytes
-        ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
+        ok, raw = box[0]
+        if not ok:
+            raise RuntimeError("pgorb_comm_unique_id failed on rank 0 (librccl not loadable?): %s" % cls.library()[0])
+        ident = (C.c_uint8 * 128).from_buffer_copy(raw)
         h = C.c_void_p()
         extractor._check(L.pgorb_comm_create_rank(extractor._h, rank, world, ident, C.byref(h)))
         return cls(h, [extractor])
+
+    @staticmethod
+    def library():
+        """(path, preloaded): the librccl libpgorb resolved -- the file ncclGetUniqueId lives in -- and whether the process
+        already had it mapped when the library asked (under torch.distributed: torch/lib/librccl.so, never a second build)."""
+        import ctypes as C
+        from . import _lib
+        buf = C.create_string_buffer(1024)
+        pre = C.c_int(0)
+        rc = _lib.lib().pgorb_comm_library(buf, len(buf), C.byref(pre))
+        text = buf.value.decode(errors="replace")
+        if rc != 0:
+            return ("unavailable: " + text, False)
+        return (text, bool(pre.value))
 
     def ranks(self):
         return self._L.pgorb_comm_ranks(self._h)

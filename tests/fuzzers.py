@@ -57,6 +57,7 @@ def fuzz_parity(cases=200, seed=1, log=True, size_range=((90, 1000), (90, 800)),
             if form == 3: ext.set_option("fast_cells_per_wave", int(rng.choice([2, 3, 7])))
             ext.set_option("quadtree_split", it % 3)           # K3's pass inside the quadtree kernel / as its own launch / chosen by the library
             ext.set_option("quadtree_threads", (0, 256, 512, 1024)[(it // 3) % 4])
+            ext.set_option("fused_levels", 0 if form else it % 2)      # the K2 tile shapes need K2 on every level; else alternate
             kp, d = ext(img)
         except Exception as e:
             kp = None; err = str(e)
@@ -118,6 +119,7 @@ def fuzz_batch_parity(cases=100, seed=1, log=True, size_range=((120, 900), (120,
         ext = pg.ORBextractor(nf, scale, nlev, ini, mn, max_width=w, max_height=h, max_batch=B)
         ext.set_option("quadtree_split", it % 3)
         ext.set_option("quadtree_threads", (0, 256, 512, 1024)[(it // 3) % 4])
+        ext.set_option("fused_levels", (it // 2) % 2)
         got = ext.extract_batch(frames)
         for k in range(B):
             if got[k][0].tobytes() != want[k][0].tobytes() or not np.array_equal(got[k][1], want[k][1]):

@@ -69,3 +69,46 @@ def test_product_never_imports_oracle():
                 assert not re.search(r"(from|import)\s+oracle", code), f
                 assert not re.search(r'#include\s+"[^"]*oracle', code), f
                 assert "liborb_oracle" not in txt, f
+
+
+def _comm_library_in_subprocess(preamble):
+    import json
+    import subprocess
+    import sys
+    code = preamble + r"""
+import ctypes as C, json, os
+L = C.CDLL(os.path.join(%r, "pilotguru_amd", "libpgorb.so"))          # (the bare library: importing the package imports torch)
+buf = C.create_string_buffer(1024); pre = C.c_int(0)
+rc = L.pgorb_comm_library(buf, len(buf), C.byref(pre))
+mapped = sorted({ln.split()[-1] for ln in open('/proc/self/maps') if 'librccl.so' in ln.rsplit('/', 1)[-1]})
+print(json.dumps({"rc": rc, "path": buf.value.decode(), "pre": pre.value, "mapped": mapped}))
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       universal_newlines=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_librccl_is_the_one_the_process_already_holds():
+    """csrc/comm.hip asks the loader for an already-mapped librccl first (RTLD_NOLOAD): inside a torch process that is torch's
+    bundled torch/lib/librccl.so, and the process ends up with exactly ONE RCCL (two builds in one process would hand the
+    ncclUniqueId of one to the other -- a failure only a multi-rank run would show)."""
+    import torch
+    bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    if not os.path.exists(bundled):
+        pytest.skip("this torch build does not bundle librccl")
+    out = _comm_library_in_subprocess("import torch\nimport torch.distributed\n"
+                                      "import ctypes as _C\n_C.CDLL(%r, mode=_C.RTLD_GLOBAL)\n" % bundled)
+    assert out["rc"] == 0, out
+    assert os.path.realpath(out["path"]) == os.path.realpath(bundled), out
+    assert out["pre"] == 1 and len(out["mapped"]) == 1, out
+
+
+def test_librccl_loaded_by_name_when_the_process_has_none():
+    out = _comm_library_in_subprocess("")
+    if out["rc"] != 0:
+        # no librccl on the loader's path in this environment: the error is a code and a message, not a crash (ADVICE r5:
+        # dlerror() read twice was a NULL dereference exactly here)
+        assert "librccl.so not found" in out["path"], out
+        return
+    assert out["pre"] == 0 and len(out["mapped"]) == 1 and "librccl" in out["path"], out

@@ -145,6 +145,11 @@ def test_multi_gpu_code_path_on_one_gpu():
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["verified"] is True
     assert out["config"]["bow_words_equal_oracle_on_every_rank"] is True and out["config"]["vocab_broadcast_s"] > 0
     assert out["barrier_inclusive_seconds"] >= out["max_rank_seconds"]
+    # ONE librccl in the process: the library took the copy torch.distributed had already mapped (csrc/comm.hip, RTLD_NOLOAD first)
+    assert out["config"]["vocab_broadcast"].startswith("pgorb_vocab_broadcast")
+    info = out["config"]["vocab_broadcast_librccl"]
+    assert len(info["mapped"]) == 1 and os.path.realpath(info["path"]) == os.path.realpath(info["mapped"][0]), info
+    assert info["held_by_process_before"] is True
 
 
 @pytest.mark.parametrize("w,h,nf,total,batch,depth", [(640, 480, 1000, 23, 8, 3), (1920, 1080, 2000, 20, 8, 2)])

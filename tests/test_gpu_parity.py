@@ -637,6 +637,7 @@ def test_fast_every_tile_shape_bit_exact(oracle, pitch, wpb, cpw):
         ora = oracle.OrbOracle(nf, 1.2, nlevels, 20, 7)
         okp, odesc = ora.extract(img)
         ext = pg.ORBextractor(nf, 1.2, nlevels, 20, 7, max_width=w, max_height=h)
+        ext.set_option("fused_levels", 0)                 # every level through K2 (the fused launch of round 6 has one tile shape)
         ext.set_option("fast_tile_pitch", pitch)
         ext.set_option("fast_waves_per_block", wpb)
         ext.set_option("fast_cells_per_wave", cpw)
@@ -657,6 +658,7 @@ def test_fast_tile_shapes_at_2160p(oracle, pitch):
     img = synth_scene(2, 3840, 2160)
     okp, odesc = oracle.OrbOracle(4000, 1.2, 8, 20, 7).extract(img)
     ext = _make(4000, 3840, 2160)
+    ext.set_option("fused_levels", 0)
     ext.set_option("fast_tile_pitch", pitch)
     kp, desc = ext(img)
     assert kp.tobytes() == okp.tobytes() and np.array_equal(desc, odesc)
@@ -898,3 +900,62 @@ def test_extract_through_the_staged_upload_twice(oracle, monkeypatch):
         assert kp.tobytes() == okp.tobytes() and np.array_equal(desc, odesc)
     kp, desc = ext(ride[0])
     assert kp.tobytes() == want[0][0].tobytes() and np.array_equal(desc, want[0][1])
+
+
+def _stage_check(oracle, ext, img, nf, scale, nlev, ini, mn, label):
+    ora = oracle.OrbOracle(nf, scale, nlev, ini, mn)
+    okp, odesc = ora.extract(img)
+    kp, desc = ext(img)
+    for l in range(nlev):
+        assert np.array_equal(ext.debug_level_image(0, l), ora.level_image(l)), "%s: pyramid level %d" % (label, l)
+        x, y, r = ext.debug_level_candidates(0, l)
+        oc = ora.level_candidates(l)
+        assert sorted(zip(y.tolist(), x.tolist(), r.tolist())) == \
+            sorted(zip(oc["y"].tolist(), oc["x"].tolist(), oc["response"].tolist())), "%s: FAST candidates level %d" % (label, l)
+    assert len(kp) == len(okp) and kp.tobytes() == okp.tobytes() and np.array_equal(desc, odesc), label
+
+
+@pytest.mark.parametrize("fused", [1, 0])
+@pytest.mark.parametrize("w,h,nf,scale,nlev", [(640, 480, 1000, 1.2, 8), (641, 479, 1000, 1.2, 8), (1920, 1080, 2000, 1.2, 8),
+                                               (1280, 720, 1500, 1.2, 6), (333, 251, 500, 1.2, 5), (800, 600, 1200, 1.25, 4),
+                                               (1000, 1000, 1500, 1.1, 8), (700, 100, 300, 1.2, 3), (2048, 96, 600, 1.2, 2),
+                                               (1024, 768, 1000, 1.5, 4), (96, 2000, 300, 1.2, 2)])
+def test_fused_resize_and_detect_every_level_bit_exact(oracle, w, h, nf, scale, nlev, fused):
+    """fused.hip (round 6): the launch that resizes level l -> l + 1 also detects level l (each level read once), against the
+    oracle stage by stage -- every pyramid level, every level's candidate set, the final output -- on textured, driving-like
+    (minThFAST retry in >= 40 % of the cells) and noise frames (list overflow -> row-chunked passes inside the fused launch), for
+    frame sizes whose tiles end in partial columns / clipped or skipped last cells / edge bands of every height, and for scale
+    factors the 4 x 4 resize does not take (those levels fall back to K1 + K2 inside the same call).  fused = 0: the two-launch
+    path, on the same frames (ORBextractor.cc:1106-1131, 765-829)."""
+    import pilotguru_amd as pg
+    from pilotguru_amd.synth import synth_scene_road
+    rng = np.random.RandomState(w + h)
+    frames = [synth_scene(w + 3 * h, w, h), synth_scene_road(h, w, h), (128 + rng.randint(-9, 10, (h, w))).astype(np.uint8)]
+    ext = pg.ORBextractor(nf, scale, nlev, 20, 7, max_width=w, max_height=h)
+    ext.set_option("fused_levels", fused)
+    assert ext.get_option("fused_levels") == fused
+    for k, img in enumerate(frames):
+        _stage_check(oracle, ext, img, nf, scale, nlev, 20, 7, "%dx%d frame %d fused %d" % (w, h, k, fused))
+
+
+def test_fused_levels_on_an_aliased_batch_with_odd_pitch(oracle):
+    """Level 0 aliases the caller's device buffer: a row pitch that is a multiple of 16 takes the fused launch on the caller's rows
+    (band chunks never pass the pitch: the last row of the last frame is the end of the caller's allocation), any other 4-aligned
+    pitch sends level 0 through K1 + K2 and the rest through the fused launches -- the same keypoints either way."""
+    import torch
+    import pilotguru_amd as pg
+    w, h, nf, B = 636, 476, 800, 3
+    ride = synth_ride(5, w, h, B)
+    want = [oracle.OrbOracle(nf, 1.2, 8, 20, 7).extract(f) for f in ride]
+    ext = pg.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B)
+    for pitch in (640, 636, 644):
+        buf = torch.zeros((B, h, pitch), dtype=torch.uint8, device="cuda")
+        buf[:, :, :w] = torch.from_numpy(np.stack(ride)).cuda()
+        kps, desc, n = ext.extract_batch_device(buf[:, :, :w])
+        ext.check_async()
+        torch.cuda.synchronize()
+        n = n.cpu().numpy()
+        for k in range(B):
+            assert n[k] == len(want[k][0]), (pitch, k)
+            assert kps[k, :n[k]].cpu().numpy().tobytes() == want[k][0].tobytes(), (pitch, k)
+            assert np.array_equal(desc[k, :n[k]].cpu().numpy(), want[k][1]), (pitch, k)
