@@ -592,6 +592,9 @@ int      pgorb_stream_frontend_results(pgorb_stream* s, int slot, const int32_t*
  * frames (default; the measured table is profiles/r04_k3_split_grid.txt).  PGORB_QT_SPLIT seeds it.
  * key "quadtree_threads": threads per K3 workgroup -- 0 = chosen per launch (default: 512 when the problems of a launch queue for the
  * chip or are small, 1024 when each has a CU to itself; profiles/r04_k3_threads_grid.txt), 256 | 512 | 1024 = that many.  PGORB_QT_THREADS seeds it.
+ * key "fused_levels": 1 = the launch that resizes level l -> l + 1 also detects level l (csrc/fused.hip: every level read from HBM
+ *     once, one wave per cell slot; bit-exact; measured SLOWER than the two launches in every form tried, profiles/r06_fused_forms.txt),
+ *     0 = K1 + K2 (default).  Levels whose geometry the fused launch does not take (cells wider than 32 px, generic scale factors) run K1 + K2 either way.
  * key "pipeline_pyramid": 1 = the resize chain on a side stream beside K2, level by level (slower).
  * key "pipeline_levels": bit l set = a group of levels starts at level l; K3 / K4-6 of one group run on side streams beside K2
  * of the next (slower for every grouping measured).  0 = one launch per kernel (default).

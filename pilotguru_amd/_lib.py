@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpgorb.so")
+# PGORB_LIBRARY: a developer build of the same ABI (e.g. a timing build made with make EXTRA=...), for the scripts under tools/experiments
+LIB_PATH = os.environ.get("PGORB_LIBRARY") or os.path.join(_HERE, "libpgorb.so")
 
 PGORB_MAX_LEVELS = 16
 PGORB_OK, PGORB_E_ARG, PGORB_E_TOOSMALL, PGORB_E_CAP = 0, -1, -2, -3

@@ -47,7 +47,7 @@ struct pgorb_ctx {
     int qtThreads = 0;                        // K3 threads per workgroup: 0 = per launch (pgorb_set_option "quadtree_threads")
     int qtSplit = 2;                          // K3's candidate pass as its own launch: 0 no, 1 yes, 2 by frame size and batch (pgorb_set_option "quadtree_split")
     PgFusePlan fuse;                          // tables of the fused launches (make_plan)
-    int fused = 1;                            // pgorb_set_option "fused_levels": resize + detect in one launch per level (fused.hip)
+    int fused = 0;                            // pgorb_set_option "fused_levels": 1 = resize + detect in one launch per level (fused.hip; measured slower, off by default)
     int fastTilePitch = 0, fastWpb = 1, fastCpw = PG_FAST_CPW_DEFAULT;       // K2 tile-shape sweep (pgorb_set_option "fast_tile_pitch" / "fast_waves_per_block")
     // K1 beside K2 (pgorb_set_option "pipeline_pyramid"): the pyramid chain on a high-priority side stream, K2 level by
     // level on a second one as the levels appear
@@ -217,7 +217,7 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
 
     // --- resize tables ---
     std::vector<uint8_t> tab;
-    struct TabOff { size_t xofs, xofs1, xalpha, yofs, ybeta, qtab, yrel, qtab2, rowgrp, tilex, fbands, fcols; int cpr, prows, fnb, fntx, fcpr, frows; bool hasQ, hasY, hasQ2; } toff[PG_MAXL];
+    struct TabOff { size_t xofs, xofs1, xalpha, yofs, ybeta, qtab, yrel, qtab2, rowgrp, tilex, fbands, fcols; int cpr, prows, fnb, fspb, frows; bool hasQ, hasY, hasQ2; } toff[PG_MAXL];
     for (int l = 0; l < PG_MAXL; l++) toff[l].fnb = 0;
     int pyrGpw = 2;                                                   // 4-row groups per wave of the LDS-staged resize
     if (const char* e = getenv("PGORB_PYR_TILE_ROWS")) { const int r = atoi(e); if (r == 16 || r == 32 || r == 64) pyrGpw = r / 16; }
@@ -329,9 +329,9 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
         {
             const LevelGeom& S = g[l - 1];
             const int ngrp = (g[l].h + 3) / 4, rowsB = S.hCell + 6;
-            bool fok = ok2 && oky && S.wCell <= 32 && S.hCell <= 40 && S.hCell >= 16 && S.wCell >= 16;
+            bool fok = ok2 && oky && S.wCell <= 32 && S.hCell <= 40 && S.hCell >= 16 && S.wCell >= 16;       // (the detector's narrow form; 3 x 21 staged rows)
             std::vector<int32_t> bands, cols;
-            int nb = 0, ntx = 0, cprF = 0;
+            int nb = 0;
             if (fok) {
                 const int maxS = rg[ngrp - 1].sFirst;
                 std::vector<int> Y{0};
@@ -344,43 +344,43 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
                         if (rg[gi].sFirst < Y[b] || rg[gi].sFirst + 5 - Y[b] > rowsB - 1) fok = false;
                         gi++;
                     }
-                    const int cellRow = (b >= 1 && (int)b - 1 < S.nRows) ? (int)b - 1 : -1;
-                    if (gi == g0 && cellRow < 0) continue;              // an edge band without destination rows
-                    bands.insert(bands.end(), {Y[b], g0, gi, cellRow});
+                    bands.insert(bands.end(), {g0, gi - g0});          // (the kernel derives the band's first row and cell row from b)
                     nb++;
                 }
                 if (gi != ngrp) fok = false;
             }
+            int spbF = 0;
             if (fok) {
-                // the widest tile column whose quads fit one wave (64 lanes)
-                for (int NS = 12; NS >= 1 && ntx == 0; NS--) {
-                    const int nt = (S.nCols + NS - 1) / NS;
-                    std::vector<int32_t> cc;
-                    int qi = 0, span = 0;
-                    bool fits = true;
-                    for (int tx = 0; tx < nt && fits; tx++) {
-                        const int xNext = tx + 1 < nt ? PG_EDGE - 1 + (tx + 1) * NS * S.wCell : INT32_MAX;
-                        const int q0 = qi;
-                        while (qi < nq && q2[qi].xb < xNext) qi++;
-                        const int c0 = tx * NS, nc = std::min(NS, S.nCols - c0);
-                        const int firstWin = PG_EDGE + c0 * S.wCell - 1, lastWin = PG_EDGE + (c0 + nc - 1) * S.wCell - 1;
-                        const int x0a = std::min(tx == 0 ? 0 : firstWin, qi > q0 ? q2[q0].xb : firstWin) & ~15;
-                        const int xEnd = std::max(lastWin + 48 + 4, qi > q0 ? q2[qi - 1].xb + 8 + 4 : 0);
-                        if (qi - q0 > 64 || x0a < 0) fits = false;
-                        span = std::max(span, xEnd - x0a);
-                        cc.insert(cc.end(), {x0a, q0, qi, c0, nc, 0, 0, 0});
-                    }
-                    if (!fits || qi != nq) continue;
-                    const int cpr = (span + 15) / 16;
-                    if (cpr > 32) continue;
-                    ntx = nt; cprF = cpr; cols = cc;
+                // slot columns: s = -1 the left edge's pseudo-cell (source columns from 0), s >= 0 from column 15 + s wCell (the cell's
+                // iniX - 1; past the last cell column: pseudo-cells that only serve the resize); a quad belongs to the column its
+                // 8-byte window starts in -- and then lies inside that column's 48 bytes
+                auto slotOf = [&](int xb) { return xb < PG_EDGE - 1 ? -1 : (xb - (PG_EDGE - 1)) / S.wCell; };
+                auto slotX = [&](int sl) { return sl < 0 ? 0 : PG_EDGE - 1 + sl * S.wCell; };
+                int nSlotsTotal = S.nCols;
+                for (int q = 0; q < nq; q++) {
+                    const int sl = slotOf(q2[q].xb), off = q2[q].xb - slotX(sl);
+                    if (q > 0 && q2[q].xb < q2[q - 1].xb) fok = false;
+                    if (off < 0 || (off & ~3) + 12 > 48) fok = false;
+                    nSlotsTotal = std::max(nSlotsTotal, sl + 1);
                 }
-                if (ntx == 0) fok = false;
+                spbF = nSlotsTotal + 1;
+                int qi = 0, maxNq = 0, maxNg = 0;
+                for (int sl = -1; sl < nSlotsTotal; sl++) {
+                    const int q0 = qi;
+                    while (qi < nq && slotOf(q2[qi].xb) <= sl) qi++;
+                    const int n = qi - q0, magic = n > 0 ? 65536 / n + 1 : 65536;
+                    for (int lane = 0; lane < 64 && n > 0; lane++) if (((lane * magic) >> 16) != lane / n) fok = false;
+                    maxNq = std::max(maxNq, n);
+                    cols.insert(cols.end(), {q0, n, magic, 0});
+                }
+                if (qi != nq) fok = false;
+                for (int b = 0; b < nb; b++) maxNg = std::max(maxNg, bands[2 * b + 1]);
+                if (maxNq * maxNg > 64) fok = false;                   // lane = (quad, group)
             }
             if (fok) {
                 toff[l].fbands = put(bands.data(), bands.size() * 4);
                 toff[l].fcols = put(cols.data(), cols.size() * 4);
-                toff[l].fnb = nb; toff[l].fntx = ntx; toff[l].fcpr = cprF; toff[l].frows = rowsB;
+                toff[l].fnb = nb; toff[l].fspb = spbF; toff[l].frows = rowsB;
             }
         }
     }
@@ -465,7 +465,7 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
             if (toff[l].fnb > 0) {                          // the fused tables belong to the SOURCE level l - 1
                 PgFuseLevel& SV = c->fuse.lvl[l - 1];
                 SV.bands = (const int32_t*)(t + toff[l].fbands); SV.cols = (const int32_t*)(t + toff[l].fcols);
-                SV.nBands = toff[l].fnb; SV.nTx = toff[l].fntx; SV.cpr = toff[l].fcpr; SV.rows = toff[l].frows;
+                SV.nBands = toff[l].fnb; SV.spb = toff[l].fspb; SV.rows = toff[l].frows;
             }
         }
     }

@@ -89,17 +89,18 @@ struct PgSelRec {
 };
 static_assert(sizeof(PgSelRec) == 32, "one s_load_dwordx8");
 
-// Fused resize + detect launch (fused.hip) with level l as the SOURCE: tiles = bands (the level's cell rows + the edge bands above and
-// below) x columns of NS cells.  bands == null when the level does not take it (no next level, cells wider than 32 px, a generic
-// scale factor).  Host-side only (not part of PgPlan, which travels to kernels by value).
+// Fused resize + detect launch (fused.hip) with level l as the SOURCE: one wave per slot = bands (the level's cell rows + the edge bands
+// above and below) x columns (the cell columns + the pseudo-cells along the left and right edge).  bands == null when the level does
+// not take it (no next level, cells wider than 32 px, a generic scale factor).  Host-side only (not part of PgPlan, which travels to
+// kernels by value).
 struct PgFuseLevel {
-    const int32_t* bands;     // [nBands] {first staged source row, first 4-row group of level + 1, end group, cell row or -1}
-    const int32_t* cols;      // [nTx] {first staged column (16-aligned), first quad of level + 1, end quad, first cell column, cells, 0, 0, 0}
-    int32_t  nBands, nTx, cpr, rows;      // 16-byte chunks per staged row; staged rows per band (hCell + 6)
+    const int32_t* bands;     // [nBands] {first 4-row group of level + 1, groups}: band 0 = the rows above the first cell row, 1 .. nRows = the cell rows, then the rows below
+    const int32_t* cols;      // [spb] {first quad of level + 1, quads, 65536 / quads + 1, 0}: entry s + 1 = slot column s (-1 = the left edge's pseudo-cell)
+    int32_t  nBands, spb, rows;           // slots per band; staged rows per slot (hCell + 6)
 };
 struct PgFusePlan {
     PgFuseLevel lvl[PG_MAXL];
-    int32_t  enabled;         // option "fused_levels": 1 (default) = levels with fused tables take fused.hip's launch, 0 = K1 + K2
+    int32_t  enabled;         // option "fused_levels": 1 = levels with fused tables take fused.hip's launch, 0 (default) = K1 + K2
 };
 
 #define PG_FAST_CPW_DEFAULT 1  // K2 cell records per wave
