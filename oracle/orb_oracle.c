@@ -35,6 +35,7 @@ static int imax(int a, int b) { return a > b ? a : b; }
 /* ------------------------------------------------------------------------ */
 struct orc_extractor {
     int nfeatures, nlevels, iniThFAST, minThFAST, blur_tie_mode;
+    int simd;                                 /* orc_set_simd: 1 = the three primitives OpenCV 2.4.9 vectorises run their SIMD variants (orb_simd.c) */
     double scaleFactor;                       /* ref: include/ORBextractor.h:95 (double member) */
     float mvScaleFactor[ORC_MAX_LEVELS + 1], mvInvScaleFactor[ORC_MAX_LEVELS + 1];
     float mvLevelSigma2[ORC_MAX_LEVELS + 1], mvInvLevelSigma2[ORC_MAX_LEVELS + 1];
@@ -102,6 +103,9 @@ static void free_intermediates(orc_extractor* e)
     }
 }
 void orc_destroy(orc_extractor* e) { if (e) { free_intermediates(e); free(e); } }
+/* 1 = FAST, the vertical resize pass and both blur passes through their SIMD variants (orb_simd.c; the same results bit for bit):
+ * what bench.py's cpu_baseline reports as "port+simd".  Returns what was set: 0 when this CPU cannot run them. */
+int orc_set_simd(orc_extractor* e, int on) { e->simd = (on && orc_simd_available()) ? 1 : 0; return e->simd; }
 
 const float* orc_scale_factors(const orc_extractor* e) { return e->mvScaleFactor; }
 const float* orc_inv_scale_factors(const orc_extractor* e) { return e->mvInvScaleFactor; }
@@ -123,6 +127,12 @@ int orc_level_keypoints(const orc_extractor* e, int l) { return e->nkp[l]; }
  * ref: src/ORBextractor.cc:1119.  Source is the level ROI only. */
 void orc_resize_linear_u8(const uint8_t* src, int sw, int sh, int sstride,
                           uint8_t* dst, int dw, int dh, int dstride)
+{
+    orc_resize_linear_u8_ex(src, sw, sh, sstride, dst, dw, dh, dstride, 0);
+}
+/* simd != 0: the vertical pass through orb_simd.c (cv2.4: VResizeLinearVec_32s8u); same result bit for bit */
+void orc_resize_linear_u8_ex(const uint8_t* src, int sw, int sh, int sstride,
+                             uint8_t* dst, int dw, int dh, int dstride, int simd)
 {
     const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
     const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
@@ -166,6 +176,7 @@ void orc_resize_linear_u8(const uint8_t* src, int sw, int sh, int sstride,
             for (; dx < dw; dx++) D[dx] = S[xofs[dx]] * 2048;
         }
         uint8_t* out = dst + (size_t)dy * dstride;
+        if (simd) { orc_vresize_row_simd(rows[0], rows[1], b0, b1, out, dw); continue; }
         for (int x = 0; x < dw; x++)
             out[x] = (uint8_t)((((b0 * (rows[0][x] >> 4)) >> 16) +
                                 ((b1 * (rows[1][x] >> 4)) >> 16) + 2) >> 2);
@@ -532,10 +543,25 @@ static int reflect101(int p, int n)
 void orc_gaussian_blur7(const uint8_t* src, int w, int h, int sstride,
                         uint8_t* dst, int dstride, int tie_mode)
 {
+    orc_gaussian_blur7_ex(src, w, h, sstride, dst, dstride, tie_mode, 0);
+}
+/* simd != 0: both passes through orb_simd.c (cv2.4: RowVec_8u32s, SymmColumnVec_32s8u); same result bit for bit */
+void orc_gaussian_blur7_ex(const uint8_t* src, int w, int h, int sstride,
+                           uint8_t* dst, int dstride, int tie_mode, int simd)
+{
     int K[7]; gauss7_kernel_q8(K);
     int* R = (int*)malloc(sizeof(int) * (size_t)w * h);
     for (int y = 0; y < h; y++) {
         const uint8_t* s = src + (size_t)y * sstride;
+        if (simd && w >= 7) {
+            orc_blur_row_simd(s, w, K, R + (size_t)y * w);            /* the interior; the six border columns below */
+            for (int x = 0; x < w; x = (x == 2 ? w - 3 : x + 1)) {
+                int acc = 0;
+                for (int i = 0; i < 7; i++) acc += K[i] * s[reflect101(x + i - 3, w)];
+                R[(size_t)y * w + x] = acc;
+            }
+            continue;
+        }
         for (int x = 0; x < w; x++) {
             int acc = 0;
             if (x >= 3 && x + 3 < w)
@@ -550,6 +576,7 @@ void orc_gaussian_blur7(const uint8_t* src, int w, int h, int sstride,
         uint8_t* d = dst + (size_t)y * dstride;
         const int* rr[7];
         for (int i = 0; i < 7; i++) rr[i] = R + (size_t)reflect101(y + i - 3, h) * w;
+        if (simd) { orc_blur_col_simd(rr, w, K, tie_mode, wvec, d); continue; }
         for (int x = 0; x < w; x++) {
             int C = K[0] * (rr[0][x] + rr[6][x]) + K[1] * (rr[1][x] + rr[5][x]) + K[2] * (rr[2][x] + rr[4][x]) + K[3] * rr[3][x];
             int v = (C + 32768) >> 16;                 /* FixedPtCastEx: half up */
@@ -729,8 +756,9 @@ static int detect_level_cells(const orc_extractor* e, const uint8_t* img, int co
             if (maxX > maxBorderX) maxX = (float)maxBorderX;
             const int x0 = (int)iniX, x1 = (int)maxX, y0 = (int)iniY, y1 = (int)maxY;
             const uint8_t* win = img + (size_t)y0 * cols + x0;
-            int nc = orc_fast9_nms(win, x1 - x0, y1 - y0, cols, e->iniThFAST, cell, ccap);
-            if (nc == 0) nc = orc_fast9_nms(win, x1 - x0, y1 - y0, cols, e->minThFAST, cell, ccap);
+            int (*const nms)(const uint8_t*, int, int, int, int, orc_cand*, int) = e->simd ? orc_fast9_nms_simd : orc_fast9_nms;
+            int nc = nms(win, x1 - x0, y1 - y0, cols, e->iniThFAST, cell, ccap);
+            if (nc == 0) nc = nms(win, x1 - x0, y1 - y0, cols, e->minThFAST, cell, ccap);
             for (int k = 0; k < nc; k++) {
                 if (n == cap) { cap *= 2; all = (orc_cand*)realloc(all, sizeof(orc_cand) * cap); }
                 all[n].x = cell[k].x + j * wCell;
@@ -768,8 +796,8 @@ int orc_extract(orc_extractor* e, const uint8_t* gray, int w, int h, int stride,
         if (level == 0)
             for (int y = 0; y < h; y++) memcpy(e->img[0] + (size_t)y * w, gray + (size_t)y * stride, w);
         else
-            orc_resize_linear_u8(e->img[level - 1], e->lw[level - 1], e->lh[level - 1], e->lw[level - 1],
-                                 e->img[level], e->lw[level], e->lh[level], e->lw[level]);
+            orc_resize_linear_u8_ex(e->img[level - 1], e->lw[level - 1], e->lh[level - 1], e->lw[level - 1],
+                                    e->img[level], e->lw[level], e->lh[level], e->lw[level], e->simd);
     }
     int total = 0;
     orc_keypoint* lk[ORC_MAX_LEVELS] = {0};
@@ -806,7 +834,7 @@ int orc_extract(orc_extractor* e, const uint8_t* gray, int w, int h, int stride,
         if (nk == 0) { free(lk[level]); continue; }
         const int cols = e->lw[level], rows = e->lh[level];
         e->blur[level] = (uint8_t*)malloc((size_t)cols * rows);
-        orc_gaussian_blur7(e->img[level], cols, rows, cols, e->blur[level], cols, e->blur_tie_mode);
+        orc_gaussian_blur7_ex(e->img[level], cols, rows, cols, e->blur[level], cols, e->blur_tie_mode, e->simd);
         for (int i = 0; i < nk; i++) {
             orc_keypoint* k = &lk[level][i];
             orc_orb_descriptor(e->blur[level], cols, cv_round(k->x), cv_round(k->y), k->angle,

@@ -81,6 +81,17 @@ void orc_orb_descriptor(const uint8_t* blurred, int stride, int x, int y,
                         float angle_deg, uint8_t desc[32]);
 void orc_rgb_to_gray(const uint8_t* rgb, int w, int h, int stride, uint8_t* gray, int gstride);
 
+/* SIMD variants of the three primitives OpenCV 2.4.9 vectorises (orb_simd.c), bit-equal to the scalar functions above */
+int  orc_simd_available(void);
+int  orc_set_simd(orc_extractor*, int on);
+void orc_resize_linear_u8_ex(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh, int dstride, int simd);
+void orc_gaussian_blur7_ex(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride, int tie_mode, int simd);
+void orc_fast9_score_map_simd(const uint8_t* img, int w, int h, int stride, int threshold, uint8_t* score);
+int  orc_fast9_nms_simd(const uint8_t* img, int w, int h, int stride, int threshold, orc_cand* out, int cap);
+void orc_vresize_row_simd(const int* r0, const int* r1, int b0, int b1, uint8_t* out, int n);
+void orc_blur_row_simd(const uint8_t* s, int w, const int K[7], int* R);
+void orc_blur_col_simd(const int* const rr[7], int n, const int K[7], int tie_mode, int wvec, uint8_t* d);
+
 /* ORBmatcher::DescriptorDistance, ORBmatcher.cc:1651-1667 */
 int  orc_descriptor_distance(const uint8_t a[32], const uint8_t b[32]);
 void orc_hamming_matrix(const uint8_t* a, int na, const uint8_t* b, int nb, uint16_t* out);

@@ -81,6 +81,16 @@ def lib():
         L.orc_sincos_checksum.argtypes = [C.c_uint32, C.c_uint32]
         L.orc_orb_descriptor.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
         L.orc_rgb_to_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        # SIMD variants of the three primitives OpenCV 2.4.9 vectorises (orb_simd.c): bit-equal to the scalar functions
+        L.orc_simd_available.restype = C.c_int
+        L.orc_set_simd.restype = C.c_int
+        L.orc_set_simd.argtypes = [C.c_void_p, C.c_int]
+        L.orc_resize_linear_u8_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_gaussian_blur7_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.orc_fast9_score_map_simd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_fast9_score_map_simd.restype = None
+        L.orc_fast9_nms_simd.restype = C.c_int
+        L.orc_fast9_nms_simd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.orc_descriptor_distance.restype = C.c_int
         L.orc_descriptor_distance.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_hamming_matrix.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
@@ -131,7 +141,7 @@ class OrbOracle:
     """Mirror of ORB_SLAM2::ORBextractor (ref: include/ORBextractor.h:44-110)."""
 
     def __init__(self, nfeatures=2000, scale_factor=1.2, nlevels=8, ini_th_fast=20,
-                 min_th_fast=7, blur_tie_mode=0):
+                 min_th_fast=7, blur_tie_mode=0, simd=False):
         self.L = lib()
         self.nlevels = nlevels
         self.nfeatures = nfeatures
@@ -139,6 +149,9 @@ class OrbOracle:
                                    min_th_fast, blur_tie_mode)
         if not self.h:
             raise ValueError("orc_create failed")
+        # simd: FAST, the vertical resize pass and both blur passes through their SIMD variants (oracle/orb_simd.c: what OpenCV
+        # 2.4.9 vectorises; same results bit for bit).  .simd says whether this CPU took them (AVX2).
+        self.simd = bool(self.L.orc_set_simd(self.h, 1 if simd else 0))
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -215,27 +228,33 @@ class OrbOracle:
         return self.L.orc_level_keypoints(self.h, level)
 
 
-def resize_linear(src, dw, dh):
+def simd_available():
+    """True when this CPU runs the SIMD variants (oracle/orb_simd.c, AVX2)."""
+    return bool(lib().orc_simd_available())
+
+
+def resize_linear(src, dw, dh, simd=False):
     src = np.ascontiguousarray(src, np.uint8)
     dst = np.zeros((dh, dw), np.uint8)
-    lib().orc_resize_linear_u8(_p(src), src.shape[1], src.shape[0], src.shape[1], _p(dst), dw, dh, dw)
+    lib().orc_resize_linear_u8_ex(_p(src), src.shape[1], src.shape[0], src.shape[1], _p(dst), dw, dh, dw, 1 if simd else 0)
     return dst
 
 
-def fast9_nms(img, threshold):
+def fast9_nms(img, threshold, simd=False):
     img = np.ascontiguousarray(img, np.uint8)
     cap = img.size
     out = np.zeros(cap, CAND_DTYPE)
-    n = lib().orc_fast9_nms(_p(img), img.shape[1], img.shape[0], img.shape[1], threshold, _p(out), cap)
+    fn = lib().orc_fast9_nms_simd if simd else lib().orc_fast9_nms
+    n = fn(_p(img), img.shape[1], img.shape[0], img.shape[1], threshold, _p(out), cap)
     return out[:n].copy()
 
 
-def fast9_score_map(img, threshold):
+def fast9_score_map(img, threshold, simd=False):
     """FAST-9/16 corner score of every pixel before NMS (0 = no corner at `threshold`)."""
     img = np.ascontiguousarray(img, dtype=np.uint8)
     h, w = img.shape
     out = np.zeros((h, w), np.uint8)
-    lib().orc_fast9_score_map(_p(img), w, h, w, int(threshold), _p(out))
+    (lib().orc_fast9_score_map_simd if simd else lib().orc_fast9_score_map)(_p(img), w, h, w, int(threshold), _p(out))
     return out
 
 
@@ -248,10 +267,10 @@ def distribute_octtree(cand, minX, maxX, minY, maxY, N):
     return out[:n].copy()
 
 
-def gaussian_blur7(img, tie_mode=0):
+def gaussian_blur7(img, tie_mode=0, simd=False):
     img = np.ascontiguousarray(img, np.uint8)
     dst = np.zeros_like(img)
-    lib().orc_gaussian_blur7(_p(img), img.shape[1], img.shape[0], img.shape[1], _p(dst), img.shape[1], tie_mode)
+    lib().orc_gaussian_blur7_ex(_p(img), img.shape[1], img.shape[0], img.shape[1], _p(dst), img.shape[1], tie_mode, 1 if simd else 0)
     return dst
 
 

@@ -9,6 +9,7 @@ import os
 
 import numpy as np
 import pytest
+from pilotguru_amd.synth import synth_scene
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -534,3 +535,59 @@ def test_gaussian_blur_integer_arithmetic_against_scipy_int32(oracle, tie):
         want = np.clip(v, 0, 255).astype(np.uint8)
         got = oracle.gaussian_blur7(img, tie_mode=tie)
         assert np.array_equal(got, want), (w, h)
+
+
+# ---- the SIMD variants of what OpenCV 2.4.9 vectorises (oracle/orb_simd.c): bit-equal to the scalar restatement ----------------
+
+def _simd_or_skip(oracle):
+    if not oracle.simd_available():
+        pytest.skip("this CPU has no AVX2: the SIMD variants of the oracle do not run here")
+
+
+@pytest.mark.parametrize("w,h", [(37, 37), (36, 31), (7, 7), (8, 40), (19, 22), (23, 9), (64, 48), (131, 67), (6, 30)])
+def test_simd_fast_equals_scalar(oracle, w, h):
+    """cv::FAST's vector form (16 pixels per vector: compass pre-test, 25-step run count on bytes, cornerScore on eight 16-bit
+    lanes; scalar row tail) against the scalar oracle: the score of EVERY pixel and the NMS output, on noise (dense corners, equal
+    neighbouring scores), on texture, on flat images with saturating v +- t, at both thresholds of the path (20, 7) and the extremes."""
+    _simd_or_skip(oracle)
+    rng = np.random.RandomState(w * 100 + h)
+    imgs = [rng.randint(0, 256, (h, w)).astype(np.uint8), (128 + rng.randint(-12, 13, (h, w))).astype(np.uint8),
+            np.full((h, w), 250, np.uint8), (rng.randint(0, 2, (h, w)) * 255).astype(np.uint8), synth_scene(w + h, max(w, 64), max(h, 64))[:h, :w]]
+    for img in imgs:
+        for t in (20, 7, 1, 60, 200, 255):
+            assert np.array_equal(oracle.fast9_score_map(img, t, simd=True), oracle.fast9_score_map(img, t)), (w, h, t)
+            a, b = oracle.fast9_nms(img, t, simd=True), oracle.fast9_nms(img, t)
+            assert a.tobytes() == b.tobytes(), (w, h, t)
+
+
+@pytest.mark.parametrize("sw,sh", [(1920, 1080), (641, 479), (333, 251), (100, 150), (17, 9), (9, 8)])
+def test_simd_resize_and_blur_equal_scalar(oracle, sw, sh):
+    """cv::resize's vertical pass (8 x 32-bit lanes) and both GaussianBlur passes, in both tie modes, against the scalar oracle
+    at the pyramid's scale factors and at odd sizes (vector tails of every length, images narrower than a vector)."""
+    _simd_or_skip(oracle)
+    rng = np.random.RandomState(sw + sh)
+    img = rng.randint(0, 256, (sh, sw)).astype(np.uint8)
+    for f in (1.2, 1.5, 2.0, 1.07):
+        dw, dh = max(int(round(sw / f)), 1), max(int(round(sh / f)), 1)
+        assert np.array_equal(oracle.resize_linear(img, dw, dh, simd=True), oracle.resize_linear(img, dw, dh)), (sw, sh, f)
+    flat = np.full((sh, sw), 77, np.uint8); flat[::2, ::3] = 78                 # many exact ties in the column pass
+    for im in (img, flat, synth_scene(3, max(sw, 64), max(sh, 64))[:sh, :sw]):
+        for tie in (0, 1):
+            assert np.array_equal(oracle.gaussian_blur7(im, tie, simd=True), oracle.gaussian_blur7(im, tie)), (sw, sh, tie)
+
+
+@pytest.mark.parametrize("w,h,nf,scale,nlev", [(640, 480, 1000, 1.2, 8), (1280, 720, 2000, 1.2, 8), (333, 251, 500, 1.5, 3)])
+def test_simd_extract_equals_scalar_extract(oracle, w, h, nf, scale, nlev):
+    """The whole extractor with the SIMD primitives switched in (bench.py's "port+simd" CPU baseline): every pyramid level, every
+    candidate, every keypoint and descriptor equal to the scalar oracle's -- on a textured, a driving-like and a noise frame."""
+    _simd_or_skip(oracle)
+    from pilotguru_amd.synth import synth_scene_road
+    rng = np.random.RandomState(5)
+    for img in (synth_scene(11, w, h), synth_scene_road(4, w, h), (128 + rng.randint(-9, 10, (h, w))).astype(np.uint8)):
+        a, b = oracle.OrbOracle(nf, scale, nlev, 20, 7, simd=True), oracle.OrbOracle(nf, scale, nlev, 20, 7)
+        assert a.simd and not b.simd
+        ka, da = a.extract(img); kb, db = b.extract(img)
+        assert ka.tobytes() == kb.tobytes() and np.array_equal(da, db)
+        for l in range(nlev):
+            assert np.array_equal(a.level_image(l), b.level_image(l))
+            assert a.level_candidates(l).tobytes() == b.level_candidates(l).tobytes()
