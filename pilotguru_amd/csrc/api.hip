@@ -510,7 +510,11 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
                     }
                 }
         }
-        if ((rc = ensure(c, c->cellTab, ct.size() * 4 + 8 * 64))) return rc;      // + 8 records of slack (fast.hip)
+        // + slack: a K2 wave loads its record BEFORE it knows whether the position exists (fast.hip), and the last workgroup's positions
+        // run up to waves per workgroup x records per wave (4 x 64) past the table (round 6: 8 records of slack faulted under
+        // "fast_cells_per_wave" = 64 when the table happened to end a mapping)
+        const size_t cellTabSlack = (size_t)(4 * 64 + 8) * 64;
+        if ((rc = ensure(c, c->cellTab, ct.size() * 4 + cellTabSlack))) return rc;
         PG_HIP(c, hipMemcpy(c->cellTab.p, ct.data(), ct.size() * 4, hipMemcpyHostToDevice));
         P.cellTab = (const uint32_t*)c->cellTab.p;
         P.pyrBase = (const uint8_t*)c->pyr.p;
@@ -531,7 +535,7 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
                 if (k < lists[x].size()) memcpy(r, &ct[(size_t)lists[x][k] * 16], 64);
                 else { r[0] = 0xFFFFFFF0u; r[2] = 1u << 16; }                                // padding: the wave returns at once
             }
-        if ((rc = ensure(c, c->cellTabBal, cb.size() * 4 + 8 * 64))) return rc;
+        if ((rc = ensure(c, c->cellTabBal, cb.size() * 4 + cellTabSlack))) return rc;
         PG_HIP(c, hipMemcpy(c->cellTabBal.p, cb.data(), cb.size() * 4, hipMemcpyHostToDevice));
         P.cellTabBal = (const uint32_t*)c->cellTabBal.p;
         P.cellsPerXcdBal = (int)per;
@@ -587,6 +591,10 @@ int make_plan(pgorb_ctx* c, int w, int h, int nframes)
     return 0;
 }
 
+// PGORB_DEBUG_SYNC=1: wait behind every kernel of the one-launch-per-kernel path and say which one completed (a GPU memory fault
+// then names its kernel: the last line printed is the kernel BEFORE the faulting one)
+#define PG_DBG_SYNC(name) do { static const bool dbg_ = getenv("PGORB_DEBUG_SYNC") != nullptr; \
+                               if (dbg_) { (void)hipStreamSynchronize(s); fprintf(stderr, "[pgorb] %s done (%dx%d x %d)\n", name, w, h, nframes); fflush(stderr); } } while (0)
 int run_batch(pgorb_ctx* c, const uint8_t* d_gray, bool resident_in_level0, int nframes, int w, int h,
               int stride, int64_t frame_stride, pgorb_keypoint* d_kps, uint8_t* d_desc,
               int cap_per_frame, int32_t* d_n, hipStream_t s)
@@ -698,17 +706,22 @@ int run_batch(pgorb_ctx* c, const uint8_t* d_gray, bool resident_in_level0, int 
         if (ev) PG_HIP(c, hipEventRecord(ev[2], s));
         if (c->evFastEnd) PG_HIP(c, hipEventRecord(c->evFastEnd, s));
     } else {
-        for (int l = 1; l < P.nlevels; l++)
+        for (int l = 1; l < P.nlevels; l++) {
             if (!pg_launch_pyramid_level(P, l, nframes, s, l == 1 ? P.status : nullptr) && l == 1) PG_HIP(c, hipMemsetAsync(P.status, 0, 16, s));
+            PG_DBG_SYNC("K1 pyramid level");
+        }
         if (ev) PG_HIP(c, hipEventRecord(ev[1], s));
         if (c->evPyrEnd) PG_HIP(c, hipEventRecord(c->evPyrEnd, s));
         pg_launch_fast(P, nframes, s);
+        PG_DBG_SYNC("K2 fast");
         if (ev) PG_HIP(c, hipEventRecord(ev[2], s));
         if (c->evFastEnd) PG_HIP(c, hipEventRecord(c->evFastEnd, s));
     }
     pg_launch_quadtree(P, nframes, s);
+    PG_DBG_SYNC("K3 quadtree");
     if (ev) PG_HIP(c, hipEventRecord(ev[3], s));
     pg_launch_describe(P, nframes, d_kps, d_desc, cap_per_frame, d_n, s);
+    PG_DBG_SYNC("K4-6 describe");
     if (ev) { PG_HIP(c, hipEventRecord(ev[4], s)); c->profExtract++; }
     PG_HIP(c, hipGetLastError());
     c->lastFrames = nframes;

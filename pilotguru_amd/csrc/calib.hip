@@ -287,24 +287,10 @@ __device__ inline void sum_chain(const double* src, int n, double& acc, double* 
 // of every s_barrier it knows about -- including the producer's stream loads for the next chunks, i.e. one trip
 // to HBM per tick (that, not arithmetic, set the pace of the first versions: 1.1 us per chunk).  Only LDS traffic
 // has to be ordered here: the streams are read-only.
-#ifdef PGORB_CALIB_PROF      // developer build (make EXTRA=-DPGORB_CALIB_PROF): cycles of work per role, block 0
-__device__ unsigned long long cb_prof[8];
-#endif
 __device__ inline void cb_tick_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
-#ifdef PGORB_CALIB_PROF
-#define CP_BEGIN unsigned long long cp_w = 0, cp_t0 = __builtin_readcyclecounter(), cp_all = cp_t0
-#define CP_WORK_DONE do { cp_w += __builtin_readcyclecounter() - cp_t0; } while (0)
-#define CP_AFTER_BARRIER do { cp_t0 = __builtin_readcyclecounter(); } while (0)
-#define CP_END(role) do { if (lane == 0 && blockIdx.x == 0) { atomicAdd(&cb_prof[role], cp_w); if (role == 0) atomicAdd(&cb_prof[5], __builtin_readcyclecounter() - cp_all); } } while (0)
-#else
-#define CP_BEGIN
-#define CP_WORK_DONE
-#define CP_AFTER_BARRIER
-#define CP_END(role)
-#endif
 
 // velocity.cc:42-180 on the prepared streams.  Every wave returns the same loss and gradient.
 // All waves run the same tick loop with the same trip count; the barrier is outside the roles.
@@ -322,7 +308,6 @@ __device__ double cal_eval(const WinView& G, int wave, int lane, const double* x
         // tick loop unrolled by two so that each set keeps its registers.
         FwdRegs fA[CB_HALVES], fB[CB_HALVES];
         for (int h = 0; h < CB_HALVES; h++) { fA[h] = load_fwd(G.F, G.S, start_of(0) + 64 * h + lane); fB[h] = load_fwd(G.F, G.S, start_of(1) + 64 * h + lane); }
-        CP_BEGIN;
         auto tick = [&](int t, FwdRegs (&fr)[CB_HALVES]) {
             const int startF = start_of(t + 2);
             const bool on = in_range(t);
@@ -349,20 +334,16 @@ __device__ double cal_eval(const WinView& G, int wave, int lane, const double* x
                     for (int k = 0; k < 3; k++) G.sm[jm & 1][row][k] = dt * G.sv[jm & 1][row][k];
                 }
             }
-            CP_WORK_DONE;
             cb_tick_barrier();
-            CP_AFTER_BARRIER;
         };
         for (int t = 0; t < T; t += 2) {
             tick(t, fA);
             if (t + 1 < T) tick(t + 1, fB);
         }
-        CP_END(3);
     } else if (wave == 4) {                               // ---- PB: gradient products of chunk t-lag+1 (velocity.cc:133-163) ----
         // lag is odd, so backward chunk jb = t - lag + 1 has the parity of t: the same two-set scheme
         BwdRegs bA[CB_HALVES], bB[CB_HALVES];
         for (int h = 0; h < CB_HALVES; h++) { bA[h] = load_bwd(G.B, G.S, start_of(0) + 64 * h + lane); bB[h] = load_bwd(G.B, G.S, start_of(1) + 64 * h + lane); }
-        CP_BEGIN;
         auto tick = [&](int t, BwdRegs (&br)[CB_HALVES]) {
             const int jb = t - G.lag + 1;
             const int startB = start_of(jb + 2), wordB = word_of(jb);
@@ -385,32 +366,24 @@ __device__ double cal_eval(const WinView& G, int wave, int lane, const double* x
                     }
                 }
             }
-            CP_WORK_DONE;
             cb_tick_barrier();
-            CP_AFTER_BARRIER;
         };
         for (int t = 0; t < T; t += 2) {
             tick(t, bA);
             if (t + 1 < T) tick(t + 1, bB);
         }
-        CP_END(4);
     } else if (wave == 0) {                               // ---- V: v += a*dt (velocity.cc:99-101), every v_i kept ----
         const int comp = lane % 3;
         double vk = x[6 + comp];
-        CP_BEGIN;
         for (int t = 0; t < T; t++) {
             const int j = t - 1;
             // three lanes only: 64 lanes storing to three words would be serialised by the LDS as 21-way conflicts
             if (in_range(j) && lane < 3) sum_chain<5, true, 8>(&G.sc[j & 3][0][comp], word_of(j) & CB_NMASK, vk, &G.sv[j & 1][0][comp]);
-            CP_WORK_DONE;
             cb_tick_barrier();
-            CP_AFTER_BARRIER;
         }
-        CP_END(0);
     } else if (wave == 1) {                               // ---- T: travel += dt*v (velocity.cc:105-108) ----
         const int comp = lane % 3;
         double tk = 0;
-        CP_BEGIN;
         for (int t = 0; t < T; t++) {
             const int j = t - 3;
             if (in_range(j)) {
@@ -421,15 +394,11 @@ __device__ double cal_eval(const WinView& G, int wave, int lane, const double* x
                     tk = 0;
                 }
             }
-            CP_WORK_DONE;
             cb_tick_barrier();
-            CP_AFTER_BARRIER;
         }
-        CP_END(1);
     } else {                                              // ---- B: interval ends and the gradient sums ----
         const int acc = lane % 9, comp = lane % 3;
         double gj = 0, result = 0;
-        CP_BEGIN;
         for (int t = 0; t < T; t++) {
             const int je = t - 4, j = t - G.lag;
             const int we = word_of(je), wj = word_of(j);
@@ -442,11 +411,8 @@ __device__ double cal_eval(const WinView& G, int wave, int lane, const double* x
                 if (lane < 3) G.dvec[r][lane] = ((2.0 * diff) * travel[comp]) / (tn + 1e-5);
             }
             if (in_range(j) && lane < 9) sum_chain<9, false, 16>(&G.sp[j & 1][0][acc], wj & CB_NMASK, gj, nullptr);
-            CP_WORK_DONE;
             cb_tick_barrier();
-            CP_AFTER_BARRIER;
         }
-        CP_END(2);
         if (lane < 9) G.xch[1 + lane] = gj;
         if (lane == 0) G.xch[0] = result;
     }
@@ -691,14 +657,6 @@ int run_windows(pgorb_ctx* c, const Packed& P, int mode, const double* xin, int 
     hipLaunchKernelGGL(k_calibrate_windows, dim3((unsigned)nw), dim3(64 * CB_WAVES), lds, 0, (const WinDesc*)dW.p, (const double*)dD.p, (const int32_t*)dI.p,
                        mode, (const double*)dXin.p, max_iters, (double*)dX.p, (double*)dF.p, (double*)dGr.p, (int32_t*)dNi.p);
     if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return pg_ctx_fail(c, PGORB_E_HIP, "k_calibrate_windows failed");
-#ifdef PGORB_CALIB_PROF
-    {
-        unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(cb_prof), sizeof(h));
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(cb_prof), z, sizeof(z));
-        fprintf(stderr, "[calib prof] work cycles per role: V %llu, T %llu, B %llu, PF %llu, PB %llu; loop %llu\n", h[0], h[1], h[2], h[3], h[4], h[5]);
-    }
-#endif
     if (timing_on())
         fprintf(stderr, "[calib] %zu windows, %.1f MB of streams: upload %.3f s, solver kernel %.1f us\n", nw, P.dblCount * 8e-6, t1 - t0, (now_s() - t1) * 1e6);
     bool ok = hipMemcpy(fx, dF.p, sizeof(double) * nw, hipMemcpyDeviceToHost) == hipSuccess;

@@ -147,19 +147,6 @@ __device__ __forceinline__ int pg_wave_sum(int x)
     return __builtin_amdgcn_readlane(v, 63);
 }
 
-#ifdef PGORB_DESC_TIMING
-// developer build only (make EXTRA=-DPGORB_DESC_TIMING): 10 ns ticks per phase of every wave,
-// read back by tools/experiments/desc_timing.py
-#define DT_MAXW (1 << 19)
-__device__ unsigned int pg_dt_log[DT_MAXW * 8];
-#define DT_TS(k) do { const unsigned long long t1_ = wall_clock64(); if (lane == 0 && dt_id < DT_MAXW) pg_dt_log[dt_id * 8 + (k)] = (unsigned)(t1_ - dt_t0); dt_t0 = t1_; } while (0)
-extern "C" int pgorb_debug_desc_times(unsigned int* out, int nwaves)
-{
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pg_dt_log), sizeof(unsigned) * 8 * (size_t)nwaves) == hipSuccess ? 0 : -1;
-}
-#else
-#define DT_TS(k) do {} while (0)
-#endif
 
 typedef __attribute__((address_space(1))) const void* pg_gptr_t;
 typedef __attribute__((address_space(3))) void* pg_lptr_t;
@@ -210,10 +197,6 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
 
     const int lane = threadIdx.x;
     const int frame = blockIdx.y;
-#ifdef PGORB_DESC_TIMING
-    unsigned long long dt_t0 = wall_clock64();
-    const int dt_id = frame * gridDim.x + blockIdx.x;
-#endif
     // XCD-contiguous keypoint ranges: consecutive workgroups go to consecutive XCDs, so give XCD x
     // the x-th eighth of the frame's keypoint list (neighbours in the list are neighbours in the
     // image: their 43x43 windows share L2 lines)
@@ -271,10 +254,6 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
     const float Lscale = __uint_as_float(rec[6]), LpatchSize = __uint_as_float(rec[7]);
     const int x = (int)(cv & 0xFFF) + PG_EDGE, y = (int)((cv >> 12) & 0xFFF) + PG_EDGE;   // :842-843
     const int resp = (int)(cv >> 24);
-#ifdef PGORB_DESC_TIMING
-    asm volatile("" :: "s"(cv));
-    DT_TS(0);
-#endif
     const int w = Lw, h = Lh;
 
     // ---- stage the raw 43x43 window: window column 0 lands on an LDS dword boundary --------
@@ -299,11 +278,6 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
         }
     }
     PG_WAVE_SYNC();
-    DT_TS(1);
-#if defined(PGORB_DESC_STOP) && PGORB_DESC_STOP == 1        // developer builds (tools/experiments/r5_k46_stages.sh): stop behind a stage, its result kept alive
-    if (lane == 0 && idx < cap_per_frame) kps[(int64_t)frame * cap_per_frame + idx].octave = raw[17 * DW_PITCH + 5];
-    return;
-#endif
 
     // ---- IC_Angle: integer moments over the radius-15 disc (:77-104) -------------------
     // One task = one aligned dword (4 pixels) of one disc row; v_dot4_u32_u8 against the
@@ -321,19 +295,7 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
     }
     m10 = pg_wave_sum(m10);
     m01 = pg_wave_sum(m01);
-#ifdef PGORB_DESC_TIMING
-    asm volatile("" :: "v"(m01), "v"(m10));
-    DT_TS(2);
-#endif
     const float angle = pg_fast_atan2((float)m01, (float)m10);
-#if defined(PGORB_DESC_STOP) && PGORB_DESC_STOP == 2
-    if (lane == 0 && idx < cap_per_frame) kps[(int64_t)frame * cap_per_frame + idx].angle = angle;
-    return;
-#endif
-#ifdef PGORB_DESC_TIMING
-    asm volatile("" :: "v"(angle));
-    DT_TS(3);
-#endif
 
     // ---- 7x7 Gaussian, fixed point, separable (OpenCV 2.4 8U path, Appendix A4) ---------
     // row pass on the matrix cores: rowsum[r][n] = sum_t K[t] * raw[r][n + t] is the product of the
@@ -369,11 +331,6 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
         }
     }
     PG_WAVE_SYNC();
-    DT_TS(4);
-#if defined(PGORB_DESC_STOP) && PGORB_DESC_STOP == 3
-    if (lane == 0 && idx < cap_per_frame) { kps[(int64_t)frame * cap_per_frame + idx].angle = angle; kps[(int64_t)frame * cap_per_frame + idx].octave = (int)hT[5 * DH_PITCH + 7]; }
-    return;
-#endif
     // column pass: on demand.  Only the 512 rotated tap positions of the 37x37 blurred tile are
     // ever read, so each lane blurs its own 8 taps from the row-pass sums (4 LDS dwords, 3
     // v_dot2_u32_u16 each) instead of the wave producing all 1369 pixels.
@@ -386,14 +343,6 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     float a, b;
     pg_sincos_f(__fmul_rn(angle, factorPI), &b, &a);
-#if defined(PGORB_DESC_STOP) && PGORB_DESC_STOP == 4
-    if (lane == 0 && idx < cap_per_frame) { kps[(int64_t)frame * cap_per_frame + idx].angle = a; kps[(int64_t)frame * cap_per_frame + idx].x = b; kps[(int64_t)frame * cap_per_frame + idx].octave = (int)hT[5 * DH_PITCH + 7]; }
-    return;
-#endif
-#ifdef PGORB_DESC_TIMING
-    asm volatile("" :: "v"(a), "v"(b));
-    DT_TS(5);
-#endif
     unsigned long long bits[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -407,10 +356,6 @@ __global__ __launch_bounds__(64) void k_describe(const PgPlan P, const PgGauss7 
         bits[r] = __ballot(t0 < t1);
     }
 
-#ifdef PGORB_DESC_TIMING
-    asm volatile("" :: "s"(bits[0]), "s"(bits[3]));
-    DT_TS(6);
-#endif
     // ---- outputs (:836-846, :1094-1102) -----------------------------------------------------
     if (idx < cap_per_frame && lane == 0) {
         const int64_t o = (int64_t)frame * cap_per_frame + idx;

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(64 * WPB, 8) void k_fast_cells(const PgFastArgs KA)
     const uint32_t frame = blockIdx.y;                             // (unsigned: 32 x 32 -> 64-bit scalar multiplies, two instructions each)
     const int slot = ((int)(blockIdx.x >> 3) * WPB + wv) * cpw + j;           // within this XCD's run of records
     const int cell = cell0 + (int)(blockIdx.x & 7) * cellsPerXcd + slot;      // position in the table
-    const uint32_t* recp = tab + 16 * (int64_t)cell;               // (the tables have 8 records of slack)
+    const uint32_t* recp = tab + 16 * (int64_t)cell;               // (the tables end in 4 x 64 + 8 records of slack: api.hip)
     pg_u32x16 rec;
     asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rec) : "s"(recp) : "memory");
     if (cell >= cellEnd || slot >= cellsPerXcd) return cpw;

@@ -259,17 +259,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_match_mfma(const uint8_t* __rest
         for (; blk + 2 <= cntFull; blk += 2, kc -= 32.f) {
             mx_load(bl + (blk + 1) * MX_BLOCK_BYTES, B1);
             mx_block(B0, A, pg_v4f{kc, kc, kc, kc}, acc);
-#ifdef PGORB_MX_SINGLE
-            mx_update<false>(acc, true, k1, k2);
-            mx_load(bl + (blk + 2) * MX_BLOCK_BYTES, B0);
-            mx_block(B1, A, pg_v4f{kc - 16.f, kc - 16.f, kc - 16.f, kc - 16.f}, acc);
-            mx_update<false>(acc, true, k1, k2);
-#else
             pg_v4f accB[4];
             mx_block(B1, A, pg_v4f{kc - 16.f, kc - 16.f, kc - 16.f, kc - 16.f}, accB);
             mx_load(bl + (blk + 2) * MX_BLOCK_BYTES, B0);
             mx_update2(acc, accB, k1, k2);
-#endif
         }
         if (blk < cntFull) {                                     // odd count: one more full block, in B0
             mx_load(bl + (blk + 1) * MX_BLOCK_BYTES, B1);

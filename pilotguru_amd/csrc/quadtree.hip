@@ -148,27 +148,6 @@ __device__ __forceinline__ int qt_quadrant(const int4 b, uint32_t cv)
     return (x < midX) ? ((y < midY) ? 0 : 2) : ((y < midY) ? 1 : 3);      // n1 n3 / n2 n4 (:515-526)
 }
 
-#ifdef PGORB_QT_TIMING
-// developer build only (make EXTRA=-DPGORB_QT_TIMING): per-phase time of workgroup (0,0) in
-// 10 ns ticks, read back by tools/experiments/qt_timing.py
-__device__ unsigned long long pg_qt_t[24];
-#ifndef QT_TIMING_LEVEL
-#define QT_TIMING_LEVEL 0
-#endif
-#define QT_TS(k) do { if (tid == 0 && blockIdx.x == 0 && blockIdx.y == QT_TIMING_LEVEL) { const unsigned long long t1_ = wall_clock64(); pg_qt_t[k] += t1_ - qt_t0; qt_t0 = t1_; } } while (0)
-#define QT_CNT(k, v) do { if (tid == 0 && blockIdx.x == 0 && blockIdx.y == QT_TIMING_LEVEL) pg_qt_t[k] += (v); } while (0)
-#define QTP_TS(k) do { if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) { const unsigned long long t1_ = wall_clock64(); pg_qt_t[k] += t1_ - qt_t0; qt_t0 = t1_; } } while (0)
-extern "C" int pgorb_debug_qt_times(unsigned long long* out24, int reset)
-{
-    if (hipMemcpyFromSymbol(out24, HIP_SYMBOL(pg_qt_t), sizeof(pg_qt_t)) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[24] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(pg_qt_t), z, sizeof(z)) != hipSuccess) return -1; }
-    return 0;
-}
-#else
-#define QT_TS(k) do {} while (0)
-#define QT_CNT(k, v) do {} while (0)
-#define QTP_TS(k) do {} while (0)
-#endif
 
 // Depth-D descendant of the root that holds candidate cv: index r * 4^D + path, where path is the
 // sequence of DivideNode quadrants (:481-537) a key at (x, y) falls through.  Pure geometry --
@@ -261,9 +240,6 @@ __global__ __launch_bounds__((WIDE == 1 || WIDE == 3) ? 512 : QT_TMAX, WIDE == 3
     __shared__ int pyr[QT_PYR_CAP];                       // count pyramid, later the node map
     extern __shared__ __attribute__((aligned(16))) int qt_lds[];     // max(30 ints per node, cells + 1)
     const int tid = threadIdx.x;
-#ifdef PGORB_QT_TIMING
-    unsigned long long qt_t0 = wall_clock64();
-#endif
     // grid = (frames, levels): the heavy level-0 problems of all frames are dispatched first and
     // spread over all CUs (with level as the fast index every 8th workgroup -- always the same
     // 32 CUs under round-robin dispatch -- got all the level-0 work)
@@ -363,7 +339,6 @@ __global__ __launch_bounds__((WIDE == 1 || WIDE == 3) ? 512 : QT_TMAX, WIDE == 3
             (isY ? yTab : xTab)[c] = qt_tab_entry(isY, c, hX, nIni, regionH, D, wCell, hCell, nCols);
         }
         __syncthreads();
-        QT_TS(8);
         int* hD = pyr + qt_pyr_off(nIni, D);
         // (the wave index as a scalar: with cb / cEnd in VGPRs the compiler made the cell loop a per-lane loop around the cross-lane
         //  shuffles below, and that build hung the kernel -- found by a timed-out run, round 4)
@@ -468,7 +443,6 @@ __global__ __launch_bounds__((WIDE == 1 || WIDE == 3) ? 512 : QT_TMAX, WIDE == 3
             if (ncand > 0 && tid == 0) atomicExch(P.status, PGORB_E_TOOSMALL);      // see api.hip level_geometry: reference UB, reported
             return;
         }
-        QT_TS(9);
         if (!rank24) {                                      // order ranks beyond 24 bits: the winners come from a key pass (64-bit bids)
             qt_build_keys(cc, slots, ncells, L.cellCap, cellOff, sh, keys, hX, nIni, regionH, D);
             keysBuilt = true;
@@ -482,7 +456,6 @@ __global__ __launch_bounds__((WIDE == 1 || WIDE == 3) ? 512 : QT_TMAX, WIDE == 3
             __syncthreads();
         }
     }
-    QT_TS(0); QT_CNT(10, ncand);
 
     // ---- initial nodes (:543-585) ------------------------------------------------------
     int size;
@@ -506,7 +479,6 @@ __global__ __launch_bounds__((WIDE == 1 || WIDE == 3) ? 512 : QT_TMAX, WIDE == 3
             for (int i = tid; i < 4 * size; i += QT_T) cnt4[i] = pyr[nIni + 4 * pidA[i >> 2] + (i & 3)];
         __syncthreads();
     }
-    QT_TS(1);
 
     // ---- generations (:594-739) ---------------------------------------------------------
     // Generation g splits depth g-1 nodes.  While g <= D the child counts come from the pyramid
@@ -606,7 +578,6 @@ __global__ __launch_bounds__((WIDE == 1 || WIDE == 3) ? 512 : QT_TMAX, WIDE == 3
                     tailpos[p] = pos; rnk[p] = -1;
                 }
             }
-            QT_CNT(11, 1);
         } else {
             // ---- "largest first" generation (:676-737) ----
             for (int p = tid; p < n; p += QT_T) rnk[p] = (cntA[p] > 1) ? 1 : 0;
@@ -715,7 +686,6 @@ __global__ __launch_bounds__((WIDE == 1 || WIDE == 3) ? 512 : QT_TMAX, WIDE == 3
             size = Ctot + U;
             if (size > NC) { if (tid == 0) atomicExch(P.status, PGORB_E_OVERFLOW); size = NC; last = true; }
             if (size >= N || size == prevSize) last = true;                    // :734
-            QT_CNT(12, 1);
         }
         if (!pyrMode) {
             // keys move to their new node; unless this was the last generation they are also
@@ -759,7 +729,6 @@ __global__ __launch_bounds__((WIDE == 1 || WIDE == 3) ? 512 : QT_TMAX, WIDE == 3
             }
         }
         __syncthreads();
-        QT_TS(2);
         { int4* t4 = bndA; bndA = bndB; bndB = t4; int* t1 = cntA; cntA = cntB; cntB = t1;
           t1 = cnt4; cnt4 = cnt4n; cnt4n = t1; t1 = pidA; pidA = pidB; pidB = t1; }
         gen++;
@@ -786,11 +755,9 @@ __global__ __launch_bounds__((WIDE == 1 || WIDE == 3) ? 512 : QT_TMAX, WIDE == 3
                 const uint32_t k = leafBest[j];
                 if (k) atomicMax(&best[qt_walk(pyr, j, nIni, D)], ((unsigned long long)(k >> 24) << 32) | (0xFF000000u | (k & 0xFFFFFFu)));   // the 64-bit bid
             }
-            QT_TS(3);
         } else {
             for (int j = tid; j < nleaf; j += QT_T) leafPos[j] = qt_walk(pyr, j, nIni, D);
             __syncthreads();
-            QT_TS(3);
             for (int b0 = 0; b0 < ncand; b0 += 4 * QT_T) {
                 uint2 kk[4];
 #pragma unroll
@@ -806,10 +773,8 @@ __global__ __launch_bounds__((WIDE == 1 || WIDE == 3) ? 512 : QT_TMAX, WIDE == 3
         }
     } else {
         best = reinterpret_cast<unsigned long long*>(cnt4);
-        QT_TS(3);
     }
     __syncthreads();
-    QT_TS(6);
     // Selection records are written in a DISPATCH order for K4-6 -- 64-px (or coarser) tiles, row-major -- as pairs
     // {record, position in the reference's output list}: K4-6 gives XCD x the x-th eighth of this order, so the
     // 43 x 43 windows one XCD's L2 sees overlap (in list order every window line was fetched from HBM about twice).
@@ -856,7 +821,6 @@ __global__ __launch_bounds__((WIDE == 1 || WIDE == 3) ? 512 : QT_TMAX, WIDE == 3
     }
     for (int p = nsel + tid; p < L.selCap; p += QT_T) sel[p].posLevel = 0xFFFFFFFFu;       // unused slots of the slab: K4-6 returns on them
     if (tid == 0) *kpc = nsel;
-    QT_TS(7);
 }
 
 // K3's candidate pass as its own launch (round 4, PgPlan::qtSplit): inside k_quadtree it is ONE workgroup's walk over up to 9e4
@@ -871,9 +835,6 @@ __global__ __launch_bounds__(QTP_T) void k_qt_leaves(const PgPlan P, int level0,
 {
     extern __shared__ __attribute__((aligned(16))) int qp_lds[];     // [regionW] x table, [band] y table (uint2), [rows * ncol] counts, best records
     const int tid = threadIdx.x, frame = blockIdx.y, lane = tid & 63;
-#ifdef PGORB_QT_TIMING
-    unsigned long long qt_t0 = wall_clock64();
-#endif
     int rem = blockIdx.x, l = level0;
     for (int k = 0; k < nlev; k++) {
         const PgLevel& V = P.lvl[level0 + k];
@@ -901,7 +862,6 @@ __global__ __launch_bounds__(QTP_T) void k_qt_leaves(const PgPlan P, int level0,
     const uint2* gy = gx + regionW;
     const uint2* gr = gy + regionH;
     const int ya = (int)gr[r0].x, yb = (int)gr[r1].x;        // the band, in K2's (region-relative) coordinates
-    QTP_TS(16);
     uint2* xT = reinterpret_cast<uint2*>(qp_lds);
     uint2* yT = xT + regionW;                                // [yb - ya], indexed y - ya
     const int nh = (r1 - r0) * ncol;
@@ -920,9 +880,7 @@ __global__ __launch_bounds__(QTP_T) void k_qt_leaves(const PgPlan P, int level0,
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cFirst = c0 + 64 * wv;
     int cntNext = (cFirst + lane < c1) ? cc[cFirst + lane] : 0;
-    QTP_TS(17);
     __syncthreads();
-    QTP_TS(18);
     struct __attribute__((packed, aligned(4))) U4 { uint32_t e[4]; };
     for (int cb = cFirst; cb < c1; cb += 64 * (QTP_T / 64)) {
         const int myc = min(cntNext, cellCap);
@@ -964,9 +922,7 @@ __global__ __launch_bounds__(QTP_T) void k_qt_leaves(const PgPlan P, int level0,
             }
         }
     }
-    QTP_TS(19);
     __syncthreads();
-    QTP_TS(20);
     uint2* gl = P.qtLeaf + ((int64_t)frame * P.nlevels + l) * PG_QT_LEAF_CAP;
     const uint32_t cmask = (1u << D) - 1;
     for (int i = tid; i < nh; i += QTP_T) {
@@ -974,7 +930,6 @@ __global__ __launch_bounds__(QTP_T) void k_qt_leaves(const PgPlan P, int level0,
         const uint32_t leaf = ((col >> D) << (2 * D)) + qt_spread_bits(col & cmask) + 2u * qt_spread_bits(row);
         gl[leaf] = make_uint2((uint32_t)hC[i], hB[i]);
     }
-    QTP_TS(21);
 }
 
 void pg_launch_quadtree(const PgPlan& P, int nframes, hipStream_t s) { pg_launch_quadtree_levels(P, nframes, 0, P.nlevels, s); }
