@@ -98,6 +98,13 @@ int  pgorb_max_keypoints(const pgorb_ctx* ctx, int w, int h);
  * their buffers come from here (pageable memory is staged by the driver at a fraction of it). */
 void* pgorb_host_alloc(int64_t bytes);
 void  pgorb_host_free(void* p);
+/* Page-lock memory the CALLER owns (a frame buffer a decoder reuses call after call, e.g. the cv::Mat behind
+ * Frame.cc:251-257): pgorb_extract* then uploads it with ONE DMA instead of copying it through the library's staging
+ * slot (the host thread's 2 MB memcpy per 1080p frame).  The caller keeps the obligation the ownership implies:
+ * pgorb_host_unregister before the memory is freed or remapped -- which is why the library does not do this behind
+ * the caller's back, keyed by address.  Returns PGORB_OK, PGORB_E_ARG, or PGORB_E_HIP (the range cannot be locked). */
+int   pgorb_host_register(void* p, int64_t bytes);
+int   pgorb_host_unregister(void* p);
 
 /* One frame, host buffers.  gray: h rows of `stride` bytes.  kps[cap], desc[cap*32]. */
 int  pgorb_extract(pgorb_ctx* ctx, const uint8_t* gray, int w, int h, int stride,

@@ -34,7 +34,7 @@ SYMBOLS = (
     "pgorb_search_by_projection_keyframe", "pgorb_search_by_projection_keyframe_batch_device",
     "pgorb_log_f", "pgorb_log_scale_factor", "pgorb_predict_scale",
     "pgorb_undistort_keypoints", "pgorb_undistort_keypoints_batch_device", "pgorb_image_bounds",
-    "pgorb_host_alloc", "pgorb_host_free", "pgorb_stream_create", "pgorb_stream_create_ingest", "pgorb_stream_create_device", "pgorb_stream_submit_device", "pgorb_stream_wait_device", "pgorb_stream_lanes", "pgorb_stream_destroy", "pgorb_stream_input", "pgorb_stream_reset", "pgorb_stream_submit",
+    "pgorb_host_alloc", "pgorb_host_free", "pgorb_host_register", "pgorb_host_unregister", "pgorb_stream_create", "pgorb_stream_create_ingest", "pgorb_stream_create_device", "pgorb_stream_submit_device", "pgorb_stream_wait_device", "pgorb_stream_lanes", "pgorb_stream_destroy", "pgorb_stream_input", "pgorb_stream_reset", "pgorb_stream_submit",
     "pgorb_stream_wait", "pgorb_stream_frontend", "pgorb_stream_frontend_results", "pgorb_set_option", "pgorb_get_option", "pgorb_matcher_is_popcount",
     "pgorb_smooth_heading_directions", "pgorb_smooth_time_series", "pgorb_trajectory_pca",
     "pgorb_project_directions", "pgorb_project_translations", "pgorb_turn_angles",
@@ -171,6 +171,8 @@ def lib():
     L.pgorb_host_alloc.argtypes = [C.c_int64]
     L.pgorb_host_free.restype = None
     L.pgorb_host_free.argtypes = [vp]
+    L.pgorb_host_register.argtypes = [vp, C.c_int64]
+    L.pgorb_host_unregister.argtypes = [vp]
     L.pgorb_vocab_load_text.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.pgorb_vocab_load_cached.argtypes = [C.c_char_p, C.POINTER(vp), i32p]
     L.pgorb_vocab_from_blob.argtypes = [vp, C.c_int64, C.POINTER(vp)]

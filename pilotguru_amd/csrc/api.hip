@@ -1188,6 +1188,20 @@ void* pgorb_host_alloc(int64_t bytes)
 
 void pgorb_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
+int pgorb_host_register(void* p, int64_t bytes)
+{
+    if (!p || bytes <= 0) return PGORB_E_ARG;
+    if (hipHostRegister(p, (size_t)bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return PGORB_E_HIP; }
+    return PGORB_OK;
+}
+
+int pgorb_host_unregister(void* p)
+{
+    if (!p) return PGORB_E_ARG;
+    if (hipHostUnregister(p) != hipSuccess) { (void)hipGetLastError(); return PGORB_E_HIP; }
+    return PGORB_OK;
+}
+
 int pgorb_extract(pgorb_ctx* c, const uint8_t* gray, int w, int h, int stride, pgorb_keypoint* kps,
                   uint8_t* desc, int cap, int* n)
 {

@@ -959,3 +959,28 @@ def test_fused_levels_on_an_aliased_batch_with_odd_pitch(oracle):
             assert n[k] == len(want[k][0]), (pitch, k)
             assert kps[k, :n[k]].cpu().numpy().tobytes() == want[k][0].tobytes(), (pitch, k)
             assert np.array_equal(desc[k, :n[k]].cpu().numpy(), want[k][1]), (pitch, k)
+
+
+def test_registered_caller_buffer_uploads_directly(oracle):
+    """pgorb_host_register: a frame buffer the caller owns and reuses, page-locked once -- pgorb_extract then takes the direct upload
+    (one DMA, no staging copy) and returns the same keypoints; unregistered again, the staged path; errors are codes."""
+    import ctypes as C
+    import pilotguru_amd as pg
+    w, h, nf = 640, 480, 800
+    ext = pg.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    L = ext._L
+    frames = [np.ascontiguousarray(f) for f in synth_ride(31, w, h, 3)]
+    want = [oracle.OrbOracle(nf, 1.2, 8, 20, 7).extract(f) for f in frames]
+    buf = np.zeros((h, w), np.uint8)                                   # "the decoder's" buffer, reused for every frame
+    assert L.pgorb_host_register(C.c_void_p(buf.ctypes.data), buf.nbytes) == 0
+    try:
+        for k in range(3):
+            buf[:] = frames[k]
+            kp, desc = ext(buf)
+            assert kp.tobytes() == want[k][0].tobytes() and np.array_equal(desc, want[k][1]), k
+    finally:
+        assert L.pgorb_host_unregister(C.c_void_p(buf.ctypes.data)) == 0
+    buf[:] = frames[1]
+    kp, desc = ext(buf)
+    assert kp.tobytes() == want[1][0].tobytes()
+    assert L.pgorb_host_register(None, 16) != 0 and L.pgorb_host_unregister(None) != 0
