@@ -76,3 +76,43 @@ def test_frame_chunks_and_window_ranges_cover_everything_once():
             w = [pgd.window_range_for_rank(n, r, world) for r in range(world)]
             assert w[0][0] == 0 and w[-1][1] == n and all(w[i][1] == w[i + 1][0] for i in range(world - 1))
             assert max(b - a for a, b in w) - min(b - a for a, b in w) <= 1
+
+
+def _id_failure_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pilotguru_amd import _lib
+    from pilotguru_amd import dist as pgd
+
+    class _NoRccl:                                             # libpgorb with a librccl that cannot make an id (rank 0 is the one that asks)
+        def __init__(self, real): self._real = real
+        def __getattr__(self, name): return getattr(self._real, name)
+        def pgorb_comm_unique_id(self, ident): return -6
+    _lib._lib = _NoRccl(_lib.lib())
+    raised = False
+    try:
+        pgd.VocabularyComm.from_torch_group(None)
+    except RuntimeError as e:
+        raised = "pgorb_comm_unique_id failed on rank 0" in str(e)
+    # every rank left the id broadcast: the NEXT collective (bench.py's all_reduce of the fallback flag) pairs up on both
+    flag = torch.tensor([0 if raised else 1], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    out.put((rank, raised, int(flag.item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_id_handover_failure_is_raised_on_every_rank_together():
+    """rank 0 used to raise BEFORE the id broadcast when pgorb_comm_unique_id failed, leaving its peers blocked in that
+    broadcast while it went on to the caller's next collective.  Now (ok, id) travels in the broadcast and every rank raises after it."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_id_failure_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == [(0, True, 0), (1, True, 0)]
