@@ -1,4 +1,6 @@
-"""Developer timing of the fused launch (libpgorb built with make EXTRA=-DPGORB_FUSE_TIMING): per-wave ticks (10 ns) at the phase
+"""Developer timing of the WORKGROUP-per-tile form of the fused launch (tools/experiments/r6_fused_cooperative_workgroup.hip.txt dropped in as
+csrc/fused.hip with its host tables, built with make EXTRA=-DPGORB_FUSE_TIMING, loaded through PGORB_LIBRARY; the shipped one-wave-per-slot form has no
+timers): the numbers of profiles/r06_fused_forms.txt -- per-wave ticks (10 ns) at the phase
 borders of k_pyr_fast for level 0 of one 1080p batch: DMA issued / landed / barrier passed / resize done / cell 1 / cell 2 / cell 3."""
 import ctypes as C
 import sys, os
