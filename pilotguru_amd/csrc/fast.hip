@@ -16,10 +16,11 @@
 // Structure per wave:
 //  (1) the (wCell+6)x(hCell+6) window is staged into LDS by LDS-DMA (global_load_lds, 16 B per
 //      lane, byte-unaligned source) so that interior column 0 sits on an LDS dword boundary;
-//      the wave finds its window through one 32-byte cell record (a single scalar load);
+//      the wave finds its window through one 64-byte cell record (a single scalar load);
 //      (persistent waves that prefetch the next window measured slower twice -- with register
-//      prefetch 2x, with LDS-DMA double buffering 1.5x: the kernel is VALU-issue bound and
-//      needs its 8 waves per SIMD more than it needs the load latency hidden)
+//      prefetch 2x, with LDS-DMA double buffering 1.5x: the kernel sits between a latency floor
+//      and the issue rate of its eight waves per SIMD, no single resource binds it (DESIGN.md
+//      section 6), and it needs those eight waves more than it needs one wave's latency hidden)
 //  (2) each lane tests a QUAD of 4 horizontally adjacent pixels per step from 5 aligned LDS
 //      dwords (centre, left, right, 3 rows up, 3 rows down), FOUR pixels per 32-bit operation
 //      (quick_pass_b: v_lerp_u8 half-differences, bytes in place; the 16-bit-field form quick_pass

@@ -14,7 +14,7 @@
 //            LDS-DMA in 16-byte chunks from byte-unaligned global addresses.  ONE 64-lane wave per slot, one-wave workgroups: K2's
 //            shape, K2's 4.9 KB of LDS per wave, eight waves per SIMD (a workgroup of four waves per TILE of cells amortised the
 //            staging but held every cell's window for the workgroup's whole life: 16 waves per CU, 1.33 ms for the seven launches
-//            against K1 + K2's 0.86 -- profiles/r06_fused_cooperative.txt, tools/experiments/r6_fused_cooperative.patch);
+//            against K1 + K2's 0.86 -- profiles/r06_fused_forms.txt, tools/experiments/r6_fused_cooperative_workgroup.hip.txt);
 //   resize   the slot owns the 4-row groups of level l+1 whose first source row falls into its band and the quads whose first
 //            tap falls into its columns (both partitions are exact: every destination pixel is written by exactly one slot):
 //            lane = (quad, group), at most 8 x 8, each lane a 4 x 4 destination block from the slot's rows -- a quad's 8-byte
