@@ -627,6 +627,10 @@ int  pgorb_debug_level_image(pgorb_ctx* ctx, int frame, int level, uint8_t* out 
 int  pgorb_debug_level_candidates(pgorb_ctx* ctx, int frame, int level,
                                   int32_t* x, int32_t* y, int32_t* response, int cap);
 int  pgorb_debug_level_keypoints(pgorb_ctx* ctx, int frame, int level);
+/* Parity tap of the device's sin / cos contract: 64-bit checksums of pg_sincos_f over `count` consecutive
+ * float bit patterns from `first_bits`, `nblocks` blocks -> out[nblocks]; compared with the oracle's for EVERY float input
+ * (tests/test_gpu_parity.py::test_device_sincos_equals_the_oracle_for_every_input).  Synchronous. */
+int  pgorb_debug_sincos_checksum(uint32_t first_bits, uint32_t count, int nblocks, unsigned long long* out);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,7 @@ SYMBOLS = (
     "pgorb_extract_batch_device", "pgorb_check_async", "pgorb_descriptor_distance",
     "pgorb_hamming_matrix", "pgorb_hamming_best2", "pgorb_match_batch_device",
     "pgorb_debug_level_size", "pgorb_debug_level_image", "pgorb_debug_level_candidates",
-    "pgorb_debug_level_keypoints", "pgorb_profile_begin", "pgorb_profile_read", "pgorb_profile_host",
+    "pgorb_debug_level_keypoints", "pgorb_debug_sincos_checksum", "pgorb_profile_begin", "pgorb_profile_read", "pgorb_profile_host",
     "pgorb_vocab_load_text", "pgorb_vocab_load_cached", "pgorb_vocab_from_blob", "pgorb_vocab_blob", "pgorb_vocab_info",
     "pgorb_vocab_free", "pgorb_vocab_upload", "pgorb_vocab_upload_device", "pgorb_bow_transform",
     "pgorb_bow_transform_device", "pgorb_bow_vectors", "pgorb_bow_score_l1",

@@ -25,6 +25,13 @@ def test_header_symbols_are_exported():
     for s in syms:
         assert hasattr(L, s), "libpgorb.so does not export %s" % s
     assert sorted(_lib.SYMBOLS) == syms, "pilotguru_amd/_lib.py SYMBOLS out of sync with include/pgorb.h"
+    # ... and nothing named pgorb_* leaves the library without a prototype (the header IS the boundary)
+    import shutil
+    import subprocess
+    if shutil.which("nm"):
+        out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+        exported = sorted({l.split()[-1] for l in out.splitlines() if " T pgorb_" in l})
+        assert exported == syms, "exports without a prototype: %s" % sorted(set(exported) - set(syms))
 
 
 def test_struct_layouts_match_header():

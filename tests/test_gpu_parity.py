@@ -919,7 +919,7 @@ def _stage_check(oracle, ext, img, nf, scale, nlev, ini, mn, label):
 @pytest.mark.parametrize("w,h,nf,scale,nlev", [(640, 480, 1000, 1.2, 8), (641, 479, 1000, 1.2, 8), (1920, 1080, 2000, 1.2, 8),
                                                (1280, 720, 1500, 1.2, 6), (333, 251, 500, 1.2, 5), (800, 600, 1200, 1.25, 4),
                                                (1000, 1000, 1500, 1.1, 8), (700, 100, 300, 1.2, 3), (2048, 96, 600, 1.2, 2),
-                                               (1024, 768, 1000, 1.5, 4), (500, 800, 600, 1.2, 4)])
+                                               (1024, 768, 1000, 1.5, 4), (500, 800, 600, 1.2, 4), (3840, 2160, 4000, 1.2, 8)])
 def test_fused_resize_and_detect_every_level_bit_exact(oracle, w, h, nf, scale, nlev, fused):
     """fused.hip (round 6): the launch that resizes level l -> l + 1 also detects level l (each level read once), against the
     oracle stage by stage -- every pyramid level, every level's candidate set, the final output -- on textured, driving-like
